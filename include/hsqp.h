@@ -1,0 +1,189 @@
+/*
+ * hsqp.h — C ABI of the MI355X-native multiple-shooting SQP iteration for the
+ * ocs2-based humanoid NMPC of manumerous/wb_humanoid_mpc (Unitree G1, whole-body
+ * acceleration-level formulation).
+ *
+ * This is the drop-in boundary.  It replaces what the reference
+ * reaches through `ocs2::SqpMpc` / `ocs2::SolverBase`:
+ *   - humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:64      (SqpMpc construction)
+ *   - humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:85-89   (solver ptr handed to MPC_ROS_Interface)
+ *   - humanoid_nmpc/humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:200-213 (advanceMpc -> SolverBase::run)
+ * The per-node callbacks the reference's solver makes into the problem
+ * definition (SystemDynamicsBase / StateInputCost / StateInputConstraint /
+ * PreComputation virtuals) do not cross this boundary: their bodies are device
+ * code, their time-varying inputs arrive as the per-node parameter table
+ * `hsqp_problem::node_params` that the adaptor samples from the reference's own
+ * ReferenceManager / SwingTrajectoryPlanner.
+ *
+ * Plain C, POD only, no exceptions, no torch types.  All floating point is IEEE
+ * double (ocs2::scalar_t).  All matrices row-major.  The caller owns every
+ * host buffer for the duration of a call; nothing is retained afterwards.
+ * A handle is used by one thread at a time (the reference's MPC thread).
+ */
+#ifndef HSQP_H
+#define HSQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- problem dimensions (G1 whole-body: WBAccelMpcRobotModel.h:47-94) -------------------- */
+#define HSQP_NJ 23              /* actuated joints kept in the MPC model            */
+#define HSQP_NV 29              /* generalized velocities: 6 base + NJ               */
+#define HSQP_NX 58              /* x = [p_b(3) eulerZYX(3) q_j | v_b(3) eulerZYXdot(3) qd_j] */
+#define HSQP_NU 35              /* u = [W_left(6)=f,m  W_right(6)  qdd_j]            */
+#define HSQP_NB 24              /* rigid bodies: base + one per joint                */
+#define HSQP_NCONTACT 2
+#define HSQP_NODE_PARAMS 72     /* doubles per shooting node in hsqp_problem::node_params */
+
+/* per-node parameter table layout (what the reference samples per node through
+ * SwitchedModelReferenceManager::getContactFlags / getDesiredState,
+ * SwingTrajectoryPlanner::getZ*Constraint / getImpactProximityFactor) */
+#define HSQP_P_XDES 0           /* [58] TargetTrajectories::getDesiredState(t)                        */
+#define HSQP_P_ARMSWING 58      /* sin(2*pi*(phase(t)-0.15)); 0 disables the arm-swing reference      */
+#define HSQP_P_CONTACT 59       /* [2]  contact flags {left,right} as 0.0/1.0                         */
+#define HSQP_P_SWING 61         /* [2][3] per foot z*, zdot*, zddot* of the swing spline               */
+#define HSQP_P_IMPACT 67        /* [2]  impact proximity factor per foot                               */
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define HSQP_OK 0
+#define HSQP_ERR_BAD_ARG (-1)
+#define HSQP_ERR_NO_DEVICE (-2)
+#define HSQP_ERR_OOM (-3)
+#define HSQP_ERR_NUMERIC (-4)   /* reduced Hessian not positive definite / rank-deficient D            */
+#define HSQP_ERR_HIP (-5)       /* HIP runtime failure, see hsqp_last_error                            */
+#define HSQP_ERR_NOT_CONVERGED (-6)
+
+typedef struct hsqp_body {
+  int32_t parent;               /* parent body index, -1 for the base (pelvis)                         */
+  int32_t reserved;
+  double R[9];                  /* joint placement in the parent body frame (rotation, row-major)      */
+  double p[3];                  /* joint placement translation                                          */
+  double axis[3];               /* revolute axis in the joint (= child body) frame                      */
+  double mass;
+  double com[3];                /* centre of mass in the body frame                                     */
+  double inertia[9];            /* rotational inertia about the com, body axes                          */
+  double q_lo, q_hi;            /* URDF position limits (unused for the base)                           */
+} hsqp_body;
+
+typedef struct hsqp_frame {
+  int32_t body;
+  int32_t reserved;
+  double p[3];                  /* translation in the body frame; rotation is identity (createPinocchioModel.cpp:77-83) */
+} hsqp_frame;
+
+/* Relaxed / piece-wise polynomial barrier settings (mu, delta). */
+typedef struct hsqp_barrier { double mu, delta; } hsqp_barrier;
+
+typedef struct hsqp_model_desc {
+  int32_t formulation;          /* 0 = whole-body acceleration-level (the only one implemented)         */
+  int32_t n_joints;             /* must equal HSQP_NJ                                                    */
+  hsqp_body bodies[HSQP_NB];    /* bodies[0] = base; bodies[1+j] moved by joint j; parents before children */
+  hsqp_frame contact[2];        /* foot_{l,r}_contact                                                    */
+  hsqp_frame collision_p1[2];   /* foot_*_contact_collision_p_1                                          */
+  hsqp_frame collision_p2[2];
+  hsqp_frame ankle[2];
+  hsqp_frame knee[2];
+  double gravity;               /* 9.81 */
+  double Q[HSQP_NX];            /* diagonal state weights  (task.info Q, scaling applied)                */
+  double R[HSQP_NU];            /* diagonal input weights                                                */
+  double Qf[HSQP_NX];           /* diagonal terminal weights (Q_final * terminalCostScaling)             */
+  double foot_sqrt_w[18];       /* sqrt of the effective EndEffectorDynamicsWeights vector               */
+  /* stance / swing foot constraint gains (ModelSettings::FootConstraintConfig) */
+  double gain_pos_z, gain_ori, gain_linvel_z, gain_linvel_xy, gain_angvel;
+  double gain_linacc_z, gain_linacc_xy, gain_angacc;
+  /* friction cone (FrictionForceConeConstraint::Config) + its relaxed barrier */
+  double friction_mu, friction_reg, friction_grip, friction_hess_shift;
+  hsqp_barrier friction_barrier;
+  /* contact moment XY: rectangle bounds in the contact frame + relaxed barrier */
+  double rect_x_min, rect_x_max, rect_y_min, rect_y_max;
+  hsqp_barrier moment_barrier;
+  hsqp_barrier joint_limit_barrier;   /* PieceWisePolynomialBarrierPenalty */
+  double r_foot, r_knee;
+  hsqp_barrier collision_barrier;     /* PieceWisePolynomialBarrierPenalty */
+  int32_t arm_swing_joint[4];   /* joint indices {l_shoulder_y, r_shoulder_y, l_elbow_y, r_elbow_y}      */
+} hsqp_model_desc;
+
+typedef struct hsqp_settings {
+  int32_t max_nodes;            /* N_max: shooting intervals per instance                                */
+  int32_t max_batch;            /* independent MPC instances per call on this device                     */
+  int32_t device;               /* HIP device ordinal                                                    */
+  int32_t flags;                /* reserved, 0                                                           */
+} hsqp_settings;
+
+typedef struct hsqp_problem {
+  int32_t batch;                /* B independent instances                                               */
+  int32_t n_nodes;              /* N shooting intervals -> N+1 nodes                                     */
+  double dt;                    /* uniform node spacing (no event nodes)                                 */
+  const double* x_init;         /* [B][58]        measured state                                          */
+  const double* x_traj;         /* [B][N+1][58]   linearisation trajectory (warm start)                   */
+  const double* u_traj;         /* [B][N][35]                                                            */
+  const double* node_params;    /* [B][N+1][HSQP_NODE_PARAMS]                                            */
+} hsqp_problem;
+
+typedef struct hsqp_perf {      /* ocs2::PerformanceIndex subset, per instance                           */
+  double merit, cost, dynamics_sse, equality_sse;
+} hsqp_perf;
+
+typedef struct hsqp_timings {   /* SqpSolver::getBenchmarks() buckets (SqpBenchmarksPublisher.cpp:54-57), seconds */
+  double lq_approximation, solve_qp, linesearch, compute_controller, total;
+} hsqp_timings;
+
+typedef struct hsqp_solution {
+  double* x;                    /* [B][N+1][58]  x + dx                                                  */
+  double* u;                    /* [B][N][35]    u + du                                                  */
+  double* dx;                   /* optional [B][N+1][58] QP step (may be NULL)                           */
+  double* du;                   /* optional [B][N][35]                                                   */
+  hsqp_perf* perf_before;       /* optional [B] performance index of the linearisation trajectory       */
+  hsqp_perf* perf_after;        /* optional [B] performance index after the full step                    */
+  double* kkt;                  /* optional [B][2] {stationarity, primal} inf-norm residual of the projected QP */
+  hsqp_timings timings;
+} hsqp_solution;
+
+typedef struct hsqp_handle hsqp_handle;
+
+/* Build the device problem image (model constants, weights) and allocate all device
+ * workspaces for (max_batch, max_nodes).  Replaces the SqpMpc/SqpSolver constructor. */
+int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsqp_handle** out);
+void hsqp_destroy(hsqp_handle* h);
+
+/* One SQP iteration for every instance: LQ approximation at all nodes, equality
+ * projection, Riccati QP, full step, performance indices.  Blocking. Replaces one
+ * pass of SqpSolver::runImpl with sqpIteration = 1. */
+int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution);
+
+/* Same, but the problem is already resident on the device from the previous
+ * hsqp_solve/hsqp_upload and the result is left there (bench / multi-iteration use). */
+int hsqp_upload(hsqp_handle* h, const hsqp_problem* problem);
+int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int take_step);
+int hsqp_download(hsqp_handle* h, hsqp_solution* solution);
+
+/* Debug/parity access to intermediate device blocks of the LAST iteration.
+ * `what` is one of the HSQP_BLK_* ids; copies min(bytes, block size) and
+ * returns the block size in bytes (negative error code on failure). */
+#define HSQP_BLK_AB 1           /* [B][N][58][93]   [A|B] of the RK4 sensitivity discretisation          */
+#define HSQP_BLK_BVEC 2         /* [B][N][58]       defect b_k                                            */
+#define HSQP_BLK_H 3            /* [B][N][93][93]   dt * Hessian of the stage cost wrt [x;u]              */
+#define HSQP_BLK_G 4            /* [B][N][93]       dt * gradient                                         */
+#define HSQP_BLK_CDE 5          /* [B][N][14][94]   [C|D|e] active equality rows (zero padded)            */
+#define HSQP_BLK_NE 6           /* [B][N] int32     number of active equality rows                        */
+#define HSQP_BLK_COST 7         /* [B][N+1]         dt*l_k (terminal: l_N)                                 */
+#define HSQP_BLK_DX 8           /* [B][N+1][58]                                                            */
+#define HSQP_BLK_DU 9           /* [B][N][35]                                                              */
+#define HSQP_BLK_FLOW 10        /* [B][N][58]       xdot at (x_k,u_k)                                      */
+long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes);
+
+/* Elapsed device time (ms) of the kernels of the last hsqp_iterate_device call,
+ * measured with HIP events on the handle's stream: {lq, project, riccati, step, total}. */
+int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]);
+
+const char* hsqp_last_error(const hsqp_handle* h);   /* h may be NULL: last creation error */
+const char* hsqp_version(void);
+int hsqp_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSQP_H */

@@ -1,0 +1,154 @@
+"""TEST INFRASTRUCTURE: ctypes front-end of the CPU oracle (oracle/oracle.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+os.environ.setdefault("OMP_STACKSIZE", "64M")
+
+from wb_humanoid_mpc_amd import _abi  # noqa: E402  (struct layouts only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborc.so")
+NX, NU, NZ, NV, NB, NP, NE_MAX = _abi.NX, _abi.NU, _abi.NZ, _abi.NV, _abi.NB, _abi.NODE_PARAMS, _abi.NE_MAX
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "liborc.so"])
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    def __init__(self, model):
+        build()
+        self.lib = C.CDLL(_LIB)
+        self.lib.orc_create.restype = C.c_void_p
+        self.lib.orc_total_mass.restype = C.c_double
+        self.lib.orc_stage_cost.restype = C.c_double
+        self.lib.orc_penalty.restype = C.c_double
+        self.model = model
+        self.h = C.c_void_p(self.lib.orc_create(C.byref(model.desc)))
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def total_mass(self):
+        return self.lib.orc_total_mass(self.h)
+
+    def flow_map(self, x, u):
+        x, u = _c(x), _c(u)
+        out = np.zeros(NX)
+        self.lib.orc_flow_map(self.h, _p(x), _p(u), _p(out))
+        return out
+
+    def flow_map_jac(self, x, u):
+        x, u = _c(x), _c(u)
+        out, J = np.zeros(NX), np.zeros((NX, NZ))
+        self.lib.orc_flow_map_jac(self.h, _p(x), _p(u), _p(out), _p(J))
+        return out, J
+
+    def base_dynamics(self, x, u):
+        x, u = _c(x), _c(u)
+        ab, M6, nle6 = np.zeros(6), np.zeros((6, NV)), np.zeros(6)
+        self.lib.orc_base_dynamics(self.h, _p(x), _p(u), _p(ab), _p(M6), _p(nle6))
+        return ab, M6, nle6
+
+    def full_dynamics(self, x):
+        x = _c(x)
+        M, nle = np.zeros((NV, NV)), np.zeros(NV)
+        self.lib.orc_full_dynamics(self.h, _p(x), _p(M), _p(nle))
+        return M, nle
+
+    def foot_kinematics(self, x, u, jac=False):
+        x, u = _c(x), _c(u)
+        out, R = np.zeros((2, 18)), np.zeros((2, 3, 3))
+        J = np.zeros((2, 18, NZ)) if jac else None
+        self.lib.orc_foot_kinematics(self.h, _p(x), _p(u), _p(out), _p(R), _p(J))
+        return (out, R, J) if jac else (out, R)
+
+    def body_placements(self, q):
+        q = _c(q)
+        R, p = np.zeros((NB, 3, 3)), np.zeros((NB, 3))
+        self.lib.orc_body_placements(self.h, _p(q), _p(R), _p(p))
+        return R, p
+
+    def collision(self, x):
+        x = _c(x)
+        h = np.zeros(16)
+        self.lib.orc_collision(self.h, _p(x), _p(h))
+        return h
+
+    def stage_cost(self, x, u, par):
+        x, u, par = _c(x), _c(u), _c(par)
+        eq = np.zeros(NE_MAX)
+        ne = C.c_int(0)
+        c = self.lib.orc_stage_cost(self.h, _p(x), _p(u), _p(par), _p(eq), C.byref(ne))
+        return c, eq[: ne.value].copy()
+
+    def rk4(self, x, u, dt):
+        x, u = _c(x), _c(u)
+        out = np.zeros(NX)
+        self.lib.orc_rk4(self.h, _p(x), _p(u), C.c_double(dt), _p(out))
+        return out
+
+    def lq(self, dt, x, u, par, threads=1):
+        """LQ approximation of all nodes of ONE instance. x:(N+1,58) u:(N,35) par:(N+1,72)."""
+        x, u, par = _c(x), _c(u), _c(par)
+        N = u.shape[0]
+        out = dict(AB=np.zeros((N, NX, NZ)), b=np.zeros((N, NX)), H=np.zeros((N, NZ, NZ)), g=np.zeros((N, NZ)),
+                   CDe=np.zeros((N, NE_MAX, NZ + 1)), ne=np.zeros(N, dtype=np.int32), cost=np.zeros(N + 1),
+                   flow=np.zeros((N, NX)))
+        self.lib.orc_lq(self.h, N, C.c_double(dt), _p(x), _p(u), _p(par), threads, _p(out["AB"]), _p(out["b"]),
+                        _p(out["H"]), _p(out["g"]), _p(out["CDe"]), out["ne"].ctypes.data_as(C.POINTER(C.c_int)),
+                        _p(out["cost"]), _p(out["flow"]))
+        return out
+
+    def sqp_iteration(self, dt, x_init, x, u, par, threads=1, want_proj=False, want_perf=True):
+        x_init, x, u, par = _c(x_init), _c(x), _c(u), _c(par)
+        N = u.shape[0]
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        pb, pa = _abi.Perf(), _abi.Perf()
+        kkt = np.zeros(2)
+        proj = np.zeros((N, NU * NX + NU + NU * NU)) if want_proj else None
+        rc = self.lib.orc_sqp_iteration(self.h, N, C.c_double(dt), _p(x_init), _p(x), _p(u), _p(par), threads,
+                                        _p(xn), _p(un), _p(dx), _p(du),
+                                        C.byref(pb) if want_perf else None, C.byref(pa) if want_perf else None,
+                                        _p(kkt), _p(proj))
+        if rc != 0:
+            raise RuntimeError(f"oracle sqp_iteration failed: {rc}")
+        res = dict(x=xn, u=un, dx=dx, du=du, kkt=kkt,
+                   perf_before=dict(merit=pb.merit, cost=pb.cost, dynamics_sse=pb.dynamics_sse, equality_sse=pb.equality_sse),
+                   perf_after=dict(merit=pa.merit, cost=pa.cost, dynamics_sse=pa.dynamics_sse, equality_sse=pa.equality_sse))
+        if want_proj:
+            res["Px"] = proj[:, : NU * NX].reshape(N, NU, NX)
+            res["Pe"] = proj[:, NU * NX: NU * NX + NU]
+            res["PuPuT"] = proj[:, NU * NX + NU:].reshape(N, NU, NU)
+        return res
+
+    def performance(self, dt, x, u, par, threads=1):
+        x, u, par = _c(x), _c(u), _c(par)
+        p = _abi.Perf()
+        self.lib.orc_performance(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(par), threads, C.byref(p))
+        return dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse)
+
+    def penalty(self, kind, mu, delta, h):
+        d1, d2 = C.c_double(), C.c_double()
+        p = self.lib.orc_penalty(kind, C.c_double(mu), C.c_double(delta), C.c_double(h), C.byref(d1), C.byref(d2))
+        return p, d1.value, d2.value
