@@ -1,0 +1,162 @@
+// Shared definitions of the HIP SQP kernels (device code) — MI355X / gfx950.
+//
+// Kernel bodies are written as a sequence of workgroup-parallel phases over an LDS
+// workspace: WG_FOR(ctx, i, n) distributes n independent work items over the
+// workgroup's threads, WG_SYNC(ctx) is the barrier between dependent phases.  Rules:
+//   * LDS / global writes happen only inside WG_FOR bodies (or under ctx.tid == 0),
+//   * no per-thread value is carried from one phase to the next (only values every
+//     thread recomputes identically from LDS).
+// With those rules the same source also compiles for the host with a one-thread
+// context (tests/hostemu), which is how the kernel arithmetic is checked against the
+// oracle in the GPU-less build container.  The host build is test infrastructure only;
+// the product library contains the device build exclusively.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/hsqp.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HSQP_HD __host__ __device__ __forceinline__
+#define HSQP_D __device__ __forceinline__
+#else
+#define HSQP_HD inline
+#define HSQP_D inline
+#endif
+
+namespace hsqp {
+
+constexpr int NJ = HSQP_NJ, NV = HSQP_NV, NX = HSQP_NX, NU = HSQP_NU, NB = HSQP_NB, NZ = NX + NU;
+constexpr int NP = HSQP_NODE_PARAMS;
+constexpr int NJC = 26;        // revolute generalized coordinates: euler z,y,x + 23 joints (coordinate index = 3 + jc)
+constexpr int NE_MAX = 14;     // max active equality rows (flight: 6+1+6+1)
+constexpr int NUT = 23;        // max projected input dimension nu - ne (padded with identity when ne > 12)
+constexpr int NR = 60;         // residual-row slots of the Gauss-Newton / penalty model (see hsqp_node.h)
+constexpr int NLEVELS = 8;     // depth of the body tree incl. the base
+
+struct Ctx {
+  int tid;
+  int nthreads;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WG_SYNC(ctx) __syncthreads()
+#else
+#define WG_SYNC(ctx) ((void)0)
+#endif
+#define WG_FOR(ctx, i, n) for (int i = (ctx).tid; i < (n); i += (ctx).nthreads)
+
+// ------------------------------------------------------------------------------------------------
+// Device image of the model constants (built on the host from hsqp_model_desc, hsqp_host.cpp).
+struct DevModel {
+  // kinematic tree, bodies in depth-first order (subtree of i = [i, i + subtree_size[i]))
+  int parent[NB];
+  int subtree_size[NB];
+  int level[NB];
+  int level_start[NLEVELS + 1];   // bodies sorted by level: level_bodies[level_start[l] .. level_start[l+1])
+  int level_bodies[NB];
+  double Rfix[NB][9];
+  double pfix[NB][3];
+  double axis[NB][3];
+  double mass[NB];
+  double com[NB][3];
+  double inertia[NB][9];          // about com, body axes
+  double q_lo[NJ], q_hi[NJ];
+  double total_mass;
+  double gravity;
+  // frames: body + offset
+  int contact_body[2];
+  double contact_p[2][3];
+  int coll_body[10];              // order: ankle_l, ankle_r, f_l, f_r, l1, r1, l2, r2, k_l, k_r
+  double coll_p[10][3];
+  // task constants
+  double Q[NX], R[NU], Qf[NX];
+  double foot_sqrt_w[18];
+  double gain_pos_z, gain_ori, gain_linvel_z, gain_linvel_xy, gain_angvel, gain_linacc_z, gain_linacc_xy, gain_angacc;
+  double friction_mu, friction_reg, friction_grip, friction_hess_shift, friction_bmu, friction_bdelta;
+  double rect_x_min, rect_x_max, rect_y_min, rect_y_max, moment_bmu, moment_bdelta;
+  double jl_bmu, jl_bdelta;
+  double r_foot, r_knee, coll_bmu, coll_bdelta;
+  int arm_swing_joint[4];
+};
+
+// ------------------------------------------------------------------------------------------------
+// 3-vectors and 6-D spatial vectors stored as plain double arrays.
+// Motion m = {ang[3], lin[3]}, force f = {moment[3], force[3]}, both about the common origin O.
+HSQP_HD void v3_cross(const double* a, const double* b, double* r) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+HSQP_HD double v3_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+HSQP_HD void m3_mulv(const double* M, const double* v, double* r) {  // r = M v (row-major), r may not alias v
+  r[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  r[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  r[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+HSQP_HD void m3_tmulv(const double* M, const double* v, double* r) {  // r = M^T v
+  r[0] = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+  r[1] = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+  r[2] = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+}
+HSQP_HD void m3_mul(const double* A, const double* B, double* C) {  // C = A B, C may not alias
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// motion x motion
+HSQP_HD void mxm(const double* a, const double* b, double* r) {
+  double w[3], l1[3], l2[3];
+  v3_cross(a, b, w);
+  v3_cross(a, b + 3, l1);
+  v3_cross(a + 3, b, l2);
+  r[0] = w[0]; r[1] = w[1]; r[2] = w[2];
+  r[3] = l1[0] + l2[0]; r[4] = l1[1] + l2[1]; r[5] = l1[2] + l2[2];
+}
+// motion x* force
+HSQP_HD void mxf(const double* m, const double* f, double* r) {
+  double n1[3], n2[3], ff[3];
+  v3_cross(m, f, n1);
+  v3_cross(m + 3, f + 3, n2);
+  v3_cross(m, f + 3, ff);
+  r[0] = n1[0] + n2[0]; r[1] = n1[1] + n2[1]; r[2] = n1[2] + n2[2];
+  r[3] = ff[0]; r[4] = ff[1]; r[5] = ff[2];
+}
+// Spatial inertia about O in world axes: In = {m, h[3] = m*c, Ibar[6] = xx,xy,xz,yy,yz,zz (about O)}
+HSQP_HD void sym3_mulv(const double* S, const double* v, double* r) {
+  r[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
+  r[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
+  r[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+}
+HSQP_HD void inertia_apply(const double* In, const double* m, double* f) {  // f = I m
+  double a[3], b[3], c[3];
+  sym3_mulv(In + 4, m, a);
+  v3_cross(In + 1, m + 3, b);
+  v3_cross(In + 1, m, c);
+  f[0] = a[0] + b[0]; f[1] = a[1] + b[1]; f[2] = a[2] + b[2];
+  f[3] = In[0] * m[3] - c[0]; f[4] = In[0] * m[4] - c[1]; f[5] = In[0] * m[5] - c[2];
+}
+// r = Minv(3x3 row-major) * v helper for the 3x3 solves
+HSQP_HD void m3_inverse(const double* a, double* c) {
+  c[0] = a[4] * a[8] - a[5] * a[7]; c[1] = a[2] * a[7] - a[1] * a[8]; c[2] = a[1] * a[5] - a[2] * a[4];
+  c[3] = a[5] * a[6] - a[3] * a[8]; c[4] = a[0] * a[8] - a[2] * a[6]; c[5] = a[2] * a[3] - a[0] * a[5];
+  c[6] = a[3] * a[7] - a[4] * a[6]; c[7] = a[1] * a[6] - a[0] * a[7]; c[8] = a[0] * a[4] - a[1] * a[3];
+  const double inv = 1.0 / (a[0] * c[0] + a[1] * c[3] + a[2] * c[6]);
+  for (int i = 0; i < 9; ++i) c[i] *= inv;
+}
+
+// Penalties (RelaxedBarrierPenalty: upstream ocs2; PieceWisePolynomialBarrierPenalty: fork-only, ASSUMPTION A1 of the oracle)
+struct Pen3 { double p, d1, d2; };
+HSQP_HD Pen3 relaxed_barrier(double mu, double delta, double h) {
+  Pen3 r;
+  if (h > delta) { r.p = -mu * log(h); r.d1 = -mu / h; r.d2 = mu / (h * h); }
+  else { const double t = (h - 2.0 * delta) / delta; r.p = mu * (-log(delta) + 0.5 * t * t - 0.5); r.d1 = mu * (h - 2.0 * delta) / (delta * delta); r.d2 = mu / (delta * delta); }
+  return r;
+}
+HSQP_HD Pen3 pwp_barrier(double mu, double delta, double h) {
+  Pen3 r;
+  if (h >= delta) { r.p = 0.0; r.d1 = 0.0; r.d2 = 0.0; }
+  else { const double t = (delta - h) / delta; r.p = mu * t * t * t; r.d1 = -3.0 * mu * t * t / delta; r.d2 = 6.0 * mu * t / (delta * delta); }
+  return r;
+}
+
+}  // namespace hsqp

@@ -1,0 +1,90 @@
+// Host-side construction of the device model image from the C-ABI model description.
+#pragma once
+#include <string.h>
+
+#include <string>
+
+#include "hsqp_common.h"
+
+namespace hsqp {
+
+// Returns an empty string on success, otherwise a description of what is wrong with the model.
+inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
+  memset(&dm, 0, sizeof(dm));
+  if (md.formulation != 0) return "only formulation 0 (whole-body acceleration-level) is implemented";
+  if (md.n_joints != NJ) return "n_joints must be " + std::to_string(NJ);
+  dm.total_mass = 0.0;
+  for (int i = 0; i < NB; ++i) {
+    const hsqp_body& b = md.bodies[i];
+    if (i == 0 ? b.parent != -1 : (b.parent < 0 || b.parent >= i)) return "bodies must be listed parents-first with bodies[0] the base";
+    dm.parent[i] = b.parent;
+    memcpy(dm.Rfix[i], b.R, sizeof(b.R));
+    memcpy(dm.pfix[i], b.p, sizeof(b.p));
+    memcpy(dm.axis[i], b.axis, sizeof(b.axis));
+    dm.mass[i] = b.mass;
+    memcpy(dm.com[i], b.com, sizeof(b.com));
+    memcpy(dm.inertia[i], b.inertia, sizeof(b.inertia));
+    dm.total_mass += b.mass;
+    if (i > 0) { dm.q_lo[i - 1] = b.q_lo; dm.q_hi[i - 1] = b.q_hi; }
+    dm.level[i] = i == 0 ? 0 : dm.level[b.parent] + 1;
+    if (dm.level[i] >= NLEVELS) return "kinematic tree deeper than NLEVELS";
+    if (i > 0) {
+      const double n = b.axis[0] * b.axis[0] + b.axis[1] * b.axis[1] + b.axis[2] * b.axis[2];
+      if (fabs(n - 1.0) > 1e-9) return "joint axes must be unit vectors";
+    }
+  }
+  // subtree sizes; depth-first (contiguous subtree) ordering is required by the composite sums
+  for (int i = NB - 1; i >= 0; --i) {
+    dm.subtree_size[i] += 1;
+    if (i > 0) dm.subtree_size[dm.parent[i]] += dm.subtree_size[i];
+  }
+  for (int i = 1; i < NB; ++i) {
+    const int p = dm.parent[i];
+    if (!(i > p && i < p + dm.subtree_size[p])) return "bodies are not in depth-first order";
+    for (int a = p; a >= 0; a = dm.parent[a])
+      if (!(i >= a && i < a + dm.subtree_size[a])) return "bodies are not in depth-first order";
+  }
+  int pos = 0;
+  for (int l = 0; l < NLEVELS; ++l) {
+    dm.level_start[l] = pos;
+    for (int i = 0; i < NB; ++i)
+      if (dm.level[i] == l) dm.level_bodies[pos++] = i;
+  }
+  dm.level_start[NLEVELS] = pos;
+  dm.gravity = md.gravity;
+  for (int f = 0; f < 2; ++f) {
+    dm.contact_body[f] = md.contact[f].body;
+    memcpy(dm.contact_p[f], md.contact[f].p, sizeof(double) * 3);
+    if (md.contact[f].body < 0 || md.contact[f].body >= NB) return "bad contact frame body";
+  }
+  const hsqp_frame* cf[10] = {&md.ankle[0], &md.ankle[1], &md.contact[0], &md.contact[1], &md.collision_p1[0],
+                              &md.collision_p1[1], &md.collision_p2[0], &md.collision_p2[1], &md.knee[0], &md.knee[1]};
+  for (int k = 0; k < 10; ++k) {
+    if (cf[k]->body < 0 || cf[k]->body >= NB) return "bad collision frame body";
+    dm.coll_body[k] = cf[k]->body;
+    memcpy(dm.coll_p[k], cf[k]->p, sizeof(double) * 3);
+  }
+  memcpy(dm.Q, md.Q, sizeof(md.Q));
+  memcpy(dm.R, md.R, sizeof(md.R));
+  memcpy(dm.Qf, md.Qf, sizeof(md.Qf));
+  memcpy(dm.foot_sqrt_w, md.foot_sqrt_w, sizeof(md.foot_sqrt_w));
+  dm.gain_pos_z = md.gain_pos_z; dm.gain_ori = md.gain_ori; dm.gain_linvel_z = md.gain_linvel_z;
+  dm.gain_linvel_xy = md.gain_linvel_xy; dm.gain_angvel = md.gain_angvel; dm.gain_linacc_z = md.gain_linacc_z;
+  dm.gain_linacc_xy = md.gain_linacc_xy; dm.gain_angacc = md.gain_angacc;
+  dm.friction_mu = md.friction_mu; dm.friction_reg = md.friction_reg; dm.friction_grip = md.friction_grip;
+  dm.friction_hess_shift = md.friction_hess_shift;
+  dm.friction_bmu = md.friction_barrier.mu; dm.friction_bdelta = md.friction_barrier.delta;
+  dm.rect_x_min = md.rect_x_min; dm.rect_x_max = md.rect_x_max; dm.rect_y_min = md.rect_y_min; dm.rect_y_max = md.rect_y_max;
+  dm.moment_bmu = md.moment_barrier.mu; dm.moment_bdelta = md.moment_barrier.delta;
+  dm.jl_bmu = md.joint_limit_barrier.mu; dm.jl_bdelta = md.joint_limit_barrier.delta;
+  dm.r_foot = md.r_foot; dm.r_knee = md.r_knee;
+  dm.coll_bmu = md.collision_barrier.mu; dm.coll_bdelta = md.collision_barrier.delta;
+  for (int k = 0; k < 4; ++k) {
+    if (md.arm_swing_joint[k] < 0 || md.arm_swing_joint[k] >= NJ) return "bad arm swing joint index";
+    dm.arm_swing_joint[k] = md.arm_swing_joint[k];
+  }
+  if (!(dm.total_mass > 0.0)) return "total mass must be positive";
+  return "";
+}
+
+}  // namespace hsqp

@@ -1,0 +1,189 @@
+// LQ approximation of one intermediate shooting node: RK4 sensitivity discretisation of the flow
+// map (upstream ocs2 SensitivityIntegrator, integratorType RK4 — task.info:92) plus the
+// node's cost model and equality rows (hsqp_node.h).
+//
+// Structure that is exploited (and is exact, not an approximation): the flow map is
+//   xdot = [ v ; a_b(q,v,u) ; qdd_j ],
+// so of the 58 rows of every stage Jacobian only the 6 base-acceleration rows are non-trivial, and
+// [A|B] = [I|0] + dt/6 (dk1 + 2 dk2 + 2 dk3 + dk4) is fully described by two 6 x 93 blocks
+//   P6 = dt^2/6 (Ab1 + Ab2 + Ab3)            (base position rows 0..5)
+//   V6 = dt/6   (Ab1 + 2 Ab2 + 2 Ab3 + Ab4)  (base velocity rows 29..34)
+// where Ab_s = d a_b(x_s,u)/dz chains the stage Jacobians G_s; the joint rows are
+//   q_j+ = q_j + dt v_j + dt^2/2 qdd_j ,  v_j+ = v_j + dt qdd_j   exactly.
+#pragma once
+#include "hsqp_node.h"
+
+namespace hsqp {
+
+// ---- per-node record written by the LQ kernel (doubles), read by the projection kernel
+constexpr int REC_PV = 0;                         // [2][6][LDJ]  P6, V6
+constexpr int REC_B = REC_PV + 2 * 6 * LDJ;       // [64]         defect b = Phi(x,u) - x_next
+constexpr int REC_J = REC_B + 64;                 // [NRS][LDJ]   residual rows (x sqrt(dt))
+constexpr int REC_RHO = REC_J + NRS * LDJ;        // [NRS]
+constexpr int REC_D = REC_RHO + NRS;              // [LDJ]        Hessian diagonal (x dt)
+constexpr int REC_GD = REC_D + LDJ;               // [LDJ]        gradient, diagonal part (x dt)
+constexpr int REC_CDE = REC_GD + LDJ;             // [NE_MAX][LDJ] rows [C|D|e]
+constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [8]  ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt)
+constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
+constexpr int REC_SIZE = REC_FLOW + 64;
+
+struct LqWS {
+  union {
+    StageWS st;
+    double Ab[4][6][LDJ];
+  };
+  NodeWS nw;
+  double Gs[4][6][LDJ];
+  double vs[4][NV];    // velocity part of the stage states
+  double as[4][6];     // base accelerations of the stages
+  double xnext[NX];
+  double bvec[64];
+};
+
+// set up the model evaluation inputs of RK4 stage s (0..3)
+HSQP_HD void rk4_stage_inputs(const Ctx& ctx, LqWS& w, int s, double dt) {
+  const double c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt);
+  WG_FOR(ctx, i, NV + NV + NJ + 12) {
+    if (i < NV) {
+      w.st.q[i] = w.nw.x[i] + (s == 0 ? 0.0 : c * w.vs[s - 1][i]);
+    } else if (i < 2 * NV) {
+      const int k = i - NV;
+      double a = 0.0;
+      if (s > 0) a = k < 6 ? w.as[s - 1][k] : w.nw.u[12 + k - 6];
+      const double v = w.nw.x[NV + k] + c * a;
+      w.st.v[k] = v;
+      w.vs[s][k] = v;
+    } else if (i < 2 * NV + NJ) {
+      w.st.qddj[i - 2 * NV] = w.nw.u[12 + i - 2 * NV];
+    } else {
+      w.st.W[i - 2 * NV - NJ] = w.nw.u[i - 2 * NV - NJ];
+    }
+  }
+  WG_SYNC(ctx);
+}
+
+// X (6 x 29 block starting at column c0 of G_s) times Vd_t = [Ab_t ; E_qdd], element (r, col)
+HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ], int r, int col) {
+  double s = 0.0;
+  for (int k = 0; k < 6; ++k) s += Gs[r][c0 + k] * Abt[k][col];
+  if (col >= NX + 12) s += Gs[r][c0 + 6 + (col - NX - 12)];
+  return s;
+}
+
+// Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory) ; DERIV = false: values only
+// (cost, defect and equality violation for the performance index).
+template <bool DERIV>
+HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* x, const double* u, const double* xnext,
+                     const double* par, double dt, double* rec) {
+  WG_FOR(ctx, i, NX + NU + NP + NX) {
+    if (i < NX) w.nw.x[i] = x[i];
+    else if (i < NX + NU) w.nw.u[i - NX] = u[i - NX];
+    else if (i < NX + NU + NP) w.nw.par[i - NX - NU] = par[i - NX - NU];
+    else w.xnext[i - NX - NU - NP] = xnext[i - NX - NU - NP];
+  }
+  WG_SYNC(ctx);
+  for (int s = 0; s < 4; ++s) {
+    rk4_stage_inputs(ctx, w, s, dt);
+    stage_eval<DERIV>(ctx, dm, w.st);
+    WG_FOR(ctx, i, 6 + (DERIV ? 6 * LDJ : 0)) {
+      if (i < 6) w.as[s][i] = w.st.ab[i];
+      else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; w.Gs[s][r][c] = c < NZ ? w.st.G[r][c] : 0.0; }
+    }
+    WG_SYNC(ctx);
+    if (s == 0) {
+      node_values(ctx, dm, w.st, w.nw);
+      node_scalars(ctx, dm, w.st, w.nw);
+      if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J);
+      WG_FOR(ctx, i, 64 + NRS) {
+        if (i < 64) {
+          double f = 0.0;
+          if (i < NV) f = w.nw.x[NV + i];
+          else if (i < NV + 6) f = w.st.ab[i - NV];
+          else if (i < NX) f = w.nw.u[12 + i - NV - 6];
+          rec[REC_FLOW + i] = f;
+        } else if (DERIV) {
+          rec[REC_RHO + i - 64] = sqrt(dt) * w.nw.rho[i - 64];
+        }
+      }
+      WG_SYNC(ctx);
+    }
+  }
+  // ---- RK4 value: x_next = x + dt/6 (k1 + 2 k2 + 2 k3 + k4), defect, performance terms
+  WG_FOR(ctx, i, 64) {
+    double b = 0.0;
+    if (i < NV) {
+      b = w.nw.x[i] + dt / 6.0 * (w.vs[0][i] + 2.0 * w.vs[1][i] + 2.0 * w.vs[2][i] + w.vs[3][i]) - w.xnext[i];
+    } else if (i < NX) {
+      const int k = i - NV;
+      const double a = k < 6 ? (w.as[0][k] + 2.0 * w.as[1][k] + 2.0 * w.as[2][k] + w.as[3][k]) / 6.0 : w.nw.u[12 + k - 6];
+      b = w.nw.x[i] + dt * a - w.xnext[i];
+    }
+    rec[REC_B + i] = b;
+    w.bvec[i] = b;
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, it, 1) {
+    double dyn = 0.0, eq = 0.0;
+    for (int i = 0; i < NX; ++i) dyn += w.bvec[i] * w.bvec[i];
+    for (int r = 0; r < w.nw.ne; ++r) eq += w.nw.eqv[r] * w.nw.eqv[r];
+    rec[REC_MISC + 0] = (double)w.nw.ne;
+    rec[REC_MISC + 1] = dt * w.nw.cost;
+    rec[REC_MISC + 2] = dt * eq;
+    rec[REC_MISC + 3] = dt * dyn;
+  }
+  if (!DERIV) return;
+  // ---- write d, gd, CDe
+  WG_FOR(ctx, i, 2 * LDJ + NE_MAX * LDJ) {
+    if (i < LDJ) rec[REC_D + i] = w.nw.d[i];
+    else if (i < 2 * LDJ) rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
+    else rec[REC_CDE + i - 2 * LDJ] = w.nw.CDe[(i - 2 * LDJ) / LDJ][(i - 2 * LDJ) % LDJ];
+  }
+  WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
+  // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
+  const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
+  WG_FOR(ctx, i, 6 * LDJ) { const int r = i / LDJ, c = i % LDJ; w.Ab[0][r][c] = w.Gs[0][r][c]; }
+  WG_SYNC(ctx);
+  for (int s = 1; s < 4; ++s) {
+    const double c = s == 1 ? c2 : (s == 2 ? c3 : c4);
+    const double cprev = s == 2 ? c2 : c3;  // coefficient of stage s-1 (used for s >= 2)
+    WG_FOR(ctx, i, 6 * LDJ) {
+      const int r = i / LDJ, col = i % LDJ;
+      double val = 0.0;
+      if (col < NZ) {
+        if (col < NV) val = w.Gs[s][r][col];
+        else if (col < NX) val = c * w.Gs[s][r][col - NV] + w.Gs[s][r][col];
+        else val = w.Gs[s][r][col];
+        val += c * times_vd(w.Gs[s], NV, w.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
+        if (s >= 2) val += c * cprev * times_vd(w.Gs[s], 0, w.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
+      }
+      w.Ab[s][r][col] = val;
+    }
+    WG_SYNC(ctx);
+  }
+  WG_FOR(ctx, i, 2 * 6 * LDJ) {
+    const int which = i / (6 * LDJ), r = (i / LDJ) % 6, col = i % LDJ;
+    double v;
+    if (which == 0) v = dt * dt / 6.0 * (w.Ab[0][r][col] + w.Ab[1][r][col] + w.Ab[2][r][col]);
+    else v = dt / 6.0 * (w.Ab[0][r][col] + 2.0 * w.Ab[1][r][col] + 2.0 * w.Ab[2][r][col] + w.Ab[3][r][col]);
+    rec[REC_PV + i] = v;
+  }
+  WG_SYNC(ctx);
+}
+
+// Expand the structured record into the dense [A|B] (58 x 93) — used by the debug/parity path and by tests.
+inline void expand_AB(const double* rec, double dt, double* AB) {
+  for (int i = 0; i < NX * NZ; ++i) AB[i] = 0.0;
+  for (int i = 0; i < NX; ++i) AB[i * NZ + i] = 1.0;
+  for (int i = 0; i < NV; ++i) AB[i * NZ + NV + i] = dt;
+  for (int j = 0; j < NJ; ++j) {
+    AB[(6 + j) * NZ + NX + 12 + j] = 0.5 * dt * dt;
+    AB[(NV + 6 + j) * NZ + NX + 12 + j] = dt;
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < NZ; ++c) {
+      AB[r * NZ + c] += rec[REC_PV + r * LDJ + c];
+      AB[(NV + r) * NZ + c] += rec[REC_PV + 6 * LDJ + r * LDJ + c];
+    }
+}
+
+}  // namespace hsqp

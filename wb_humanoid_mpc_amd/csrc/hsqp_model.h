@@ -1,0 +1,288 @@
+// Rigid-body model evaluation of the whole-body flow map and its analytic Jacobian.
+//
+// What it computes (reference: computeBaseAcceleration,
+//   humanoid_nmpc/humanoid_wb_mpc/src/dynamics/DynamicsHelperFunctions.cpp:52-82 and
+//   humanoid_nmpc/humanoid_common_mpc/src/pinocchio_model/DynamicsHelperFunctions.cpp:197-218):
+//     blkdiag(M_lin, M_ang) a_b = -nle_b(q,v) - M_bj(q) qdd_j + sum_i J_b,i(q)^T W_i
+// The reference differentiates this with a CppAD tape.  Here the base rows are evaluated
+// as a Newton-Euler momentum balance about the base origin O (world axes),
+//     F(q,v,vd) = sum_i  I_i a_i + v_i x* I_i v_i          (vd_base = 0, gravity via a_root = +g e_z)
+//     m a_lin = (F_ext - F).force,     Ibar_tot (E a_ang) = (F_ext - F).moment,   E = euler-rate axes,
+// and differentiated in closed form with spatial-vector identities (S_c = joint motion axis,
+// Sd = v_c x S_c, Sdd = a_c x S_c + v_c x Sd; ^c = composite over the subtree of c):
+//     dF/dq_c   = S_c x* f^c + BB^c Sd_c + I^c Sdd_c
+//     dF/dqd_c  = 2 I^c Sd_c + BB^c S_c ,        BB_i m = -I_i (v_i x m) + m x* (I_i v_i) + v_i x* (I_i m)
+//     dF/dqdd_c = I^c S_c
+// The floating base is treated as the chain prismatic x,y,z -> revolute z -> y' -> x'' which
+// reproduces Pinocchio's JointModelComposite(Translation, SphericalZYX) coordinates exactly.
+// Derivatives w.r.t. the base position and base linear velocity vanish identically.
+#pragma once
+#include "hsqp_common.h"
+
+namespace hsqp {
+
+struct StageWS {
+  // ---- inputs of one evaluation
+  double q[NV], v[NV], qddj[NJ], W[12];
+  // ---- base
+  double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
+  double Einv[9];
+  // ---- revolute coordinates jc = 0..25 (euler z,y,x, then joints); generalized coordinate = 3 + jc
+  double S[NJC][6], Sd[NJC][6], Sdd[NJC][6];
+  double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
+  // ---- bodies
+  double R[NB][9], r[NB][3];       // world rotation, origin relative to the base origin O
+  double In[NB][10], f[NB][6], BB[NB][36];
+  double Ic[NB][10], fc[NB][6], BBc[NB][36];
+  double rP[2][3];                 // contact points relative to O
+  // ---- results
+  double Ftil[6];                  // F_ext - F  {moment, force}
+  double Iinv[9];                  // inverse of the total rotational inertia about O
+  double y[3];                     // E a_ang
+  double ab[6];                    // base acceleration {lin, euler-rate acc}
+  double G[6][96];                 // d ab / d[x;u]   (columns 0..92 used)
+};
+
+HSQP_HD void rot_axis(const double* ax, double q, double* Rm) {
+  const double c = cos(q), s = sin(q), t = 1.0 - c, x = ax[0], y = ax[1], z = ax[2];
+  Rm[0] = t * x * x + c;     Rm[1] = t * x * y - s * z; Rm[2] = t * x * z + s * y;
+  Rm[3] = t * x * y + s * z; Rm[4] = t * y * y + c;     Rm[5] = t * y * z - s * x;
+  Rm[6] = t * x * z - s * y; Rm[7] = t * y * z + s * x; Rm[8] = t * z * z + c;
+}
+
+HSQP_HD void joint_motion(const double* vpar, const double* apar, const double* Sx, double qd, double qdd,
+                          double* vl, double* al, double* Sd, double* Sdd) {
+  for (int k = 0; k < 6; ++k) vl[k] = vpar[k] + Sx[k] * qd;
+  mxm(vl, Sx, Sd);
+  for (int k = 0; k < 6; ++k) al[k] = apar[k] + Sx[k] * qdd + Sd[k] * qd;
+  double t1[6], t2[6];
+  mxm(al, Sx, t1);
+  mxm(vl, Sd, t2);
+  for (int k = 0; k < 6; ++k) Sdd[k] = t1[k] + t2[k];
+}
+
+// BB_i m for one body (see header comment)
+HSQP_HD void bb_apply(const double* In, const double* vl, const double* m, double* out) {
+  double h[6], x[6], t1[6], t2[6], yv[6], t3[6];
+  inertia_apply(In, vl, h);
+  mxm(vl, m, x);
+  inertia_apply(In, x, t1);
+  mxf(m, h, t2);
+  inertia_apply(In, m, yv);
+  mxf(vl, yv, t3);
+  for (int k = 0; k < 6; ++k) out[k] = -t1[k] + t2[k] + t3[k];
+}
+
+HSQP_HD void mat6_mulv(const double* M, const double* v, double* r) {
+  for (int i = 0; i < 6; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += M[6 * i + k] * v[k];
+    r[i] = s;
+  }
+}
+
+// One evaluation of a_b (and, if DERIV, of G = d a_b / d[x;u]) at ws.q, ws.v, ws.qddj, ws.W.
+template <bool DERIV>
+HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
+  // ---- base chain (one item)
+  WG_FOR(ctx, it, 1) {
+    const double cz = cos(ws.q[3]), sz = sin(ws.q[3]), cy = cos(ws.q[4]), sy = sin(ws.q[4]), cx = cos(ws.q[5]), sx = sin(ws.q[5]);
+    const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
+    for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
+    m3_inverse(ws.E, ws.Einv);
+    // R0 = Rz Ry Rx
+    double* R0 = ws.R[0];
+    R0[0] = cz * cy; R0[1] = cz * sy * sx - sz * cx; R0[2] = cz * sy * cx + sz * sx;
+    R0[3] = sz * cy; R0[4] = sz * sy * sx + cz * cx; R0[5] = sz * sy * cx - cz * sx;
+    R0[6] = -sy;     R0[7] = cy * sx;                R0[8] = cy * cx;
+    ws.r[0][0] = ws.r[0][1] = ws.r[0][2] = 0.0;
+    double vP[6] = {0.0, 0.0, 0.0, ws.v[0], ws.v[1], ws.v[2]};
+    double aP[6] = {0.0, 0.0, 0.0, 0.0, 0.0, dm.gravity};
+    const double* ax[3] = {wz, wy, wx};
+    const double* vpar = vP;
+    const double* apar = aP;
+    for (int e = 0; e < 3; ++e) {
+      for (int k = 0; k < 3; ++k) { ws.S[e][k] = ax[e][k]; ws.S[e][3 + k] = 0.0; }
+      joint_motion(vpar, apar, ws.S[e], ws.v[3 + e], 0.0, ws.vl[e], ws.al[e], ws.Sd[e], ws.Sdd[e]);
+      vpar = ws.vl[e];
+      apar = ws.al[e];
+    }
+  }
+  WG_SYNC(ctx);
+  // ---- forward kinematics, one phase per tree level
+  for (int l = 1; l < NLEVELS; ++l) {
+    const int b0 = dm.level_start[l], b1 = dm.level_start[l + 1];
+    WG_FOR(ctx, it, b1 - b0) {
+      const int i = dm.level_bodies[b0 + it];
+      const int pb = dm.parent[i], jc = i + 2, pjc = pb + 2;
+      double Rj[9], Rq[9], rr[3], w[3];
+      m3_mul(ws.R[pb], dm.Rfix[i], Rj);
+      rot_axis(dm.axis[i], ws.q[5 + i], Rq);
+      m3_mul(Rj, Rq, ws.R[i]);
+      m3_mulv(ws.R[pb], dm.pfix[i], rr);
+      for (int k = 0; k < 3; ++k) ws.r[i][k] = ws.r[pb][k] + rr[k];
+      m3_mulv(Rj, dm.axis[i], w);
+      double* Sx = ws.S[jc];
+      Sx[0] = w[0]; Sx[1] = w[1]; Sx[2] = w[2];
+      v3_cross(ws.r[i], w, Sx + 3);
+      joint_motion(ws.vl[pjc], ws.al[pjc], Sx, ws.v[5 + i], ws.qddj[i - 1], ws.vl[jc], ws.al[jc], ws.Sd[jc], ws.Sdd[jc]);
+    }
+    WG_SYNC(ctx);
+  }
+  // ---- per-body spatial inertia about O and net force
+  WG_FOR(ctx, i, NB) {
+    const double* Rb = ws.R[i];
+    double c[3], t[9], Iw[9];
+    m3_mulv(Rb, dm.com[i], c);
+    for (int k = 0; k < 3; ++k) c[k] += ws.r[i][k];
+    m3_mul(Rb, dm.inertia[i], t);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) Iw[3 * a + b] = t[3 * a] * Rb[3 * b] + t[3 * a + 1] * Rb[3 * b + 1] + t[3 * a + 2] * Rb[3 * b + 2];
+    const double m = dm.mass[i], cc = v3_dot(c, c);
+    double* In = ws.In[i];
+    In[0] = m; In[1] = m * c[0]; In[2] = m * c[1]; In[3] = m * c[2];
+    In[4] = Iw[0] + m * (cc - c[0] * c[0]); In[5] = Iw[1] - m * c[0] * c[1]; In[6] = Iw[2] - m * c[0] * c[2];
+    In[7] = Iw[4] + m * (cc - c[1] * c[1]); In[8] = Iw[5] - m * c[1] * c[2]; In[9] = Iw[8] + m * (cc - c[2] * c[2]);
+    const int jc = i + 2;
+    double h[6], fa[6], fv[6];
+    inertia_apply(In, ws.vl[jc], h);
+    inertia_apply(In, ws.al[jc], fa);
+    mxf(ws.vl[jc], h, fv);
+    for (int k = 0; k < 6; ++k) ws.f[i][k] = fa[k] + fv[k];
+  }
+  WG_SYNC(ctx);
+  if (DERIV) {
+    WG_FOR(ctx, it, NB * 6) {
+      const int i = it / 6, k = it % 6;
+      double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, col[6];
+      m[k] = 1.0;
+      bb_apply(ws.In[i], ws.vl[i + 2], m, col);
+      for (int r = 0; r < 6; ++r) ws.BB[i][6 * r + k] = col[r];
+    }
+    WG_SYNC(ctx);
+    // composites over subtrees (bodies are in depth-first order)
+    WG_FOR(ctx, it, NB * 52) {
+      const int i = it / 52, e = it % 52;
+      const int end = i + dm.subtree_size[i];
+      double s = 0.0;
+      if (e < 10) { for (int d = i; d < end; ++d) s += ws.In[d][e]; ws.Ic[i][e] = s; }
+      else if (e < 16) { for (int d = i; d < end; ++d) s += ws.f[d][e - 10]; ws.fc[i][e - 10] = s; }
+      else { for (int d = i; d < end; ++d) s += ws.BB[d][e - 16]; ws.BBc[i][e - 16] = s; }
+    }
+  } else {
+    WG_FOR(ctx, e, 16) {
+      double s = 0.0;
+      if (e < 10) { for (int d = 0; d < NB; ++d) s += ws.In[d][e]; ws.Ic[0][e] = s; }
+      else { for (int d = 0; d < NB; ++d) s += ws.f[d][e - 10]; ws.fc[0][e - 10] = s; }
+    }
+  }
+  WG_SYNC(ctx);
+  // ---- totals and the block-diagonal base solve
+  WG_FOR(ctx, it, 1) {
+    double Fext[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int f = 0; f < 2; ++f) {
+      const int b = dm.contact_body[f];
+      double rr[3], mom[3];
+      m3_mulv(ws.R[b], dm.contact_p[f], rr);
+      for (int k = 0; k < 3; ++k) { rr[k] += ws.r[b][k]; ws.rP[f][k] = rr[k]; }
+      v3_cross(rr, ws.W + 6 * f, mom);
+      for (int k = 0; k < 3; ++k) { Fext[k] += ws.W[6 * f + 3 + k] + mom[k]; Fext[3 + k] += ws.W[6 * f + k]; }
+    }
+    for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ws.fc[0][k];
+    const double* I6 = ws.Ic[0] + 4;
+    const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
+    m3_inverse(Ib, ws.Iinv);
+    m3_mulv(ws.Iinv, ws.Ftil, ws.y);
+    const double minv = 1.0 / ws.Ic[0][0];
+    for (int k = 0; k < 3; ++k) ws.ab[k] = ws.Ftil[3 + k] * minv;
+    m3_mulv(ws.Einv, ws.y, ws.ab + 3);
+  }
+  WG_SYNC(ctx);
+  if (!DERIV) return;
+  // ---- Jacobian columns: items (jc, kind in {q, qd, qdd}) and the 12 wrench components
+  WG_FOR(ctx, it, NJC * 3 + 12) {
+    double rhs[3], lin[3];
+    int col;
+    if (it < NJC * 3) {
+      const int jc = it / 3, kind = it % 3;
+      const int bi = jc < 3 ? 0 : jc - 2;
+      const double* Sx = ws.S[jc];
+      const double* Ic = ws.Ic[bi];
+      double dF[6];
+      if (kind == 0) {
+        col = 3 + jc;
+        double t1[6], t2[6], t3[6];
+        mxf(Sx, ws.fc[bi], t1);
+        mat6_mulv(ws.BBc[bi], ws.Sd[jc], t2);
+        inertia_apply(Ic, ws.Sdd[jc], t3);
+        for (int k = 0; k < 6; ++k) dF[k] = t1[k] + t2[k] + t3[k];
+        // (dI_tot/dq_c) y6 = S x* (I^c y6) - I^c (S x y6),  y6 = {y, 0}
+        const double y6[6] = {ws.y[0], ws.y[1], ws.y[2], 0.0, 0.0, 0.0};
+        double iy[6], a1[6], sy[6], a2[6];
+        inertia_apply(Ic, y6, iy);
+        mxf(Sx, iy, a1);
+        mxm(Sx, y6, sy);
+        inertia_apply(Ic, sy, a2);
+        double extra[3] = {a1[0] - a2[0], a1[1] - a2[1], a1[2] - a2[2]};
+        if (jc < 2) {  // d(S_E)/dq_c a_ang = {w_c x sum_{e>c} w_e a_e, 0}
+          double z[3] = {0.0, 0.0, 0.0}, wz[3], t[3];
+          for (int e = jc + 1; e < 3; ++e)
+            for (int k = 0; k < 3; ++k) z[k] += ws.E[3 * k + e] * ws.ab[3 + e];
+          v3_cross(Sx, z, wz);
+          sym3_mulv(ws.Ic[0] + 4, wz, t);
+          for (int k = 0; k < 3; ++k) extra[k] += t[k];
+        }
+        double dext[3] = {0.0, 0.0, 0.0};
+        for (int f = 0; f < 2; ++f) {
+          const int cb = dm.contact_body[f];
+          if (jc < 3 || (cb >= bi && cb < bi + dm.subtree_size[bi])) {
+            double d[3], dr[3], t[3];
+            for (int k = 0; k < 3; ++k) d[k] = ws.rP[f][k] - (jc < 3 ? 0.0 : ws.r[bi][k]);
+            v3_cross(Sx, d, dr);
+            v3_cross(dr, ws.W + 6 * f, t);
+            for (int k = 0; k < 3; ++k) dext[k] += t[k];
+          }
+        }
+        for (int k = 0; k < 3; ++k) rhs[k] = dext[k] - dF[k] - extra[k];
+      } else if (kind == 1) {
+        col = NV + 3 + jc;
+        double t1[6], t2[6];
+        inertia_apply(Ic, ws.Sd[jc], t1);
+        mat6_mulv(ws.BBc[bi], Sx, t2);
+        for (int k = 0; k < 6; ++k) dF[k] = 2.0 * t1[k] + t2[k];
+        for (int k = 0; k < 3; ++k) rhs[k] = -dF[k];
+      } else {
+        if (jc < 3) continue;
+        col = NX + 12 + (jc - 3);
+        inertia_apply(Ic, Sx, dF);
+        for (int k = 0; k < 3; ++k) rhs[k] = -dF[k];
+      }
+      const double minv = 1.0 / ws.Ic[0][0];
+      for (int k = 0; k < 3; ++k) lin[k] = -dF[3 + k] * minv;
+    } else {
+      const int wi = it - NJC * 3, f = wi / 6, k6 = wi % 6;
+      col = NX + wi;
+      double e[3] = {0.0, 0.0, 0.0};
+      e[k6 % 3] = 1.0;
+      if (k6 < 3) {
+        v3_cross(ws.rP[f], e, rhs);
+        const double minv = 1.0 / ws.Ic[0][0];
+        for (int k = 0; k < 3; ++k) lin[k] = e[k] * minv;
+      } else {
+        for (int k = 0; k < 3; ++k) { rhs[k] = e[k]; lin[k] = 0.0; }
+      }
+    }
+    double t[3], ang[3];
+    m3_mulv(ws.Iinv, rhs, t);
+    m3_mulv(ws.Einv, t, ang);
+    for (int k = 0; k < 3; ++k) { ws.G[k][col] = lin[k]; ws.G[3 + k][col] = ang[k]; }
+  }
+  // columns with identically zero derivative: base position (0..2) and base linear velocity (29..31)
+  WG_FOR(ctx, it, 36) {
+    const int r = it / 6, c = it % 6;
+    ws.G[r][c < 3 ? c : NV + (c - 3)] = 0.0;
+  }
+  WG_SYNC(ctx);
+}
+
+}  // namespace hsqp

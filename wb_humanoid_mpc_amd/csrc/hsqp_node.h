@@ -1,0 +1,434 @@
+// Stage cost / soft-constraint quadratic model and equality-constraint linearisation of one
+// shooting node, evaluated from the stage-1 model workspace (hsqp_model.h).
+//
+// Terms and their order follow WBMpcInterface::setupOptimalControlProblem
+// (humanoid_nmpc/humanoid_wb_mpc/src/WBMpcInterface.cpp:131-199); each block cites its source.
+// The cost model is emitted in "diagonal + residual rows" form
+//       H = diag(d) + J^T J ,     g = gd + J^T rho ,
+// which is exact for every term of this problem: Gauss-Newton costs (J = sqrt(w) dr/dz), penalties on
+// linear-order constraints (J = sqrt(p'') dh/dz, rho = p'/sqrt(p'')) and the friction cone's
+// second-order term p' d2h (p' < 0, d2h negative semidefinite => three more rows).
+// Row slots (NR = 64): [15 f + k] foot f task-space rows k = ori(3) vlin(3) vang(3) alin(3) aang(3);
+// [30 + 4 f + k] friction cone; [38 + 4 f + k] contact moment XY; [46 + k] foot collision (16); 62,63 unused.
+#pragma once
+#include "hsqp_model.h"
+
+namespace hsqp {
+
+constexpr int NRS = 64;          // residual row slots
+constexpr int ROW_FOOT = 0, ROW_FRIC = 30, ROW_MXY = 38, ROW_COLL = 46;
+constexpr int LDJ = 96;          // leading dimension of J rows / CDe rows in memory (cols 0..92 used; CDe col 93 = e)
+
+struct NodeWS {
+  double x[NX], u[NU], par[NP];
+  double xnom[NX], unom[NU];
+  int contact[2];
+  int eq_off[2];                 // first equality row of each foot
+  int ne;
+  // values
+  double fkv[2][18];             // pos, ori, vlin, vang, alin, aang per foot
+  double Rf[2][9];               // contact frame rotation
+  double pts[10][3];             // collision points rel. to O (order of DevModel::coll_body)
+  double hfric[2], hmxy[2][4], hcoll[16];
+  double scale[NRS];             // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive
+  double rho[NRS];
+  double d[LDJ], gd[LDJ];
+  double CDe[NE_MAX][LDJ];
+  double eqv[NE_MAX];
+  double cost;
+};
+
+// orientation error wrt the ground plane (oracle ASSUMPTION A2): e = (n x a)/sqrt(2(1+a.n)), a = R e_z, n = e_z
+HSQP_HD void ori_error(const double* R, double* e) {
+  const double a[3] = {R[2], R[5], R[8]};
+  const double s = sqrt(2.0 * (1.0 + a[2]));
+  e[0] = -a[1] / s; e[1] = a[0] / s; e[2] = 0.0;
+}
+HSQP_HD void ori_error_d(const double* R, const double* da, double* de) {  // differential for a -> a + da
+  const double a[3] = {R[2], R[5], R[8]};
+  const double s = sqrt(2.0 * (1.0 + a[2]));
+  const double ds = da[2] / s;
+  de[0] = -da[1] / s + a[1] * ds / (s * s);
+  de[1] = da[0] / s - a[0] * ds / (s * s);
+  de[2] = 0.0;
+}
+
+// does revolute coordinate jc move body b?
+HSQP_HD bool supports(const DevModel& dm, int jc, int b) {
+  if (jc < 3) return true;
+  const int bi = jc - 2;
+  return b >= bi && b < bi + dm.subtree_size[bi];
+}
+
+// Values of everything that does not need derivatives.  Requires stage_eval() results in ws for (x,u).
+HSQP_HD void node_values(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw) {
+  // ---- nominal state / input, contact flags, equality row layout (one item)
+  WG_FOR(ctx, it, 1) {
+    // StateInputQuadraticCost::getStateInputDeviation (humanoid_common_mpc/src/cost/StateInputQuadraticCost.cpp:67-78)
+    for (int i = 0; i < NX; ++i) nw.xnom[i] = nw.par[HSQP_P_XDES + i];
+    const double yaw = nw.x[3];
+    const double vloc = cos(yaw) * nw.xnom[NV] + sin(yaw) * nw.xnom[NV + 1];
+    const double gcf = nw.par[HSQP_P_ARMSWING] * vloc;  // SwitchedModelReferenceManager.cpp:110-135
+    nw.xnom[6 + dm.arm_swing_joint[0]] += -0.15 * gcf;
+    nw.xnom[6 + dm.arm_swing_joint[1]] += 0.15 * gcf;
+    nw.xnom[6 + dm.arm_swing_joint[2]] += -0.15 * gcf;
+    nw.xnom[6 + dm.arm_swing_joint[3]] += 0.15 * gcf;
+    const int c0 = nw.par[HSQP_P_CONTACT] > 0.5, c1 = nw.par[HSQP_P_CONTACT + 1] > 0.5;
+    nw.contact[0] = c0; nw.contact[1] = c1;
+    for (int i = 0; i < NU; ++i) nw.unom[i] = 0.0;
+    if (c0 + c1 > 0) {  // weightCompensatingInput (DynamicsHelperFunctions.h:178-193), 9.81 hard-coded there
+      const double fz = dm.total_mass * 9.81 / (c0 + c1);
+      if (c0) nw.unom[2] = fz;
+      if (c1) nw.unom[8] = fz;
+    }
+    nw.eq_off[0] = 0;
+    nw.eq_off[1] = c0 ? 6 : 7;
+    nw.ne = nw.eq_off[1] + (c1 ? 6 : 7);
+  }
+  // ---- foot frames: value quantities
+  WG_FOR(ctx, f, 2) {
+    const int b = dm.contact_body[f], jc = b + 2;
+    const double* rP = ws.rP[f];
+    const double* vl = ws.vl[jc];
+    // full spatial acceleration of the body: trick acceleration (vd_base = 0) + {E a_ang, a_lin} - gravity
+    double a[6];
+    for (int k = 0; k < 3; ++k) { a[k] = ws.al[jc][k] + ws.y[k]; a[3 + k] = ws.al[jc][3 + k] + ws.ab[k]; }
+    a[5] -= dm.gravity;
+    double* o = nw.fkv[f];
+    for (int k = 0; k < 3; ++k) o[k] = nw.x[k] + rP[k];
+    ori_error(ws.R[b], o + 3);
+    double t[3], t2[3];
+    v3_cross(vl, rP, t);
+    for (int k = 0; k < 3; ++k) { o[6 + k] = vl[3 + k] + t[k]; o[9 + k] = vl[k]; }
+    v3_cross(a, rP, t);
+    v3_cross(vl, o + 6, t2);
+    for (int k = 0; k < 3; ++k) { o[12 + k] = a[3 + k] + t[k] + t2[k]; o[15 + k] = a[k]; }
+    for (int k = 0; k < 9; ++k) nw.Rf[f][k] = ws.R[b][k];
+  }
+  // ---- collision points
+  WG_FOR(ctx, p, 10) {
+    const int b = dm.coll_body[p];
+    double t[3];
+    m3_mulv(ws.R[b], dm.coll_p[p], t);
+    for (int k = 0; k < 3; ++k) nw.pts[p][k] = ws.r[b][k] + t[k];
+  }
+  WG_SYNC(ctx);
+}
+
+// pairs of collision points per constraint row (FootCollisionConstraint.cpp:118-141); point ids follow DevModel::coll_body:
+// 0 ankle_l, 1 ankle_r, 2 f_l, 3 f_r, 4 l1, 5 r1, 6 l2, 7 r2, 8 k_l, 9 k_r
+HSQP_HD void coll_pair(int row, int& a, int& b) {
+  const int A[16] = {4, 4, 6, 6, 2, 2, 3, 3, 2, 8, 2, 4, 6, 3, 5, 7};
+  const int B[16] = {5, 7, 5, 7, 5, 7, 4, 6, 3, 9, 1, 1, 1, 0, 0, 0};
+  a = A[row]; b = B[row];
+}
+
+// Constraint values, penalties, row scalings, equality values, cost.  After node_values().
+HSQP_HD void node_scalars(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw) {
+  WG_FOR(ctx, it, 2 + 8 + 16) {
+    if (it < 2) {  // friction cone value (FrictionForceConeConstraint.cpp:180-185)
+      const int f = it;
+      const double Fx = nw.u[6 * f], Fy = nw.u[6 * f + 1], Fz = nw.u[6 * f + 2];
+      nw.hfric[f] = dm.friction_mu * (Fz + dm.friction_grip) - sqrt(Fx * Fx + Fy * Fy + dm.friction_reg);
+    } else if (it < 10) {  // contact moment XY (ContactMomentXYConstraintCppAd.cpp:87-104)
+      const int f = (it - 2) / 4, r = (it - 2) % 4;
+      double lf[3], lm[3];
+      m3_tmulv(nw.Rf[f], nw.u + 6 * f, lf);
+      m3_tmulv(nw.Rf[f], nw.u + 6 * f + 3, lm);
+      double h;
+      if (r == 0) h = lm[0] - dm.rect_y_min * lf[2];
+      else if (r == 1) h = -lm[0] + dm.rect_y_max * lf[2];
+      else if (r == 2) h = -lm[1] - dm.rect_x_min * lf[2];
+      else h = lm[1] + dm.rect_x_max * lf[2];
+      nw.hmxy[f][r] = h;
+    } else {
+      const int r = it - 10;
+      int a, b;
+      coll_pair(r, a, b);
+      double dd[3];
+      for (int k = 0; k < 3; ++k) dd[k] = nw.pts[a][k] - nw.pts[b][k];
+      nw.hcoll[r] = sqrt(v3_dot(dd, dd)) - 2.0 * (r == 9 ? dm.r_knee : dm.r_foot);
+    }
+  }
+  WG_SYNC(ctx);
+  // ---- row scalings, rho, equality values
+  WG_FOR(ctx, s, NRS + NE_MAX) {
+    if (s < NRS) {
+      double sc = 0.0, rho = 0.0;
+      if (s < ROW_FRIC) {  // EndEffectorDynamicsFootCost.cpp:91-124: r = err .* sqrtW * impactProximity
+        const int f = s / 15, k = s % 15;
+        sc = dm.foot_sqrt_w[3 + k] * nw.par[HSQP_P_IMPACT + f];
+        rho = sc * nw.fkv[f][3 + k];
+      } else if (s < ROW_MXY) {
+        const int f = (s - ROW_FRIC) / 4, k = (s - ROW_FRIC) % 4;
+        if (nw.contact[f]) {
+          const Pen3 p = relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, nw.hfric[f]);
+          const double Fx = nw.u[6 * f], Fy = nw.u[6 * f + 1];
+          const double T2 = Fx * Fx + Fy * Fy + dm.friction_reg, T3 = T2 * sqrt(T2);
+          if (k == 0) { sc = sqrt(p.d2); rho = p.d1 / sc; }
+          else if (k == 3) sc = sqrt(-p.d1 / T3);
+          else sc = sqrt(-p.d1 * dm.friction_reg / T3);
+        }
+      } else if (s < ROW_COLL) {
+        const int f = (s - ROW_MXY) / 4, k = (s - ROW_MXY) % 4;
+        if (nw.contact[f]) {
+          const Pen3 p = relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, nw.hmxy[f][k]);
+          sc = sqrt(p.d2); rho = p.d1 / sc;
+        }
+      } else if (s < ROW_COLL + 16) {
+        if (!(nw.contact[0] && nw.contact[1])) {
+          const Pen3 p = pwp_barrier(dm.coll_bmu, dm.coll_bdelta, nw.hcoll[s - ROW_COLL]);
+          if (p.d2 > 0.0) { sc = sqrt(p.d2); rho = p.d1 / sc; }
+        }
+      }
+      nw.scale[s] = sc;
+      nw.rho[s] = rho;
+    } else {
+      const int r = s - NRS;
+      if (r < nw.ne) {
+        const int f = r >= nw.eq_off[1] ? 1 : 0, k = r - nw.eq_off[f];
+        const double* o = nw.fkv[f];
+        double e;
+        if (nw.contact[f]) {  // EndEffectorDynamicsAccelerationsConstraint.cpp:82-103, gains WBMpcInterface.cpp:205-229
+          const int c = k % 3;
+          const double gp = k < 2 ? 0.0 : (k == 2 ? dm.gain_pos_z : dm.gain_ori);
+          const double gv = k < 2 ? dm.gain_linvel_xy : (k == 2 ? dm.gain_linvel_z : dm.gain_angvel);
+          const double ga = k < 2 ? dm.gain_linacc_xy : (k == 2 ? dm.gain_linacc_z : dm.gain_angacc);
+          e = k < 3 ? gp * o[c] + gv * o[6 + c] + ga * o[12 + c] : gp * o[3 + c] + gv * o[9 + c] + ga * o[15 + c];
+        } else if (k < 6) {   // ZeroWrenchConstraint.cpp:59-84
+          e = nw.u[6 * f + k];
+        } else {              // EndEffectorDynamicsLinearAccConstraint.cpp:69-83, config WBMpcPreComputation.cpp:91-104
+          const double* sw = nw.par + HSQP_P_SWING + 3 * f;
+          e = -dm.gain_linvel_z * sw[1] - dm.gain_linacc_z * sw[2] - dm.gain_pos_z * sw[0] + dm.gain_pos_z * o[2] +
+              dm.gain_linvel_z * o[8] + dm.gain_linacc_z * o[14];
+        }
+        nw.eqv[r] = e;
+      }
+    }
+  }
+  WG_SYNC(ctx);
+  // ---- stage cost value (one item; ~250 terms)
+  WG_FOR(ctx, it, 1) {
+    double c = 0.0;
+    for (int i = 0; i < NX; ++i) { const double dxx = nw.x[i] - nw.xnom[i]; c += 0.5 * dm.Q[i] * dxx * dxx; }
+    for (int i = 0; i < NU; ++i) { const double duu = nw.u[i] - nw.unom[i]; c += 0.5 * dm.R[i] * duu * duu; }
+    for (int s = 0; s < ROW_FRIC; ++s) c += 0.5 * nw.rho[s] * nw.rho[s];
+    for (int f = 0; f < 2; ++f) {
+      if (!nw.contact[f]) continue;
+      c += relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, nw.hfric[f]).p;
+      for (int k = 0; k < 4; ++k) c += relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, nw.hmxy[f][k]).p;
+    }
+    for (int j = 0; j < NJ; ++j) {  // JointLimitsSoftConstraint.cpp:64-100
+      c += pwp_barrier(dm.jl_bmu, dm.jl_bdelta, nw.x[6 + j] - dm.q_lo[j]).p + pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - nw.x[6 + j]).p;
+    }
+    if (!(nw.contact[0] && nw.contact[1]))
+      for (int k = 0; k < 16; ++k) c += pwp_barrier(dm.coll_bmu, dm.coll_bdelta, nw.hcoll[k]).p;
+    nw.cost = c;
+  }
+  WG_SYNC(ctx);
+}
+
+// partial derivatives of one foot frame's kinematic quantities w.r.t. ONE column of z = [x;u]
+// out[18] = d{pos, ori, vlin, vang, alin, aang}/dz_col
+HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw, int f, int col, double* out) {
+  const int b = dm.contact_body[f], jb = b + 2;
+  const double* rP = ws.rP[f];
+  const double* vi = ws.vl[jb];
+  const double* o = nw.fkv[f];
+  double dv[6] = {0, 0, 0, 0, 0, 0}, da[6] = {0, 0, 0, 0, 0, 0}, drP[3] = {0, 0, 0}, dpos_extra[3] = {0, 0, 0};
+  bool rot = false;  // whether the foot frame rotates with this column (orientation partial)
+  double wax[3] = {0, 0, 0};
+  if (col < 3) {
+    dpos_extra[col] = 1.0;
+  } else if (col < NV) {
+    const int jc = col - 3;
+    if (supports(dm, jc, b)) {
+      const double* Sx = ws.S[jc];
+      double dvv[6], daa[6], t[6], pc[3];
+      for (int k = 0; k < 6; ++k) dvv[k] = vi[k] - ws.vl[jc][k];
+      for (int k = 0; k < 6; ++k) daa[k] = ws.al[jb][k] - ws.al[jc][k];
+      if (jc < 2)  // euler links z, y do not carry the later euler accelerations: add {sum_{e>jc} w_e a_e, 0}
+        for (int e = jc + 1; e < 3; ++e)
+          for (int k = 0; k < 3; ++k) daa[k] += ws.E[3 * k + e] * ws.ab[3 + e];
+      mxm(Sx, dvv, dv);
+      mxm(Sx, daa, da);
+      mxm(ws.Sd[jc], dvv, t);
+      for (int k = 0; k < 6; ++k) da[k] += t[k];
+      for (int k = 0; k < 3; ++k) pc[k] = rP[k] - (jc < 3 ? 0.0 : ws.r[jc - 2][k]);
+      v3_cross(Sx, pc, drP);
+      rot = true;
+      for (int k = 0; k < 3; ++k) wax[k] = Sx[k];
+    }
+  } else if (col < NX) {
+    const int c = col - NV;
+    if (c < 3) {
+      dv[3 + c] = 1.0;  // prismatic S = {0, e}; classical acceleration does not depend on it
+      // spatial-acceleration partial -v_i x S cancels in the classical acceleration; keep da consistent:
+      double Sx[6] = {0, 0, 0, 0, 0, 0}, t[6];
+      Sx[3 + c] = 1.0;
+      mxm(vi, Sx, t);
+      for (int k = 0; k < 6; ++k) da[k] = -t[k];
+    } else {
+      const int jc = c - 3;
+      if (supports(dm, jc, b)) {
+        const double* Sx = ws.S[jc];
+        double t[6];
+        for (int k = 0; k < 6; ++k) dv[k] = Sx[k];
+        mxm(vi, Sx, t);
+        for (int k = 0; k < 6; ++k) da[k] = 2.0 * ws.Sd[jc][k] - t[k];
+      }
+    }
+  } else if (col >= NX + 12) {
+    const int jc = 3 + (col - NX - 12);
+    if (supports(dm, jc, b))
+      for (int k = 0; k < 6; ++k) da[k] = ws.S[jc][k];
+  }
+  // chain through the base acceleration a_b(z): d alpha += E G[3:6], d aO += G[0:3]  (S_e pass through O)
+  {
+    double gy[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+      for (int e = 0; e < 3; ++e) gy[k] += ws.E[3 * k + e] * ws.G[3 + e][col];
+    for (int k = 0; k < 3; ++k) { da[k] += gy[k]; da[3 + k] += ws.G[k][col]; }
+  }
+  // frame level
+  const double* om = vi;           // omega_i
+  const double* al = o + 15;       // full angular acceleration
+  const double* vP = o + 6;
+  double t1[3], t2[3], t3[3], t4[3], dvP[3];
+  for (int k = 0; k < 3; ++k) out[k] = drP[k] + dpos_extra[k];
+  if (rot) {
+    const double a[3] = {nw.Rf[f][2], nw.Rf[f][5], nw.Rf[f][8]};
+    double dvec[3];
+    v3_cross(wax, a, dvec);
+    ori_error_d(nw.Rf[f], dvec, out + 3);
+  } else {
+    out[3] = out[4] = out[5] = 0.0;
+  }
+  v3_cross(dv, rP, t1);
+  v3_cross(om, drP, t2);
+  for (int k = 0; k < 3; ++k) { dvP[k] = dv[3 + k] + t1[k] + t2[k]; out[6 + k] = dvP[k]; out[9 + k] = dv[k]; }
+  v3_cross(da, rP, t1);
+  v3_cross(al, drP, t2);
+  v3_cross(dv, vP, t3);
+  v3_cross(om, dvP, t4);
+  for (int k = 0; k < 3; ++k) { out[12 + k] = da[3 + k] + t1[k] + t2[k] + t3[k] + t4[k]; out[15 + k] = da[k]; }
+}
+
+// derivative of a body-fixed point position w.r.t. generalized coordinate c (0..28); returns false if zero
+HSQP_HD bool point_column(const DevModel& dm, const StageWS& ws, int body, const double* rpt, int c, double* d) {
+  if (c < 3) { d[0] = d[1] = d[2] = 0.0; d[c] = 1.0; return true; }
+  const int jc = c - 3;
+  if (!supports(dm, jc, body)) return false;
+  double pc[3];
+  for (int k = 0; k < 3; ++k) pc[k] = rpt[k] - (jc < 3 ? 0.0 : ws.r[jc - 2][k]);
+  v3_cross(ws.S[jc], pc, d);
+  return true;
+}
+
+// First-order data: residual rows J (written to Jout[NRS][LDJ], scaled by sqrt(dt)), d, gd (x dt), CDe.
+// After node_values() and node_scalars(); ws.G must hold the stage-1 Jacobian.
+HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw, double dt, double* Jout) {
+  const double sdt = sqrt(dt);
+  // ---- foot columns: task-space cost rows + stance / swing equality rows
+  WG_FOR(ctx, it, 2 * LDJ) {
+    const int f = it / LDJ, col = it % LDJ;
+    if (col >= NZ) {
+      for (int k = 0; k < 15; ++k) Jout[(ROW_FOOT + 15 * f + k) * LDJ + col] = 0.0;
+      continue;
+    }
+    double dq[18];
+    foot_column(dm, ws, nw, f, col, dq);
+    for (int k = 0; k < 15; ++k) Jout[(ROW_FOOT + 15 * f + k) * LDJ + col] = sdt * nw.scale[ROW_FOOT + 15 * f + k] * dq[3 + k];
+    const int r0 = nw.eq_off[f];
+    if (nw.contact[f]) {
+      for (int k = 0; k < 6; ++k) {
+        const int c = k % 3;
+        const double gp = k < 2 ? 0.0 : (k == 2 ? dm.gain_pos_z : dm.gain_ori);
+        const double gv = k < 2 ? dm.gain_linvel_xy : (k == 2 ? dm.gain_linvel_z : dm.gain_angvel);
+        const double ga = k < 2 ? dm.gain_linacc_xy : (k == 2 ? dm.gain_linacc_z : dm.gain_angacc);
+        nw.CDe[r0 + k][col] = k < 3 ? gp * dq[c] + gv * dq[6 + c] + ga * dq[12 + c] : gp * dq[3 + c] + gv * dq[9 + c] + ga * dq[15 + c];
+      }
+    } else {
+      for (int k = 0; k < 6; ++k) nw.CDe[r0 + k][col] = (col == NX + 6 * f + k) ? 1.0 : 0.0;
+      nw.CDe[r0 + 6][col] = dm.gain_pos_z * dq[2] + dm.gain_linvel_z * dq[8] + dm.gain_linacc_z * dq[14];
+    }
+  }
+  // ---- friction, moment XY and collision rows, one item per (row slot, column)
+  WG_FOR(ctx, it, (NRS - ROW_FRIC) * LDJ) {
+    const int s = ROW_FRIC + it / LDJ, col = it % LDJ;
+    const double sc = nw.scale[s];
+    double val = 0.0;
+    if (sc != 0.0 && col < NZ) {
+      if (s < ROW_MXY) {  // FrictionForceConeConstraint.cpp:153-178 (first and second derivative of the cone)
+        const int f = (s - ROW_FRIC) / 4, k = (s - ROW_FRIC) % 4, c = col - (NX + 6 * f);
+        if (c >= 0 && c < 3) {
+          const double Fx = nw.u[6 * f], Fy = nw.u[6 * f + 1];
+          if (k == 0) { const double Tn = sqrt(Fx * Fx + Fy * Fy + dm.friction_reg); val = c == 0 ? -Fx / Tn : (c == 1 ? -Fy / Tn : dm.friction_mu); }
+          else if (k == 1) val = c == 0 ? 1.0 : 0.0;
+          else if (k == 2) val = c == 1 ? 1.0 : 0.0;
+          else val = c == 0 ? Fy : (c == 1 ? -Fx : 0.0);
+        }
+      } else if (s < ROW_COLL) {  // d/dz of (R^T m)_x,y and (R^T f)_z
+        const int f = (s - ROW_MXY) / 4, k = (s - ROW_MXY) % 4;
+        const double* Rf = nw.Rf[f];
+        double dlf[3] = {0, 0, 0}, dlm[3] = {0, 0, 0};
+        const int cu = col - (NX + 6 * f);
+        if (col >= 3 && col < NV) {
+          const int jc = col - 3;
+          if (supports(dm, jc, dm.contact_body[f])) {
+            double t[3];
+            v3_cross(nw.u + 6 * f, ws.S[jc], t);
+            m3_tmulv(Rf, t, dlf);
+            v3_cross(nw.u + 6 * f + 3, ws.S[jc], t);
+            m3_tmulv(Rf, t, dlm);
+          }
+        } else if (cu >= 0 && cu < 3) {
+          for (int r = 0; r < 3; ++r) dlf[r] = Rf[3 * cu + r];
+        } else if (cu >= 3 && cu < 6) {
+          for (int r = 0; r < 3; ++r) dlm[r] = Rf[3 * (cu - 3) + r];
+        }
+        if (k == 0) val = dlm[0] - dm.rect_y_min * dlf[2];
+        else if (k == 1) val = -dlm[0] + dm.rect_y_max * dlf[2];
+        else if (k == 2) val = -dlm[1] - dm.rect_x_min * dlf[2];
+        else val = dlm[1] + dm.rect_x_max * dlf[2];
+      } else if (s < ROW_COLL + 16 && col < NV) {
+        int a, b;
+        coll_pair(s - ROW_COLL, a, b);
+        double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd[3];
+        point_column(dm, ws, dm.coll_body[a], nw.pts[a], col, da);
+        point_column(dm, ws, dm.coll_body[b], nw.pts[b], col, db);
+        for (int k = 0; k < 3; ++k) dd[k] = nw.pts[a][k] - nw.pts[b][k];
+        const double n = sqrt(v3_dot(dd, dd));
+        val = (dd[0] * (da[0] - db[0]) + dd[1] * (da[1] - db[1]) + dd[2] * (da[2] - db[2])) / n;
+      }
+      val *= sc * sdt;
+    }
+    Jout[s * LDJ + col] = val;
+  }
+  // ---- diagonal part
+  WG_FOR(ctx, i, LDJ) {
+    double d = 0.0, g = 0.0;
+    if (i < NX) { d = dm.Q[i]; g = dm.Q[i] * (nw.x[i] - nw.xnom[i]); }
+    else if (i < NZ) { d = dm.R[i - NX]; g = dm.R[i - NX] * (nw.u[i - NX] - nw.unom[i - NX]); }
+    if (i >= 6 && i < NV) {
+      const int j = i - 6;
+      const Pen3 lo = pwp_barrier(dm.jl_bmu, dm.jl_bdelta, nw.x[i] - dm.q_lo[j]);
+      const Pen3 hi = pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - nw.x[i]);
+      d += lo.d2 + hi.d2;
+      g += lo.d1 - hi.d1;
+    }
+    if (i < NZ)
+      for (int f = 0; f < 2; ++f)  // friction cone: hessianDiagonalShift on every state and input (FrictionForceConeConstraint.cpp:213-224)
+        if (nw.contact[f]) d += -relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, nw.hfric[f]).d1 * dm.friction_hess_shift;
+    nw.d[i] = dt * d;
+    nw.gd[i] = dt * g;
+  }
+  WG_FOR(ctx, r, NE_MAX) {
+    if (r < nw.ne) nw.CDe[r][NZ] = nw.eqv[r];
+    for (int c = NZ + (r < nw.ne ? 1 : 0); c < LDJ; ++c) nw.CDe[r][c] = 0.0;
+    if (r >= nw.ne) for (int c = 0; c < NZ + 1; ++c) nw.CDe[r][c] = 0.0;
+  }
+  WG_SYNC(ctx);
+}
+
+}  // namespace hsqp
