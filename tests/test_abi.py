@@ -1,0 +1,61 @@
+"""The C-ABI library: every symbol of include/hsqp.h is exported, struct layouts agree, and the product
+path refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from wb_humanoid_mpc_amd import _abi, solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "hsqp.h")).read()
+    return sorted(set(re.findall(r"\b(hsqp_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert _header_functions() == sorted([
+        "hsqp_create", "hsqp_destroy", "hsqp_solve", "hsqp_upload", "hsqp_iterate_device", "hsqp_download",
+        "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_version", "hsqp_device_count"])
+
+
+def test_library_exports_every_declared_symbol():
+    lib = solver.load_library()
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.hsqp_version()
+
+
+def test_struct_sizes_match_the_c_compiler(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "hsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(hsqp_body),sizeof(hsqp_frame),sizeof(hsqp_model_desc),sizeof(hsqp_settings),sizeof(hsqp_problem),"
+                   "sizeof(hsqp_perf),sizeof(hsqp_timings),sizeof(hsqp_solution));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(s) for s in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(t) for t in (_abi.Body, _abi.Frame, _abi.ModelDesc, _abi.Settings, _abi.Problem, _abi.Perf,
+                                           _abi.Timings, _abi.Solution)]
+
+
+def test_no_cpu_fallback(model):
+    """Without a HIP device hsqp_create must fail loudly with HSQP_ERR_NO_DEVICE (skipped when a GPU is present)."""
+    lib = solver.load_library()
+    if lib.hsqp_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(solver.HsqpError) as ei:
+        solver.HipSqpSolver(model, max_nodes=4)
+    assert ei.value.code == _abi.ERR_NO_DEVICE
+
+
+def test_product_sources_never_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wb_humanoid_mpc_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "hsqp_oracle" not in text and "liborc" not in text and "hostemu" not in text.replace("tests/hostemu", ""), f

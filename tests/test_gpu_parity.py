@@ -1,0 +1,136 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden fixtures.  Tolerances (BASELINE.md §6, f64 end to end): trajectories/steps max-abs <= 1e-8 * scale,
+QP KKT residuals <= 1e-9 * max(1, |g|_inf), performance-index terms rel <= 1e-9."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_lq import perturbed_problem
+from wb_humanoid_mpc_amd import _abi
+from wb_humanoid_mpc_amd.reference import make_problem
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NX, NU, NZ = _abi.NX, _abi.NU, _abi.NZ
+
+
+@pytest.fixture(scope="module")
+def gpu_solver(model):
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    s = HipSqpSolver(model, max_nodes=100, max_batch=8)
+    yield s
+    s.close()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("name", ["wb_stance_n4", "wb_walk_n8", "wb_run_n14"])
+def test_against_golden_fixtures(gpu_solver, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = gpu_solver.run(g["x_init"], g["x"], g["u"], g["par"], float(g["dt"]))
+    sc = max(1.0, np.abs(g["dx"]).max(), np.abs(g["du"]).max())
+    assert np.abs(out["dx"][0] - g["dx"]).max() <= 1e-8 * sc
+    assert np.abs(out["du"][0] - g["du"]).max() <= 1e-8 * sc
+    assert np.allclose(out["x"][0], g["x"] + g["dx"], atol=1e-8 * sc) and np.allclose(out["u"][0], g["u"] + g["du"], atol=1e-8 * sc)
+    pb, pa = out["perf_before"][0], out["perf_after"][0]
+    for got, want in ((pb, g["perf_before"]), (pa, g["perf_after"])):
+        assert np.allclose([got["cost"], got["dynamics_sse"], got["equality_sse"]], want, rtol=1e-9, atol=1e-12)
+    assert out["kkt"][0, 0] <= 1e-9 * max(1.0, np.abs(g["g"]).max()) * sc and out["kkt"][0, 1] <= 1e-10 * sc
+    # intermediate blocks
+    assert rel(gpu_solver.debug_read(_abi.BLK_BVEC)[0], g["b"]) <= 1e-12
+    assert rel(gpu_solver.debug_read(_abi.BLK_G)[0], g["g"]) <= 1e-11
+    assert rel(gpu_solver.debug_read(_abi.BLK_COST)[0], g["cost"]) <= 1e-11
+    assert rel(gpu_solver.debug_read(_abi.BLK_FLOW)[0], g["flow"]) <= 1e-12
+    assert np.array_equal(gpu_solver.debug_read(_abi.BLK_NE)[0], g["ne"])
+    assert rel(gpu_solver.debug_read(_abi.BLK_CDE)[0][:, :, -1], g["e"]) <= 1e-11
+    assert rel(gpu_solver.debug_read(_abi.BLK_AB)[0][:, 29, :], g["AB_row29"]) <= 1e-11
+    assert rel(np.einsum("kii->ki", gpu_solver.debug_read(_abi.BLK_H)[0]), g["H_diag"]) <= 1e-11
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 5), ("walk", 10), ("run", 14)])
+def test_lq_blocks_against_oracle(gpu_solver, model, oracle, gait, n):
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=31)
+    gpu_solver.run(x0, x, u, par, dt)
+    lq = oracle.lq(dt, x, u, par, threads=4)
+    for blk, key in ((_abi.BLK_AB, "AB"), (_abi.BLK_BVEC, "b"), (_abi.BLK_H, "H"), (_abi.BLK_G, "g"), (_abi.BLK_CDE, "CDe"),
+                     (_abi.BLK_COST, "cost"), (_abi.BLK_FLOW, "flow")):
+        assert rel(gpu_solver.debug_read(blk)[0], lq[key]) <= 1e-11, key
+    assert np.array_equal(gpu_solver.debug_read(_abi.BLK_NE)[0], lq["ne"])
+
+
+def test_batch_of_perturbed_instances_against_oracle(gpu_solver, model, oracle):
+    """BASELINE config 4 inputs at a size the oracle finishes in seconds: B = 6 perturbed instances, N = 16."""
+    x0, x, u, par, dt = make_problem(model, n_nodes=16, batch=6, perturb=True)
+    out = gpu_solver.run(x0, x, u, par, dt)
+    for b in range(6):
+        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=4)
+        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+        assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc, b
+        assert np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc, b
+        for key in ("cost", "dynamics_sse", "equality_sse"):
+            assert np.isclose(out["perf_before"][b][key], r["perf_before"][key], rtol=1e-9, atol=1e-12)
+            assert np.isclose(out["perf_after"][b][key], r["perf_after"][key], rtol=1e-8, atol=1e-10)
+    # instances are independent: solving one alone gives the same bits as inside the batch
+    solo = gpu_solver.run(x0[3], x[3], u[3], par[3], dt)
+    assert np.array_equal(solo["dx"][0], out["dx"][3]) and np.array_equal(solo["du"][0], out["du"][3])
+
+
+def test_full_size_properties(gpu_solver, model):
+    """BASELINE config 3/4 size (N = 100): size-independent properties of the QP step, no oracle needed."""
+    x0, x, u, par, dt = make_problem(model, n_nodes=100, batch=4, perturb=True)
+    x0 = x0 + 1e-3  # non-zero dx_0
+    out = gpu_solver.run(x0, x, u, par, dt)
+    dx, du = out["dx"], out["du"]
+    AB = gpu_solver.debug_read(_abi.BLK_AB)
+    b = gpu_solver.debug_read(_abi.BLK_BVEC)
+    CDe = gpu_solver.debug_read(_abi.BLK_CDE)
+    ne = gpu_solver.debug_read(_abi.BLK_NE)
+    sc = max(1.0, np.abs(dx).max(), np.abs(du).max())
+    assert np.abs(dx[:, 0] - (x0 - x[:, 0])).max() <= 1e-12
+    z = np.concatenate([dx[:, :-1], du], axis=2)
+    defect = dx[:, 1:] - np.einsum("bkij,bkj->bki", AB, z) - b
+    assert np.abs(defect).max() <= 1e-9 * sc                      # linearised dynamics hold
+    eq = np.einsum("bkrj,bkj->bkr", CDe[..., :NZ], z) + CDe[..., NZ]
+    assert np.abs(eq).max() <= 1e-7 * sc                          # linearised equality constraints hold
+    assert set(np.unique(ne)) <= {12, 13, 14} and 13 in ne
+    assert out["kkt"][:, 1].max() <= 1e-9 * sc
+    g = gpu_solver.debug_read(_abi.BLK_G)
+    assert out["kkt"][:, 0].max() <= 1e-9 * max(1.0, np.abs(g).max()) * sc
+    assert np.all(np.isfinite(out["x"])) and np.all(np.isfinite(out["u"]))
+    # the full step is x + dx
+    assert np.allclose(out["x"], x + dx, atol=1e-12 * sc) and np.allclose(out["u"], u + du, atol=1e-12 * sc)
+
+
+def test_device_resident_iterations_equal_repeated_solves(gpu_solver, model):
+    x0, x, u, par, dt = make_problem(model, n_nodes=12, batch=2, gait="stance", v_cmd=(0, 0, 0.7925, 0))
+    a = gpu_solver.run(x0, x, u, par, dt)
+    b = gpu_solver.run(x0, a["x"], a["u"], par, dt)
+    gpu_solver.upload(x0, x, u, par, dt)
+    gpu_solver.iterate(2, take_step=True)
+    c = gpu_solver.download()
+    assert np.array_equal(b["x"], c["x"]) and np.array_equal(b["u"], c["u"])
+    ms = gpu_solver.kernel_ms()
+    assert ms["total"] > 0.0 and abs(ms["total"] - (ms["lq"] + ms["project"] + ms["riccati"] + ms["step_perf"])) < 1e-9
+    # stance from rest converges (same behaviour as the oracle, tests/test_oracle_lq.py::test_sqp_converges_on_stance)
+    assert np.abs(c["dx"]).max() < np.abs(a["dx"]).max()
+
+
+def test_error_behaviour(gpu_solver, model):
+    from wb_humanoid_mpc_amd.solver import HsqpError
+    x0, x, u, par, dt = make_problem(model, n_nodes=4, batch=1)
+    with pytest.raises(HsqpError) as e:
+        gpu_solver.run(x0, x, u, par, -1.0)
+    assert e.value.code == _abi.ERR_BAD_ARG
+    big = make_problem(model, n_nodes=101, batch=1)
+    with pytest.raises(HsqpError) as e:
+        gpu_solver.run(*big)
+    assert e.value.code == _abi.ERR_BAD_ARG
+    # rank-deficient equality Jacobian is impossible to construct through valid inputs; a NaN state must surface as NUMERIC, not hang
+    xb = x.copy()
+    xb[0, 2, 7] = np.nan
+    with pytest.raises(HsqpError) as e:
+        gpu_solver.run(x0, xb, u, par, dt)
+    assert e.value.code == _abi.ERR_NUMERIC

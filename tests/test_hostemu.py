@@ -1,0 +1,74 @@
+"""The kernel SOURCES (wb_humanoid_mpc_amd/csrc/*.h) compiled for the host with a one-thread context
+(tests/hostemu) against the oracle: checks the arithmetic of the HIP kernels in the GPU-less container.
+The GPU tests (-m gpu) check the same thing through the real device build and the C ABI."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import random_state_input
+from test_oracle_lq import perturbed_problem
+from wb_humanoid_mpc_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def emu(model):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu")])
+    lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
+    lib.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(model.desc), err, 256))
+    assert h.value, err.value
+    return lib, h
+
+
+def test_analytic_flow_jacobian(model, oracle, emu, rng):
+    lib, h = emu
+    for _ in range(5):
+        x, u = random_state_input(model, rng)
+        ab, G = np.zeros(6), np.zeros((6, 93))
+        lib.emu_stage_eval(h, P(x), P(u), 1, P(ab), P(G))
+        f, J = oracle.flow_map_jac(x, u)
+        assert np.abs(ab - f[29:35]).max() <= 1e-11 * max(1.0, np.abs(f).max())
+        assert np.abs(G - J[29:35]).max() <= 1e-10 * max(1.0, np.abs(J).max())
+        ab2 = np.zeros(6)
+        lib.emu_stage_eval(h, P(x), P(u), 0, P(ab2), None)
+        assert np.array_equal(ab, ab2)
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 6), ("run", 12)])
+def test_lq_record_expands_to_the_oracle_blocks(model, oracle, emu, gait, n):
+    lib, h = emu
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=5)
+    lq = oracle.lq(dt, x, u, par)
+    RS = lib.emu_rec_size()
+    for k in range(n):
+        rec = np.zeros(RS)
+        lib.emu_lq_node(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dt), 1, P(rec))
+        AB, H, g, CDe = np.zeros((58, 93)), np.zeros((93, 93)), np.zeros(93), np.zeros((14, 94))
+        lib.emu_expand(P(rec), C.c_double(dt), P(AB), P(H), P(g), P(CDe))
+        for a, b in ((AB, lq["AB"][k]), (H, lq["H"][k]), (g, lq["g"][k]), (CDe, lq["CDe"][k])):
+            assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14)])
+def test_full_iteration_matches_oracle(model, oracle, emu, gait, n):
+    lib, h = emu
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=5)
+    r = oracle.sqp_iteration(dt, x0, x, u, par, want_proj=True)
+    xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+    kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+    qp = np.zeros((n, lib.emu_qp_size()))
+    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+    assert rc == 0
+    sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+    assert np.abs(dx - r["dx"]).max() <= 1e-9 * sc and np.abs(du - r["du"]).max() <= 1e-9 * sc
+    assert kkt[0] <= 1e-9 * sc and kkt[1] <= 1e-10 * sc
+    for got, want in ((pb, r["perf_before"]), (pa, r["perf_after"])):
+        assert np.allclose(got, [want["cost"], want["dynamics_sse"], want["equality_sse"]], rtol=1e-9, atol=1e-12)

@@ -1,0 +1,33 @@
+"""Build the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libhsqp_hip.so")
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False, verbose=False, extra=()):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_HERE, "..", "include", "hsqp.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+           os.path.join(CSRC, "hsqp_capi.hip"), "-o", LIB, *extra]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_hip(force="-f" in sys.argv, verbose=True,
+                    extra=("-Rpass-analysis=kernel-resource-usage",) if "-r" in sys.argv else ()))

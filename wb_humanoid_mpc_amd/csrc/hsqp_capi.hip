@@ -1,0 +1,384 @@
+// C ABI (include/hsqp.h) of the MI355X SQP library: HIP kernels + host orchestration.
+// Product path: there is NO CPU fallback — without a usable HIP device every entry point fails with
+// HSQP_ERR_NO_DEVICE / HSQP_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "hsqp_host.h"
+#include "hsqp_riccati.h"
+
+using namespace hsqp;
+
+namespace {
+
+constexpr int LQ_THREADS = 256;
+constexpr int PROJ_THREADS = 256;
+constexpr int RIC_THREADS = 256;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
+
+// ---- LQ approximation: one workgroup per (instance, node)
+template <bool DERIV>
+__global__ __launch_bounds__(LQ_THREADS, 2) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
+                                                   const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
+                                                   double* __restrict__ rec, double* __restrict__ misc) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  LqWS& w = *reinterpret_cast<LqWS*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  lq_node<DERIV>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt,
+                 DERIV ? rec + (size_t)node * REC_SIZE : nullptr,
+                 DERIV ? rec + (size_t)node * REC_SIZE + REC_MISC : misc + (size_t)node * 8);
+}
+
+// ---- projection: one workgroup per (instance, node)
+__global__ __launch_bounds__(PROJ_THREADS) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp) {
+  ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE);
+}
+
+// ---- Riccati backward + forward + KKT residual: one workgroup per instance
+__global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
+                                                         const double* __restrict__ x, const double* __restrict__ u,
+                                                         const double* __restrict__ par, const double* __restrict__ qp,
+                                                         double* __restrict__ ric, int N, double alpha, double* __restrict__ dx,
+                                                         double* __restrict__ du, double* __restrict__ ut, double* __restrict__ x_new,
+                                                         double* __restrict__ u_new, double* __restrict__ kkt, int* __restrict__ status,
+                                                         int want_kkt) {
+  const int b = blockIdx.x;
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  const double* xb = x + (size_t)b * (N + 1) * NX;
+  const double* ub = u + (size_t)b * N * NU;
+  const double* parN = par + ((size_t)b * (N + 1) + N) * NP;
+  const double* qpb = qp + (size_t)b * N * QP_SIZE;
+  double* ricb = ric + (size_t)b * N * RIC_SIZE;
+  // projection failures of this instance (rank-deficient D)
+  int mybad = 0;
+  for (int k = threadIdx.x; k < N; k += blockDim.x)
+    if (qpb[(size_t)k * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
+  const int bad = __syncthreads_or(mybad);
+  riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N);
+  double* dxb = dx + (size_t)b * (N + 1) * NX;
+  double* utb = ut + (size_t)b * N * NUT;
+  riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ub, qpb, ricb, N, alpha, dxb, du + (size_t)b * N * NU, utb,
+                  x_new + (size_t)b * (N + 1) * NX, u_new + (size_t)b * N * NU);
+  if (want_kkt) kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, xb, parN, qpb, dxb, utb, N, kkt + 2 * b);
+  if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
+}
+
+// ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
+__global__ void k_perf_reduce(const DevModel* __restrict__ dm, const double* __restrict__ misc, int misc_stride, const double* __restrict__ x,
+                              const double* __restrict__ par, int N, hsqp_perf* __restrict__ out) {
+  const int b = blockIdx.x;
+  __shared__ double red[3][64];
+  double c = 0.0, e = 0.0, d = 0.0;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    const double* m = misc + ((size_t)b * N + k) * misc_stride;
+    c += m[1]; e += m[2]; d += m[3];
+  }
+  if (threadIdx.x < NX) {  // terminal QuadraticStateCost(Q_final * scaling): HumanoidCostConstraintFactory.cpp:218-228
+    const double dd = x[((size_t)b * (N + 1) + N) * NX + threadIdx.x] - par[((size_t)b * (N + 1) + N) * NP + HSQP_P_XDES + threadIdx.x];
+    c += 0.5 * dm->Qf[threadIdx.x] * dd * dd;
+  }
+  red[0][threadIdx.x] = c; red[1][threadIdx.x] = e; red[2][threadIdx.x] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double cs = 0.0, es = 0.0, ds = 0.0;
+    for (int i = 0; i < 64; ++i) { cs += red[0][i]; es += red[1][i]; ds += red[2][i]; }
+    out[b].cost = cs; out[b].merit = cs; out[b].equality_sse = es; out[b].dynamics_sse = ds;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+struct hsqp_handle {
+  hsqp_model_desc md;
+  hsqp_settings st;
+  DevModel hdm;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  DevModel* d_dm = nullptr;
+  double *d_xinit = nullptr, *d_x = nullptr, *d_u = nullptr, *d_par = nullptr;
+  double *d_rec = nullptr, *d_qp = nullptr, *d_ric = nullptr;
+  double *d_dx = nullptr, *d_du = nullptr, *d_ut = nullptr, *d_xnew = nullptr, *d_unew = nullptr;
+  double *d_misc = nullptr, *d_kkt = nullptr;
+  hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
+  int* d_status = nullptr;
+  int B = 0, N = 0;
+  double dt = 0.0;
+  bool have_problem = false, have_solution = false;
+  double kernel_ms[5] = {0, 0, 0, 0, 0};
+  std::string err;
+};
+
+static std::string g_create_error;
+
+#define HCHECK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                                      \
+      return HSQP_ERR_HIP;                                                                             \
+    }                                                                                                  \
+  } while (0)
+
+extern "C" {
+
+const char* hsqp_version(void) { return "hsqp-hip 0.1 (gfx950, f64)"; }
+
+int hsqp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* hsqp_last_error(const hsqp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void hsqp_destroy(hsqp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status};
+  for (void* p : bufs)
+    if (p) (void)hipFree(p);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsqp_handle** out) {
+  if (!model || !settings || !out) { g_create_error = "null argument"; return HSQP_ERR_BAD_ARG; }
+  *out = nullptr;
+  if (settings->max_nodes < 1 || settings->max_batch < 1) { g_create_error = "max_nodes and max_batch must be >= 1"; return HSQP_ERR_BAD_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device visible (this library has no CPU path)"; return HSQP_ERR_NO_DEVICE; }
+  if (settings->device < 0 || settings->device >= ndev) { g_create_error = "device ordinal out of range"; return HSQP_ERR_BAD_ARG; }
+  hsqp_handle* h = new hsqp_handle;
+  h->md = *model;
+  h->st = *settings;
+  h->device = settings->device;
+  const std::string e = build_dev_model(*model, h->hdm);
+  if (!e.empty()) { g_create_error = e; delete h; return HSQP_ERR_BAD_ARG; }
+  auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
+  if (hipSetDevice(h->device) != hipSuccess) return fail(HSQP_ERR_HIP, "hipSetDevice failed");
+  if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
+  for (auto& ev : h->ev)
+    if (hipEventCreate(&ev) != hipSuccess) return fail(HSQP_ERR_HIP, "hipEventCreate failed");
+  const size_t B = settings->max_batch, N = settings->max_nodes;
+  struct Alloc { void** p; size_t bytes; };
+  const Alloc allocs[] = {
+      {(void**)&h->d_dm, sizeof(DevModel)},
+      {(void**)&h->d_xinit, B * NX * 8}, {(void**)&h->d_x, B * (N + 1) * NX * 8}, {(void**)&h->d_u, B * N * NU * 8},
+      {(void**)&h->d_par, B * (N + 1) * NP * 8}, {(void**)&h->d_rec, B * N * (size_t)REC_SIZE * 8},
+      {(void**)&h->d_qp, B * N * (size_t)QP_SIZE * 8}, {(void**)&h->d_ric, B * N * (size_t)RIC_SIZE * 8},
+      {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
+      {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
+      {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
+      {(void**)&h->d_status, B * sizeof(int)}};
+  for (const Alloc& a : allocs)
+    if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
+  if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
+  // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
+  hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
+  hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
+  hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
+  hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  *out = h;
+  g_create_error.clear();
+  return HSQP_OK;
+}
+
+int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!p || !p->x_init || !p->x_traj || !p->u_traj || !p->node_params) { h->err = "null problem pointer"; return HSQP_ERR_BAD_ARG; }
+  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || !(p->dt > 0.0)) {
+    h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
+    return HSQP_ERR_BAD_ARG;
+  }
+  HCHECK(hipSetDevice(h->device));
+  const size_t B = p->batch, N = p->n_nodes;
+  HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_x, p->x_traj, B * (N + 1) * NX * 8, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_par, p->node_params, B * (N + 1) * NP * 8, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));
+  h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
+  h->have_problem = true; h->have_solution = false;
+  return HSQP_OK;
+}
+
+int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int take_step) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!h->have_problem || n_iterations < 1) { h->err = "no problem uploaded or n_iterations < 1"; return HSQP_ERR_BAD_ARG; }
+  HCHECK(hipSetDevice(h->device));
+  const int B = h->B, N = h->N;
+  const int nodes = B * N;
+  for (int it = 0; it < n_iterations; ++it) {
+    const bool last = it == n_iterations - 1;
+    if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
+                       h->d_rec, (double*)nullptr);
+    if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp);
+    if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par,
+                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, 1);
+    if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
+    hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+                       N, (double*)nullptr, h->d_misc);
+    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before);
+    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after);
+    if (last) HCHECK(hipEventRecord(h->ev[4], h->stream));
+    if (take_step && !last) {
+      HCHECK(hipMemcpyAsync(h->d_x, h->d_xnew, (size_t)B * (N + 1) * NX * 8, hipMemcpyDeviceToDevice, h->stream));
+      HCHECK(hipMemcpyAsync(h->d_u, h->d_unew, (size_t)B * N * NU * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+  }
+  HCHECK(hipGetLastError());
+  HCHECK(hipStreamSynchronize(h->stream));
+  float ms[4];
+  for (int i = 0; i < 4; ++i) HCHECK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  h->kernel_ms[0] = ms[0]; h->kernel_ms[1] = ms[1]; h->kernel_ms[2] = ms[2]; h->kernel_ms[3] = ms[3];
+  h->kernel_ms[4] = ms[0] + ms[1] + ms[2] + ms[3];
+  h->have_solution = true;
+  return HSQP_OK;
+}
+
+int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!s || !h->have_solution) { h->err = "no solution on the device"; return HSQP_ERR_BAD_ARG; }
+  HCHECK(hipSetDevice(h->device));
+  const size_t B = h->B, N = h->N;
+  if (s->x) HCHECK(hipMemcpy(s->x, h->d_xnew, B * (N + 1) * NX * 8, hipMemcpyDeviceToHost));
+  if (s->u) HCHECK(hipMemcpy(s->u, h->d_unew, B * N * NU * 8, hipMemcpyDeviceToHost));
+  if (s->dx) HCHECK(hipMemcpy(s->dx, h->d_dx, B * (N + 1) * NX * 8, hipMemcpyDeviceToHost));
+  if (s->du) HCHECK(hipMemcpy(s->du, h->d_du, B * N * NU * 8, hipMemcpyDeviceToHost));
+  if (s->perf_before) HCHECK(hipMemcpy(s->perf_before, h->d_perf_before, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
+  if (s->perf_after) HCHECK(hipMemcpy(s->perf_after, h->d_perf_after, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
+  if (s->kkt) HCHECK(hipMemcpy(s->kkt, h->d_kkt, B * 2 * 8, hipMemcpyDeviceToHost));
+  std::vector<int> status(B);
+  HCHECK(hipMemcpy(status.data(), h->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
+  s->timings.lq_approximation = 1e-3 * (h->kernel_ms[0] + h->kernel_ms[1]);
+  s->timings.solve_qp = 1e-3 * h->kernel_ms[2];
+  s->timings.linesearch = 1e-3 * h->kernel_ms[3];
+  s->timings.compute_controller = 0.0;
+  s->timings.total = 1e-3 * h->kernel_ms[4];
+  for (size_t b = 0; b < B; ++b)
+    if (status[b]) {
+      h->err = "instance " + std::to_string(b) + ": " + ((status[b] & 1) ? "rank-deficient equality Jacobian D " : "") +
+               ((status[b] & 2) ? "reduced Hessian not positive definite" : "");
+      return HSQP_ERR_NUMERIC;
+    }
+  return HSQP_OK;
+}
+
+int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
+  int rc = hsqp_upload(h, problem);
+  if (rc != HSQP_OK) return rc;
+  rc = hsqp_iterate_device(h, 1, 1);
+  if (rc != HSQP_OK) return rc;
+  return hsqp_download(h, solution);
+}
+
+int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
+  if (!h || !out_ms) return HSQP_ERR_BAD_ARG;
+  for (int i = 0; i < 5; ++i) out_ms[i] = h->kernel_ms[i];
+  return HSQP_OK;
+}
+
+long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!h->have_solution) { h->err = "no iteration has run"; return HSQP_ERR_BAD_ARG; }
+  if (hipSetDevice(h->device) != hipSuccess) return HSQP_ERR_HIP;
+  const size_t B = h->B, N = h->N, nodes = B * N;
+  std::vector<double> out;
+  std::vector<int> iout;
+  auto fetch_rec = [&](std::vector<double>& rec) {
+    rec.resize(nodes * (size_t)REC_SIZE);
+    return hipMemcpy(rec.data(), h->d_rec, rec.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  };
+  std::vector<double> rec;
+  switch (what) {
+    case HSQP_BLK_AB: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      out.resize(nodes * NX * NZ);
+      for (size_t n = 0; n < nodes; ++n) expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
+      break;
+    }
+    case HSQP_BLK_BVEC: case HSQP_BLK_FLOW: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      out.resize(nodes * NX);
+      const int off = what == HSQP_BLK_BVEC ? REC_B : REC_FLOW;
+      for (size_t n = 0; n < nodes; ++n) memcpy(&out[n * NX], &rec[n * REC_SIZE + off], NX * 8);
+      break;
+    }
+    case HSQP_BLK_H: case HSQP_BLK_G: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      const bool isH = what == HSQP_BLK_H;
+      out.assign(nodes * (isH ? NZ * NZ : NZ), 0.0);
+      for (size_t n = 0; n < nodes; ++n) {
+        const double* r = &rec[n * REC_SIZE];
+        for (int a = 0; a < NZ; ++a) {
+          if (isH) {
+            for (int b = 0; b < NZ; ++b) {
+              double s = a == b ? r[REC_D + a] : 0.0;
+              for (int k = 0; k < NRS; ++k) s += r[REC_J + k * LDJ + a] * r[REC_J + k * LDJ + b];
+              out[n * NZ * NZ + a * NZ + b] = s;
+            }
+          } else {
+            double s = r[REC_GD + a];
+            for (int k = 0; k < NRS; ++k) s += r[REC_J + k * LDJ + a] * r[REC_RHO + k];
+            out[n * NZ + a] = s;
+          }
+        }
+      }
+      break;
+    }
+    case HSQP_BLK_CDE: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      out.resize(nodes * NE_MAX * (NZ + 1));
+      for (size_t n = 0; n < nodes; ++n)
+        for (int r = 0; r < NE_MAX; ++r) memcpy(&out[(n * NE_MAX + r) * (NZ + 1)], &rec[n * REC_SIZE + REC_CDE + r * LDJ], (NZ + 1) * 8);
+      break;
+    }
+    case HSQP_BLK_NE: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      iout.resize(nodes);
+      for (size_t n = 0; n < nodes; ++n) iout[n] = (int)rec[n * REC_SIZE + REC_MISC];
+      break;
+    }
+    case HSQP_BLK_COST: {
+      if (!fetch_rec(rec)) return HSQP_ERR_HIP;
+      std::vector<double> x(B * (N + 1) * NX), par(B * (N + 1) * NP);
+      if (hipMemcpy(x.data(), h->d_x, x.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP;
+      if (hipMemcpy(par.data(), h->d_par, par.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP;
+      out.resize(B * (N + 1));
+      for (size_t b = 0; b < B; ++b) {
+        for (size_t k = 0; k < N; ++k) out[b * (N + 1) + k] = rec[(b * N + k) * REC_SIZE + REC_MISC + 1];
+        double c = 0.0;
+        for (int i = 0; i < NX; ++i) { const double d = x[(b * (N + 1) + N) * NX + i] - par[(b * (N + 1) + N) * NP + HSQP_P_XDES + i]; c += 0.5 * h->hdm.Qf[i] * d * d; }
+        out[b * (N + 1) + N] = c;
+      }
+      break;
+    }
+    case HSQP_BLK_DX: out.resize(B * (N + 1) * NX); if (hipMemcpy(out.data(), h->d_dx, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;
+    case HSQP_BLK_DU: out.resize(B * N * NU); if (hipMemcpy(out.data(), h->d_du, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;
+    default: h->err = "unknown block id"; return HSQP_ERR_BAD_ARG;
+  }
+  const long long size = iout.empty() ? (long long)out.size() * 8 : (long long)iout.size() * 4;
+  const void* src = iout.empty() ? (const void*)out.data() : (const void*)iout.data();
+  if (dst && bytes > 0) memcpy(dst, src, (size_t)(bytes < size ? bytes : size));
+  return size;
+}
+
+}  // extern "C"

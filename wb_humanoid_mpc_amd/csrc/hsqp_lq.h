@@ -70,11 +70,11 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
   return s;
 }
 
-// Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory) ; DERIV = false: values only
-// (cost, defect and equality violation for the performance index).
+// Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory); misc[0..3] = {ne, dt*cost, dt*|eq|^2, dt*|b|^2}.
+// DERIV = false: values only (performance index); rec is not touched and may be null.
 template <bool DERIV>
 HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* x, const double* u, const double* xnext,
-                     const double* par, double dt, double* rec) {
+                     const double* par, double dt, double* rec, double* misc) {
   WG_FOR(ctx, i, NX + NU + NP + NX) {
     if (i < NX) w.nw.x[i] = x[i];
     else if (i < NX + NU) w.nw.u[i - NX] = u[i - NX];
@@ -94,14 +94,14 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
       node_values(ctx, dm, w.st, w.nw);
       node_scalars(ctx, dm, w.st, w.nw);
       if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J);
-      WG_FOR(ctx, i, 64 + NRS) {
+      if (DERIV) WG_FOR(ctx, i, 64 + NRS) {
         if (i < 64) {
           double f = 0.0;
           if (i < NV) f = w.nw.x[NV + i];
           else if (i < NV + 6) f = w.st.ab[i - NV];
           else if (i < NX) f = w.nw.u[12 + i - NV - 6];
           rec[REC_FLOW + i] = f;
-        } else if (DERIV) {
+        } else {
           rec[REC_RHO + i - 64] = sqrt(dt) * w.nw.rho[i - 64];
         }
       }
@@ -118,7 +118,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
       const double a = k < 6 ? (w.as[0][k] + 2.0 * w.as[1][k] + 2.0 * w.as[2][k] + w.as[3][k]) / 6.0 : w.nw.u[12 + k - 6];
       b = w.nw.x[i] + dt * a - w.xnext[i];
     }
-    rec[REC_B + i] = b;
+    if (DERIV) rec[REC_B + i] = b;
     w.bvec[i] = b;
   }
   WG_SYNC(ctx);
@@ -126,10 +126,10 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
     double dyn = 0.0, eq = 0.0;
     for (int i = 0; i < NX; ++i) dyn += w.bvec[i] * w.bvec[i];
     for (int r = 0; r < w.nw.ne; ++r) eq += w.nw.eqv[r] * w.nw.eqv[r];
-    rec[REC_MISC + 0] = (double)w.nw.ne;
-    rec[REC_MISC + 1] = dt * w.nw.cost;
-    rec[REC_MISC + 2] = dt * eq;
-    rec[REC_MISC + 3] = dt * dyn;
+    misc[0] = (double)w.nw.ne;
+    misc[1] = dt * w.nw.cost;
+    misc[2] = dt * eq;
+    misc[3] = dt * dyn;
   }
   if (!DERIV) return;
   // ---- write d, gd, CDe

@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's solver interface over the HIP C ABI.
+
+The reference drives its solver through ocs2::SolverBase / MPC_BASE
+(humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:64-89,
+ humanoid_nmpc/humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:200-213):
+reset(), run(t0, x0, tf), getPrimalSolution(), getPerformanceIndeces(), and the fork's
+SqpSolver::getBenchmarks() (humanoid_common_mpc_ros2/src/benchmarks/SqpBenchmarksPublisher.cpp:44-57).
+HipSqpSolver keeps those names and meanings for a batch of independent MPC instances; the C++
+adaptor of INTEGRATION.md is the same thin layer in the reference's own language.
+
+There is no CPU path: constructing a solver without the built HIP library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhsqp_hip.so")
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+class HsqpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hsqp error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """Load libhsqp_hip.so (built in-tree by wb_humanoid_mpc_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m wb_humanoid_mpc_amd.build` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.hsqp_create.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Settings), C.POINTER(C.c_void_p)]
+    lib.hsqp_destroy.argtypes = [C.c_void_p]
+    lib.hsqp_solve.argtypes = [C.c_void_p, C.POINTER(_abi.Problem), C.POINTER(_abi.Solution)]
+    lib.hsqp_upload.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
+    lib.hsqp_iterate_device.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hsqp_download.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
+    lib.hsqp_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+    lib.hsqp_debug_read.restype = C.c_longlong
+    lib.hsqp_last_kernel_ms.argtypes = [C.c_void_p, _dp]
+    lib.hsqp_last_error.argtypes = [C.c_void_p]
+    lib.hsqp_last_error.restype = C.c_char_p
+    lib.hsqp_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipSqpSolver:
+    def __init__(self, model, max_nodes, max_batch=1, device=0):
+        self.lib = load_library()
+        self.model = model
+        st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=0)
+        h = C.c_void_p()
+        rc = self.lib.hsqp_create(C.byref(model.desc), C.byref(st), C.byref(h))
+        if rc != 0:
+            raise HsqpError(rc, self.lib.hsqp_last_error(None).decode())
+        self.h = h
+        self.max_nodes, self.max_batch = max_nodes, max_batch
+        self._shape = None
+        self._sol = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsqp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HsqpError(rc, self.lib.hsqp_last_error(self.h).decode())
+
+    # ---- SolverBase::reset
+    def reset(self):
+        self._shape = None
+        self._sol = None
+
+    def _problem(self, x_init, x_traj, u_traj, params, dt):
+        x_traj, u_traj, params, x_init = _c(x_traj), _c(u_traj), _c(params), _c(x_init)
+        if x_traj.ndim == 2:
+            x_traj, u_traj, params, x_init = x_traj[None], u_traj[None], params[None], x_init[None]
+        B, N = u_traj.shape[0], u_traj.shape[1]
+        if x_traj.shape != (B, N + 1, _abi.NX) or u_traj.shape != (B, N, _abi.NU) or \
+                params.shape != (B, N + 1, _abi.NODE_PARAMS) or x_init.shape != (B, _abi.NX):
+            raise ValueError("inconsistent problem array shapes")
+        keep = (x_init, x_traj, u_traj, params)
+        p = _abi.Problem(batch=B, n_nodes=N, dt=dt, x_init=x_init.ctypes.data_as(_dp), x_traj=x_traj.ctypes.data_as(_dp),
+                         u_traj=u_traj.ctypes.data_as(_dp), node_params=params.ctypes.data_as(_dp))
+        return p, keep, (B, N)
+
+    def _alloc_solution(self, B, N):
+        out = dict(x=np.zeros((B, N + 1, _abi.NX)), u=np.zeros((B, N, _abi.NU)), dx=np.zeros((B, N + 1, _abi.NX)),
+                   du=np.zeros((B, N, _abi.NU)), kkt=np.zeros((B, 2)))
+        pb, pa = (_abi.Perf * B)(), (_abi.Perf * B)()
+        s = _abi.Solution(x=out["x"].ctypes.data_as(_dp), u=out["u"].ctypes.data_as(_dp), dx=out["dx"].ctypes.data_as(_dp),
+                          du=out["du"].ctypes.data_as(_dp), perf_before=pb, perf_after=pa, kkt=out["kkt"].ctypes.data_as(_dp))
+        return s, out, pb, pa
+
+    @staticmethod
+    def _perf(arr):
+        return [dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse) for p in arr]
+
+    def _finish(self, s, out, pb, pa):
+        out["perf_before"], out["perf_after"] = self._perf(pb), self._perf(pa)
+        t = s.timings
+        out["benchmarks"] = dict(linearQuadraticApproximationTime=t.lq_approximation, solveQpTime=t.solve_qp,
+                                 linesearchTime=t.linesearch, computeControllerTime=t.compute_controller, total=t.total)
+        self._sol = out
+        return out
+
+    # ---- SolverBase::run (one SQP iteration, sqpIteration = 1 as in task.info:81)
+    def run(self, x_init, x_traj, u_traj, params, dt):
+        p, keep, (B, N) = self._problem(x_init, x_traj, u_traj, params, dt)
+        s, out, pb, pa = self._alloc_solution(B, N)
+        self._check(self.lib.hsqp_solve(self.h, C.byref(p), C.byref(s)))
+        self._shape = (B, N)
+        return self._finish(s, out, pb, pa)
+
+    # ---- device-resident loop (bench): upload once, iterate, download
+    def upload(self, x_init, x_traj, u_traj, params, dt):
+        p, keep, self._shape = self._problem(x_init, x_traj, u_traj, params, dt)
+        self._check(self.lib.hsqp_upload(self.h, C.byref(p)))
+
+    def iterate(self, n_iterations=1, take_step=False):
+        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, int(take_step)))
+
+    def download(self):
+        B, N = self._shape
+        s, out, pb, pa = self._alloc_solution(B, N)
+        self._check(self.lib.hsqp_download(self.h, C.byref(s)))
+        return self._finish(s, out, pb, pa)
+
+    def kernel_ms(self):
+        ms = np.zeros(5)
+        self._check(self.lib.hsqp_last_kernel_ms(self.h, ms.ctypes.data_as(_dp)))
+        return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
+
+    # ---- reference-named accessors
+    def getPrimalSolution(self):
+        return self._sol["x"], self._sol["u"]
+
+    def getPerformanceIndeces(self):
+        return self._sol["perf_after"]
+
+    def getBenchmarks(self):
+        return self._sol["benchmarks"]
+
+    # ---- parity/debug access to intermediate blocks of the last iteration
+    def debug_read(self, what):
+        B, N = self._shape
+        shapes = {_abi.BLK_AB: (B, N, _abi.NX, _abi.NZ), _abi.BLK_BVEC: (B, N, _abi.NX), _abi.BLK_H: (B, N, _abi.NZ, _abi.NZ),
+                  _abi.BLK_G: (B, N, _abi.NZ), _abi.BLK_CDE: (B, N, _abi.NE_MAX, _abi.NZ + 1), _abi.BLK_NE: (B, N),
+                  _abi.BLK_COST: (B, N + 1), _abi.BLK_DX: (B, N + 1, _abi.NX), _abi.BLK_DU: (B, N, _abi.NU),
+                  _abi.BLK_FLOW: (B, N, _abi.NX)}
+        a = np.zeros(shapes[what], dtype=np.int32 if what == _abi.BLK_NE else np.float64)
+        n = self.lib.hsqp_debug_read(self.h, what, a.ctypes.data_as(C.c_void_p), a.nbytes)
+        if n < 0:
+            raise HsqpError(n, self.lib.hsqp_last_error(self.h).decode())
+        assert n == a.nbytes, (n, a.nbytes)
+        return a
