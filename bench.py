@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py — SQP iterations/sec of the G1 whole-body MPC (N = 100) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+One "step" = one SQP iteration of every resident MPC instance: LQ approximation at all nodes,
+equality projection, Riccati QP, full step (alpha = 1) and the performance index before/after
+(SURVEY.md §8d).  Inputs are resident in HBM before the timed region (hsqp_upload); nothing is
+skipped inside it.  Rank 0 prints ONE JSON line.
+
+Workload: whole-body G1, N = 100 nodes, dt = 0.035 s, gait `walk`,
+v_cmd = (0.3, 0, 0.7925, 0), 256 perturbed instances PER GPU (numpy PCG64 seed 20250808 + rank),
+cold-start trajectory.  Weak scaling: per-GPU work is fixed, instances are independent, there is no
+data-path collective (RCCL is used only for the barrier / result gather around the timed region).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+# algorithmic flops per node (SURVEY.md §8d / BASELINE.md §5; dense count, mul+add, no symmetry credit)
+NX, NU, NE, NUT, MROWS = 58, 35, 12, 23, 18
+F_RK4 = 6 * NX * NX * (NX + NU)
+F_GN = 2 * (2 * MROWS * (NX + NU) ** 2 + 2 * MROWS * (NX + NU))
+F_PROJ = (2 * NU * NE ** 2 + 2 * NX * NU * NUT + 2 * NX ** 2 * NU + 2 * NU ** 2 * NUT + 2 * NUT ** 2 * NU + 2 * NU ** 2 * NX +
+          2 * NUT * NU * NX + 4 * NX ** 2 * NU + 2 * NU ** 2 * NX)
+F_RIC = 7.0 / 3.0 * NX ** 3 + 4 * NX ** 2 * NUT + 2 * NX * NUT ** 2 + NUT ** 3 / 3.0
+F_NODE = F_RK4 + F_GN + F_PROJ + F_RIC
+BYTES_NODE = 404 * 1024          # unfused dataflow bytes per node
+PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355X_MICROARCH.md chip table; FP64 runs at half the FP32 rate)
+PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
+
+
+def cpu_baseline(model, n_nodes, seed):
+    """The CPU oracle (oracle/oracle.cpp, kind 'port') on a bounded sample of the same workload."""
+    from hsqp_oracle import Oracle
+    from wb_humanoid_mpc_amd.reference import make_problem
+    threads = os.cpu_count() or 1
+    n_inst = 4
+    x0, x, u, par, dt = make_problem(model, n_nodes=n_nodes, batch=n_inst, perturb=True, seed=seed)
+    oracle = Oracle(model)
+    oracle.sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=threads)  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_inst or time.perf_counter() - t0 < 10.0:
+        b = done % n_inst
+        oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=threads)
+        done += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    wall = time.perf_counter() - t0
+    return {"value": done / wall, "unit": "SQP iters/s", "cores": threads, "kind": "port",
+            "sample": f"{done} single-instance iterations (N={n_nodes}, same perturbed walk inputs), node-parallel LQ on {threads} OpenMP threads, "
+                      f"serial Riccati, {wall:.1f} s; forward-mode dual-number oracle, not the reference's CppAD/HPIPM build"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="MPC instances per GPU")
+    ap.add_argument("--nodes", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # our library first (binds the system HIP runtime), torch afterwards (shares it: same soname)
+    from wb_humanoid_mpc_amd import load_model
+    from wb_humanoid_mpc_amd.reference import BENCH_SEED, make_problem
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver, load_library
+    load_library()
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    model = load_model()
+    B, N = args.batch, args.nodes
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=BENCH_SEED + rank)
+    solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank)
+    solver.upload(x0, x, u, par, dt)      # inputs resident in HBM before the timed region
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.iterate(1, take_step=False)
+    sync()
+    kms = np.zeros(5)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.iterate(1, take_step=False)   # blocking: synchronises the library's stream
+        k = solver.kernel_ms()
+        kms += [k["lq"], k["project"], k["riccati"], k["step_perf"], k["total"]]
+    sync()
+    elapsed = time.perf_counter() - t0
+    kms /= args.steps
+    out = solver.download()
+    kkt = float(np.max(out["kkt"]))
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    kk = torch.tensor([kkt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+    elapsed, kkt = float(t.item()), float(kk.item())
+
+    if rank == 0:
+        iters = B * world * args.steps
+        value = iters / elapsed
+        nodes = B * N
+        # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
+        kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN), "projection(k_project)": (kms[1], F_PROJ), "riccati(k_riccati)": (kms[2], F_RIC)}
+        dom = max(kern, key=lambda n: kern[n][0])
+        dom_ms, dom_flops = kern[dom]
+        ach_tf = nodes * dom_flops / (dom_ms * 1e-3) / 1e12
+        step_tf = nodes * F_NODE / (elapsed / args.steps) / 1e12
+        step_tbs = nodes * BYTES_NODE / (elapsed / args.steps) / 1e12
+        res = {
+            "metric": "SQP iters/sec (G1 WB-MPC, N=100)", "value": value, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: G1 whole-body MPC, N={N}, dt={dt}, gait walk, {B} perturbed instances per GPU, "
+                                   "1 SQP iteration per step (LQ + projection + Riccati + full step + performance index), cold-start trajectory",
+                       "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                         "note": "achieved = ALGORITHMIC (dense-count) flops of the dominant kernel / its HIP-event duration; the kernels exploit "
+                                 "the flow map's structure and execute fewer flops than the dense count (DESIGN.md)",
+                         "whole_step_algorithmic_TFLOPs": step_tf, "whole_step_frac_fp64": step_tf / PEAK_FP64_TFLOPS,
+                         "whole_step_unfused_TBs": step_tbs, "whole_step_frac_hbm": step_tbs / PEAK_HBM_TBS},
+            "kernel_ms": {"lq": kms[0], "project": kms[1], "riccati": kms[2], "step_perf": kms[3], "sum": kms[4]},
+            "kkt_residual_max": kkt,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model, N, BENCH_SEED)
+            res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
