@@ -78,16 +78,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    # our library first (binds the system HIP runtime), torch afterwards (shares it: same soname)
+    # torch FIRST: its bundled libamdhip64.so.7 must be the one HIP runtime of the process; libhsqp_hip.so then
+    # binds to it by soname (measured on the GPU box: the other order leaves torch.cuda unavailable)
+    import torch
+    import torch.distributed as dist
     from wb_humanoid_mpc_amd import load_model
     from wb_humanoid_mpc_amd.reference import BENCH_SEED, make_problem
     from wb_humanoid_mpc_amd.solver import HipSqpSolver, load_library
-    load_library()
-    import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")  # initialise the HIP runtime through torch before the library touches it
+    load_library()
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 

@@ -113,7 +113,7 @@ def test_device_resident_iterations_equal_repeated_solves(gpu_solver, model):
     c = gpu_solver.download()
     assert np.array_equal(b["x"], c["x"]) and np.array_equal(b["u"], c["u"])
     ms = gpu_solver.kernel_ms()
-    assert ms["total"] > 0.0 and abs(ms["total"] - (ms["lq"] + ms["project"] + ms["riccati"] + ms["step_perf"])) < 1e-9
+    assert ms["total"] > 0.0 and abs(ms["total"] - (ms["lq"] + ms["project"] + ms["riccati"] + ms["step_perf"])) < 1e-4
     # stance from rest converges (same behaviour as the oracle, tests/test_oracle_lq.py::test_sqp_converges_on_stance)
     assert np.abs(c["dx"]).max() < np.abs(a["dx"]).max()
 
