@@ -157,7 +157,9 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 /* Same, but the problem is already resident on the device from the previous
  * hsqp_solve/hsqp_upload and the result is left there (bench / multi-iteration use). */
 int hsqp_upload(hsqp_handle* h, const hsqp_problem* problem);
-int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int take_step);
+#define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
+#define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */
+int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags);
 int hsqp_download(hsqp_handle* h, hsqp_solution* solution);
 
 /* Debug/parity access to intermediate device blocks of the LAST iteration.

@@ -109,7 +109,7 @@ def test_device_resident_iterations_equal_repeated_solves(gpu_solver, model):
     a = gpu_solver.run(x0, x, u, par, dt)
     b = gpu_solver.run(x0, a["x"], a["u"], par, dt)
     gpu_solver.upload(x0, x, u, par, dt)
-    gpu_solver.iterate(2, take_step=True)
+    gpu_solver.iterate(2, take_step=True, kkt=True)
     c = gpu_solver.download()
     assert np.array_equal(b["x"], c["x"]) and np.array_equal(b["u"], c["u"])
     ms = gpu_solver.kernel_ms()

@@ -19,7 +19,7 @@ def build_hip(force=False, verbose=False, extra=()):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_HERE, "..", "include", "hsqp.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            os.path.join(CSRC, "hsqp_capi.hip"), "-o", LIB, *extra]
     if verbose:
         print(" ".join(cmd))

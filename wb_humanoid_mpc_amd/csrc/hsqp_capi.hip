@@ -217,7 +217,8 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
   return HSQP_OK;
 }
 
-int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int take_step) {
+int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
+  const int take_step = flags & HSQP_ITER_TAKE_STEP, want_kkt = (flags & HSQP_ITER_KKT) ? 1 : 0;
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!h->have_problem || n_iterations < 1) { h->err = "no problem uploaded or n_iterations < 1"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
@@ -232,7 +233,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int take_step) {
     hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par,
-                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, 1);
+                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, want_kkt);
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
                        N, (double*)nullptr, h->d_misc);
@@ -285,7 +286,7 @@ int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
 int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
   int rc = hsqp_upload(h, problem);
   if (rc != HSQP_OK) return rc;
-  rc = hsqp_iterate_device(h, 1, 1);
+  rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT);
   if (rc != HSQP_OK) return rc;
   return hsqp_download(h, solution);
 }

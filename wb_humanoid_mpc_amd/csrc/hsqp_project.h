@@ -8,6 +8,7 @@
 // The projected input dimension is padded to NUT = 23 with identity (R~ = 1, everything else 0) when
 // more than 12 equality rows are active, so the Riccati kernel sees a fixed stage size.
 #pragma once
+#include "hsqp_linalg.h"
 #include "hsqp_lq.h"
 
 namespace hsqp {
@@ -28,29 +29,28 @@ constexpr int QP_NUT = QP_PE + NU;             // [1]  nu - ne, or -1 if D was r
 constexpr int QP_SIZE = ((QP_NUT + 1 + 7) / 8) * 8;
 
 constexpr int NTW = NX + NUT;                  // 81: projected stage variable [dx; ut]
-constexpr int LDT = 82;                        // leading dimension of J~ in LDS
+constexpr int LDTM = 84;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
+constexpr int NRX = 100;                       // residual rows after projection: 64 slots + 35 input-weight rows + 1 zero row
 
 struct ProjWS {
   union {
     struct {
       double CDe[NE_MAX][LDJ];
       double Rm[NU][NE_MAX];     // D^T, overwritten by R1
-      double Qm[NU][NU];
-      double Wm[NE_MAX][NX + 1]; // R1^-T [C|e]
+      double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
+      double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double hv[NU];             // Householder vector
-      double hs[2];              // {2/|v|^2, ok flag}
+      double hs[2];              // {2/|v|^2}
     } qr;
-    double Ju[NRS][NU];          // input block of the residual rows (staged after the QR data is dead)
+    double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
   };
   int ne, nut, ok;
-  double Px[NU][NX], Pu[NU][NUT], Pe[NU];
+  double Tm[NU][LDTM];           // [Px (58) | Pu (23) | Pe | 0 0]
   double PV[2][6][LDJ];
   double bvec[64];
-  double d[LDJ], gd[LDJ], rho[NRS], gu[NU];
-  double Jt[NRS][LDT];
+  double d[LDJ], gd[LDJ], rho[NRS];
+  double Jt[NRX][LDTM];          // rows 0..63: J T with rho' in column 81; rows 64..98: sqrt(d_u) [Px|Pu|Pe]; row 99: 0
 };
-
-HSQP_HD double tu(const ProjWS& w, int k, int a) { return a < NX ? w.Px[k][a] : w.Pu[k][a - NX]; }
 
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp) {
   // ---- load
@@ -73,10 +73,10 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut;
-  // ---- Householder QR of D^T
+  // ---- Householder QR of D^T, accumulating Q^T
   WG_FOR(ctx, i, NU * NE_MAX + NU * NU) {
     if (i < NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
-    else { const int r = (i - NU * NE_MAX) / NU, c = (i - NU * NE_MAX) % NU; w.qr.Qm[r][c] = r == c ? 1.0 : 0.0; }
+    else { const int r = (i - NU * NE_MAX) / NU, c = (i - NU * NE_MAX) % NU; w.qr.QT[r][c] = r == c ? 1.0 : 0.0; }
   }
   WG_SYNC(ctx);
   for (int k = 0; k < ne; ++k) {
@@ -84,7 +84,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       double nrm = 0.0;
       for (int i = k; i < NU; ++i) nrm += w.qr.Rm[i][k] * w.qr.Rm[i][k];
       nrm = sqrt(nrm);
-      if (nrm < 1e-12) w.ok = 0;
+      if (!(nrm >= 1e-12)) w.ok = 0;
       const double alpha = w.qr.Rm[k][k] >= 0.0 ? -nrm : nrm;
       double vn = 0.0;
       for (int i = 0; i < NU; ++i) {
@@ -96,21 +96,16 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       w.qr.hs[0] = vn > 1e-300 ? 2.0 / vn : 0.0;
     }
     WG_SYNC(ctx);
-    WG_FOR(ctx, it, (ne - k) + NU) {
+    WG_FOR(ctx, it, (ne - k) + NU) {   // apply (I - beta v v^T) from the left to the columns of R and of Q^T
       const double beta = w.qr.hs[0];
-      if (it < ne - k) {  // R(:,c) <- (I - beta v v^T) R(:,c)
-        const int c = k + it;
-        double s = 0.0;
-        for (int i = k; i < NU; ++i) s += w.qr.hv[i] * w.qr.Rm[i][c];
-        s *= beta;
-        for (int i = k; i < NU; ++i) w.qr.Rm[i][c] -= s * w.qr.hv[i];
-      } else {            // Q(r,:) <- Q(r,:) (I - beta v v^T)
-        const int r = it - (ne - k);
-        double s = 0.0;
-        for (int i = k; i < NU; ++i) s += w.qr.Qm[r][i] * w.qr.hv[i];
-        s *= beta;
-        for (int i = k; i < NU; ++i) w.qr.Qm[r][i] -= s * w.qr.hv[i];
-      }
+      const bool isR = it < ne - k;
+      const int c = isR ? k + it : it - (ne - k);
+      double s = 0.0;
+      if (isR) { for (int i = k; i < NU; ++i) s += w.qr.hv[i] * w.qr.Rm[i][c]; }
+      else { for (int i = k; i < NU; ++i) s += w.qr.hv[i] * w.qr.QT[i][c]; }
+      s *= beta;
+      if (isR) { for (int i = k; i < NU; ++i) w.qr.Rm[i][c] -= s * w.qr.hv[i]; }
+      else { for (int i = k; i < NU; ++i) w.qr.QT[i][c] -= s * w.qr.hv[i]; }
     }
     WG_SYNC(ctx);
   }
@@ -123,90 +118,76 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
   }
   WG_SYNC(ctx);
-  WG_FOR(ctx, i, NU * (NX + 1 + NUT)) {
-    const int r = i / (NX + 1 + NUT), c = i % (NX + 1 + NUT);
-    if (c <= NX) {
-      double s = 0.0;
-      for (int j = 0; j < ne; ++j) s += w.qr.Qm[r][j] * w.qr.Wm[j][c];
-      if (c < NX) w.Px[r][c] = -s; else w.Pe[r] = -s;
-    } else {
-      const int cc = c - NX - 1;
-      w.Pu[r][cc] = cc < nut ? w.qr.Qm[r][ne + cc] : 0.0;
-    }
+  // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
+  wg_xty<4, 4>(ctx, NU, NX + 1, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, AllTiles(),
+               [&](int r, int c, double v) { w.Tm[r][c < NX ? c : NTW] = -v; });
+  WG_FOR(ctx, i, NU * (NUT + 2)) {
+    const int r = i / (NUT + 2), cc = i % (NUT + 2);
+    if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ne + cc][r] : 0.0;
+    else w.Tm[r][NTW + 1 + (cc - NUT)] = 0.0;
   }
-  WG_SYNC(ctx);  // QR data dead from here: Ju aliases it
-  // ---- stage the input block of the residual rows, write the projection
+  WG_SYNC(ctx);  // QR data dead from here: JuT aliases it
+  // ---- stage the (transposed) input block of the residual rows, write the projection
   WG_FOR(ctx, i, NRS * NU + NU * (NX + NUT + 1) + 1) {
-    if (i < NRS * NU) { const int r = i / NU, k = i % NU; w.Ju[r][k] = rec[REC_J + r * LDJ + NX + k]; continue; }
+    if (i < NRS * NU) { const int r = i / NU, k = i % NU; w.JuT[k][r] = rec[REC_J + r * LDJ + NX + k]; continue; }
     int j = i - NRS * NU;
-    if (j < NU * NX) { qp[QP_PX + j] = w.Px[j / NX][j % NX]; continue; }
+    if (j < NU * NX) { qp[QP_PX + j] = w.Tm[j / NX][j % NX]; continue; }
     j -= NU * NX;
-    if (j < NU * NUT) { qp[QP_PU + j] = w.Pu[j / NUT][j % NUT]; continue; }
+    if (j < NU * NUT) { qp[QP_PU + j] = w.Tm[j / NUT][NX + j % NUT]; continue; }
     j -= NU * NUT;
-    if (j < NU) { qp[QP_PE + j] = w.Pe[j]; w.gu[j] = w.gd[NX + j] + w.d[NX + j] * w.Pe[j]; continue; }
+    if (j < NU) { qp[QP_PE + j] = w.Tm[j][NTW]; continue; }
     qp[QP_NUT] = w.ok ? (double)nut : -1.0;
   }
-  WG_SYNC(ctx);
   // ---- dynamics: A~ = A + B Px, B~ = B Pu, b~ = b + B Pe  with the structured [A|B] (hsqp_lq.h)
-  WG_FOR(ctx, i, NX * (NX + NUT + 1)) {
-    const int r = i / (NX + NUT + 1), c = i % (NX + NUT + 1);
-    // B row r applied to column c of [Px | Pu | Pe]
+  WG_FOR(ctx, i, NX * (NTW + 1)) {
+    const int r = i / (NTW + 1), c = i % (NTW + 1);
     double s = 0.0;
     const bool base = (r < 6) || (r >= NV && r < NV + 6);
-    if (base) {
+    if (base) {  // B row r applied to column c of [Px | Pu | Pe]
       const double* Brow = &w.PV[r < 6 ? 0 : 1][r < 6 ? r : r - NV][NX];
-      if (c < NX) for (int k = 0; k < NU; ++k) s += Brow[k] * w.Px[k][c];
-      else if (c < NX + NUT) for (int k = 0; k < NU; ++k) s += Brow[k] * w.Pu[k][c - NX];
-      else for (int k = 0; k < NU; ++k) s += Brow[k] * w.Pe[k];
+#pragma unroll 5
+      for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][c];
     } else {
       const int j = r < NV ? r - 6 : r - NV - 6;
-      const double coef = r < NV ? 0.5 * dt * dt : dt;
-      s = coef * (c < NX ? w.Px[12 + j][c] : (c < NX + NUT ? w.Pu[12 + j][c - NX] : w.Pe[12 + j]));
+      s = (r < NV ? 0.5 * dt * dt : dt) * w.Tm[12 + j][c];
     }
     if (c < NX) {
       double a = (r == c) ? 1.0 : 0.0;
       if (r < NV && c == NV + r) a += dt;
       if (base) a += w.PV[r < 6 ? 0 : 1][r < 6 ? r : r - NV][c];
       qp[QP_A + r * NX + c] = a + s;
-    } else if (c < NX + NUT) {
+    } else if (c < NTW) {
       qp[QP_B + r * NUT + (c - NX)] = s;
     } else {
       qp[QP_BV + r] = w.bvec[r] + s;
     }
   }
-  // ---- J~ = J T (state block read from global, input block from LDS), rho' = rho + J_u Pe
-  WG_FOR(ctx, i, NRS * (NTW + 1)) {
-    const int r = i / (NTW + 1), a = i % (NTW + 1);
-    double s = 0.0;
-    if (a < NX) { s = rec[REC_J + r * LDJ + a]; for (int k = 0; k < NU; ++k) s += w.Ju[r][k] * w.Px[k][a]; w.Jt[r][a] = s; }
-    else if (a < NTW) { for (int k = 0; k < NU; ++k) s += w.Ju[r][k] * w.Pu[k][a - NX]; w.Jt[r][a] = s; }
-    else { s = w.rho[r]; for (int k = 0; k < NU; ++k) s += w.Ju[r][k] * w.Pe[k]; w.Jt[r][LDT - 1] = s; }
+  WG_SYNC(ctx);
+  // ---- residual rows after projection: J T (+ rho' in column 81), then the input-weight rows sqrt(d_u) [Px|Pu|Pe]
+  wg_xty<4, 4>(ctx, NRS, NTW + 1, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, AllTiles(),
+               [&](int r, int a, double v) { w.Jt[r][a] = v + (a < NX ? rec[REC_J + r * LDJ + a] : (a == NTW ? w.rho[r] : 0.0)); });
+  WG_FOR(ctx, i, (NU + 1) * LDTM) {
+    const int k = i / LDTM, a = i % LDTM;
+    w.Jt[NRS + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
   }
   WG_SYNC(ctx);
-  // ---- projected gradient and Hessian (upper triangle computed, mirrored on write)
-  WG_FOR(ctx, i, NTW + NTW * (NTW + 1) / 2) {
-    if (i < NTW) {
-      const int a = i;
-      double s = a < NX ? w.gd[a] : 0.0;
-      for (int k = 0; k < NU; ++k) s += tu(w, k, a) * w.gu[k];
-      for (int r = 0; r < NRS; ++r) s += w.Jt[r][a] * w.Jt[r][LDT - 1];
+  // ---- projected Hessian (upper triangle, mirrored on write) and gradient (column 81 of the same product)
+  wg_xty<4, 4>(ctx, NTW, NTW + 1, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, UpperTiles(), [&](int a, int b, double s) {
+    if (b == NTW) {   // gradient: g~ = T^T gd + J~ext^T rho'
+      if (a < NX) s += w.gd[a];
+      for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
       if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
-      continue;
+      return;
     }
-    // unrank the upper-triangular pair (a <= b)
-    int t = i - NTW, a = 0;
-    while (t >= NTW - a) { t -= NTW - a; ++a; }
-    const int b = a + t;
-    double s = (a == b && a < NX) ? w.d[a] : 0.0;
-    for (int k = 0; k < NU; ++k) s += w.d[NX + k] * tu(w, k, a) * tu(w, k, b);
-    for (int r = 0; r < NRS; ++r) s += w.Jt[r][a] * w.Jt[r][b];
+    if (b < a) return;
+    if (a == b && a < NX) s += w.d[a];
     if (b < NX) { qp[QP_Q + a * NX + b] = s; qp[QP_Q + b * NX + a] = s; }
     else if (a < NX) { qp[QP_P + (b - NX) * NX + a] = s; }
     else {
       if (a - NX >= nut || b - NX >= nut) s = (a == b) ? 1.0 : 0.0;  // identity padding of the unused projected inputs
       qp[QP_R + (a - NX) * NUT + (b - NX)] = s; qp[QP_R + (b - NX) * NUT + (a - NX)] = s;
     }
-  }
+  });
   WG_SYNC(ctx);
 }
 

@@ -3,8 +3,12 @@
 //   backward  Lam = R~ + B~^T S+ B~ (Cholesky),  K = -Lam^-1 (P~ + B~^T S+ A~),  k = -Lam^-1 (r~ + B~^T (s+ + S+ b~))
 //             S = Q~ + A~^T S+ A~ + G^T K,  s = q~ + A~^T (s+ + S+ b~) + G^T k,   S_N = diag(Qf), s_N = Qf (x_N - x_des)
 //   forward   ut = K dx + k,  dx+ = A~ dx + B~ ut + b~,  du = Px dx + Pu ut + Pe
-// One workgroup per MPC instance; the stage matrices live in LDS for the whole backward step.
+// One workgroup per MPC instance; the stage matrices live in LDS for the whole backward step and every
+// product is a register-tiled X^T Y contraction (hsqp_linalg.h):
+//   SA = S^T A, SB = S^T B (S symmetric), Lam = R + B^T SB, G = P + B^T SA, Z = (L^-T)^T G, K = -(L^-1)^T Z,
+//   S <- Q + A^T SA + G^T K (upper tiles, mirrored).
 #pragma once
+#include "hsqp_linalg.h"
 #include "hsqp_project.h"
 
 namespace hsqp {
@@ -12,13 +16,20 @@ namespace hsqp {
 constexpr int RIC_K = 0;                     // [23][58]
 constexpr int RIC_KV = RIC_K + NUT * NX;     // [23]
 constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
+constexpr int LDB = 24;                      // leading dimension of the 23-wide LDS matrices (16-byte aligned rows)
 
 struct RicWS {
-  double S[NX][NX], Sn[NX][NX], A[NX][NX], SA[NX][NX];
-  double B[NX][NUT], SB[NX][NUT];
+  double S[NX][NX], A[NX][NX], SA[NX][NX];
+  double B[NX][LDB];
+  union {
+    double SB[NX][LDB];
+    double Z[NUT][NX];                       // L^-1 G (SB is dead once Lam and G are formed)
+  };
   double Gm[NUT][NX], Km[NUT][NX];
-  double Lam[NUT][NUT];
-  double sv[NX], sb[NX], bt[NX], gv[NUT], kv[NUT], dx[NX], dxn[NX], ut[NUT];
+  double Lam[LDB][LDB], M1[LDB][LDB], M1T[LDB][LDB];   // Cholesky factor (lower, in place), L^-1 and its transpose
+  double dsq[LDB];
+  double sv[NX], sn[NX], sb[NX], bt[NX], gv[NUT], kv[NUT], zv[NUT], dx[NX], dxn[NX], ut[NUT];
+  double part[(NX + NU) * 4];
   int ok;
 };
 
@@ -33,111 +44,105 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
   WG_SYNC(ctx);
   for (int k = N - 1; k >= 0; --k) {
     const double* q = qp + (size_t)k * QP_SIZE;
-    WG_FOR(ctx, i, NX * NX + NX * NUT + NX) {
-      if (i < NX * NX) w.A[i / NX][i % NX] = q[QP_A + i];
-      else if (i < NX * NX + NX * NUT) { const int j = i - NX * NX; w.B[j / NUT][j % NUT] = q[QP_B + j]; }
-      else w.bt[i - NX * NX - NX * NUT] = q[QP_BV + i - NX * NX - NX * NUT];
-    }
-    WG_SYNC(ctx);
-    // SA = S A, SB = S B, sb = s + S b
-    WG_FOR(ctx, i, NX * (NX + NUT + 1)) {
-      const int r = i / (NX + NUT + 1), c = i % (NX + NUT + 1);
-      double s = 0.0;
-      if (c < NX) { for (int l = 0; l < NX; ++l) s += w.S[r][l] * w.A[l][c]; w.SA[r][c] = s; }
-      else if (c < NX + NUT) { const int cc = c - NX; for (int l = 0; l < NX; ++l) s += w.S[r][l] * w.B[l][cc]; w.SB[r][cc] = s; }
-      else { s = w.sv[r]; for (int l = 0; l < NX; ++l) s += w.S[r][l] * w.bt[l]; w.sb[r] = s; }
-    }
-    WG_SYNC(ctx);
-    // Lam = R + B^T SB (symmetrised), G = P + B^T SA, g = r + B^T sb
-    WG_FOR(ctx, i, NUT * (NUT + NX + 1)) {
-      const int r = i / (NUT + NX + 1), c = i % (NUT + NX + 1);
-      if (c < NUT) {
-        if (c < r) continue;
-        double s1 = q[QP_R + r * NUT + c], s2 = q[QP_R + c * NUT + r];
-        for (int l = 0; l < NX; ++l) { s1 += w.B[l][r] * w.SB[l][c]; s2 += w.B[l][c] * w.SB[l][r]; }
-        const double a = 0.5 * (s1 + s2);
-        w.Lam[r][c] = a; w.Lam[c][r] = a;
-      } else if (c < NUT + NX) {
-        const int cc = c - NUT;
-        double s = q[QP_P + r * NX + cc];
-        for (int l = 0; l < NX; ++l) s += w.B[l][r] * w.SA[l][cc];
-        w.Gm[r][cc] = s;
-      } else {
-        double s = q[QP_RV + r];
-        for (int l = 0; l < NX; ++l) s += w.B[l][r] * w.sb[l];
-        w.gv[r] = s;
-      }
-    }
-    WG_SYNC(ctx);
-    // Cholesky Lam = L L^T (lower, in place)
-    for (int j = 0; j < NUT; ++j) {
-      WG_FOR(ctx, it, 1) {
-        double dj = w.Lam[j][j];
-        for (int l = 0; l < j; ++l) dj -= w.Lam[j][l] * w.Lam[j][l];
-        if (!(dj > 0.0)) { w.ok = 0; dj = 1.0; }
-        w.Lam[j][j] = sqrt(dj);
-      }
-      WG_SYNC(ctx);
-      WG_FOR(ctx, it, NUT - 1 - j) {
-        const int i = j + 1 + it;
-        double s = w.Lam[i][j];
-        for (int l = 0; l < j; ++l) s -= w.Lam[i][l] * w.Lam[j][l];
-        w.Lam[i][j] = s / w.Lam[j][j];
-      }
-      WG_SYNC(ctx);
-    }
-    // K = -Lam^-1 G, kv = -Lam^-1 g: one item per right-hand side
-    WG_FOR(ctx, c, NX + 1) {   // solved in place in the item's own column of Km / kv (no private arrays)
-      for (int i = 0; i < NUT; ++i) {
-        double s = c < NX ? w.Gm[i][c] : w.gv[i];
-        for (int l = 0; l < i; ++l) s -= w.Lam[i][l] * (c < NX ? w.Km[l][c] : w.kv[l]);
-        s /= w.Lam[i][i];
-        if (c < NX) w.Km[i][c] = s; else w.kv[i] = s;
-      }
-      for (int i = NUT - 1; i >= 0; --i) {
-        double s = c < NX ? w.Km[i][c] : w.kv[i];
-        for (int l = i + 1; l < NUT; ++l) s -= w.Lam[l][i] * (c < NX ? w.Km[l][c] : w.kv[l]);
-        s /= w.Lam[i][i];
-        if (c < NX) w.Km[i][c] = s; else w.kv[i] = s;
-      }
-      for (int i = 0; i < NUT; ++i) { if (c < NX) w.Km[i][c] = -w.Km[i][c]; else w.kv[i] = -w.kv[i]; }
-    }
-    WG_SYNC(ctx);
-    // Sn = Q + A^T SA + G^T K (symmetrised on the next phase), sn = q + A^T sb + G^T kv ; store K, kv
     double* rk = ric + (size_t)k * RIC_SIZE;
-    WG_FOR(ctx, i, NX * (NX + 1) + NUT * NX + NUT) {
-      if (i < NX * (NX + 1)) {
-        const int r = i / (NX + 1), c = i % (NX + 1);
-        if (c < NX) {
-          double s = q[QP_Q + r * NX + c];
-          for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.SA[l][c];
-          for (int l = 0; l < NUT; ++l) s += w.Gm[l][r] * w.Km[l][c];
-          w.Sn[r][c] = s;
-        } else {
-          double s = q[QP_QV + r];
-          for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.sb[l];
-          for (int l = 0; l < NUT; ++l) s += w.Gm[l][r] * w.kv[l];
-          w.dxn[r] = s;  // staged: sv is still being read by nobody, but keep phases simple
+    // ---- P1: stage data -> LDS (coalesced)
+    WG_FOR(ctx, i, NX * NX + NX * LDB + NX) {
+      if (i < NX * NX) w.A[i / NX][i % NX] = q[QP_A + i];
+      else if (i < NX * NX + NX * LDB) { const int j = i - NX * NX, r = j / LDB, c = j % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : 0.0; }
+      else w.bt[i - NX * NX - NX * LDB] = q[QP_BV + i - NX * NX - NX * LDB];
+    }
+    WG_SYNC(ctx);
+    // ---- P2: SA = S A, SB = S B (S symmetric => X = S), sb = s + S b
+    wg_xty<4, 4>(ctx, NX, NX, NX, &w.S[0][0], NX, &w.A[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.SA[r][c] = v; });
+    wg_xty<4, 4>(ctx, NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, AllTiles(), [&](int r, int c, double v) { w.SB[r][c] = v; });
+    WG_FOR(ctx, r, NX) {
+      double s = w.sv[r];
+      for (int l = 0; l < NX; ++l) s += w.S[l][r] * w.bt[l];
+      w.sb[r] = s;
+    }
+    WG_SYNC(ctx);
+    // ---- P3: Lam = R + B^T SB, G = P + B^T SA, g = r + B^T sb
+    wg_xty<4, 4>(ctx, NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, AllTiles(),
+                 [&](int r, int c, double v) { w.Lam[r][c] = v + q[QP_R + r * NUT + c]; });
+    wg_xty<4, 4>(ctx, NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, AllTiles(),
+                 [&](int r, int c, double v) { w.Gm[r][c] = v + q[QP_P + r * NX + c]; });
+    WG_FOR(ctx, r, NUT) {
+      double s = q[QP_RV + r];
+      for (int l = 0; l < NX; ++l) s += w.B[l][r] * w.sb[l];
+      w.gv[r] = s;
+    }
+    WG_SYNC(ctx);
+    // ---- P4: right-looking Cholesky of Lam (lower triangle; the diagonal square roots go to dsq)
+    for (int j = 0; j < NUT; ++j) {
+      WG_FOR(ctx, it, NUT - j) {
+        const int i = j + it;
+        double dj = w.Lam[j][j];
+        if (!(dj > 0.0)) { dj = 1.0; if (it == 0) w.ok = 0; }
+        const double sq = sqrt(dj);
+        if (it == 0) w.dsq[j] = sq; else w.Lam[i][j] = w.Lam[i][j] / sq;
+      }
+      WG_SYNC(ctx);
+      const int m = NUT - 1 - j;
+      WG_FOR(ctx, it, m * m) {
+        const int i = j + 1 + it / m, c = j + 1 + it % m;
+        if (c <= i) w.Lam[i][c] -= w.Lam[i][j] * w.Lam[c][j];
+      }
+      WG_SYNC(ctx);
+    }
+    // ---- P5: M1 = L^-1 (lower) and its transpose, one column per item (forward substitution)
+    WG_FOR(ctx, j, NUT) {
+      for (int i = 0; i < NUT; ++i) {
+        double s = 0.0;
+        if (i >= j) {
+          s = i == j ? 1.0 : 0.0;
+          for (int l = j; l < i; ++l) s -= w.Lam[i][l] * w.M1[l][j];
+          s /= w.dsq[i];
         }
-      } else if (i < NX * (NX + 1) + NUT * NX) {
-        const int j = i - NX * (NX + 1);
-        rk[RIC_K + j] = w.Km[j / NX][j % NX];
-      } else {
-        const int j = i - NX * (NX + 1) - NUT * NX;
-        rk[RIC_KV + j] = w.kv[j];
+        w.M1[i][j] = s;
+        w.M1T[j][i] = s;
       }
     }
     WG_SYNC(ctx);
+    // ---- P6: Z = L^-1 G = (M1T)^T G, z = L^-1 g
+    wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1T[0][0], LDB, &w.Gm[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.Z[r][c] = v; });
+    WG_FOR(ctx, r, NUT) {
+      double s = 0.0;
+      for (int l = 0; l <= r; ++l) s += w.M1[r][l] * w.gv[l];
+      w.zv[r] = s;
+    }
+    WG_SYNC(ctx);
+    // ---- P7: K = -L^-T Z = -(M1)^T Z, k = -L^-T z ; stored for the forward pass
+    wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1[0][0], LDB, &w.Z[0][0], NX, AllTiles(),
+                 [&](int r, int c, double v) { w.Km[r][c] = -v; rk[RIC_K + r * NX + c] = -v; });
+    WG_FOR(ctx, r, NUT) {
+      double s = 0.0;
+      for (int l = r; l < NUT; ++l) s += w.M1[l][r] * w.zv[l];
+      w.kv[r] = -s;
+      rk[RIC_KV + r] = -s;
+    }
+    WG_SYNC(ctx);
+    // ---- P8: S <- Q + A^T SA + G^T K (upper tiles; S itself is dead since P2), s <- q + A^T sb + G^T k
+    wg_xty2<4, 4>(ctx, NX, NX, NX, &w.A[0][0], NX, &w.SA[0][0], NX, NUT, &w.Gm[0][0], NX, &w.Km[0][0], NX, UpperTiles(),
+                  [&](int r, int c, double v) { if (c >= r) w.S[r][c] = v + q[QP_Q + r * NX + c]; });
+    WG_FOR(ctx, r, NX) {
+      double s = q[QP_QV + r];
+      for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.sb[l];
+      for (int l = 0; l < NUT; ++l) s += w.Gm[l][r] * w.kv[l];
+      w.sn[r] = s;
+    }
+    WG_SYNC(ctx);
+    // ---- P9: mirror the upper triangle, roll s
     WG_FOR(ctx, i, NX * NX + NX) {
-      if (i < NX * NX) { const int r = i / NX, c = i % NX; w.S[r][c] = 0.5 * (w.Sn[r][c] + w.Sn[c][r]); }
-      else w.sv[i - NX * NX] = w.dxn[i - NX * NX];
+      if (i < NX * NX) { const int r = i / NX, c = i % NX; if (r > c) w.S[r][c] = w.S[c][r]; }
+      else w.sv[i - NX * NX] = w.sn[i - NX * NX];
     }
     WG_SYNC(ctx);
   }
 }
 
-// Forward roll-out of the QP solution and the full step.  x,u: linearisation trajectory of the instance;
-// outputs dx [N+1][58], du [N][35], ut [N][23], x_new, u_new (any of the output pointers may alias nothing).
+// Forward roll-out of the QP solution and the step of length alpha.  x,u: linearisation trajectory of the instance;
+// outputs dx [N+1][58], du [N][35], ut [N][23], x_new, u_new.  Matrix-vector products read the stage matrices from
+// global memory with 4 work items per row and a deterministic two-phase reduction.
 HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* u, const double* qp,
                              const double* ric, int N, double alpha, double* dx_out, double* du_out, double* ut_out, double* x_new,
                              double* u_new) {
@@ -151,26 +156,34 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
   for (int k = 0; k < N; ++k) {
     const double* q = qp + (size_t)k * QP_SIZE;
     const double* rk = ric + (size_t)k * RIC_SIZE;
+    wg_matvec_partial(ctx, NUT, NX, rk + RIC_K, NX, w.dx, w.part);
+    WG_SYNC(ctx);
     WG_FOR(ctx, i, NUT) {
-      double s = rk[RIC_KV + i];
-      for (int l = 0; l < NX; ++l) s += rk[RIC_K + i * NX + l] * w.dx[l];
+      const double s = rk[RIC_KV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
       w.ut[i] = s;
       ut_out[(size_t)k * NUT + i] = s;
     }
     WG_SYNC(ctx);
+    WG_FOR(ctx, it, (NX + NU) * 4) {
+      const int r = it >> 2, p = it & 3;
+      const double* Ax = r < NX ? q + QP_A + r * NX : q + QP_PX + (r - NX) * NX;
+      const double* Bx = r < NX ? q + QP_B + r * NUT : q + QP_PU + (r - NX) * NUT;
+      double s = 0.0;
+      for (int c = p; c < NX; c += 4) s += Ax[c] * w.dx[c];
+      for (int c = p; c < NUT; c += 4) s += Bx[c] * w.ut[c];
+      w.part[it] = s;
+    }
+    WG_SYNC(ctx);
     WG_FOR(ctx, i, NX + NU) {
+      const double s4 = (w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]);
       if (i < NX) {
-        double s = q[QP_BV + i];
-        for (int l = 0; l < NX; ++l) s += q[QP_A + i * NX + l] * w.dx[l];
-        for (int l = 0; l < NUT; ++l) s += q[QP_B + i * NUT + l] * w.ut[l];
+        const double s = q[QP_BV + i] + s4;
         w.dxn[i] = s;
         dx_out[(size_t)(k + 1) * NX + i] = s;
         x_new[(size_t)(k + 1) * NX + i] = x[(size_t)(k + 1) * NX + i] + alpha * s;
       } else {
         const int r = i - NX;
-        double s = q[QP_PE + r];
-        for (int l = 0; l < NX; ++l) s += q[QP_PX + r * NX + l] * w.dx[l];
-        for (int l = 0; l < NUT; ++l) s += q[QP_PU + r * NUT + l] * w.ut[l];
+        const double s = q[QP_PE + r] + s4;
         du_out[(size_t)k * NU + r] = s;
         u_new[(size_t)k * NU + r] = u[(size_t)k * NU + r] + alpha * s;
       }
@@ -189,7 +202,7 @@ HSQP_HD void kkt_residual(const Ctx& ctx, RicWS& w, const double* Qf, const doub
   WG_FOR(ctx, i, NX) {
     const double dN = dx[(size_t)N * NX + i];
     w.sv[i] = Qf[i] * dN + Qf[i] * (x[(size_t)N * NX + i] - parN[HSQP_P_XDES + i]);
-    w.sb[i] = fabs(dx[i] - (x_init[i] - x[i]));   // primal residual accumulator (per lane-owned slot)
+    w.sb[i] = fabs(dx[i] - (x_init[i] - x[i]));   // primal residual accumulator (one slot per row)
     w.bt[i] = 0.0;                                 // stationarity accumulator
   }
   WG_SYNC(ctx);

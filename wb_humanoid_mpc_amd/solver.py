@@ -138,8 +138,8 @@ class HipSqpSolver:
         p, keep, self._shape = self._problem(x_init, x_traj, u_traj, params, dt)
         self._check(self.lib.hsqp_upload(self.h, C.byref(p)))
 
-    def iterate(self, n_iterations=1, take_step=False):
-        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, int(take_step)))
+    def iterate(self, n_iterations=1, take_step=False, kkt=False):
+        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0)))
 
     def download(self):
         B, N = self._shape
