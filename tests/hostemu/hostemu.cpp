@@ -23,7 +23,7 @@ void emu_destroy(void* h) { delete static_cast<DevModel*>(h); }
 void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double* ab, double* G) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   auto ws = std::make_unique<StageWS>();
-  Ctx ctx{0, 1};
+  Ctx ctx{0, 1, nullptr};
   for (int i = 0; i < NV; ++i) { ws->q[i] = x[i]; ws->v[i] = x[NV + i]; }
   for (int i = 0; i < 12; ++i) ws->W[i] = u[i];
   for (int i = 0; i < NJ; ++i) ws->qddj[i] = u[12 + i];
@@ -38,7 +38,7 @@ int emu_rec_size() { return REC_SIZE; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   auto w = std::make_unique<LqWS>();
-  Ctx ctx{0, 1};
+  Ctx ctx{0, 1, nullptr};
   if (deriv) lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); else lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC);
 }
 // dense blocks from a record: AB[58*93], H[93*93], g[93], CDe[14*94]
@@ -61,7 +61,7 @@ int emu_qp_size() { return QP_SIZE; }
 int emu_ric_size() { return RIC_SIZE; }
 void emu_project_node(const double* rec, double dt, double* qp) {
   auto w = std::make_unique<ProjWS>();
-  Ctx ctx{0, 1};
+  Ctx ctx{0, 1, nullptr};
   project_node(ctx, *w, rec, dt, qp);
 }
 // one full SQP iteration of one instance through the kernel sources; returns 0 or HSQP_ERR_NUMERIC
@@ -69,7 +69,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
                       double* x_new, double* u_new, double* dx, double* du, double* kkt, double* perf_before /*3: cost,dyn,eq*/,
                       double* perf_after, double* qp_out) {
   const DevModel& dm = *static_cast<DevModel*>(h);
-  Ctx ctx{0, 1};
+  Ctx ctx{0, 1, nullptr};
   std::vector<double> rec((size_t)N * REC_SIZE), qp((size_t)N * QP_SIZE), ric((size_t)N * RIC_SIZE), ut((size_t)N * NUT);
   auto lw = std::make_unique<LqWS>();
   auto pw = std::make_unique<ProjWS>();

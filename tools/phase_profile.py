@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock profile of the kernels (GPU box): builds/uses libhsqp_hip_prof.so (-DHSQP_PHASE_PROFILE),
+runs a few iterations of the bench workload and prints ticks per phase for workgroup 0 of each kernel."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HSQP_LIB"] = os.path.join(ROOT, "wb_humanoid_mpc_amd", "libhsqp_hip_prof.so")
+import numpy as np  # noqa: E402
+
+from wb_humanoid_mpc_amd import load_model  # noqa: E402
+from wb_humanoid_mpc_amd.reference import make_problem  # noqa: E402
+from wb_humanoid_mpc_amd.solver import HipSqpSolver  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+iters = 3
+m = load_model()
+x0, x, u, par, dt = make_problem(m, n_nodes=N, batch=B, perturb=True)
+s = HipSqpSolver(m, max_nodes=N, max_batch=B)
+s.upload(x0, x, u, par, dt)
+for _ in range(iters):
+    s.iterate(1, kkt=True)
+print("kernel ms (last iteration):", {k: round(v, 3) for k, v in s.kernel_ms().items()})
+t = np.zeros((4, 128), dtype=np.int64)
+s.lib.hsqp_debug_read(s.h, 100, t.ctypes.data_as(C.c_void_p), t.nbytes)
+names = ["k_lq<true>", "k_project", "k_riccati", "k_lq<false>"]
+for k in range(4):
+    tot = t[k, :126].sum()
+    print(f"== {names[k]}: {tot / iters:.0f} ticks per launch (workgroup 0)  [~{tot / iters / 2.4e3:.1f} us at 2.4 GHz]")
+    for i in range(126):
+        if t[k, i]:
+            print(f"   phase {i:3d}: {t[k, i] / iters:12.0f} ticks  {100.0 * t[k, i] / tot:5.1f}%")

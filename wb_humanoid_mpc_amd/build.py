@@ -15,7 +15,16 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False, verbose=False, extra=()):
+def build_hip(force=False, verbose=False, extra=(), phase_profile=False):
+    """phase_profile=True builds libhsqp_hip_prof.so with -DHSQP_PHASE_PROFILE (tools/phase_profile.py)."""
+    global LIB
+    lib = LIB.replace(".so", "_prof.so") if phase_profile else LIB
+    if phase_profile:
+        extra = tuple(extra) + ("-DHSQP_PHASE_PROFILE",)
+    return _build(lib, force, verbose, extra)
+
+
+def _build(LIB, force, verbose, extra):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_HERE, "..", "include", "hsqp.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB

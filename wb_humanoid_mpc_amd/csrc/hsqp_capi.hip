@@ -25,10 +25,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 template <bool DERIV>
 __global__ __launch_bounds__(LQ_THREADS, 2) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
                                                    const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
-                                                   double* __restrict__ rec, double* __restrict__ misc) {
+                                                   double* __restrict__ rec, double* __restrict__ misc, long long* prof) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   LqWS& w = *reinterpret_cast<LqWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   lq_node<DERIV>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt,
                  DERIV ? rec + (size_t)node * REC_SIZE : nullptr,
@@ -36,9 +37,10 @@ __global__ __launch_bounds__(LQ_THREADS, 2) void k_lq(const DevModel* __restrict
 }
 
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp) {
+__global__ __launch_bounds__(PROJ_THREADS) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE);
 }
 
@@ -49,10 +51,11 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
                                                          double* __restrict__ ric, int N, double alpha, double* __restrict__ dx,
                                                          double* __restrict__ du, double* __restrict__ ut, double* __restrict__ x_new,
                                                          double* __restrict__ u_new, double* __restrict__ kkt, int* __restrict__ status,
-                                                         int want_kkt) {
+                                                         int want_kkt, long long* prof) {
   const int b = blockIdx.x;
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xb = x + (size_t)b * (N + 1) * NX;
   const double* ub = u + (size_t)b * N * NU;
   const double* parN = par + ((size_t)b * (N + 1) + N) * NP;
@@ -66,9 +69,12 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N);
   double* dxb = dx + (size_t)b * (N + 1) * NX;
   double* utb = ut + (size_t)b * N * NUT;
+  PH_TICK(ctx, 0);
   riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ub, qpb, ricb, N, alpha, dxb, du + (size_t)b * N * NU, utb,
                   x_new + (size_t)b * (N + 1) * NX, u_new + (size_t)b * N * NU);
+  PH_TICK(ctx, 10);
   if (want_kkt) kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, xb, parN, qpb, dxb, utb, N, kkt + 2 * b);
+  PH_TICK(ctx, 11);
   if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
 }
 
@@ -112,6 +118,7 @@ struct hsqp_handle {
   double *d_misc = nullptr, *d_kkt = nullptr;
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
+  long long* d_prof = nullptr;   // [4][128] phase-profile ticks (k_lq<true>, k_project, k_riccati, k_lq<false>)
   int B = 0, N = 0;
   double dt = 0.0;
   bool have_problem = false, have_solution = false;
@@ -146,7 +153,7 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status};
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -183,10 +190,11 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
       {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
-      {(void**)&h->d_status, B * sizeof(int)}};
+      {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)}};
   for (const Alloc& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
+  if (hipMemset(h->d_prof, 0, 4 * 128 * sizeof(long long)) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
@@ -228,15 +236,15 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool last = it == n_iterations - 1;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
-                       h->d_rec, (double*)nullptr);
+                       h->d_rec, (double*)nullptr, h->d_prof);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp);
+    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par,
-                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, want_kkt);
+                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, want_kkt, h->d_prof + 256);
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
-                       N, (double*)nullptr, h->d_misc);
+                       N, (double*)nullptr, h->d_misc, h->d_prof + 384);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after);
     if (last) HCHECK(hipEventRecord(h->ev[4], h->stream));
@@ -374,6 +382,12 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
     }
     case HSQP_BLK_DX: out.resize(B * (N + 1) * NX); if (hipMemcpy(out.data(), h->d_dx, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;
     case HSQP_BLK_DU: out.resize(B * N * NU); if (hipMemcpy(out.data(), h->d_du, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;
+    case 100: {  // phase-profile ticks (only meaningful in -DHSQP_PHASE_PROFILE builds)
+      std::vector<long long> t(4 * 128);
+      if (hipMemcpy(t.data(), h->d_prof, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP;
+      if (dst && bytes > 0) memcpy(dst, t.data(), (size_t)(bytes < (long long)t.size() * 8 ? bytes : (long long)t.size() * 8));
+      return (long long)t.size() * 8;
+    }
     default: h->err = "unknown block id"; return HSQP_ERR_BAD_ARG;
   }
   const long long size = iout.empty() ? (long long)out.size() * 8 : (long long)iout.size() * 4;

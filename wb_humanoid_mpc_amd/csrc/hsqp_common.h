@@ -38,7 +38,22 @@ constexpr int NLEVELS = 8;     // depth of the body tree incl. the base
 struct Ctx {
   int tid;
   int nthreads;
+  long long* prof;   // phase-profile buffer of workgroup 0 (only in -DHSQP_PHASE_PROFILE builds), else null
 };
+
+// Phase profiling (tools/phase_profile.py): thread 0 of workgroup 0 accumulates shader-clock ticks per phase id.
+#if defined(HSQP_PHASE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define PH_TICK(ctx, id)                                                             \
+  do {                                                                               \
+    if ((ctx).tid == 0 && (ctx).prof) {                                              \
+      const long long t_ = clock64();                                                \
+      (ctx).prof[id] += t_ - (ctx).prof[127];                                        \
+      (ctx).prof[127] = t_;                                                          \
+    }                                                                                \
+  } while (0)
+#else
+#define PH_TICK(ctx, id) ((void)0)
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WG_SYNC(ctx) __syncthreads()

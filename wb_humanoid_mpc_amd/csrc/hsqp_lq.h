@@ -83,17 +83,23 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
   }
   WG_SYNC(ctx);
   for (int s = 0; s < 4; ++s) {
+    PH_TICK(ctx, 1);
     rk4_stage_inputs(ctx, w, s, dt);
     stage_eval<DERIV>(ctx, dm, w.st);
+    PH_TICK(ctx, 2);
     WG_FOR(ctx, i, 6 + (DERIV ? 6 * LDJ : 0)) {
       if (i < 6) w.as[s][i] = w.st.ab[i];
       else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; w.Gs[s][r][c] = c < NZ ? w.st.G[r][c] : 0.0; }
     }
     WG_SYNC(ctx);
     if (s == 0) {
+      PH_TICK(ctx, 3);
       node_values(ctx, dm, w.st, w.nw);
+      PH_TICK(ctx, 4);
       node_scalars(ctx, dm, w.st, w.nw);
+      PH_TICK(ctx, 5);
       if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J);
+      PH_TICK(ctx, 6);
       if (DERIV) WG_FOR(ctx, i, 64 + NRS) {
         if (i < 64) {
           double f = 0.0;
@@ -108,6 +114,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
       WG_SYNC(ctx);
     }
   }
+  PH_TICK(ctx, 7);
   // ---- RK4 value: x_next = x + dt/6 (k1 + 2 k2 + 2 k3 + k4), defect, performance terms
   WG_FOR(ctx, i, 64) {
     double b = 0.0;
@@ -160,6 +167,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
     }
     WG_SYNC(ctx);
   }
+  PH_TICK(ctx, 8);
   WG_FOR(ctx, i, 2 * 6 * LDJ) {
     const int which = i / (6 * LDJ), r = (i / LDJ) % 6, col = i % LDJ;
     double v;
@@ -168,6 +176,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* 
     rec[REC_PV + i] = v;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 9);
 }
 
 // Expand the structured record into the dense [A|B] (58 x 93) — used by the debug/parity path and by tests.

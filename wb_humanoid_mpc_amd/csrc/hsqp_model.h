@@ -109,6 +109,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 20);
   // ---- forward kinematics, one phase per tree level
   for (int l = 1; l < NLEVELS; ++l) {
     const int b0 = dm.level_start[l], b1 = dm.level_start[l + 1];
@@ -129,6 +130,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     }
     WG_SYNC(ctx);
   }
+  PH_TICK(ctx, 21);
   // ---- per-body spatial inertia about O and net force
   WG_FOR(ctx, i, NB) {
     const double* Rb = ws.R[i];
@@ -151,6 +153,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     for (int k = 0; k < 6; ++k) ws.f[i][k] = fa[k] + fv[k];
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 22);
   if (DERIV) {
     WG_FOR(ctx, it, NB * 6) {
       const int i = it / 6, k = it % 6;
@@ -160,6 +163,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
       for (int r = 0; r < 6; ++r) ws.BB[i][6 * r + k] = col[r];
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 23);
     // composites over subtrees (bodies are in depth-first order)
     WG_FOR(ctx, it, NB * 52) {
       const int i = it / 52, e = it % 52;
@@ -177,6 +181,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 24);
   // ---- totals and the block-diagonal base solve
   WG_FOR(ctx, it, 1) {
     double Fext[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -198,6 +203,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     m3_mulv(ws.Einv, ws.y, ws.ab + 3);
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 25);
   if (!DERIV) return;
   // ---- Jacobian columns: items (jc, kind in {q, qd, qdd}) and the 12 wrench components
   WG_FOR(ctx, it, NJC * 3 + 12) {
@@ -283,6 +289,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     ws.G[r][c < 3 ? c : NV + (c - 3)] = 0.0;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 26);
 }
 
 }  // namespace hsqp

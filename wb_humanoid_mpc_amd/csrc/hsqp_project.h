@@ -73,6 +73,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut;
+  PH_TICK(ctx, 1);
   // ---- Householder QR of D^T, accumulating Q^T
   WG_FOR(ctx, i, NU * NE_MAX + NU * NU) {
     if (i < NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
@@ -109,6 +110,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
     WG_SYNC(ctx);
   }
+  PH_TICK(ctx, 2);
   // ---- W = R1^-T [C | e]: forward substitution per column
   WG_FOR(ctx, c, NX + 1) {
     for (int i = 0; i < ne; ++i) {
@@ -118,6 +120,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 3);
   // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
   wg_xty<4, 4>(ctx, NU, NX + 1, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, AllTiles(),
                [&](int r, int c, double v) { w.Tm[r][c < NX ? c : NTW] = -v; });
@@ -127,6 +130,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     else w.Tm[r][NTW + 1 + (cc - NUT)] = 0.0;
   }
   WG_SYNC(ctx);  // QR data dead from here: JuT aliases it
+  PH_TICK(ctx, 4);
   // ---- stage the (transposed) input block of the residual rows, write the projection
   WG_FOR(ctx, i, NRS * NU + NU * (NX + NUT + 1) + 1) {
     if (i < NRS * NU) { const int r = i / NU, k = i % NU; w.JuT[k][r] = rec[REC_J + r * LDJ + NX + k]; continue; }
@@ -163,6 +167,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 5);
   // ---- residual rows after projection: J T (+ rho' in column 81), then the input-weight rows sqrt(d_u) [Px|Pu|Pe]
   wg_xty<4, 4>(ctx, NRS, NTW + 1, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, AllTiles(),
                [&](int r, int a, double v) { w.Jt[r][a] = v + (a < NX ? rec[REC_J + r * LDJ + a] : (a == NTW ? w.rho[r] : 0.0)); });
@@ -171,6 +176,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     w.Jt[NRS + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 6);
   // ---- projected Hessian (upper triangle, mirrored on write) and gradient (column 81 of the same product)
   wg_xty<4, 4>(ctx, NTW, NTW + 1, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, UpperTiles(), [&](int a, int b, double s) {
     if (b == NTW) {   // gradient: g~ = T^T gd + J~ext^T rho'
@@ -189,6 +195,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
   });
   WG_SYNC(ctx);
+  PH_TICK(ctx, 7);
 }
 
 }  // namespace hsqp

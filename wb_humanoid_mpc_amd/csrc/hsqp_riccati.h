@@ -45,6 +45,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
   for (int k = N - 1; k >= 0; --k) {
     const double* q = qp + (size_t)k * QP_SIZE;
     double* rk = ric + (size_t)k * RIC_SIZE;
+    PH_TICK(ctx, 9);
     // ---- P1: stage data -> LDS (coalesced)
     WG_FOR(ctx, i, NX * NX + NX * LDB + NX) {
       if (i < NX * NX) w.A[i / NX][i % NX] = q[QP_A + i];
@@ -52,6 +53,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       else w.bt[i - NX * NX - NX * LDB] = q[QP_BV + i - NX * NX - NX * LDB];
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 1);
     // ---- P2: SA = S A, SB = S B (S symmetric => X = S), sb = s + S b
     wg_xty<4, 4>(ctx, NX, NX, NX, &w.S[0][0], NX, &w.A[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.SA[r][c] = v; });
     wg_xty<4, 4>(ctx, NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, AllTiles(), [&](int r, int c, double v) { w.SB[r][c] = v; });
@@ -61,6 +63,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       w.sb[r] = s;
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 2);
     // ---- P3: Lam = R + B^T SB, G = P + B^T SA, g = r + B^T sb
     wg_xty<4, 4>(ctx, NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, AllTiles(),
                  [&](int r, int c, double v) { w.Lam[r][c] = v + q[QP_R + r * NUT + c]; });
@@ -72,6 +75,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       w.gv[r] = s;
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 3);
     // ---- P4: right-looking Cholesky of Lam (lower triangle; the diagonal square roots go to dsq)
     for (int j = 0; j < NUT; ++j) {
       WG_FOR(ctx, it, NUT - j) {
@@ -89,6 +93,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       }
       WG_SYNC(ctx);
     }
+    PH_TICK(ctx, 4);
     // ---- P5: M1 = L^-1 (lower) and its transpose, one column per item (forward substitution)
     WG_FOR(ctx, j, NUT) {
       for (int i = 0; i < NUT; ++i) {
@@ -103,6 +108,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       }
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 5);
     // ---- P6: Z = L^-1 G = (M1T)^T G, z = L^-1 g
     wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1T[0][0], LDB, &w.Gm[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.Z[r][c] = v; });
     WG_FOR(ctx, r, NUT) {
@@ -111,6 +117,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       w.zv[r] = s;
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 6);
     // ---- P7: K = -L^-T Z = -(M1)^T Z, k = -L^-T z ; stored for the forward pass
     wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1[0][0], LDB, &w.Z[0][0], NX, AllTiles(),
                  [&](int r, int c, double v) { w.Km[r][c] = -v; rk[RIC_K + r * NX + c] = -v; });
@@ -121,6 +128,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       rk[RIC_KV + r] = -s;
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 7);
     // ---- P8: S <- Q + A^T SA + G^T K (upper tiles; S itself is dead since P2), s <- q + A^T sb + G^T k
     wg_xty2<4, 4>(ctx, NX, NX, NX, &w.A[0][0], NX, &w.SA[0][0], NX, NUT, &w.Gm[0][0], NX, &w.Km[0][0], NX, UpperTiles(),
                   [&](int r, int c, double v) { if (c >= r) w.S[r][c] = v + q[QP_Q + r * NX + c]; });
@@ -131,6 +139,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       w.sn[r] = s;
     }
     WG_SYNC(ctx);
+    PH_TICK(ctx, 8);
     // ---- P9: mirror the upper triangle, roll s
     WG_FOR(ctx, i, NX * NX + NX) {
       if (i < NX * NX) { const int r = i / NX, c = i % NX; if (r > c) w.S[r][c] = w.S[c][r]; }

@@ -18,7 +18,7 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsqp_hip.so")
+LIB_PATH = os.environ.get("HSQP_LIB") or os.path.join(_HERE, "libhsqp_hip.so")   # HSQP_LIB: debug builds only
 _dp = C.POINTER(C.c_double)
 _lib = None
 
