@@ -85,8 +85,14 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   pb[0] += terminal(x);
   riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N);
   if (!rw->ok) return HSQP_ERR_NUMERIC;
-  riccati_forward(ctx, *rw, x_init, x, u, qp.data(), ric.data(), N, 1.0, dx, du, ut.data(), x_new, u_new);
-  kkt_residual(ctx, *rw, dm.Qf, x_init, x, par + N * NP, qp.data(), dx, ut.data(), N, kkt);
+  riccati_forward(ctx, *rw, x_init, x, ric.data(), N, dx);
+  auto sw = std::make_unique<StepWS>();
+  for (int k = 0; k < N; ++k)
+    step_node(ctx, *sw, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],
+              du + k * NU, x_new + k * NX, u_new + k * NU);
+  for (int i = 0; i < NX; ++i) x_new[N * NX + i] = x[N * NX + i] + dx[N * NX + i];
+  auto kw = std::make_unique<KktWS>();
+  kkt_residual(ctx, *kw, dm.Qf, x_init, x, par + N * NP, qp.data(), dx, ut.data(), N, kkt);
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {

@@ -44,38 +44,54 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project(const double* __restri
   project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE);
 }
 
-// ---- Riccati backward + forward + KKT residual: one workgroup per instance
+// ---- Riccati backward sweep + closed-loop forward sweep (dx): one workgroup per instance
 __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
-                                                         const double* __restrict__ x, const double* __restrict__ u,
-                                                         const double* __restrict__ par, const double* __restrict__ qp,
-                                                         double* __restrict__ ric, int N, double alpha, double* __restrict__ dx,
-                                                         double* __restrict__ du, double* __restrict__ ut, double* __restrict__ x_new,
-                                                         double* __restrict__ u_new, double* __restrict__ kkt, int* __restrict__ status,
-                                                         int want_kkt, long long* prof) {
+                                                         const double* __restrict__ x, const double* __restrict__ par,
+                                                         const double* __restrict__ qp, double* __restrict__ ric, int N,
+                                                         double* __restrict__ dx, int* __restrict__ status, long long* prof) {
   const int b = blockIdx.x;
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xb = x + (size_t)b * (N + 1) * NX;
-  const double* ub = u + (size_t)b * N * NU;
   const double* parN = par + ((size_t)b * (N + 1) + N) * NP;
   const double* qpb = qp + (size_t)b * N * QP_SIZE;
   double* ricb = ric + (size_t)b * N * RIC_SIZE;
-  // projection failures of this instance (rank-deficient D)
-  int mybad = 0;
+  int mybad = 0;  // projection failures of this instance (rank-deficient D)
   for (int k = threadIdx.x; k < N; k += blockDim.x)
     if (qpb[(size_t)k * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
   const int bad = __syncthreads_or(mybad);
   riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N);
-  double* dxb = dx + (size_t)b * (N + 1) * NX;
-  double* utb = ut + (size_t)b * N * NUT;
   PH_TICK(ctx, 0);
-  riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ub, qpb, ricb, N, alpha, dxb, du + (size_t)b * N * NU, utb,
-                  x_new + (size_t)b * (N + 1) * NX, u_new + (size_t)b * N * NU);
+  riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
-  if (want_kkt) kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, xb, parN, qpb, dxb, utb, N, kkt + 2 * b);
-  PH_TICK(ctx, 11);
   if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
+}
+
+// ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
+__global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, const double* __restrict__ ric, const double* __restrict__ dx,
+                                             const double* __restrict__ x, const double* __restrict__ u, int N, double alpha,
+                                             double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
+                                             double* __restrict__ u_new) {
+  __shared__ StepWS w;
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
+  step_node(ctx, w, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
+            du + uo, x_new + xo, u_new + uo);
+  if (k == N - 1)
+    for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
+}
+
+// ---- KKT residual of the projected QP: one workgroup per instance (reporting only, not part of an SQP step)
+__global__ __launch_bounds__(128) void k_kkt(const DevModel* __restrict__ dm, const double* __restrict__ x_init, const double* __restrict__ x,
+                                             const double* __restrict__ par, const double* __restrict__ qp, const double* __restrict__ dx,
+                                             const double* __restrict__ ut, int N, double* __restrict__ kkt) {
+  __shared__ KktWS w;
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, par + ((size_t)b * (N + 1) + N) * NP,
+               qp + (size_t)b * N * QP_SIZE, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT, N, kkt + 2 * b);
 }
 
 // ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
@@ -240,8 +256,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par,
-                       h->d_qp, h->d_ric, N, 1.0, h->d_dx, h->d_du, h->d_ut, h->d_xnew, h->d_unew, h->d_kkt, h->d_status, want_kkt, h->d_prof + 256);
+    hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                       h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256);
+    hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+                       h->d_xnew, h->d_unew);
+    if (want_kkt)
+      hipLaunchKernelGGL(k_kkt, dim3(B), dim3(128), 0, h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dx, h->d_ut, N, h->d_kkt);
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
                        N, (double*)nullptr, h->d_misc, h->d_prof + 384);

@@ -11,22 +11,21 @@
 
 namespace hsqp {
 
-// Generic tile loop:  C = X1^T Y1 + X2^T Y2  (second product optional: L2 = 0).
-// store(r, c, value) is called for every in-range element of the tile; tile_ok(tr, tc) lets the caller skip
-// tiles (e.g. the strictly lower part of a symmetric result).
-template <int TM, int TN, class TileOk, class Store>
+// Generic tile loop:  C = X1^T Y1 + sign2 * X2^T Y2  (second product optional: L2 = 0; sign2 = +1 or -1).
+// A work item owns the STRIDED tile  rows {tr + i*tm}, cols {tc + j*tn}  (tm = ceil(M/TM), tn = ceil(N/TN)):
+// consecutive lanes then read consecutive LDS words of a row of X / Y (conflict-free ds_read_b64) instead of
+// words 8*TN bytes apart.  store(r, c, value) is called for every in-range element of the tile.
+template <int TM, int TN, class Store>
 HSQP_HD void wg_xty2(const Ctx& ctx, int M, int N, int L1, const double* X1, int ldx1, const double* Y1, int ldy1, int L2,
-                     const double* X2, int ldx2, const double* Y2, int ldy2, TileOk tile_ok, Store store) {
+                     const double* X2, int ldx2, const double* Y2, int ldy2, double sign2, Store store) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   WG_FOR(ctx, t, tm * tn) {
     const int tr = t / tn, tc = t % tn;
-    if (!tile_ok(tr, tc)) continue;
-    const int r0 = tr * TM, c0 = tc * TN;
     int xo[TM], yo[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xo[i] = (r0 + i < M) ? r0 + i : M - 1;   // clamp: duplicates are computed, never stored
+    for (int i = 0; i < TM; ++i) xo[i] = (tr + i * tm < M) ? tr + i * tm : M - 1;   // clamp: duplicates are computed, never stored
 #pragma unroll
-    for (int j = 0; j < TN; ++j) yo[j] = (c0 + j < N) ? c0 + j : N - 1;
+    for (int j = 0; j < TN; ++j) yo[j] = (tc + j * tn < N) ? tc + j * tn : N - 1;
     double acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -43,7 +42,7 @@ HSQP_HD void wg_xty2(const Ctx& ctx, int M, int N, int L1, const double* X1, int
         const double* xr = X + l * ldx;
         const double* yr = Y + l * ldy;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = xr[xo[i]];
+        for (int i = 0; i < TM; ++i) a[i] = seg ? sign2 * xr[xo[i]] : xr[xo[i]];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = yr[yo[j]];
 #pragma unroll
@@ -56,21 +55,14 @@ HSQP_HD void wg_xty2(const Ctx& ctx, int M, int N, int L1, const double* X1, int
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        if (r0 + i < M && c0 + j < N) store(r0 + i, c0 + j, acc[i][j]);
+        if (tr + i * tm < M && tc + j * tn < N) store(tr + i * tm, tc + j * tn, acc[i][j]);
   }
 }
 
-template <int TM, int TN, class TileOk, class Store>
-HSQP_HD void wg_xty(const Ctx& ctx, int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, TileOk tile_ok, Store store) {
-  wg_xty2<TM, TN>(ctx, M, N, L, X, ldx, Y, ldy, 0, X, ldx, Y, ldy, tile_ok, store);
+template <int TM, int TN, class Store>
+HSQP_HD void wg_xty(const Ctx& ctx, int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, Store store) {
+  wg_xty2<TM, TN>(ctx, M, N, L, X, ldx, Y, ldy, 0, X, ldx, Y, ldy, 1.0, store);
 }
-
-struct AllTiles {
-  HSQP_HD bool operator()(int, int) const { return true; }
-};
-struct UpperTiles {  // tiles that contain at least one element with c >= r (square tiles)
-  HSQP_HD bool operator()(int tr, int tc) const { return tc >= tr; }
-};
 
 // y[r] (+)= sum_c A[r][c] x[c] for a row-major matrix in GLOBAL memory, 4 work items per row with a
 // deterministic two-phase reduction through `part` (LDS, rows x 4).

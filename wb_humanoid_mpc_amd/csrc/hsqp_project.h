@@ -39,8 +39,8 @@ struct ProjWS {
       double Rm[NU][NE_MAX];     // D^T, overwritten by R1
       double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
-      double hv[NU];             // Householder vector
-      double hs[2];              // {2/|v|^2}
+      double V[NE_MAX][NU + 1];  // Householder vectors
+      double beta[NE_MAX], Rdiag[NE_MAX];
     } qr;
     double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
   };
@@ -74,55 +74,67 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut;
   PH_TICK(ctx, 1);
-  // ---- Householder QR of D^T, accumulating Q^T
-  WG_FOR(ctx, i, NU * NE_MAX + NU * NU) {
-    if (i < NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
-    else { const int r = (i - NU * NE_MAX) / NU, c = (i - NU * NE_MAX) % NU; w.qr.QT[r][c] = r == c ? 1.0 : 0.0; }
-  }
+  // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
+  // left untouched: its final diagonal goes to Rdiag, the vector to V), so one barrier per step suffices.
+  WG_FOR(ctx, i, NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
   WG_SYNC(ctx);
   for (int k = 0; k < ne; ++k) {
-    WG_FOR(ctx, it, 1) {
-      double nrm = 0.0;
-      for (int i = k; i < NU; ++i) nrm += w.qr.Rm[i][k] * w.qr.Rm[i][k];
-      nrm = sqrt(nrm);
-      if (!(nrm >= 1e-12)) w.ok = 0;
-      const double alpha = w.qr.Rm[k][k] >= 0.0 ? -nrm : nrm;
-      double vn = 0.0;
-      for (int i = 0; i < NU; ++i) {
-        double v = i < k ? 0.0 : w.qr.Rm[i][k];
-        if (i == k) v -= alpha;
-        w.qr.hv[i] = v;
-        vn += v * v;
+    WG_FOR(ctx, it, ne - k) {
+      const int c = k + it;
+      double nrm2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { const double xv = i >= k ? w.qr.Rm[i][k] : 0.0; nrm2 += xv * xv; }
+      const double nrm = sqrt(nrm2), rkk = w.qr.Rm[k][k];
+      const double alpha = rkk >= 0.0 ? -nrm : nrm;
+      const double vn = 2.0 * (nrm2 - alpha * rkk);
+      const double beta = vn > 1e-300 ? 2.0 / vn : 0.0;
+      if (c == k) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) w.qr.V[k][i] = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0));
+        w.qr.beta[k] = beta;
+        w.qr.Rdiag[k] = alpha;
+        if (!(nrm >= 1e-12)) w.ok = 0;
+      } else {
+        double sdot = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0)); sdot += vi * w.qr.Rm[i][c]; }
+        sdot *= beta;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0)); if (i >= k) w.qr.Rm[i][c] -= sdot * vi; }
       }
-      w.qr.hs[0] = vn > 1e-300 ? 2.0 / vn : 0.0;
-    }
-    WG_SYNC(ctx);
-    WG_FOR(ctx, it, (ne - k) + NU) {   // apply (I - beta v v^T) from the left to the columns of R and of Q^T
-      const double beta = w.qr.hs[0];
-      const bool isR = it < ne - k;
-      const int c = isR ? k + it : it - (ne - k);
-      double s = 0.0;
-      if (isR) { for (int i = k; i < NU; ++i) s += w.qr.hv[i] * w.qr.Rm[i][c]; }
-      else { for (int i = k; i < NU; ++i) s += w.qr.hv[i] * w.qr.QT[i][c]; }
-      s *= beta;
-      if (isR) { for (int i = k; i < NU; ++i) w.qr.Rm[i][c] -= s * w.qr.hv[i]; }
-      else { for (int i = k; i < NU; ++i) w.qr.QT[i][c] -= s * w.qr.hv[i]; }
     }
     WG_SYNC(ctx);
   }
+  // Q^T = H_{ne-1} ... H_0: one column per item, the column lives in registers while the reflectors are applied
+  WG_FOR(ctx, c, NU) {
+    double col[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) col[i] = i == c ? 1.0 : 0.0;
+    for (int k = 0; k < ne; ++k) {
+      double sdot = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) sdot += w.qr.V[k][i] * col[i];
+      sdot *= w.qr.beta[k];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) col[i] -= sdot * w.qr.V[k][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) w.qr.QT[i][c] = col[i];
+  }
+  WG_SYNC(ctx);
   PH_TICK(ctx, 2);
   // ---- W = R1^-T [C | e]: forward substitution per column
   WG_FOR(ctx, c, NX + 1) {
     for (int i = 0; i < ne; ++i) {
       double s = c < NX ? w.qr.CDe[i][c] : w.qr.CDe[i][NZ];
       for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * w.qr.Wm[j][c];
-      w.qr.Wm[i][c] = s / w.qr.Rm[i][i];
+      w.qr.Wm[i][c] = s / w.qr.Rdiag[i];
     }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 3);
   // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
-  wg_xty<4, 4>(ctx, NU, NX + 1, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, AllTiles(),
+  wg_xty<4, 4>(ctx, NU, NX + 1, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2,
                [&](int r, int c, double v) { w.Tm[r][c < NX ? c : NTW] = -v; });
   WG_FOR(ctx, i, NU * (NUT + 2)) {
     const int r = i / (NUT + 2), cc = i % (NUT + 2);
@@ -169,7 +181,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   PH_TICK(ctx, 5);
   // ---- residual rows after projection: J T (+ rho' in column 81), then the input-weight rows sqrt(d_u) [Px|Pu|Pe]
-  wg_xty<4, 4>(ctx, NRS, NTW + 1, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, AllTiles(),
+  wg_xty<4, 4>(ctx, NRS, NTW + 1, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM,
                [&](int r, int a, double v) { w.Jt[r][a] = v + (a < NX ? rec[REC_J + r * LDJ + a] : (a == NTW ? w.rho[r] : 0.0)); });
   WG_FOR(ctx, i, (NU + 1) * LDTM) {
     const int k = i / LDTM, a = i % LDTM;
@@ -177,21 +189,22 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 6);
-  // ---- projected Hessian (upper triangle, mirrored on write) and gradient (column 81 of the same product)
-  wg_xty<4, 4>(ctx, NTW, NTW + 1, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, UpperTiles(), [&](int a, int b, double s) {
+  // ---- projected Hessian and gradient (column 81 of the same product): H~ = diag + J~ext^T J~ext
+  wg_xty<8, 4>(ctx, NTW, NTW + 1, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, [&](int a, int b, double s) {
     if (b == NTW) {   // gradient: g~ = T^T gd + J~ext^T rho'
       if (a < NX) s += w.gd[a];
       for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
       if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
       return;
     }
-    if (b < a) return;
     if (a == b && a < NX) s += w.d[a];
-    if (b < NX) { qp[QP_Q + a * NX + b] = s; qp[QP_Q + b * NX + a] = s; }
-    else if (a < NX) { qp[QP_P + (b - NX) * NX + a] = s; }
-    else {
+    if (a < NX) {
+      if (b < NX) qp[QP_Q + a * NX + b] = s;
+    } else if (b < NX) {
+      qp[QP_P + (a - NX) * NX + b] = s;
+    } else {
       if (a - NX >= nut || b - NX >= nut) s = (a == b) ? 1.0 : 0.0;  // identity padding of the unused projected inputs
-      qp[QP_R + (a - NX) * NUT + (b - NX)] = s; qp[QP_R + (b - NX) * NUT + (a - NX)] = s;
+      qp[QP_R + (a - NX) * NUT + (b - NX)] = s;
     }
   });
   WG_SYNC(ctx);

@@ -1,39 +1,43 @@
 // Riccati recursion of the projected, equality-free stage QP (the reference solves
-// the same QP with HPIPM through ocs2's HpipmInterface — the minimiser is unique, A.1):
-//   backward  Lam = R~ + B~^T S+ B~ (Cholesky),  K = -Lam^-1 (P~ + B~^T S+ A~),  k = -Lam^-1 (r~ + B~^T (s+ + S+ b~))
-//             S = Q~ + A~^T S+ A~ + G^T K,  s = q~ + A~^T (s+ + S+ b~) + G^T k,   S_N = diag(Qf), s_N = Qf (x_N - x_des)
-//   forward   ut = K dx + k,  dx+ = A~ dx + B~ ut + b~,  du = Px dx + Pu ut + Pe
-// One workgroup per MPC instance; the stage matrices live in LDS for the whole backward step and every
-// product is a register-tiled X^T Y contraction (hsqp_linalg.h):
-//   SA = S^T A, SB = S^T B (S symmetric), Lam = R + B^T SB, G = P + B^T SA, Z = (L^-T)^T G, K = -(L^-1)^T Z,
-//   S <- Q + A^T SA + G^T K (upper tiles, mirrored).
+// the same QP with HPIPM through ocs2's HpipmInterface — the minimiser is unique, A.1).
+//
+// Backward sweep, one workgroup per MPC instance, stage matrices in LDS:
+//   SA = S+ A~, SB = S+ B~, sb = s+ + S+ b~
+//   [Lam | G | g | B~^T] = [R~ + B~^T SB | P~ + B~^T SA | r~ + B~^T sb | B~^T]            (23 x 140, augmented)
+//   right-looking Cholesky of Lam applied to the whole augmented matrix:  U = L^T, Z = L^-1 G, z = L^-1 g, Y = L^-1 B~^T
+//   S = Q~ + A~^T SA - Z^T Z,  s = q~ + A~^T sb - Z^T z          (= Q + A^T S A - G^T Lam^-1 G)
+//   Acl = A~ - Y^T Z,  bcl = b~ - Y^T z                           (closed loop: dx+ = Acl dx + bcl)
+// so no triangular back-substitution sits on the serial critical path.  The forward sweep is the
+// 58x58 mat-vec chain dx+ = Acl dx + bcl; the feed-forward/feedback inputs
+//   ut = -U^-1 (Z dx + z),  du = Px dx + Pu ut + Pe
+// are then recovered for all nodes in parallel (step_node).  Every product is a register-tiled
+// X^T Y contraction (hsqp_linalg.h).
 #pragma once
 #include "hsqp_linalg.h"
 #include "hsqp_project.h"
 
 namespace hsqp {
 
-constexpr int RIC_K = 0;                     // [23][58]
-constexpr int RIC_KV = RIC_K + NUT * NX;     // [23]
-constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
-constexpr int LDB = 24;                      // leading dimension of the 23-wide LDS matrices (16-byte aligned rows)
+constexpr int RIC_ACL = 0;                     // [58][58] closed-loop transition
+constexpr int RIC_BCL = RIC_ACL + NX * NX;     // [58]
+constexpr int RIC_U = RIC_BCL + NX;            // [23][23] upper Cholesky factor of Lam (U^T U = Lam)
+constexpr int RIC_Z = RIC_U + NUT * NUT;       // [23][58] L^-1 G
+constexpr int RIC_ZV = RIC_Z + NUT * NX;       // [23]     L^-1 g
+constexpr int RIC_SIZE = ((RIC_ZV + NUT + 7) / 8) * 8;
+constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices
+constexpr int EM_G = NUT, EM_GV = NUT + NX, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns
 
 struct RicWS {
   double S[NX][NX], A[NX][NX], SA[NX][NX];
-  double B[NX][LDB];
-  union {
-    double SB[NX][LDB];
-    double Z[NUT][NX];                       // L^-1 G (SB is dead once Lam and G are formed)
-  };
-  double Gm[NUT][NX], Km[NUT][NX];
-  double Lam[LDB][LDB], M1[LDB][LDB], M1T[LDB][LDB];   // Cholesky factor (lower, in place), L^-1 and its transpose
+  double B[NX][LDB], SB[NX][LDB];
+  double Em[NUT][LDE];                         // [Lam | G | g | B^T], factorised in place
   double dsq[LDB];
-  double sv[NX], sn[NX], sb[NX], bt[NX], gv[NUT], kv[NUT], zv[NUT], dx[NX], dxn[NX], ut[NUT];
-  double part[(NX + NU) * 4];
+  double sv[NX], sn[NX], sb[NX], bt[NX], dx[NX], dxn[NX];
+  double part[NX * 4];
   int ok;
 };
 
-// Returns through w.ok whether every Lam was positive definite.  qp: [N][QP_SIZE], ric: [N][RIC_SIZE].
+// qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
 HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const double* xN, const double* parN, const double* qp,
                               double* ric, int N) {
   WG_FOR(ctx, i, NX * NX + NX + 1) {
@@ -55,8 +59,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     WG_SYNC(ctx);
     PH_TICK(ctx, 1);
     // ---- P2: SA = S A, SB = S B (S symmetric => X = S), sb = s + S b
-    wg_xty<4, 4>(ctx, NX, NX, NX, &w.S[0][0], NX, &w.A[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.SA[r][c] = v; });
-    wg_xty<4, 4>(ctx, NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, AllTiles(), [&](int r, int c, double v) { w.SB[r][c] = v; });
+    wg_xty<4, 4>(ctx, NX, NX, NX, &w.S[0][0], NX, &w.A[0][0], NX, [&](int r, int c, double v) { w.SA[r][c] = v; });
+    wg_xty<4, 4>(ctx, NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, [&](int r, int c, double v) { w.SB[r][c] = v; });
     WG_FOR(ctx, r, NX) {
       double s = w.sv[r];
       for (int l = 0; l < NX; ++l) s += w.S[l][r] * w.bt[l];
@@ -64,155 +68,156 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
-    // ---- P3: Lam = R + B^T SB, G = P + B^T SA, g = r + B^T sb
-    wg_xty<4, 4>(ctx, NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, AllTiles(),
-                 [&](int r, int c, double v) { w.Lam[r][c] = v + q[QP_R + r * NUT + c]; });
-    wg_xty<4, 4>(ctx, NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, AllTiles(),
-                 [&](int r, int c, double v) { w.Gm[r][c] = v + q[QP_P + r * NX + c]; });
-    WG_FOR(ctx, r, NUT) {
-      double s = q[QP_RV + r];
-      for (int l = 0; l < NX; ++l) s += w.B[l][r] * w.sb[l];
-      w.gv[r] = s;
+    // ---- P3: augmented matrix [Lam | G | g | B^T]
+    wg_xty<4, 4>(ctx, NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, [&](int r, int c, double v) { w.Em[r][c] = v + q[QP_R + r * NUT + c]; });
+    wg_xty<4, 4>(ctx, NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, [&](int r, int c, double v) { w.Em[r][EM_G + c] = v + q[QP_P + r * NX + c]; });
+    WG_FOR(ctx, i, NUT + NUT * NX) {
+      if (i < NUT) {
+        double s = q[QP_RV + i];
+        for (int l = 0; l < NX; ++l) s += w.B[l][i] * w.sb[l];
+        w.Em[i][EM_GV] = s;
+      } else {
+        const int r = (i - NUT) / NX, c = (i - NUT) % NX;
+        w.Em[r][EM_BT + c] = w.B[c][r];
+      }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
-    // ---- P4: right-looking Cholesky of Lam (lower triangle; the diagonal square roots go to dsq)
+    // ---- P4: right-looking Cholesky (upper storage, U = L^T) carried through the augmented columns
     for (int j = 0; j < NUT; ++j) {
-      WG_FOR(ctx, it, NUT - j) {
-        const int i = j + it;
-        double dj = w.Lam[j][j];
+      WG_FOR(ctx, it, LDE - j) {
+        const int c = j + it;
+        double dj = w.Em[j][j];
         if (!(dj > 0.0)) { dj = 1.0; if (it == 0) w.ok = 0; }
         const double sq = sqrt(dj);
-        if (it == 0) w.dsq[j] = sq; else w.Lam[i][j] = w.Lam[i][j] / sq;
+        if (it == 0) w.dsq[j] = sq; else w.Em[j][c] = w.Em[j][c] / sq;
       }
       WG_SYNC(ctx);
-      const int m = NUT - 1 - j;
-      WG_FOR(ctx, it, m * m) {
-        const int i = j + 1 + it / m, c = j + 1 + it % m;
-        if (c <= i) w.Lam[i][c] -= w.Lam[i][j] * w.Lam[c][j];
+      const int m = NUT - 1 - j, nc = LDE - 1 - j;
+      WG_FOR(ctx, it, m * nc) {
+        const int i = j + 1 + it / nc, c = j + 1 + it % nc;
+        if (c >= i) w.Em[i][c] -= w.Em[j][i] * w.Em[j][c];
       }
       WG_SYNC(ctx);
     }
     PH_TICK(ctx, 4);
-    // ---- P5: M1 = L^-1 (lower) and its transpose, one column per item (forward substitution)
-    WG_FOR(ctx, j, NUT) {
-      for (int i = 0; i < NUT; ++i) {
-        double s = 0.0;
-        if (i >= j) {
-          s = i == j ? 1.0 : 0.0;
-          for (int l = j; l < i; ++l) s -= w.Lam[i][l] * w.M1[l][j];
-          s /= w.dsq[i];
-        }
-        w.M1[i][j] = s;
-        w.M1T[j][i] = s;
+    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A - Y^T Z, s <- q + A^T sb - Z^T z, bcl = b - Y^T z ; factors -> global
+    wg_xty2<4, 4>(ctx, NX, NX, NX, &w.A[0][0], NX, &w.SA[0][0], NX, NUT, &w.Em[0][EM_G], LDE, &w.Em[0][EM_G], LDE, -1.0,
+                  [&](int r, int c, double v) { w.S[r][c] = v + q[QP_Q + r * NX + c]; });
+    wg_xty<4, 4>(ctx, NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, [&](int r, int c, double v) { rk[RIC_ACL + r * NX + c] = w.A[r][c] - v; });
+    WG_FOR(ctx, i, 2 * NX + NUT * (NUT + NX + 1)) {
+      if (i < NX) {
+        const int r = i;
+        double s = q[QP_QV + r];
+        for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.sb[l];
+        for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
+        w.sn[r] = s;
+      } else if (i < 2 * NX) {
+        const int r = i - NX;
+        double s = w.bt[r];
+        for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
+        rk[RIC_BCL + r] = s;
+      } else {
+        const int j = i - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
+        if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
+        else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
+        else rk[RIC_ZV + r] = w.Em[r][EM_GV];
       }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
-    // ---- P6: Z = L^-1 G = (M1T)^T G, z = L^-1 g
-    wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1T[0][0], LDB, &w.Gm[0][0], NX, AllTiles(), [&](int r, int c, double v) { w.Z[r][c] = v; });
-    WG_FOR(ctx, r, NUT) {
-      double s = 0.0;
-      for (int l = 0; l <= r; ++l) s += w.M1[r][l] * w.gv[l];
-      w.zv[r] = s;
+    // ---- P6: symmetrise S (round-off only), roll s
+    WG_FOR(ctx, i, NX * (NX + 1) / 2 + NX) {
+      if (i < NX * (NX + 1) / 2) {
+        int t = i, r = 0;
+        while (t >= NX - r) { t -= NX - r; ++r; }
+        const int c = r + t;
+        if (c > r) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
+      } else {
+        w.sv[i - NX * (NX + 1) / 2] = w.sn[i - NX * (NX + 1) / 2];
+      }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 6);
-    // ---- P7: K = -L^-T Z = -(M1)^T Z, k = -L^-T z ; stored for the forward pass
-    wg_xty<4, 4>(ctx, NUT, NX, NUT, &w.M1[0][0], LDB, &w.Z[0][0], NX, AllTiles(),
-                 [&](int r, int c, double v) { w.Km[r][c] = -v; rk[RIC_K + r * NX + c] = -v; });
-    WG_FOR(ctx, r, NUT) {
-      double s = 0.0;
-      for (int l = r; l < NUT; ++l) s += w.M1[l][r] * w.zv[l];
-      w.kv[r] = -s;
-      rk[RIC_KV + r] = -s;
-    }
+  }
+}
+
+// Forward sweep dx+ = Acl dx + bcl (serial over stages); writes dx [N+1][58].
+HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* ric, int N, double* dx_out) {
+  WG_FOR(ctx, i, NX) {
+    const double d = x_init[i] - x[i];
+    w.dx[i] = d;
+    dx_out[i] = d;
+  }
+  WG_SYNC(ctx);
+  for (int k = 0; k < N; ++k) {
+    const double* rk = ric + (size_t)k * RIC_SIZE;
+    wg_matvec_partial(ctx, NX, NX, rk + RIC_ACL, NX, w.dx, w.part);
     WG_SYNC(ctx);
-    PH_TICK(ctx, 7);
-    // ---- P8: S <- Q + A^T SA + G^T K (upper tiles; S itself is dead since P2), s <- q + A^T sb + G^T k
-    wg_xty2<4, 4>(ctx, NX, NX, NX, &w.A[0][0], NX, &w.SA[0][0], NX, NUT, &w.Gm[0][0], NX, &w.Km[0][0], NX, UpperTiles(),
-                  [&](int r, int c, double v) { if (c >= r) w.S[r][c] = v + q[QP_Q + r * NX + c]; });
-    WG_FOR(ctx, r, NX) {
-      double s = q[QP_QV + r];
-      for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.sb[l];
-      for (int l = 0; l < NUT; ++l) s += w.Gm[l][r] * w.kv[l];
-      w.sn[r] = s;
-    }
-    WG_SYNC(ctx);
-    PH_TICK(ctx, 8);
-    // ---- P9: mirror the upper triangle, roll s
-    WG_FOR(ctx, i, NX * NX + NX) {
-      if (i < NX * NX) { const int r = i / NX, c = i % NX; if (r > c) w.S[r][c] = w.S[c][r]; }
-      else w.sv[i - NX * NX] = w.sn[i - NX * NX];
+    WG_FOR(ctx, i, NX) {
+      const double s = rk[RIC_BCL + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
+      w.dx[i] = s;
+      dx_out[(size_t)(k + 1) * NX + i] = s;
     }
     WG_SYNC(ctx);
   }
 }
 
-// Forward roll-out of the QP solution and the step of length alpha.  x,u: linearisation trajectory of the instance;
-// outputs dx [N+1][58], du [N][35], ut [N][23], x_new, u_new.  Matrix-vector products read the stage matrices from
-// global memory with 4 work items per row and a deterministic two-phase reduction.
-HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* u, const double* qp,
-                             const double* ric, int N, double alpha, double* dx_out, double* du_out, double* ut_out, double* x_new,
-                             double* u_new) {
-  WG_FOR(ctx, i, NX) {
-    const double d = x_init[i] - x[i];
-    w.dx[i] = d;
-    dx_out[i] = d;
-    x_new[i] = x[i] + alpha * d;
+// Per-node recovery of the inputs and the step of length alpha (parallel over all nodes of all instances):
+//   ut = -U^-1 (Z dx + z),  du = Px dx + Pu ut + Pe,  x_new = x + alpha dx,  u_new = u + alpha du.
+struct StepWS {
+  double dx[NX], t[NUT], ut[NUT];
+  double part[(NX + NU) * 4];
+};
+HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double* rk, const double* dx, const double* x, const double* u,
+                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new) {
+  WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
+  WG_SYNC(ctx);
+  wg_matvec_partial(ctx, NUT, NX, rk + RIC_Z, NX, w.dx, w.part);
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, NUT) w.t[i] = -(rk[RIC_ZV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3])));
+  WG_SYNC(ctx);
+  WG_FOR(ctx, it, 1) {  // back substitution U ut = t
+    for (int i = NUT - 1; i >= 0; --i) {
+      double s = w.t[i];
+      for (int c = i + 1; c < NUT; ++c) s -= rk[RIC_U + i * NUT + c] * w.ut[c];
+      w.ut[i] = s / rk[RIC_U + i * NUT + i];
+    }
   }
   WG_SYNC(ctx);
-  for (int k = 0; k < N; ++k) {
-    const double* q = qp + (size_t)k * QP_SIZE;
-    const double* rk = ric + (size_t)k * RIC_SIZE;
-    wg_matvec_partial(ctx, NUT, NX, rk + RIC_K, NX, w.dx, w.part);
-    WG_SYNC(ctx);
-    WG_FOR(ctx, i, NUT) {
-      const double s = rk[RIC_KV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
-      w.ut[i] = s;
-      ut_out[(size_t)k * NUT + i] = s;
-    }
-    WG_SYNC(ctx);
-    WG_FOR(ctx, it, (NX + NU) * 4) {
+  WG_FOR(ctx, it, NU * 4 + NUT) {
+    if (it < NU * 4) {
       const int r = it >> 2, p = it & 3;
-      const double* Ax = r < NX ? q + QP_A + r * NX : q + QP_PX + (r - NX) * NX;
-      const double* Bx = r < NX ? q + QP_B + r * NUT : q + QP_PU + (r - NX) * NUT;
       double s = 0.0;
-      for (int c = p; c < NX; c += 4) s += Ax[c] * w.dx[c];
-      for (int c = p; c < NUT; c += 4) s += Bx[c] * w.ut[c];
+      for (int c = p; c < NX; c += 4) s += q[QP_PX + r * NX + c] * w.dx[c];
+      for (int c = p; c < NUT; c += 4) s += q[QP_PU + r * NUT + c] * w.ut[c];
       w.part[it] = s;
+    } else {
+      ut_out[it - NU * 4] = w.ut[it - NU * 4];
     }
-    WG_SYNC(ctx);
-    WG_FOR(ctx, i, NX + NU) {
-      const double s4 = (w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]);
-      if (i < NX) {
-        const double s = q[QP_BV + i] + s4;
-        w.dxn[i] = s;
-        dx_out[(size_t)(k + 1) * NX + i] = s;
-        x_new[(size_t)(k + 1) * NX + i] = x[(size_t)(k + 1) * NX + i] + alpha * s;
-      } else {
-        const int r = i - NX;
-        const double s = q[QP_PE + r] + s4;
-        du_out[(size_t)k * NU + r] = s;
-        u_new[(size_t)k * NU + r] = u[(size_t)k * NU + r] + alpha * s;
-      }
-    }
-    WG_SYNC(ctx);
-    WG_FOR(ctx, i, NX) w.dx[i] = w.dxn[i];
-    WG_SYNC(ctx);
   }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, r, NU) {
+    const double s = q[QP_PE + r] + ((w.part[4 * r] + w.part[4 * r + 1]) + (w.part[4 * r + 2] + w.part[4 * r + 3]));
+    du_out[r] = s;
+    u_new[r] = u[r] + alpha * s;
+  }
+  WG_SYNC(ctx);
 }
 
 // KKT residual of the projected QP at (dx, ut): costates by the backward stationarity recursion
 //   lam_N = Qf dx_N + g_N,  lam_k = Q~ dx + P~^T ut + q~ + A~^T lam+   (x-stationarity holds by construction)
 // reported: max | R~ ut + P~ dx + r~ + B~^T lam+ |  and  max | dx+ - A~ dx - B~ ut - b~ |, | dx_0 - (x_init - x_0) |.
-HSQP_HD void kkt_residual(const Ctx& ctx, RicWS& w, const double* Qf, const double* x_init, const double* x, const double* parN,
+struct KktWS {
+  double lam[NX], lamn[NX], pr[NX], st[NUT];
+};
+HSQP_HD void kkt_residual(const Ctx& ctx, KktWS& w, const double* Qf, const double* x_init, const double* x, const double* parN,
                           const double* qp, const double* dx, const double* ut, int N, double* out2) {
   WG_FOR(ctx, i, NX) {
     const double dN = dx[(size_t)N * NX + i];
-    w.sv[i] = Qf[i] * dN + Qf[i] * (x[(size_t)N * NX + i] - parN[HSQP_P_XDES + i]);
-    w.sb[i] = fabs(dx[i] - (x_init[i] - x[i]));   // primal residual accumulator (one slot per row)
-    w.bt[i] = 0.0;                                 // stationarity accumulator
+    w.lam[i] = Qf[i] * dN + Qf[i] * (x[(size_t)N * NX + i] - parN[HSQP_P_XDES + i]);
+    w.pr[i] = fabs(dx[i] - (x_init[i] - x[i]));
+    if (i < NUT) w.st[i] = 0.0;
   }
   WG_SYNC(ctx);
   for (int k = N - 1; k >= 0; --k) {
@@ -224,26 +229,26 @@ HSQP_HD void kkt_residual(const Ctx& ctx, RicWS& w, const double* Qf, const doub
       if (i < NX) {
         double l = q[QP_QV + i];
         double pr = dxn[i] - q[QP_BV + i];
-        for (int j = 0; j < NX; ++j) { l += q[QP_Q + i * NX + j] * dxk[j] + q[QP_A + j * NX + i] * w.sv[j]; pr -= q[QP_A + i * NX + j] * dxk[j]; }
+        for (int j = 0; j < NX; ++j) { l += q[QP_Q + i * NX + j] * dxk[j] + q[QP_A + j * NX + i] * w.lam[j]; pr -= q[QP_A + i * NX + j] * dxk[j]; }
         for (int j = 0; j < NUT; ++j) { l += q[QP_P + j * NX + i] * utk[j]; pr -= q[QP_B + i * NUT + j] * utk[j]; }
-        w.dxn[i] = l;
-        w.sb[i] = fmax(w.sb[i], fabs(pr));
+        w.lamn[i] = l;
+        w.pr[i] = fmax(w.pr[i], fabs(pr));
       } else {
         const int r = i - NX;
         double s = q[QP_RV + r];
-        for (int j = 0; j < NX; ++j) s += q[QP_P + r * NX + j] * dxk[j] + q[QP_B + j * NUT + r] * w.sv[j];
+        for (int j = 0; j < NX; ++j) s += q[QP_P + r * NX + j] * dxk[j] + q[QP_B + j * NUT + r] * w.lam[j];
         for (int j = 0; j < NUT; ++j) s += q[QP_R + r * NUT + j] * utk[j];
-        w.bt[r] = fmax(w.bt[r], fabs(s));
+        w.st[r] = fmax(w.st[r], fabs(s));
       }
     }
     WG_SYNC(ctx);
-    WG_FOR(ctx, i, NX) w.sv[i] = w.dxn[i];
+    WG_FOR(ctx, i, NX) w.lam[i] = w.lamn[i];
     WG_SYNC(ctx);
   }
   WG_FOR(ctx, it, 1) {
     double st = 0.0, pr = 0.0;
-    for (int i = 0; i < NX; ++i) pr = fmax(pr, w.sb[i]);
-    for (int i = 0; i < NUT; ++i) st = fmax(st, w.bt[i]);
+    for (int i = 0; i < NX; ++i) pr = fmax(pr, w.pr[i]);
+    for (int i = 0; i < NUT; ++i) st = fmax(st, w.st[i]);
     out2[0] = st;
     out2[1] = pr;
   }
