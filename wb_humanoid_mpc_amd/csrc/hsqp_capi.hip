@@ -16,8 +16,8 @@ using namespace hsqp;
 namespace {
 
 constexpr int LQ_THREADS = 256;
-constexpr int PROJ_THREADS = 256;
-constexpr int RIC_THREADS = 256;
+constexpr int PROJ_THREADS = 512;
+constexpr int RIC_THREADS = 512;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 

@@ -159,6 +159,15 @@ HSQP_HD void m3_inverse(const double* a, double* c) {
   for (int i = 0; i < 9; ++i) c[i] *= inv;
 }
 
+// 1/sqrt(x) for the Cholesky pivots
+HSQP_HD double inv_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(x);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // Penalties (RelaxedBarrierPenalty: upstream ocs2; PieceWisePolynomialBarrierPenalty: fork-only, ASSUMPTION A1 of the oracle)
 struct Pen3 { double p, d1, d2; };
 HSQP_HD Pen3 relaxed_barrier(double mu, double delta, double h) {

@@ -15,64 +15,196 @@ namespace hsqp {
 // A work item owns the STRIDED tile  rows {tr + i*tm}, cols {tc + j*tn}  (tm = ceil(M/TM), tn = ceil(N/TN)):
 // consecutive lanes then read consecutive LDS words of a row of X / Y (conflict-free ds_read_b64) instead of
 // words 8*TN bytes apart.  store(r, c, value) is called for every in-range element of the tile.
+// One tile (index t of ceil(M/TM) * ceil(N/TN)) of  C = X1^T Y1 + sign2 * X2^T Y2.
+template <int TM, int TN, class Store>
+HSQP_HD void xty_tile2(int t, int M, int N, int L1, const double* X1, int ldx1, const double* Y1, int ldy1, int L2, const double* X2,
+                       int ldx2, const double* Y2, int ldy2, double sign2, Store store) {
+  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
+  const int tr = t / tn, tc = t % tn;
+  int xo[TM], yo[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) xo[i] = (tr + i * tm < M) ? tr + i * tm : M - 1;   // clamp: duplicates are computed, never stored
+#pragma unroll
+  for (int j = 0; j < TN; ++j) yo[j] = (tc + j * tn < N) ? tc + j * tn : N - 1;
+  double acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int L = seg ? L2 : L1;
+    const double* X = seg ? X2 : X1;
+    const double* Y = seg ? Y2 : Y1;
+    const int ldx = seg ? ldx2 : ldx1, ldy = seg ? ldy2 : ldy1;
+#pragma unroll 2
+    for (int l = 0; l < L; ++l) {
+      double a[TM], b[TN];
+      const double* xr = X + l * ldx;
+      const double* yr = Y + l * ldy;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = seg ? sign2 * xr[xo[i]] : xr[xo[i]];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = yr[yo[j]];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] += a[i] * b[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (tr + i * tm < M && tc + j * tn < N) store(tr + i * tm, tc + j * tn, acc[i][j]);
+}
+template <int TM, int TN, class Store>
+HSQP_HD void xty_tile(int t, int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, Store store) {
+  xty_tile2<TM, TN>(t, M, N, L, X, ldx, Y, ldy, 0, X, ldx, Y, ldy, 1.0, store);
+}
+constexpr int ntiles(int M, int N, int TM, int TN) { return ((M + TM - 1) / TM) * ((N + TN - 1) / TN); }
+
+// NOTE: independent products of one phase must share ONE WG_FOR item space (item ranges -> jobs); two consecutive
+// wg_xty calls are executed one after the other by every thread.
 template <int TM, int TN, class Store>
 HSQP_HD void wg_xty2(const Ctx& ctx, int M, int N, int L1, const double* X1, int ldx1, const double* Y1, int ldy1, int L2,
                      const double* X2, int ldx2, const double* Y2, int ldy2, double sign2, Store store) {
-  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
-  WG_FOR(ctx, t, tm * tn) {
-    const int tr = t / tn, tc = t % tn;
-    int xo[TM], yo[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) xo[i] = (tr + i * tm < M) ? tr + i * tm : M - 1;   // clamp: duplicates are computed, never stored
-#pragma unroll
-    for (int j = 0; j < TN; ++j) yo[j] = (tc + j * tn < N) ? tc + j * tn : N - 1;
-    double acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
-    for (int seg = 0; seg < 2; ++seg) {
-      const int L = seg ? L2 : L1;
-      const double* X = seg ? X2 : X1;
-      const double* Y = seg ? Y2 : Y1;
-      const int ldx = seg ? ldx2 : ldx1, ldy = seg ? ldy2 : ldy1;
-#pragma unroll 2
-      for (int l = 0; l < L; ++l) {
-        double a[TM], b[TN];
-        const double* xr = X + l * ldx;
-        const double* yr = Y + l * ldy;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = seg ? sign2 * xr[xo[i]] : xr[xo[i]];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = yr[yo[j]];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] += a[i] * b[j];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        if (tr + i * tm < M && tc + j * tn < N) store(tr + i * tm, tc + j * tn, acc[i][j]);
-  }
+  WG_FOR(ctx, t, ntiles(M, N, TM, TN)) xty_tile2<TM, TN>(t, M, N, L1, X1, ldx1, Y1, ldy1, L2, X2, ldx2, Y2, ldy2, sign2, store);
 }
-
 template <int TM, int TN, class Store>
 HSQP_HD void wg_xty(const Ctx& ctx, int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, Store store) {
   wg_xty2<TM, TN>(ctx, M, N, L, X, ldx, Y, ldy, 0, X, ldx, Y, ldy, 1.0, store);
 }
 
-// y[r] (+)= sum_c A[r][c] x[c] for a row-major matrix in GLOBAL memory, 4 work items per row with a
-// deterministic two-phase reduction through `part` (LDS, rows x 4).
-HSQP_HD void wg_matvec_partial(const Ctx& ctx, int rows, int cols, const double* A, int lda, const double* x, double* part) {
-  WG_FOR(ctx, it, rows * 4) {
-    const int r = it >> 2, p = it & 3;
-    double s = 0.0;
-    for (int c = p; c < cols; c += 4) s += A[r * lda + c] * x[c];
-    part[it] = s;
+// sum_l X[l*ldx] * v[l], l < L, with the loads issued ahead of the dependent FMA chain
+template <int L>
+HSQP_HD double dot_strided(const double* X, int ldx, const double* v) {
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int l = 0; l + 1 < L; l += 2) { s0 += X[l * ldx] * v[l]; s1 += X[(l + 1) * ldx] * v[l + 1]; }
+  if (L & 1) s0 += X[(L - 1) * ldx] * v[L - 1];
+  return s0 + s1;
+}
+
+// Partial products of y = A x for a row-major matrix (global or LDS), 4 work items per row; the caller adds the
+// four partials in a second phase (deterministic reduction).  COLS is a compile-time constant so that the
+// loads are issued ahead of the dependent FMA chain.
+template <int COLS>
+HSQP_HD double matvec_part(const double* Arow, const double* x, int p) {
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < (COLS + 3) / 4; ++c) {
+    const int cc = p + 4 * c;
+    if (cc < COLS) s += Arow[cc] * x[cc];
   }
+  return s;
+}
+
+// Batched global -> LDS copy: work item b of nb = ceil(count / NBATCH) moves elements {b + j*nb}; the NBATCH loads are
+// issued before the first store so that their latencies overlap.
+template <int NBATCH, class Dst>
+HSQP_HD void copy_batch(int b, int count, const double* src, Dst dst) {
+  const int nb = (count + NBATCH - 1) / NBATCH;
+  double t[NBATCH];
+#pragma unroll
+  for (int j = 0; j < NBATCH; ++j) { const int idx = b + j * nb; t[j] = idx < count ? src[idx] : 0.0; }
+#pragma unroll
+  for (int j = 0; j < NBATCH; ++j) { const int idx = b + j * nb; if (idx < count) dst(idx, t[j]); }
+}
+constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nbatch; }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// FP64 matrix-core path.  Measured on MI355X (tools/microbench/f64_rates.hip): v_mfma_f64_16x16x4_f64 issues every
+// 64 cycles per SIMD = 32 flop/clk/SIMD already from ONE wave per SIMD, whereas v_fma_f64 issues every 8 cycles per
+// wave and needs >= 2 waves per SIMD for the same rate.  The LDS-resident stage kernels run one 4-8 wave workgroup
+// per CU, so their dense products go through MFMA.  Operand fragments of  C = X^T Y  are plain row reads:
+//   A[i][k] = X[k0 + (lane >> 4)][r0 + (lane & 15)],  B[k][j] = Y[k0 + (lane >> 4)][c0 + (lane & 15)],
+//   D: lane holds rows (lane >> 4) + 4 reg, column lane & 15  (reg = 0..3).
+// A job list is executed cooperatively: 16x16 output tiles are dealt round-robin to the waves of the workgroup.
+struct XtyJob {
+  int M, N;                       // output size
+  int L1; const double* X1; int ldx1; const double* Y1; int ldy1;
+  int L2; const double* X2; int ldx2; const double* Y2; int ldy2;   // optional second product, added with sign2
+  double sign2;
+  double scale;                   // C = scale * acc + Add
+  const double* Add; int ldadd;   // optional (may be global memory)
+  double* C; int ldc;             // destination (LDS or global)
+};
+
+HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, double* C, int ldc,
+                       const double* Add = nullptr, int ldadd = 0, double scale = 1.0) {
+  XtyJob j;
+  j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
+  j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc;
+  return j;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
+HSQP_D void xty_job_tile_mfma(const XtyJob& j, int tile, int lane) {
+  const int tn = (j.N + 15) >> 4;
+  const int r0 = (tile / tn) << 4, c0 = (tile % tn) << 4;
+  const int i = lane & 15, kk = lane >> 4;
+  const int xr = r0 + i < j.M ? r0 + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
+  const int yc = c0 + i < j.N ? c0 + i : j.N - 1;
+  hsqp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < j.L1; k0 += 4) {
+    const int k = k0 + kk;
+    const bool ok = k < j.L1;
+    const double a = ok ? j.X1[k * j.ldx1 + xr] : 0.0;
+    const double b = ok ? j.Y1[k * j.ldy1 + yc] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  for (int k0 = 0; k0 < j.L2; k0 += 4) {
+    const int k = k0 + kk;
+    const bool ok = k < j.L2;
+    const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr] : 0.0;
+    const double b = ok ? j.Y2[k * j.ldy2 + yc] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  const int c = c0 + i;
+  if (c < j.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + kk + 4 * r;
+      if (row < j.M) {
+        double v = j.scale * acc[r];
+        if (j.Add) v += j.Add[row * j.ldadd + c];
+        j.C[row * j.ldc + c] = v;
+      }
+    }
+  }
+}
+#endif
+
+// Executes `njobs` independent products; must be called by every thread of the workgroup (no barrier inside).
+// `wave_offset` rotates the tile -> wave assignment so that other work of the phase can be placed on the idle waves.
+HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int wave = ctx.tid >> 6, nwaves = ctx.nthreads >> 6, lane = ctx.tid & 63;
+  int base = 0;
+  for (int jn = 0; jn < njobs; ++jn) {
+    const XtyJob& j = jobs[jn];
+    const int nt = ((j.M + 15) >> 4) * ((j.N + 15) >> 4);
+    // first tile of this job owned by this wave: tiles are numbered globally (base + t) and dealt round-robin
+    for (int t = (wave - base % nwaves + nwaves) % nwaves; t < nt; t += nwaves) xty_job_tile_mfma(j, t, lane);
+    base += nt;
+  }
+#else
+  for (int jn = 0; jn < njobs; ++jn) {
+    const XtyJob& j = jobs[jn];
+    WG_FOR(ctx, e, j.M * j.N) {
+      const int r = e / j.N, c = e % j.N;
+      double acc = 0.0;
+      for (int l = 0; l < j.L1; ++l) acc += j.X1[l * j.ldx1 + r] * j.Y1[l * j.ldy1 + c];
+      for (int l = 0; l < j.L2; ++l) acc += j.sign2 * j.X2[l * j.ldx2 + r] * j.Y2[l * j.ldy2 + c];
+      double v = j.scale * acc;
+      if (j.Add) v += j.Add[r * j.ldadd + c];
+      j.C[r * j.ldc + c] = v;
+    }
+  }
+#endif
 }
 
 }  // namespace hsqp

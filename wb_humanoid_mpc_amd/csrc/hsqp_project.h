@@ -78,33 +78,43 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // left untouched: its final diagonal goes to Rdiag, the vector to V), so one barrier per step suffices.
   WG_FOR(ctx, i, NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 8);
   for (int k = 0; k < ne; ++k) {
     WG_FOR(ctx, it, ne - k) {
       const int c = k + it;
+      double xk[NU], xc[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { xk[i] = w.qr.Rm[i][k]; xc[i] = w.qr.Rm[i][c]; }
       double nrm2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < NU; ++i) { const double xv = i >= k ? w.qr.Rm[i][k] : 0.0; nrm2 += xv * xv; }
-      const double nrm = sqrt(nrm2), rkk = w.qr.Rm[k][k];
+      for (int i = 0; i < NU; ++i) { if (i < k) xk[i] = 0.0; nrm2 += xk[i] * xk[i]; }
+      const double nrm = sqrt(nrm2);
+      double rkk = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) if (i == k) rkk = xk[i];
       const double alpha = rkk >= 0.0 ? -nrm : nrm;
       const double vn = 2.0 * (nrm2 - alpha * rkk);
       const double beta = vn > 1e-300 ? 2.0 / vn : 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) if (i == k) xk[i] -= alpha;   // xk is now the Householder vector v
       if (c == k) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) w.qr.V[k][i] = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0));
+        for (int i = 0; i < NU; ++i) w.qr.V[k][i] = xk[i];
         w.qr.beta[k] = beta;
         w.qr.Rdiag[k] = alpha;
         if (!(nrm >= 1e-12)) w.ok = 0;
       } else {
         double sdot = 0.0;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0)); sdot += vi * w.qr.Rm[i][c]; }
+        for (int i = 0; i < NU; ++i) sdot += xk[i] * xc[i];
         sdot *= beta;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0)); if (i >= k) w.qr.Rm[i][c] -= sdot * vi; }
+        for (int i = 0; i < NU; ++i) if (i >= k) w.qr.Rm[i][c] = xc[i] - sdot * xk[i];
       }
     }
     WG_SYNC(ctx);
   }
+  PH_TICK(ctx, 9);
   // Q^T = H_{ne-1} ... H_0: one column per item, the column lives in registers while the reflectors are applied
   WG_FOR(ctx, c, NU) {
     double col[NU];
@@ -134,12 +144,15 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   PH_TICK(ctx, 3);
   // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
-  wg_xty<4, 4>(ctx, NU, NX + 1, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2,
-               [&](int r, int c, double v) { w.Tm[r][c < NX ? c : NTW] = -v; });
-  WG_FOR(ctx, i, NU * (NUT + 2)) {
-    const int r = i / (NUT + 2), cc = i % (NUT + 2);
-    if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ne + cc][r] : 0.0;
-    else w.Tm[r][NTW + 1 + (cc - NUT)] = 0.0;
+  {
+    const XtyJob job = xty_job(NU, NX, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
+    wg_xty_jobs(ctx, &job, 1);
+    WG_FOR(ctx, i, NU * (NUT + 3)) {
+      const int r = i / (NUT + 3), cc = i % (NUT + 3);
+      if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ne + cc][r] : 0.0;
+      else if (cc == NUT) { double sdot = 0.0; for (int j = 0; j < ne; ++j) sdot += w.qr.QT[j][r] * w.qr.Wm[j][NX]; w.Tm[r][NTW] = -sdot; }
+      else w.Tm[r][NTW + (cc - NUT)] = 0.0;
+    }
   }
   WG_SYNC(ctx);  // QR data dead from here: JuT aliases it
   PH_TICK(ctx, 4);
@@ -181,32 +194,50 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   PH_TICK(ctx, 5);
   // ---- residual rows after projection: J T (+ rho' in column 81), then the input-weight rows sqrt(d_u) [Px|Pu|Pe]
-  wg_xty<4, 4>(ctx, NRS, NTW + 1, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM,
-               [&](int r, int a, double v) { w.Jt[r][a] = v + (a < NX ? rec[REC_J + r * LDJ + a] : (a == NTW ? w.rho[r] : 0.0)); });
-  WG_FOR(ctx, i, (NU + 1) * LDTM) {
-    const int k = i / LDTM, a = i % LDTM;
-    w.Jt[NRS + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
+  {
+    const XtyJob jobs[2] = {xty_job(NRS, NX, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J, LDJ),
+                            xty_job(NRS, NUT, NU, &w.JuT[0][0], NRS, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
+    wg_xty_jobs(ctx, jobs, 2);
+    WG_FOR(ctx, i, NRS + (NU + 1) * LDTM) {
+      if (i < NRS) {
+        double sdot = w.rho[i];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) sdot += w.JuT[k][i] * w.Tm[k][NTW];
+        w.Jt[i][NTW] = sdot;
+      } else {
+        const int k = (i - NRS) / LDTM, a = (i - NRS) % LDTM;
+        w.Jt[NRS + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
+      }
+    }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 6);
-  // ---- projected Hessian and gradient (column 81 of the same product): H~ = diag + J~ext^T J~ext
-  wg_xty<8, 4>(ctx, NTW, NTW + 1, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, [&](int a, int b, double s) {
-    if (b == NTW) {   // gradient: g~ = T^T gd + J~ext^T rho'
+  // ---- projected Hessian H~ = diag(d_x, 0) + J~ext^T J~ext on the matrix cores (blocks Q~, P~, R~ straight to the QP
+  //      record) and gradient g~ = T^T gd + J~ext^T rho'
+  {
+    const XtyJob jobs[3] = {xty_job(NX, NX, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX),
+                            xty_job(NUT, NX, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX),
+                            xty_job(NUT, NUT, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT)};
+    wg_xty_jobs(ctx, jobs, 3);
+    WG_FOR(ctx, a, NTW) {
+      double s = 0.0;
+#pragma unroll 10
+      for (int r = 0; r < NRX; ++r) s += w.Jt[r][a] * w.Jt[r][NTW];
       if (a < NX) s += w.gd[a];
+#pragma unroll
       for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
       if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
-      return;
     }
-    if (a == b && a < NX) s += w.d[a];
-    if (a < NX) {
-      if (b < NX) qp[QP_Q + a * NX + b] = s;
-    } else if (b < NX) {
-      qp[QP_P + (a - NX) * NX + b] = s;
-    } else {
-      if (a - NX >= nut || b - NX >= nut) s = (a == b) ? 1.0 : 0.0;  // identity padding of the unused projected inputs
-      qp[QP_R + (a - NX) * NUT + (b - NX)] = s;
+  }
+  WG_SYNC(ctx);
+  // diagonal of Q~ and the identity padding of the unused projected inputs (read-modify-write of this node's own record)
+  WG_FOR(ctx, i, NX + NUT * NUT) {
+    if (i < NX) qp[QP_Q + i * NX + i] += w.d[i];
+    else {
+      const int a = (i - NX) / NUT, b = (i - NX) % NUT;
+      if (a >= nut || b >= nut) qp[QP_R + a * NUT + b] = (a == b) ? 1.0 : 0.0;
     }
-  });
+  }
   WG_SYNC(ctx);
   PH_TICK(ctx, 7);
 }

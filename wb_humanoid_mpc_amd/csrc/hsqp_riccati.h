@@ -28,11 +28,11 @@ constexpr int LDB = 24;                        // leading dimension of the 23-wi
 constexpr int EM_G = NUT, EM_GV = NUT + NX, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns
 
 struct RicWS {
-  double S[NX][NX], A[NX][NX], SA[NX][NX];
+  double S[NX][NX], A2[2][NX][NX], SA[NX][NX];   // A2: double-buffered A~ (stage k uses A2[k & 1])
   double B[NX][LDB], SB[NX][LDB];
   double Em[NUT][LDE];                         // [Lam | G | g | B^T], factorised in place
   double dsq[LDB];
-  double sv[NX], sn[NX], sb[NX], bt[NX], dx[NX], dxn[NX];
+  double sv[NX], sn[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX];
   double part[NX * 4];
   int ok;
 };
@@ -46,95 +46,128 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     else w.ok = 1;
   }
   WG_SYNC(ctx);
+  // stage N-1 data -> LDS (the later stages are prefetched while the previous one is being processed)
+  {
+    const double* q = qp + (size_t)(N - 1) * QP_SIZE;
+    double(*An)[NX] = w.A2[(N - 1) & 1];
+    constexpr int na = nbatches(NX * NX, 8);
+    WG_FOR(ctx, it, na + NX * LDB + NX) {
+      if (it < na) copy_batch<8>(it, NX * NX, q + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+      else if (it < na + NX * LDB) { const int i = it - na, r = i / LDB, c = i % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : 0.0; }
+      else w.bt[it - na - NX * LDB] = q[QP_BV + it - na - NX * LDB];
+    }
+  }
+  WG_SYNC(ctx);
   for (int k = N - 1; k >= 0; --k) {
     const double* q = qp + (size_t)k * QP_SIZE;
+    const double* qn = qp + (size_t)(k > 0 ? k - 1 : 0) * QP_SIZE;   // next stage to be processed
     double* rk = ric + (size_t)k * RIC_SIZE;
-    PH_TICK(ctx, 9);
-    // ---- P1: stage data -> LDS (coalesced)
-    WG_FOR(ctx, i, NX * NX + NX * LDB + NX) {
-      if (i < NX * NX) w.A[i / NX][i % NX] = q[QP_A + i];
-      else if (i < NX * NX + NX * LDB) { const int j = i - NX * NX, r = j / LDB, c = j % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : 0.0; }
-      else w.bt[i - NX * NX - NX * LDB] = q[QP_BV + i - NX * NX - NX * LDB];
-    }
-    WG_SYNC(ctx);
+    double(*A)[NX] = w.A2[k & 1];
+    double(*An)[NX] = w.A2[(k + 1) & 1];
     PH_TICK(ctx, 1);
-    // ---- P2: SA = S A, SB = S B (S symmetric => X = S), sb = s + S b
-    wg_xty<4, 4>(ctx, NX, NX, NX, &w.S[0][0], NX, &w.A[0][0], NX, [&](int r, int c, double v) { w.SA[r][c] = v; });
-    wg_xty<4, 4>(ctx, NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, [&](int r, int c, double v) { w.SB[r][c] = v; });
-    WG_FOR(ctx, r, NX) {
-      double s = w.sv[r];
-      for (int l = 0; l < NX; ++l) s += w.S[l][r] * w.bt[l];
-      w.sb[r] = s;
+    // ---- P2: SA = S A, SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
+    {
+      const XtyJob jobs[2] = {xty_job(NX, NX, NX, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
+                              xty_job(NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
+      wg_xty_jobs(ctx, jobs, 2);
+      WG_FOR(ctx, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt);
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
-    // ---- P3: augmented matrix [Lam | G | g | B^T]
-    wg_xty<4, 4>(ctx, NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, [&](int r, int c, double v) { w.Em[r][c] = v + q[QP_R + r * NUT + c]; });
-    wg_xty<4, 4>(ctx, NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, [&](int r, int c, double v) { w.Em[r][EM_G + c] = v + q[QP_P + r * NX + c]; });
-    WG_FOR(ctx, i, NUT + NUT * NX) {
-      if (i < NUT) {
-        double s = q[QP_RV + i];
-        for (int l = 0; l < NX; ++l) s += w.B[l][i] * w.sb[l];
-        w.Em[i][EM_GV] = s;
-      } else {
-        const int r = (i - NUT) / NX, c = (i - NUT) % NX;
-        w.Em[r][EM_BT + c] = w.B[c][r];
+    // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
+    {
+      const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
+                              xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.Em[0][0], LDE, q + QP_R, NUT)};
+      constexpr int na = nbatches(NX * NX, 8);
+      WG_FOR(ctx, it, na) {
+        if (k > 0) copy_batch<8>(it, NX * NX, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+      }
+      wg_xty_jobs(ctx, jobs, 2);
+      WG_FOR(ctx, it, NUT + NUT * NX) {
+        if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
+        else { const int j = it - NUT, r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
       }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
-    // ---- P4: right-looking Cholesky (upper storage, U = L^T) carried through the augmented columns
-    for (int j = 0; j < NUT; ++j) {
-      WG_FOR(ctx, it, LDE - j) {
-        const int c = j + it;
-        double dj = w.Em[j][j];
-        if (!(dj > 0.0)) { dj = 1.0; if (it == 0) w.ok = 0; }
-        const double sq = sqrt(dj);
-        if (it == 0) w.dsq[j] = sq; else w.Em[j][c] = w.Em[j][c] / sq;
-      }
-      WG_SYNC(ctx);
-      const int m = NUT - 1 - j, nc = LDE - 1 - j;
-      WG_FOR(ctx, it, m * nc) {
-        const int i = j + 1 + it / nc, c = j + 1 + it % nc;
-        if (c >= i) w.Em[i][c] -= w.Em[j][i] * w.Em[j][c];
+    // ---- P4: right-looking elimination of Lam carried through the augmented columns.  Rows stay UNSCALED during the
+    // sweep (row j holds d_j * L^-1[...]), so a step needs no pivot broadcast phase: one barrier per column.  The
+    // Cholesky scaling U = D^-1/2 (...) is applied to all rows at the end.
+    for (int j = 0; j < NUT - 1; ++j) {
+      const int m = NUT - 1 - j, nch = (LDE - 1 - j + 7) / 8;   // rows below the pivot, 8-column chunks right of it
+      WG_FOR(ctx, it, m * nch) {
+        const int i = j + 1 + it / nch, c0 = j + 1 + (it % nch);
+        const double f = w.Em[j][i] / w.Em[j][j];
+        double ej[8], ei[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int c = c0 + t * nch; ej[t] = c < LDE ? w.Em[j][c] : 0.0; ei[t] = (c < LDE && c >= i) ? w.Em[i][c] : 0.0; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int c = c0 + t * nch; if (c < LDE && c >= i) w.Em[i][c] = ei[t] - f * ej[t]; }
       }
       WG_SYNC(ctx);
     }
+    WG_FOR(ctx, it, NUT * LDE) {
+      const int j = it / LDE, c = it % LDE;
+      double dj = w.Em[j][j];
+      if (!(dj > 0.0)) { dj = 1.0; if (c == 0) w.ok = 0; }
+      const double rs = inv_sqrt(dj);
+      if (c == j) w.dsq[j] = dj * rs;
+      else if (c > j) w.Em[j][c] = w.Em[j][c] * rs;
+    }
+    WG_SYNC(ctx);
     PH_TICK(ctx, 4);
-    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A - Y^T Z, s <- q + A^T sb - Z^T z, bcl = b - Y^T z ; factors -> global
-    wg_xty2<4, 4>(ctx, NX, NX, NX, &w.A[0][0], NX, &w.SA[0][0], NX, NUT, &w.Em[0][EM_G], LDE, &w.Em[0][EM_G], LDE, -1.0,
-                  [&](int r, int c, double v) { w.S[r][c] = v + q[QP_Q + r * NX + c]; });
-    wg_xty<4, 4>(ctx, NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, [&](int r, int c, double v) { rk[RIC_ACL + r * NX + c] = w.A[r][c] - v; });
-    WG_FOR(ctx, i, 2 * NX + NUT * (NUT + NX + 1)) {
-      if (i < NX) {
-        const int r = i;
-        double s = q[QP_QV + r];
-        for (int l = 0; l < NX; ++l) s += w.A[l][r] * w.sb[l];
-        for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
-        w.sn[r] = s;
-      } else if (i < 2 * NX) {
-        const int r = i - NX;
-        double s = w.bt[r];
-        for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
-        rk[RIC_BCL + r] = s;
-      } else {
-        const int j = i - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
-        if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
-        else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
-        else rk[RIC_ZV + r] = w.Em[r][EM_GV];
+    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A - Y^T Z, s <- q + A^T sb - Z^T z, bcl = b - Y^T z ; factors -> global;
+    //          prefetch of the next stage's B~, b~ (B is dead since P3)
+    {
+      XtyJob js = xty_job(NX, NX, NX, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
+      js.L2 = NUT; js.X2 = &w.Em[0][EM_G]; js.ldx2 = LDE; js.Y2 = &w.Em[0][EM_G]; js.ldy2 = LDE; js.sign2 = -1.0;
+      const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX, -1.0)};
+      constexpr int nbb = nbatches(NX * LDB, 8);
+      WG_FOR(ctx, bb, nbb + NX) {
+        if (k > 0) {
+          if (bb < nbb) {
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb, r = i / LDB, c = i % LDB; t[j] = (i < NX * LDB && c < NUT) ? qn[QP_B + r * NUT + c] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb; if (i < NX * LDB) w.B[i / LDB][i % LDB] = t[j]; }
+          } else {
+            w.btn[bb - nbb] = qn[QP_BV + bb - nbb];
+          }
+        }
+      }
+      wg_xty_jobs(ctx, jobs, 2);
+      WG_FOR(ctx, it, 2 * NX + NUT * (NUT + NX + 1)) {
+        if (it < NX) {
+          const int r = it;
+          double s = q[QP_QV + r] + dot_strided<NX>(&A[0][r], NX, w.sb);
+#pragma unroll
+          for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
+          w.sn[r] = s;
+        } else if (it < 2 * NX) {
+          const int r = it - NX;
+          double s = w.bt[r];
+#pragma unroll
+          for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
+          rk[RIC_BCL + r] = s;
+        } else {
+          const int j = it - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
+          if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
+          else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
+          else rk[RIC_ZV + r] = w.Em[r][EM_GV];
+        }
       }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
-    // ---- P6: symmetrise S (round-off only), roll s
-    WG_FOR(ctx, i, NX * (NX + 1) / 2 + NX) {
-      if (i < NX * (NX + 1) / 2) {
-        int t = i, r = 0;
-        while (t >= NX - r) { t -= NX - r; ++r; }
-        const int c = r + t;
+    // ---- P6: symmetrise S (round-off only), roll s and b~
+    WG_FOR(ctx, i, NX * NX + NX) {
+      if (i < NX * NX) {
+        const int r = i / NX, c = i % NX;
         if (c > r) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
       } else {
-        w.sv[i - NX * (NX + 1) / 2] = w.sn[i - NX * (NX + 1) / 2];
+        w.sv[i - NX * NX] = w.sn[i - NX * NX];
+        if (k > 0) w.bt[i - NX * NX] = w.btn[i - NX * NX];
       }
     }
     WG_SYNC(ctx);
@@ -152,7 +185,7 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
   WG_SYNC(ctx);
   for (int k = 0; k < N; ++k) {
     const double* rk = ric + (size_t)k * RIC_SIZE;
-    wg_matvec_partial(ctx, NX, NX, rk + RIC_ACL, NX, w.dx, w.part);
+    WG_FOR(ctx, it, NX * 4) w.part[it] = matvec_part<NX>(rk + RIC_ACL + (it >> 2) * NX, w.dx, it & 3);
     WG_SYNC(ctx);
     WG_FOR(ctx, i, NX) {
       const double s = rk[RIC_BCL + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
@@ -173,7 +206,7 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
                        double alpha, double* ut_out, double* du_out, double* x_new, double* u_new) {
   WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
   WG_SYNC(ctx);
-  wg_matvec_partial(ctx, NUT, NX, rk + RIC_Z, NX, w.dx, w.part);
+  WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_Z + (it >> 2) * NX, w.dx, it & 3);
   WG_SYNC(ctx);
   WG_FOR(ctx, i, NUT) w.t[i] = -(rk[RIC_ZV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3])));
   WG_SYNC(ctx);
@@ -188,10 +221,7 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
   WG_FOR(ctx, it, NU * 4 + NUT) {
     if (it < NU * 4) {
       const int r = it >> 2, p = it & 3;
-      double s = 0.0;
-      for (int c = p; c < NX; c += 4) s += q[QP_PX + r * NX + c] * w.dx[c];
-      for (int c = p; c < NUT; c += 4) s += q[QP_PU + r * NUT + c] * w.ut[c];
-      w.part[it] = s;
+      w.part[it] = matvec_part<NX>(q + QP_PX + r * NX, w.dx, p) + matvec_part<NUT>(q + QP_PU + r * NUT, w.ut, p);
     } else {
       ut_out[it - NU * 4] = w.ut[it - NU * 4];
     }
