@@ -74,6 +74,13 @@ struct DevModel {
   double Rfix[NB][9];
   double pfix[NB][3];
   double axis[NB][3];
+  double axis_p[NB][3];            // Rfix * axis: joint axis in the parent body frame
+  // chains: maximal single-child paths; a chain is walked by ONE work item with the parent state in registers
+  int n_chains, n_chain_phases;
+  int chain_start[NB], chain_len[NB], chain_phase[NB];
+  // children lists and the 'heavy' bodies (large subtrees) for the two-step composite sums
+  int child_start[NB + 1], child_list[NB];
+  int n_heavy, heavy[NB];         // in decreasing index order
   double mass[NB];
   double com[NB][3];
   double inertia[NB][9];          // about com, body axes
@@ -165,6 +172,18 @@ HSQP_HD double inv_sqrt(double x) {
   return rsqrt(x);
 #else
   return 1.0 / sqrt(x);
+#endif
+}
+
+// 1/x: hardware reciprocal + two Newton steps on the device (the elimination steps need a reciprocal pivot per item)
+HSQP_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+#else
+  return 1.0 / x;
 #endif
 }
 

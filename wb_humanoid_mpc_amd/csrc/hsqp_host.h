@@ -44,6 +44,39 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
     for (int a = p; a >= 0; a = dm.parent[a])
       if (!(i >= a && i < a + dm.subtree_size[a])) return "bodies are not in depth-first order";
   }
+  // chains, children, heavy bodies
+  {
+    int nchild[NB] = {0};
+    for (int i = 1; i < NB; ++i) nchild[dm.parent[i]]++;
+    int cpos = 0;
+    for (int i = 0; i < NB; ++i) {
+      dm.child_start[i] = cpos;
+      for (int c = i + 1; c < NB; ++c) if (dm.parent[c] == i) dm.child_list[cpos++] = c;
+    }
+    dm.child_start[NB] = cpos;
+    int chain_of[NB];
+    chain_of[0] = -1;
+    dm.n_chains = 0; dm.n_chain_phases = 0;
+    for (int i = 1; i < NB; ++i) {
+      const int p = dm.parent[i];
+      if (p != 0 && nchild[p] == 1 && i == p + 1) {
+        chain_of[i] = chain_of[p];
+        dm.chain_len[chain_of[i]]++;
+      } else {
+        const int c = dm.n_chains++;
+        chain_of[i] = c;
+        dm.chain_start[c] = i; dm.chain_len[c] = 1;
+        dm.chain_phase[c] = p == 0 ? 0 : dm.chain_phase[chain_of[p]] + 1;
+        if (dm.chain_phase[c] + 1 > dm.n_chain_phases) dm.n_chain_phases = dm.chain_phase[c] + 1;
+      }
+    }
+    dm.n_heavy = 0;
+    for (int i = NB - 1; i >= 0; --i) if (dm.subtree_size[i] > 8) dm.heavy[dm.n_heavy++] = i;
+    for (int i = 1; i < NB; ++i) {
+      const hsqp_body& b = md.bodies[i];
+      for (int r = 0; r < 3; ++r) dm.axis_p[i][r] = b.R[3 * r] * b.axis[0] + b.R[3 * r + 1] * b.axis[1] + b.R[3 * r + 2] * b.axis[2];
+    }
+  }
   int pos = 0;
   for (int l = 0; l < NLEVELS; ++l) {
     dm.level_start[l] = pos;

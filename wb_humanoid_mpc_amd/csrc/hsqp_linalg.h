@@ -149,6 +149,13 @@ HSQP_D void xty_job_tile_mfma(const XtyJob& j, int tile, int lane) {
   const int xr = r0 + i < j.M ? r0 + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
   const int yc = c0 + i < j.N ? c0 + i : j.N - 1;
   hsqp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  // the additive term may live in HBM: issue its loads before the MFMA loop, consume them in the epilogue
+  const int cst = c0 + i;
+  double addv[4] = {0.0, 0.0, 0.0, 0.0};
+  if (j.Add && cst < j.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r; if (row < j.M) addv[r] = j.Add[row * j.ldadd + cst]; }
+  }
   for (int k0 = 0; k0 < j.L1; k0 += 4) {
     const int k = k0 + kk;
     const bool ok = k < j.L1;
@@ -169,9 +176,7 @@ HSQP_D void xty_job_tile_mfma(const XtyJob& j, int tile, int lane) {
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + kk + 4 * r;
       if (row < j.M) {
-        double v = j.scale * acc[r];
-        if (j.Add) v += j.Add[row * j.ldadd + c];
-        j.C[row * j.ldc + c] = v;
+        j.C[row * j.ldc + c] = j.scale * acc[r] + addv[r];
       }
     }
   }

@@ -65,6 +65,7 @@ HSQP_HD void rk4_stage_inputs(const Ctx& ctx, LqWS& w, int s, double dt) {
 // X (6 x 29 block starting at column c0 of G_s) times Vd_t = [Ab_t ; E_qdd], element (r, col)
 HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ], int r, int col) {
   double s = 0.0;
+#pragma unroll
   for (int k = 0; k < 6; ++k) s += Gs[r][c0 + k] * Abt[k][col];
   if (col >= NX + 12) s += Gs[r][c0 + 6 + (col - NX - 12)];
   return s;

@@ -24,6 +24,7 @@ namespace hsqp {
 struct StageWS {
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
+  double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
   // ---- base
   double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
   double Einv[9];
@@ -81,17 +82,36 @@ HSQP_HD void mat6_mulv(const double* M, const double* v, double* r) {
   }
 }
 
+HSQP_HD void rot_axis_cs(const double* ax, double c, double s, double* Rm) {
+  const double t = 1.0 - c, x = ax[0], y = ax[1], z = ax[2];
+  Rm[0] = t * x * x + c;     Rm[1] = t * x * y - s * z; Rm[2] = t * x * z + s * y;
+  Rm[3] = t * x * y + s * z; Rm[4] = t * y * y + c;     Rm[5] = t * y * z - s * x;
+  Rm[6] = t * x * z - s * y; Rm[7] = t * y * z + s * x; Rm[8] = t * z * z + c;
+}
+
 // One evaluation of a_b (and, if DERIV, of G = d a_b / d[x;u]) at ws.q, ws.v, ws.qddj, ws.W.
+//
+// Serial depth: the kinematic tree is walked chain by chain (DevModel::chain_*): one work item per chain keeps the
+// parent state in registers, so a 6-body leg costs 6 dependent body updates and no barrier; chains hanging off
+// another chain (the arms) run in the next phase.  Everything that is not needed by a child (Sdd, inertia, net
+// force, BB) is deferred to fully parallel phases.
 template <bool DERIV>
 HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
-  // ---- base chain (one item)
-  WG_FOR(ctx, it, 1) {
+  // ---- phase T: joint rotations (parallel over the joints) and the base chain (one item)
+  WG_FOR(ctx, it, NB) {
+    if (it > 0) {
+      const int i = it;
+      double Rq[9];
+      const double qi = ws.q[5 + i];
+      rot_axis_cs(dm.axis[i], cos(qi), sin(qi), Rq);
+      m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
+      continue;
+    }
     const double cz = cos(ws.q[3]), sz = sin(ws.q[3]), cy = cos(ws.q[4]), sy = sin(ws.q[4]), cx = cos(ws.q[5]), sx = sin(ws.q[5]);
     const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
     for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
     m3_inverse(ws.E, ws.Einv);
-    // R0 = Rz Ry Rx
-    double* R0 = ws.R[0];
+    double* R0 = ws.R[0];   // R0 = Rz Ry Rx
     R0[0] = cz * cy; R0[1] = cz * sy * sx - sz * cx; R0[2] = cz * sy * cx + sz * sx;
     R0[3] = sz * cy; R0[4] = sz * sy * sx + cz * cx; R0[5] = sz * sy * cx - cz * sx;
     R0[6] = -sy;     R0[7] = cy * sx;                R0[8] = cy * cx;
@@ -110,23 +130,31 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 20);
-  // ---- forward kinematics, one phase per tree level
-  for (int l = 1; l < NLEVELS; ++l) {
-    const int b0 = dm.level_start[l], b1 = dm.level_start[l + 1];
-    WG_FOR(ctx, it, b1 - b0) {
-      const int i = dm.level_bodies[b0 + it];
-      const int pb = dm.parent[i], jc = i + 2, pjc = pb + 2;
-      double Rj[9], Rq[9], rr[3], w[3];
-      m3_mul(ws.R[pb], dm.Rfix[i], Rj);
-      rot_axis(dm.axis[i], ws.q[5 + i], Rq);
-      m3_mul(Rj, Rq, ws.R[i]);
-      m3_mulv(ws.R[pb], dm.pfix[i], rr);
-      for (int k = 0; k < 3; ++k) ws.r[i][k] = ws.r[pb][k] + rr[k];
-      m3_mulv(Rj, dm.axis[i], w);
-      double* Sx = ws.S[jc];
-      Sx[0] = w[0]; Sx[1] = w[1]; Sx[2] = w[2];
-      v3_cross(ws.r[i], w, Sx + 3);
-      joint_motion(ws.vl[pjc], ws.al[pjc], Sx, ws.v[5 + i], ws.qddj[i - 1], ws.vl[jc], ws.al[jc], ws.Sd[jc], ws.Sdd[jc]);
+  // ---- chain phases: one work item per chain, parent state carried in registers
+  for (int ph = 0; ph < dm.n_chain_phases; ++ph) {
+    WG_FOR(ctx, ch, dm.n_chains) {
+      if (dm.chain_phase[ch] != ph) continue;
+      const int b0 = dm.chain_start[ch], pb = dm.parent[b0];
+      double Rp[9], rp[3], vp[6], ap[6];
+      for (int k = 0; k < 9; ++k) Rp[k] = ws.R[pb][k];
+      for (int k = 0; k < 3; ++k) rp[k] = ws.r[pb][k];
+      for (int k = 0; k < 6; ++k) { vp[k] = ws.vl[pb + 2][k]; ap[k] = ws.al[pb + 2][k]; }
+      for (int n = 0; n < dm.chain_len[ch]; ++n) {
+        const int i = b0 + n, jc = i + 2;
+        double Rn[9], rr[3], Sx[6], vl[6], al[6], Sd[6];
+        m3_mul(Rp, ws.Mq[i], Rn);
+        m3_mulv(Rp, dm.pfix[i], rr);
+        m3_mulv(Rp, dm.axis_p[i], Sx);
+        for (int k = 0; k < 3; ++k) rr[k] += rp[k];
+        v3_cross(rr, Sx, Sx + 3);
+        const double qd = ws.v[5 + i], qdd = ws.qddj[i - 1];
+        for (int k = 0; k < 6; ++k) vl[k] = vp[k] + Sx[k] * qd;
+        mxm(vl, Sx, Sd);
+        for (int k = 0; k < 6; ++k) al[k] = ap[k] + Sx[k] * qdd + Sd[k] * qd;
+        for (int k = 0; k < 9; ++k) { ws.R[i][k] = Rn[k]; Rp[k] = Rn[k]; }
+        for (int k = 0; k < 3; ++k) { ws.r[i][k] = rr[k]; rp[k] = rr[k]; }
+        for (int k = 0; k < 6; ++k) { ws.S[jc][k] = Sx[k]; ws.vl[jc][k] = vl[k]; ws.al[jc][k] = al[k]; ws.Sd[jc][k] = Sd[k]; vp[k] = vl[k]; ap[k] = al[k]; }
+      }
     }
     WG_SYNC(ctx);
   }
@@ -151,6 +179,12 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     inertia_apply(In, ws.al[jc], fa);
     mxf(ws.vl[jc], h, fv);
     for (int k = 0; k < 6; ++k) ws.f[i][k] = fa[k] + fv[k];
+    if (DERIV && i > 0) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
+      double t1[6], t2[6];
+      mxm(ws.al[jc], ws.S[jc], t1);
+      mxm(ws.vl[jc], ws.Sd[jc], t2);
+      for (int k = 0; k < 6; ++k) ws.Sdd[jc][k] = t1[k] + t2[k];
+    }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 22);
@@ -164,14 +198,28 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 23);
-    // composites over subtrees (bodies are in depth-first order)
+    // composites over subtrees: direct sums for the light bodies (subtrees are contiguous in depth-first order) ...
     WG_FOR(ctx, it, NB * 52) {
       const int i = it / 52, e = it % 52;
+      if (dm.subtree_size[i] > 8) continue;
       const int end = i + dm.subtree_size[i];
       double s = 0.0;
       if (e < 10) { for (int d = i; d < end; ++d) s += ws.In[d][e]; ws.Ic[i][e] = s; }
       else if (e < 16) { for (int d = i; d < end; ++d) s += ws.f[d][e - 10]; ws.fc[i][e - 10] = s; }
       else { for (int d = i; d < end; ++d) s += ws.BB[d][e - 16]; ws.BBc[i][e - 16] = s; }
+    }
+    WG_SYNC(ctx);
+    // ... then own + children for the heavy ones, leaves-first, one item per quantity
+    WG_FOR(ctx, e, 52) {
+      for (int hb = 0; hb < dm.n_heavy; ++hb) {
+        const int i = dm.heavy[hb];
+        double s = e < 10 ? ws.In[i][e] : (e < 16 ? ws.f[i][e - 10] : ws.BB[i][e - 16]);
+        for (int cc = dm.child_start[i]; cc < dm.child_start[i + 1]; ++cc) {
+          const int c = dm.child_list[cc];
+          s += e < 10 ? ws.Ic[c][e] : (e < 16 ? ws.fc[c][e - 10] : ws.BBc[c][e - 16]);
+        }
+        if (e < 10) ws.Ic[i][e] = s; else if (e < 16) ws.fc[i][e - 10] = s; else ws.BBc[i][e - 16] = s;
+      }
     }
   } else {
     WG_FOR(ctx, e, 16) {

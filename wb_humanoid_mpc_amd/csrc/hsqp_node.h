@@ -35,6 +35,7 @@ struct NodeWS {
   double d[LDJ], gd[LDJ];
   double CDe[NE_MAX][LDJ];
   double eqv[NE_MAX];
+  double terms[208], tsum[16];   // stage-cost terms and their partial sums
   double cost;
 };
 
@@ -207,22 +208,34 @@ HSQP_HD void node_scalars(const Ctx& ctx, const DevModel& dm, const StageWS& ws,
     }
   }
   WG_SYNC(ctx);
-  // ---- stage cost value (one item; ~250 terms)
+  // ---- stage cost: one work item per term (195 terms), 16 partial sums, final sum
+  WG_FOR(ctx, t, 208) {
+    double c = 0.0;
+    if (t < NX) { const double dxx = nw.x[t] - nw.xnom[t]; c = 0.5 * dm.Q[t] * dxx * dxx; }
+    else if (t < NZ) { const int i = t - NX; const double duu = nw.u[i] - nw.unom[i]; c = 0.5 * dm.R[i] * duu * duu; }
+    else if (t < NZ + ROW_FRIC) { const double r = nw.rho[t - NZ]; c = 0.5 * r * r; }
+    else if (t < NZ + ROW_FRIC + 2) { const int f = t - NZ - ROW_FRIC; if (nw.contact[f]) c = relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, nw.hfric[f]).p; }
+    else if (t < NZ + ROW_FRIC + 10) { const int k = t - NZ - ROW_FRIC - 2, f = k / 4; if (nw.contact[f]) c = relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, nw.hmxy[f][k % 4]).p; }
+    else if (t < NZ + ROW_FRIC + 10 + 2 * NJ) {   // JointLimitsSoftConstraint.cpp:64-100
+      const int k = t - NZ - ROW_FRIC - 10, j = k >> 1;
+      c = (k & 1) ? pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - nw.x[6 + j]).p : pwp_barrier(dm.jl_bmu, dm.jl_bdelta, nw.x[6 + j] - dm.q_lo[j]).p;
+    } else if (t < NZ + ROW_FRIC + 10 + 2 * NJ + 16) {
+      if (!(nw.contact[0] && nw.contact[1])) c = pwp_barrier(dm.coll_bmu, dm.coll_bdelta, nw.hcoll[t - (NZ + ROW_FRIC + 10 + 2 * NJ)]).p;
+    }
+    nw.terms[t] = c;
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, p, 16) {
+    double c = 0.0;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) c += nw.terms[p * 13 + k];
+    nw.tsum[p] = c;
+  }
+  WG_SYNC(ctx);
   WG_FOR(ctx, it, 1) {
     double c = 0.0;
-    for (int i = 0; i < NX; ++i) { const double dxx = nw.x[i] - nw.xnom[i]; c += 0.5 * dm.Q[i] * dxx * dxx; }
-    for (int i = 0; i < NU; ++i) { const double duu = nw.u[i] - nw.unom[i]; c += 0.5 * dm.R[i] * duu * duu; }
-    for (int s = 0; s < ROW_FRIC; ++s) c += 0.5 * nw.rho[s] * nw.rho[s];
-    for (int f = 0; f < 2; ++f) {
-      if (!nw.contact[f]) continue;
-      c += relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, nw.hfric[f]).p;
-      for (int k = 0; k < 4; ++k) c += relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, nw.hmxy[f][k]).p;
-    }
-    for (int j = 0; j < NJ; ++j) {  // JointLimitsSoftConstraint.cpp:64-100
-      c += pwp_barrier(dm.jl_bmu, dm.jl_bdelta, nw.x[6 + j] - dm.q_lo[j]).p + pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - nw.x[6 + j]).p;
-    }
-    if (!(nw.contact[0] && nw.contact[1]))
-      for (int k = 0; k < 16; ++k) c += pwp_barrier(dm.coll_bmu, dm.coll_bdelta, nw.hcoll[k]).p;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c += nw.tsum[k];
     nw.cost = c;
   }
   WG_SYNC(ctx);

@@ -41,6 +41,7 @@ struct ProjWS {
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double V[NE_MAX][NU + 1];  // Householder vectors
       double beta[NE_MAX], Rdiag[NE_MAX];
+      double part[NE_MAX][4], yk[NE_MAX], hsc[2];   // per-step scratch: partial dots, row k of R, {alpha, beta}
     } qr;
     double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
   };
@@ -80,37 +81,39 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
   for (int k = 0; k < ne; ++k) {
-    WG_FOR(ctx, it, ne - k) {
-      const int c = k + it;
-      double xk[NU], xc[NU];
+    // (a) partial dots x . R(:,c) of the pivot column x = R(k:,k) with every remaining column (4 items per column)
+    WG_FOR(ctx, it, (ne - k) * 4) {
+      const int c = k + (it >> 2), p = it & 3;
+      double sdot = 0.0;
 #pragma unroll
-      for (int i = 0; i < NU; ++i) { xk[i] = w.qr.Rm[i][k]; xc[i] = w.qr.Rm[i][c]; }
-      double nrm2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) { if (i < k) xk[i] = 0.0; nrm2 += xk[i] * xk[i]; }
-      const double nrm = sqrt(nrm2);
-      double rkk = 0.0;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) if (i == k) rkk = xk[i];
+      for (int t = 0; t < (NU + 3) / 4; ++t) { const int i = p + 4 * t; if (i < NU && i >= k) sdot += w.qr.Rm[i][k] * w.qr.Rm[i][c]; }
+      w.qr.part[c - k][p] = sdot;
+      if (p == 0) w.qr.yk[c - k] = w.qr.Rm[k][c];
+    }
+    WG_SYNC(ctx);
+    // (b) reflector scalars (one item)
+    WG_FOR(ctx, it, 1) {
+      const double nrm2 = (w.qr.part[0][0] + w.qr.part[0][1]) + (w.qr.part[0][2] + w.qr.part[0][3]);
+      const double nrm = sqrt(nrm2), rkk = w.qr.yk[0];
       const double alpha = rkk >= 0.0 ? -nrm : nrm;
       const double vn = 2.0 * (nrm2 - alpha * rkk);
-      const double beta = vn > 1e-300 ? 2.0 / vn : 0.0;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) if (i == k) xk[i] -= alpha;   // xk is now the Householder vector v
-      if (c == k) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) w.qr.V[k][i] = xk[i];
-        w.qr.beta[k] = beta;
-        w.qr.Rdiag[k] = alpha;
-        if (!(nrm >= 1e-12)) w.ok = 0;
-      } else {
-        double sdot = 0.0;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) sdot += xk[i] * xc[i];
-        sdot *= beta;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) if (i >= k) w.qr.Rm[i][c] = xc[i] - sdot * xk[i];
-      }
+      w.qr.hsc[0] = alpha;
+      w.qr.hsc[1] = vn > 1e-300 ? 2.0 / vn : 0.0;
+      w.qr.beta[k] = w.qr.hsc[1];
+      w.qr.Rdiag[k] = alpha;
+      if (!(nrm >= 1e-12)) w.ok = 0;
+    }
+    WG_SYNC(ctx);
+    // (c) v = x - alpha e_k;  R(:,c) -= beta (v . R(:,c)) v  with  v . y = x . y - alpha y_k ;  column k is recorded in V
+    WG_FOR(ctx, it, (ne - k) * NU) {
+      const int c = k + it / NU, i = it % NU;
+      const double alpha = w.qr.hsc[0], beta = w.qr.hsc[1];
+      const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0));
+      if (c == k) { w.qr.V[k][i] = vi; continue; }
+      if (i < k) continue;
+      const double* pp = w.qr.part[c - k];
+      const double sdot = beta * (((pp[0] + pp[1]) + (pp[2] + pp[3])) - alpha * w.qr.yk[c - k]);
+      w.qr.Rm[i][c] -= sdot * vi;
     }
     WG_SYNC(ctx);
   }

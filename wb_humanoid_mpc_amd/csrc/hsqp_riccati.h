@@ -94,15 +94,16 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     // sweep (row j holds d_j * L^-1[...]), so a step needs no pivot broadcast phase: one barrier per column.  The
     // Cholesky scaling U = D^-1/2 (...) is applied to all rows at the end.
     for (int j = 0; j < NUT - 1; ++j) {
-      const int m = NUT - 1 - j, nch = (LDE - 1 - j + 7) / 8;   // rows below the pivot, 8-column chunks right of it
-      WG_FOR(ctx, it, m * nch) {
-        const int i = j + 1 + it / nch, c0 = j + 1 + (it % nch);
-        const double f = w.Em[j][i] / w.Em[j][j];
+      constexpr int NCH = (LDE + 7) / 8;   // 8 strided columns per item: fixed (row, chunk) grid, masked
+      WG_FOR(ctx, it, NUT * NCH) {
+        const int i = it / NCH, c0 = it % NCH;
+        if (i <= j) continue;
+        const double f = w.Em[j][i] * fast_rcp(w.Em[j][j]);
         double ej[8], ei[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const int c = c0 + t * nch; ej[t] = c < LDE ? w.Em[j][c] : 0.0; ei[t] = (c < LDE && c >= i) ? w.Em[i][c] : 0.0; }
+        for (int t = 0; t < 8; ++t) { const int c = c0 + t * NCH; const bool on = c < LDE && c >= i; ej[t] = on ? w.Em[j][c] : 0.0; ei[t] = on ? w.Em[i][c] : 0.0; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const int c = c0 + t * nch; if (c < LDE && c >= i) w.Em[i][c] = ei[t] - f * ej[t]; }
+        for (int t = 0; t < 8; ++t) { const int c = c0 + t * NCH; if (c < LDE && c >= i) w.Em[i][c] = ei[t] - f * ej[t]; }
       }
       WG_SYNC(ctx);
     }
