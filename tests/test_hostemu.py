@@ -39,7 +39,7 @@ def test_analytic_flow_jacobian(model, oracle, emu, rng):
         assert np.abs(G - J[29:35]).max() <= 1e-10 * max(1.0, np.abs(J).max())
         ab2 = np.zeros(6)
         lib.emu_stage_eval(h, P(x), P(u), 0, P(ab2), None)
-        assert np.array_equal(ab, ab2)
+        assert np.allclose(ab, ab2, rtol=1e-13, atol=1e-13)   # the value-only path sums the body forces in a different order
 
 
 @pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 6), ("run", 12)])

@@ -62,6 +62,14 @@ struct Ctx {
 #endif
 #define WG_FOR(ctx, i, n) for (int i = (ctx).tid; i < (n); i += (ctx).nthreads)
 
+// Wave specialisation inside one phase: the LOWER half of the workgroup's waves feeds the matrix cores (one wave per
+// SIMD saturates the FP64 MFMA pipe), the UPPER half runs the phase's copies / vector work concurrently.
+// The one-thread host context plays both roles.
+HSQP_HD bool is_mfma_half(const Ctx& c) { return c.nthreads < 128 || c.tid < c.nthreads / 2; }
+HSQP_HD bool is_helper_half(const Ctx& c) { return c.nthreads < 128 || c.tid >= c.nthreads / 2; }
+HSQP_HD Ctx mfma_ctx(const Ctx& c) { return c.nthreads < 128 ? c : Ctx{c.tid, c.nthreads / 2, c.prof}; }
+HSQP_HD Ctx helper_ctx(const Ctx& c) { return c.nthreads < 128 ? c : Ctx{c.tid - c.nthreads / 2, c.nthreads / 2, nullptr}; }
+
 // ------------------------------------------------------------------------------------------------
 // Device image of the model constants (built on the host from hsqp_model_desc, hsqp_host.cpp).
 struct DevModel {

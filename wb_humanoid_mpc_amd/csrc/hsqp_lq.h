@@ -28,6 +28,7 @@ constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
 constexpr int REC_SIZE = REC_FLOW + 64;
 
 struct LqWS {
+  DevModel dml;        // the model constants, copied to LDS once per workgroup (they are read on every serial path)
   union {
     StageWS st;
     double Ab[4][6][LDJ];
@@ -74,8 +75,16 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
 // Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory); misc[0..3] = {ne, dt*cost, dt*|eq|^2, dt*|b|^2}.
 // DERIV = false: values only (performance index); rec is not touched and may be null.
 template <bool DERIV>
-HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm, LqWS& w, const double* x, const double* u, const double* xnext,
+HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const double* x, const double* u, const double* xnext,
                      const double* par, double dt, double* rec, double* misc) {
+  {
+    constexpr int nw = (int)(sizeof(DevModel) / sizeof(double));
+    static_assert(sizeof(DevModel) % sizeof(double) == 0, "DevModel must be a whole number of doubles");
+    const double* src = reinterpret_cast<const double*>(&dm_global);
+    double* dst = reinterpret_cast<double*>(&w.dml);
+    WG_FOR(ctx, i, nw) dst[i] = src[i];
+  }
+  const DevModel& dm = w.dml;
   WG_FOR(ctx, i, NX + NU + NP + NX) {
     if (i < NX) w.nw.x[i] = x[i];
     else if (i < NX + NU) w.nw.u[i - NX] = u[i - NX];

@@ -25,6 +25,7 @@ struct StageWS {
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
   double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
+  double ecs[3][2];                // cos, sin of the euler angles z, y, x
   // ---- base
   double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
   double Einv[9];
@@ -97,17 +98,19 @@ HSQP_HD void rot_axis_cs(const double* ax, double c, double s, double* Rm) {
 // force, BB) is deferred to fully parallel phases.
 template <bool DERIV>
 HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
-  // ---- phase T: joint rotations (parallel over the joints) and the base chain (one item)
-  WG_FOR(ctx, it, NB) {
-    if (it > 0) {
-      const int i = it;
-      double Rq[9];
-      const double qi = ws.q[5 + i];
-      rot_axis_cs(dm.axis[i], cos(qi), sin(qi), Rq);
-      m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
-      continue;
-    }
-    const double cz = cos(ws.q[3]), sz = sin(ws.q[3]), cy = cos(ws.q[4]), sy = sin(ws.q[4]), cx = cos(ws.q[5]), sx = sin(ws.q[5]);
+  // ---- phase T0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
+  WG_FOR(ctx, it, NB + 2) {
+    if (it < 3) { ws.ecs[it][0] = cos(ws.q[3 + it]); ws.ecs[it][1] = sin(ws.q[3 + it]); continue; }
+    const int i = it - 2;
+    double Rq[9];
+    const double qi = ws.q[5 + i];
+    rot_axis_cs(dm.axis[i], cos(qi), sin(qi), Rq);
+    m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
+  }
+  WG_SYNC(ctx);
+  // ---- phase T1: the base chain (one item)
+  WG_FOR(ctx, it, 1) {
+    const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
     const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
     for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
     m3_inverse(ws.E, ws.Einv);

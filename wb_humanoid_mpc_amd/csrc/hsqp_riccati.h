@@ -69,8 +69,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     {
       const XtyJob jobs[2] = {xty_job(NX, NX, NX, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
                               xty_job(NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
-      wg_xty_jobs(ctx, jobs, 2);
-      WG_FOR(ctx, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt);
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
+      if (is_helper_half(ctx)) { const Ctx hc = helper_ctx(ctx); WG_FOR(hc, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt); }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
@@ -79,13 +79,16 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
                               xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.Em[0][0], LDE, q + QP_R, NUT)};
       constexpr int na = nbatches(NX * NX, 8);
-      WG_FOR(ctx, it, na) {
-        if (k > 0) copy_batch<8>(it, NX * NX, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
-      }
-      wg_xty_jobs(ctx, jobs, 2);
-      WG_FOR(ctx, it, NUT + NUT * NX) {
-        if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
-        else { const int j = it - NUT, r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
+      if (is_helper_half(ctx)) {
+        const Ctx hc = helper_ctx(ctx);
+        WG_FOR(hc, it, na) {
+          if (k > 0) copy_batch<8>(it, NX * NX, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+        }
+        WG_FOR(hc, it, NUT + NUT * NX) {
+          if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
+          else { const int j = it - NUT, r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
+        }
       }
     }
     WG_SYNC(ctx);
@@ -124,38 +127,41 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       js.L2 = NUT; js.X2 = &w.Em[0][EM_G]; js.ldx2 = LDE; js.Y2 = &w.Em[0][EM_G]; js.ldy2 = LDE; js.sign2 = -1.0;
       const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX, -1.0)};
       constexpr int nbb = nbatches(NX * LDB, 8);
-      WG_FOR(ctx, bb, nbb + NX) {
-        if (k > 0) {
-          if (bb < nbb) {
-            double t[8];
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
+      if (is_helper_half(ctx)) {
+        const Ctx hc = helper_ctx(ctx);
+        WG_FOR(hc, it, 2 * NX + NUT * (NUT + NX + 1)) {
+          if (it < NX) {
+            const int r = it;
+            double s = q[QP_QV + r] + dot_strided<NX>(&A[0][r], NX, w.sb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb, r = i / LDB, c = i % LDB; t[j] = (i < NX * LDB && c < NUT) ? qn[QP_B + r * NUT + c] : 0.0; }
+            for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
+            w.sn[r] = s;
+          } else if (it < 2 * NX) {
+            const int r = it - NX;
+            double s = w.bt[r];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb; if (i < NX * LDB) w.B[i / LDB][i % LDB] = t[j]; }
+            for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
+            rk[RIC_BCL + r] = s;
           } else {
-            w.btn[bb - nbb] = qn[QP_BV + bb - nbb];
+            const int j = it - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
+            if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
+            else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
+            else rk[RIC_ZV + r] = w.Em[r][EM_GV];
           }
         }
-      }
-      wg_xty_jobs(ctx, jobs, 2);
-      WG_FOR(ctx, it, 2 * NX + NUT * (NUT + NX + 1)) {
-        if (it < NX) {
-          const int r = it;
-          double s = q[QP_QV + r] + dot_strided<NX>(&A[0][r], NX, w.sb);
+        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage (B is dead since P3)
+          if (k > 0) {
+            if (bb < nbb) {
+              double t[8];
 #pragma unroll
-          for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
-          w.sn[r] = s;
-        } else if (it < 2 * NX) {
-          const int r = it - NX;
-          double s = w.bt[r];
+              for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb, r = i / LDB, c = i % LDB; t[j] = (i < NX * LDB && c < NUT) ? qn[QP_B + r * NUT + c] : 0.0; }
 #pragma unroll
-          for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
-          rk[RIC_BCL + r] = s;
-        } else {
-          const int j = it - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
-          if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
-          else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
-          else rk[RIC_ZV + r] = w.Em[r][EM_GV];
+              for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb; if (i < NX * LDB) w.B[i / LDB][i % LDB] = t[j]; }
+            } else {
+              w.btn[bb - nbb] = qn[QP_BV + bb - nbb];
+            }
+          }
         }
       }
     }
