@@ -142,41 +142,56 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
-HSQP_D void xty_job_tile_mfma(const XtyJob& j, int tile, int lane) {
+// NT = 1 or 2 output tiles of one job processed together: two independent accumulator chains keep the FP64 matrix
+// pipe busy from a single wave (a dependent v_mfma_f64 chain alone leaves it half idle).
+template <int NT>
+HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
   const int tn = (j.N + 15) >> 4;
-  const int r0 = (tile / tn) << 4, c0 = (tile % tn) << 4;
   const int i = lane & 15, kk = lane >> 4;
-  const int xr = r0 + i < j.M ? r0 + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
-  const int yc = c0 + i < j.N ? c0 + i : j.N - 1;
-  hsqp_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  // the additive term may live in HBM: issue its loads before the MFMA loop, consume them in the epilogue
-  const int cst = c0 + i;
-  double addv[4] = {0.0, 0.0, 0.0, 0.0};
-  if (j.Add && cst < j.N) {
+  int r0[NT], c0[NT], xr[NT], yc[NT];
+  hsqp_d4 acc[NT];
+  double addv[NT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r; if (row < j.M) addv[r] = j.Add[row * j.ldadd + cst]; }
+  for (int t = 0; t < NT; ++t) {
+    r0[t] = (tiles[t] / tn) << 4; c0[t] = (tiles[t] % tn) << 4;
+    xr[t] = r0[t] + i < j.M ? r0[t] + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
+    yc[t] = c0[t] + i < j.N ? c0[t] + i : j.N - 1;
+    acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
+    // the additive term may live in HBM: issue its loads before the MFMA loop, consume them in the epilogue
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0[t] + kk + 4 * r;
+      addv[t][r] = (j.Add && c0[t] + i < j.N && row < j.M) ? j.Add[row * j.ldadd + c0[t] + i] : 0.0;
+    }
   }
   for (int k0 = 0; k0 < j.L1; k0 += 4) {
     const int k = k0 + kk;
     const bool ok = k < j.L1;
-    const double a = ok ? j.X1[k * j.ldx1 + xr] : 0.0;
-    const double b = ok ? j.Y1[k * j.ldy1 + yc] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double a = ok ? j.X1[k * j.ldx1 + xr[t]] : 0.0;
+      const double b = ok ? j.Y1[k * j.ldy1 + yc[t]] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
   }
   for (int k0 = 0; k0 < j.L2; k0 += 4) {
     const int k = k0 + kk;
     const bool ok = k < j.L2;
-    const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr] : 0.0;
-    const double b = ok ? j.Y2[k * j.ldy2 + yc] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  const int c = c0 + i;
-  if (c < j.N) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0 + kk + 4 * r;
-      if (row < j.M) {
-        j.C[row * j.ldc + c] = j.scale * acc[r] + addv[r];
+    for (int t = 0; t < NT; ++t) {
+      const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr[t]] : 0.0;
+      const double b = ok ? j.Y2[k * j.ldy2 + yc[t]] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = c0[t] + i;
+    if (c < j.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0[t] + kk + 4 * r;
+        if (row < j.M) j.C[row * j.ldc + c] = j.scale * acc[t][r] + addv[t][r];
       }
     }
   }
@@ -192,8 +207,10 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
   for (int jn = 0; jn < njobs; ++jn) {
     const XtyJob& j = jobs[jn];
     const int nt = ((j.M + 15) >> 4) * ((j.N + 15) >> 4);
-    // first tile of this job owned by this wave: tiles are numbered globally (base + t) and dealt round-robin
-    for (int t = (wave - base % nwaves + nwaves) % nwaves; t < nt; t += nwaves) xty_job_tile_mfma(j, t, lane);
+    // tiles are numbered globally (base + t) and dealt round-robin; a wave takes its tiles two at a time
+    int t = (wave - base % nwaves + nwaves) % nwaves;
+    for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {t, t + nwaves}; xty_job_tiles_mfma<2>(j, pair, lane); }
+    if (t < nt) xty_job_tiles_mfma<1>(j, &t, lane);
     base += nt;
   }
 #else

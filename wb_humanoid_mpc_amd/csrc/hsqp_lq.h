@@ -25,16 +25,19 @@ constexpr int REC_GD = REC_D + LDJ;               // [LDJ]        gradient, diag
 constexpr int REC_CDE = REC_GD + LDJ;             // [NE_MAX][LDJ] rows [C|D|e]
 constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [8]  ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt)
 constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
-constexpr int REC_SIZE = REC_FLOW + 64;
+constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel)
+constexpr int REC_SIZE = REC_GS + 4 * 6 * LDJ;
 
 struct LqWS {
   DevModel dml;        // the model constants, copied to LDS once per workgroup (they are read on every serial path)
   union {
     StageWS st;
-    double Ab[4][6][LDJ];
+    struct {
+      double Gs[4][6][LDJ];
+      double Ab[4][6][LDJ];
+    } ch;              // RK4 chain workspace: aliases the stage workspace, which is dead after stage 4
   };
   NodeWS nw;
-  double Gs[4][6][LDJ];
   double vs[4][NV];    // velocity part of the stage states
   double as[4][6];     // base accelerations of the stages
   double xnext[NX];
@@ -99,7 +102,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
     PH_TICK(ctx, 2);
     WG_FOR(ctx, i, 6 + (DERIV ? 6 * LDJ : 0)) {
       if (i < 6) w.as[s][i] = w.st.ab[i];
-      else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; w.Gs[s][r][c] = c < NZ ? w.st.G[r][c] : 0.0; }
+      else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; rec[REC_GS + (s * 6 + r) * LDJ + c] = c < NZ ? w.st.G[r][c] : 0.0; }
     }
     WG_SYNC(ctx);
     if (s == 0) {
@@ -158,7 +161,11 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
   WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
   // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
   const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
-  WG_FOR(ctx, i, 6 * LDJ) { const int r = i / LDJ, c = i % LDJ; w.Ab[0][r][c] = w.Gs[0][r][c]; }
+  WG_FOR(ctx, i, 4 * 6 * LDJ) {   // stage Jacobians back from the record (written by this workgroup, L2-resident)
+    const double g = rec[REC_GS + i];
+    w.ch.Gs[i / (6 * LDJ)][(i / LDJ) % 6][i % LDJ] = g;
+    if (i < 6 * LDJ) w.ch.Ab[0][i / LDJ][i % LDJ] = g;
+  }
   WG_SYNC(ctx);
   for (int s = 1; s < 4; ++s) {
     const double c = s == 1 ? c2 : (s == 2 ? c3 : c4);
@@ -167,13 +174,13 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
       const int r = i / LDJ, col = i % LDJ;
       double val = 0.0;
       if (col < NZ) {
-        if (col < NV) val = w.Gs[s][r][col];
-        else if (col < NX) val = c * w.Gs[s][r][col - NV] + w.Gs[s][r][col];
-        else val = w.Gs[s][r][col];
-        val += c * times_vd(w.Gs[s], NV, w.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
-        if (s >= 2) val += c * cprev * times_vd(w.Gs[s], 0, w.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
+        if (col < NV) val = w.ch.Gs[s][r][col];
+        else if (col < NX) val = c * w.ch.Gs[s][r][col - NV] + w.ch.Gs[s][r][col];
+        else val = w.ch.Gs[s][r][col];
+        val += c * times_vd(w.ch.Gs[s], NV, w.ch.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
+        if (s >= 2) val += c * cprev * times_vd(w.ch.Gs[s], 0, w.ch.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
       }
-      w.Ab[s][r][col] = val;
+      w.ch.Ab[s][r][col] = val;
     }
     WG_SYNC(ctx);
   }
@@ -181,8 +188,8 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
   WG_FOR(ctx, i, 2 * 6 * LDJ) {
     const int which = i / (6 * LDJ), r = (i / LDJ) % 6, col = i % LDJ;
     double v;
-    if (which == 0) v = dt * dt / 6.0 * (w.Ab[0][r][col] + w.Ab[1][r][col] + w.Ab[2][r][col]);
-    else v = dt / 6.0 * (w.Ab[0][r][col] + 2.0 * w.Ab[1][r][col] + 2.0 * w.Ab[2][r][col] + w.Ab[3][r][col]);
+    if (which == 0) v = dt * dt / 6.0 * (w.ch.Ab[0][r][col] + w.ch.Ab[1][r][col] + w.ch.Ab[2][r][col]);
+    else v = dt / 6.0 * (w.ch.Ab[0][r][col] + 2.0 * w.ch.Ab[1][r][col] + 2.0 * w.ch.Ab[2][r][col] + w.ch.Ab[3][r][col]);
     rec[REC_PV + i] = v;
   }
   WG_SYNC(ctx);
