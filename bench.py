@@ -72,16 +72,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from wb_humanoid_mpc_amd.distributed import Group, aggregate_throughput, env_rank, shard_seed
+    rank, local_rank, world = env_rank()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # torch FIRST: its bundled libamdhip64.so.7 must be the one HIP runtime of the process; libhsqp_hip.so then
     # binds to it by soname (measured on the GPU box: the other order leaves torch.cuda unavailable)
     import torch
-    import torch.distributed as dist
     from wb_humanoid_mpc_amd import load_model
     from wb_humanoid_mpc_amd.reference import BENCH_SEED, make_problem
     from wb_humanoid_mpc_amd.solver import HipSqpSolver, load_library
@@ -90,19 +88,17 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")  # initialise the HIP runtime through torch before the library touches it
     load_library()
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    group = Group(world, backend="nccl", device=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     model = load_model()
     B, N = args.batch, args.nodes
-    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=BENCH_SEED + rank)
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=shard_seed(BENCH_SEED, rank))
     solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank)
     solver.upload(x0, x, u, par, dt)      # inputs resident in HBM before the timed region
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -121,16 +117,10 @@ def main():
     out = solver.download()
     kkt = float(np.max(out["kkt"]))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    kk = torch.tensor([kkt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
-    elapsed, kkt = float(t.item()), float(kk.item())
+    elapsed, kkt = group.max([elapsed, kkt])   # max over ranks
 
     if rank == 0:
-        iters = B * world * args.steps
-        value = iters / elapsed
+        value = aggregate_throughput([B] * world, args.steps, elapsed)
         nodes = B * N
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
         kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN), "projection(k_project)": (kms[1], F_PROJ), "riccati(k_riccati)": (kms[2], F_RIC)}
@@ -160,8 +150,7 @@ def main():
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     solver.close()
-    if world > 1:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

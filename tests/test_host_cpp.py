@@ -1,0 +1,43 @@
+"""The C++ host wrapper (wb_humanoid_mpc_amd/host/HipSqpSolver.h) compiles against the C ABI and, like the library,
+refuses to run without a GPU (std::runtime_error from the constructor)."""
+import os
+import subprocess
+
+import pytest
+
+from wb_humanoid_mpc_amd import solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r'''
+#include <cstdio>
+#include <cstring>
+#include "HipSqpSolver.h"
+int main() {
+  hsqp_model_desc md;
+  std::memset(&md, 0, sizeof(md));
+  md.n_joints = HSQP_NJ;
+  try {
+    hsqp_host::HipSqpSolver s(md, 8, 1, 0);
+    std::printf("constructed\n");
+    return 0;
+  } catch (const std::runtime_error& e) {
+    std::printf("runtime_error: %s\n", e.what());
+    return 3;
+  }
+}
+'''
+
+
+def test_cpp_wrapper_compiles_and_fails_loudly_without_device_or_model(tmp_path):
+    solver.load_library()
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    libdir = os.path.join(ROOT, "wb_humanoid_mpc_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(libdir, "host"), str(src), "-L", libdir, "-lhsqp_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    # no GPU: NO_DEVICE; with a GPU: the all-zero model description is rejected (BAD_ARG). Either way a runtime_error.
+    assert r.returncode == 3 and "runtime_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert ("(-2)" in r.stdout) or ("(-1)" in r.stdout)

@@ -1,0 +1,82 @@
+// C++ host side of the drop-in boundary: a thin RAII class over the C ABI (include/hsqp.h) with the method names
+// and meanings of the surface the reference consumes from its solver —
+//   ocs2::SolverBase::reset / run / getPrimalSolution / getPerformanceIndeces   (lib/ocs2_ros2, missing submodule;
+//     used through humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:64-89 and
+//     humanoid_nmpc/humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:200-213)
+//   SqpSolver::getBenchmarks() {linearQuadraticApproximationTime, solveQpTime, linesearchTime, computeControllerTime}
+//     (humanoid_nmpc/humanoid_common_mpc_ros2/src/benchmarks/SqpBenchmarksPublisher.cpp:44-57)
+// for a batch of independent MPC instances.  It has no dependency on ocs2; the ocs2 adaptor that derives from
+// ocs2::SolverBase and owns one of these is shown in INTEGRATION.md.  Failures map to std::runtime_error, which is
+// what the reference's MPC thread expects from its solver (WBMpcMrtJointController.cpp:210-213).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hsqp.h"
+
+namespace hsqp_host {
+
+struct Benchmarks {
+  double linearQuadraticApproximationTime = 0.0, solveQpTime = 0.0, linesearchTime = 0.0, computeControllerTime = 0.0;
+};
+
+struct PrimalSolution {
+  int batch = 0, nodes = 0;
+  std::vector<double> stateTrajectory;   // [batch][nodes + 1][HSQP_NX]
+  std::vector<double> inputTrajectory;   // [batch][nodes][HSQP_NU]
+};
+
+class HipSqpSolver {
+ public:
+  HipSqpSolver(const hsqp_model_desc& model, int maxNodes, int maxBatch = 1, int device = 0) {
+    hsqp_settings st{maxNodes, maxBatch, device, 0};
+    const int rc = hsqp_create(&model, &st, &h_);
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_create failed (" + std::to_string(rc) + "): " + hsqp_last_error(nullptr));
+  }
+  ~HipSqpSolver() { hsqp_destroy(h_); }
+  HipSqpSolver(const HipSqpSolver&) = delete;
+  HipSqpSolver& operator=(const HipSqpSolver&) = delete;
+
+  /** SolverBase::reset: forget the previous solution (the next run is a cold start supplied by the caller). */
+  void reset() { solution_ = PrimalSolution(); perf_.clear(); }
+
+  /**
+   * SolverBase::run for `batch` instances on a uniform grid of `nodes` intervals: one SQP iteration
+   * (task.info: sqpIteration 1) from the linearisation trajectory (xTraj, uTraj); xInit is the measured state.
+   */
+  void run(int batch, int nodes, double dt, const double* xInit, const double* xTraj, const double* uTraj, const double* nodeParams) {
+    hsqp_problem p{batch, nodes, dt, xInit, xTraj, uTraj, nodeParams};
+    solution_.batch = batch; solution_.nodes = nodes;
+    solution_.stateTrajectory.assign((size_t)batch * (nodes + 1) * HSQP_NX, 0.0);
+    solution_.inputTrajectory.assign((size_t)batch * nodes * HSQP_NU, 0.0);
+    perf_.assign(batch, hsqp_perf{});
+    perfBefore_.assign(batch, hsqp_perf{});
+    kkt_.assign((size_t)batch * 2, 0.0);
+    hsqp_solution s{};
+    s.x = solution_.stateTrajectory.data(); s.u = solution_.inputTrajectory.data();
+    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = kkt_.data();
+    const int rc = hsqp_solve(h_, &p, &s);
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_solve failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+    bench_.linearQuadraticApproximationTime = s.timings.lq_approximation;
+    bench_.solveQpTime = s.timings.solve_qp;
+    bench_.linesearchTime = s.timings.linesearch;
+    bench_.computeControllerTime = s.timings.compute_controller;
+  }
+
+  const PrimalSolution& getPrimalSolution() const { return solution_; }
+  const std::vector<hsqp_perf>& getPerformanceIndeces() const { return perf_; }
+  const std::vector<hsqp_perf>& getPerformanceIndecesBeforeStep() const { return perfBefore_; }
+  const std::vector<double>& getKktResiduals() const { return kkt_; }
+  Benchmarks getBenchmarks() const { return bench_; }
+  hsqp_handle* handle() { return h_; }
+
+ private:
+  hsqp_handle* h_ = nullptr;
+  PrimalSolution solution_;
+  std::vector<hsqp_perf> perf_, perfBefore_;
+  std::vector<double> kkt_;
+  Benchmarks bench_;
+};
+
+}  // namespace hsqp_host
