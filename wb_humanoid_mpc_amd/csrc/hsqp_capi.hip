@@ -23,7 +23,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 
 // ---- LQ approximation: one workgroup per (instance, node)
 template <bool DERIV>
-__global__ __launch_bounds__(LQ_THREADS, 2) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
+__global__ __launch_bounds__(LQ_THREADS, 3) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
                                                    const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
                                                    double* __restrict__ rec, double* __restrict__ misc, long long* prof) {
   const int node = blockIdx.x, b = node / N, k = node % N;

@@ -33,7 +33,7 @@ struct LqWS {
   union {
     StageWS st;
     struct {
-      double Gs[4][6][LDJ];
+      double Gs[3][6][LDJ];   // stage Jacobians of stages 2..4 (stage 1 is Ab[0])
       double Ab[4][6][LDJ];
     } ch;              // RK4 chain workspace: aliases the stage workspace, which is dead after stage 4
   };
@@ -111,7 +111,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
       PH_TICK(ctx, 4);
       node_scalars(ctx, dm, w.st, w.nw);
       PH_TICK(ctx, 5);
-      if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J);
+      if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J, rec + REC_CDE);
       PH_TICK(ctx, 6);
       if (DERIV) WG_FOR(ctx, i, 64 + NRS) {
         if (i < 64) {
@@ -152,19 +152,18 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
     misc[3] = dt * dyn;
   }
   if (!DERIV) return;
-  // ---- write d, gd, CDe
-  WG_FOR(ctx, i, 2 * LDJ + NE_MAX * LDJ) {
+  // ---- write d, gd (the equality rows went straight to the record)
+  WG_FOR(ctx, i, 2 * LDJ) {
     if (i < LDJ) rec[REC_D + i] = w.nw.d[i];
-    else if (i < 2 * LDJ) rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
-    else rec[REC_CDE + i - 2 * LDJ] = w.nw.CDe[(i - 2 * LDJ) / LDJ][(i - 2 * LDJ) % LDJ];
+    else rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
   }
   WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
   // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
   const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
   WG_FOR(ctx, i, 4 * 6 * LDJ) {   // stage Jacobians back from the record (written by this workgroup, L2-resident)
     const double g = rec[REC_GS + i];
-    w.ch.Gs[i / (6 * LDJ)][(i / LDJ) % 6][i % LDJ] = g;
     if (i < 6 * LDJ) w.ch.Ab[0][i / LDJ][i % LDJ] = g;
+    else w.ch.Gs[i / (6 * LDJ) - 1][(i / LDJ) % 6][i % LDJ] = g;
   }
   WG_SYNC(ctx);
   for (int s = 1; s < 4; ++s) {
@@ -174,11 +173,11 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
       const int r = i / LDJ, col = i % LDJ;
       double val = 0.0;
       if (col < NZ) {
-        if (col < NV) val = w.ch.Gs[s][r][col];
-        else if (col < NX) val = c * w.ch.Gs[s][r][col - NV] + w.ch.Gs[s][r][col];
-        else val = w.ch.Gs[s][r][col];
-        val += c * times_vd(w.ch.Gs[s], NV, w.ch.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
-        if (s >= 2) val += c * cprev * times_vd(w.ch.Gs[s], 0, w.ch.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
+        if (col < NV) val = w.ch.Gs[s - 1][r][col];
+        else if (col < NX) val = c * w.ch.Gs[s - 1][r][col - NV] + w.ch.Gs[s - 1][r][col];
+        else val = w.ch.Gs[s - 1][r][col];
+        val += c * times_vd(w.ch.Gs[s - 1], NV, w.ch.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
+        if (s >= 2) val += c * cprev * times_vd(w.ch.Gs[s - 1], 0, w.ch.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
       }
       w.ch.Ab[s][r][col] = val;
     }

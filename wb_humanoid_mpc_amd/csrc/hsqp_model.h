@@ -34,7 +34,11 @@ struct StageWS {
   double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
   // ---- bodies
   double R[NB][9], r[NB][3];       // world rotation, origin relative to the base origin O
-  double In[NB][10], f[NB][6], BB[NB][36];
+  double In[NB][10], f[NB][6];
+  union {
+    double BB[NB][36];             // per-body BB (dead once the composites are formed)
+    double G[6][96];               // d ab / d[x;u], columns 0..92 used (written after the composites)
+  };
   double Ic[NB][10], fc[NB][6], BBc[NB][36];
   double rP[2][3];                 // contact points relative to O
   // ---- results
@@ -42,7 +46,6 @@ struct StageWS {
   double Iinv[9];                  // inverse of the total rotational inertia about O
   double y[3];                     // E a_ang
   double ab[6];                    // base acceleration {lin, euler-rate acc}
-  double G[6][96];                 // d ab / d[x;u]   (columns 0..92 used)
 };
 
 HSQP_HD void rot_axis(const double* ax, double q, double* Rm) {

@@ -33,7 +33,6 @@ struct NodeWS {
   double scale[NRS];             // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive
   double rho[NRS];
   double d[LDJ], gd[LDJ];
-  double CDe[NE_MAX][LDJ];
   double eqv[NE_MAX];
   double terms[208], tsum[16];   // stage-cost terms and their partial sums
   double cost;
@@ -340,7 +339,7 @@ HSQP_HD bool point_column(const DevModel& dm, const StageWS& ws, int body, const
 
 // First-order data: residual rows J (written to Jout[NRS][LDJ], scaled by sqrt(dt)), d, gd (x dt), CDe.
 // After node_values() and node_scalars(); ws.G must hold the stage-1 Jacobian.
-HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw, double dt, double* Jout) {
+HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw, double dt, double* Jout, double* CDe /*[NE_MAX][LDJ], global*/) {
   const double sdt = sqrt(dt);
   // ---- foot columns: task-space cost rows + stance / swing equality rows
   WG_FOR(ctx, it, 2 * LDJ) {
@@ -359,11 +358,11 @@ HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS&
         const double gp = k < 2 ? 0.0 : (k == 2 ? dm.gain_pos_z : dm.gain_ori);
         const double gv = k < 2 ? dm.gain_linvel_xy : (k == 2 ? dm.gain_linvel_z : dm.gain_angvel);
         const double ga = k < 2 ? dm.gain_linacc_xy : (k == 2 ? dm.gain_linacc_z : dm.gain_angacc);
-        nw.CDe[r0 + k][col] = k < 3 ? gp * dq[c] + gv * dq[6 + c] + ga * dq[12 + c] : gp * dq[3 + c] + gv * dq[9 + c] + ga * dq[15 + c];
+        CDe[(r0 + k) * LDJ + col] = k < 3 ? gp * dq[c] + gv * dq[6 + c] + ga * dq[12 + c] : gp * dq[3 + c] + gv * dq[9 + c] + ga * dq[15 + c];
       }
     } else {
-      for (int k = 0; k < 6; ++k) nw.CDe[r0 + k][col] = (col == NX + 6 * f + k) ? 1.0 : 0.0;
-      nw.CDe[r0 + 6][col] = dm.gain_pos_z * dq[2] + dm.gain_linvel_z * dq[8] + dm.gain_linacc_z * dq[14];
+      for (int k = 0; k < 6; ++k) CDe[(r0 + k) * LDJ + col] = (col == NX + 6 * f + k) ? 1.0 : 0.0;
+      CDe[(r0 + 6) * LDJ + col] = dm.gain_pos_z * dq[2] + dm.gain_linvel_z * dq[8] + dm.gain_linacc_z * dq[14];
     }
   }
   // ---- friction, moment XY and collision rows, one item per (row slot, column)
@@ -437,9 +436,9 @@ HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS&
     nw.gd[i] = dt * g;
   }
   WG_FOR(ctx, r, NE_MAX) {
-    if (r < nw.ne) nw.CDe[r][NZ] = nw.eqv[r];
-    for (int c = NZ + (r < nw.ne ? 1 : 0); c < LDJ; ++c) nw.CDe[r][c] = 0.0;
-    if (r >= nw.ne) for (int c = 0; c < NZ + 1; ++c) nw.CDe[r][c] = 0.0;
+    if (r < nw.ne) CDe[r * LDJ + NZ] = nw.eqv[r];
+    for (int c = NZ + (r < nw.ne ? 1 : 0); c < LDJ; ++c) CDe[r * LDJ + c] = 0.0;
+    if (r >= nw.ne) for (int c = 0; c < NZ + 1; ++c) CDe[r * LDJ + c] = 0.0;
   }
   WG_SYNC(ctx);
 }
