@@ -62,6 +62,23 @@ struct Ctx {
 #endif
 #define WG_FOR(ctx, i, n) for (int i = (ctx).tid; i < (n); i += (ctx).nthreads)
 
+// Wave-local section: code executed by ONE wave (wave 0) needs no workgroup barrier between its dependent steps — the
+// LDS processes a wave's instructions in order; WV_SYNC only has to stop the compiler from reordering across the step
+// boundary and make the wave wait for its outstanding LDS operations.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WV_SYNC()                                              \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */       \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
+#else
+#define WV_SYNC() ((void)0)
+#endif
+HSQP_HD bool is_wave0(const Ctx& c) { return c.nthreads < 128 || c.tid < 64; }
+HSQP_HD Ctx wave0_ctx(const Ctx& c) { return c.nthreads < 128 ? c : Ctx{c.tid, 64, c.prof}; }
+
 // Wave specialisation inside one phase: the LOWER half of the workgroup's waves feeds the matrix cores (one wave per
 // SIMD saturates the FP64 MFMA pipe), the UPPER half runs the phase's copies / vector work concurrently.
 // The one-thread host context plays both roles.

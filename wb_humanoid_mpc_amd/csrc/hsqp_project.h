@@ -32,16 +32,17 @@ constexpr int NTW = NX + NUT;                  // 81: projected stage variable [
 constexpr int LDTM = 84;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
 constexpr int NRX = 100;                       // residual rows after projection: 64 slots + 35 input-weight rows + 1 zero row
 
+constexpr int LDR = 16;
 struct ProjWS {
   union {
     struct {
       double CDe[NE_MAX][LDJ];
-      double Rm[NU][NE_MAX];     // D^T, overwritten by R1
+      double Rm[NU + 1][LDR];    // D^T (zero padded to 36 x 16), overwritten by R1
       double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double V[NE_MAX][NU + 1];  // Householder vectors
       double beta[NE_MAX], Rdiag[NE_MAX];
-      double part[NE_MAX][4], yk[NE_MAX], hsc[2];   // per-step scratch: partial dots, row k of R, {alpha, beta}
+      double part[LDR][4], yk[LDR];   // per-step scratch: partial dots, row k of R
     } qr;
     double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
   };
@@ -76,44 +77,47 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   const int ne = w.ne, nut = w.nut;
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
-  // left untouched: its final diagonal goes to Rdiag, the vector to V), so one barrier per step suffices.
-  WG_FOR(ctx, i, NU * NE_MAX) { const int r = i / NE_MAX, c = i % NE_MAX; w.qr.Rm[r][c] = c < ne ? w.qr.CDe[c][NX + r] : 0.0; }
+  // left untouched: its final diagonal goes to Rdiag, the vector to V).
+  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; }
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
+  // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
+  // phase is one LDS round trip; masks are applied to values, not to control flow.
   for (int k = 0; k < ne; ++k) {
-    // (a) partial dots x . R(:,c) of the pivot column x = R(k:,k) with every remaining column (4 items per column)
-    WG_FOR(ctx, it, (ne - k) * 4) {
-      const int c = k + (it >> 2), p = it & 3;
+    // (a) partial dots x . R(:,c) of the pivot column x = R(k:,k) with every column (item = column c, row residue p mod 4)
+    WG_FOR(ctx, it, LDR * 4) {
+      const int c = it >> 2, p = it & 3;
+      double xk[9], yc[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { xk[t] = w.qr.Rm[p + 4 * t][k]; yc[t] = w.qr.Rm[p + 4 * t][c]; }
       double sdot = 0.0;
 #pragma unroll
-      for (int t = 0; t < (NU + 3) / 4; ++t) { const int i = p + 4 * t; if (i < NU && i >= k) sdot += w.qr.Rm[i][k] * w.qr.Rm[i][c]; }
-      w.qr.part[c - k][p] = sdot;
-      if (p == 0) w.qr.yk[c - k] = w.qr.Rm[k][c];
+      for (int t = 0; t < 9; ++t) sdot += (p + 4 * t >= k ? xk[t] : 0.0) * yc[t];
+      w.qr.part[c][p] = sdot;
+      if (p == 0) w.qr.yk[c] = w.qr.Rm[k][c];
     }
     WG_SYNC(ctx);
-    // (b) reflector scalars (one item)
-    WG_FOR(ctx, it, 1) {
-      const double nrm2 = (w.qr.part[0][0] + w.qr.part[0][1]) + (w.qr.part[0][2] + w.qr.part[0][3]);
-      const double nrm = sqrt(nrm2), rkk = w.qr.yk[0];
+    // (b) every item recomputes the reflector scalars (no broadcast phase); v = x - alpha e_k;
+    //     R(:,c) -= beta (v . R(:,c)) v  with  v . y = x . y - alpha y_k ;  column k itself is recorded in V
+    WG_FOR(ctx, it, NE_MAX * (NU + 1)) {
+      const int c = it / (NU + 1), i = it % (NU + 1);
+      const double p0 = w.qr.part[k][0], p1 = w.qr.part[k][1], p2 = w.qr.part[k][2], p3 = w.qr.part[k][3], rkk = w.qr.yk[k];
+      const double q0 = w.qr.part[c][0], q1 = w.qr.part[c][1], q2 = w.qr.part[c][2], q3 = w.qr.part[c][3], ykc = w.qr.yk[c];
+      const double xi = w.qr.Rm[i][k], rc = w.qr.Rm[i][c];
+      const double nrm2 = (p0 + p1) + (p2 + p3);
+      const double nrm = nrm2 * inv_sqrt(nrm2 > 1e-300 ? nrm2 : 1e-300);
       const double alpha = rkk >= 0.0 ? -nrm : nrm;
-      const double vn = 2.0 * (nrm2 - alpha * rkk);
-      w.qr.hsc[0] = alpha;
-      w.qr.hsc[1] = vn > 1e-300 ? 2.0 / vn : 0.0;
-      w.qr.beta[k] = w.qr.hsc[1];
-      w.qr.Rdiag[k] = alpha;
-      if (!(nrm >= 1e-12)) w.ok = 0;
-    }
-    WG_SYNC(ctx);
-    // (c) v = x - alpha e_k;  R(:,c) -= beta (v . R(:,c)) v  with  v . y = x . y - alpha y_k ;  column k is recorded in V
-    WG_FOR(ctx, it, (ne - k) * NU) {
-      const int c = k + it / NU, i = it % NU;
-      const double alpha = w.qr.hsc[0], beta = w.qr.hsc[1];
-      const double vi = i < k ? 0.0 : (w.qr.Rm[i][k] - (i == k ? alpha : 0.0));
-      if (c == k) { w.qr.V[k][i] = vi; continue; }
-      if (i < k) continue;
-      const double* pp = w.qr.part[c - k];
-      const double sdot = beta * (((pp[0] + pp[1]) + (pp[2] + pp[3])) - alpha * w.qr.yk[c - k]);
-      w.qr.Rm[i][c] -= sdot * vi;
+      const double hv = nrm2 - alpha * rkk;      // = |v|^2 / 2
+      const double beta = hv > 1e-300 ? fast_rcp(hv) : 0.0;
+      if (it == 0) {
+        w.qr.beta[k] = beta;
+        w.qr.Rdiag[k] = alpha;
+        if (!(nrm >= 1e-12)) w.ok = 0;
+      }
+      const double vi = i < k ? 0.0 : (xi - (i == k ? alpha : 0.0));
+      const double sdot = beta * (((q0 + q1) + (q2 + q3)) - alpha * ykc);
+      if (c == k) w.qr.V[k][i] = vi;
+      else if (c > k && i >= k) w.qr.Rm[i][c] = rc - sdot * vi;
     }
     WG_SYNC(ctx);
   }

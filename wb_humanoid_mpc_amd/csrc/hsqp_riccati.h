@@ -20,19 +20,30 @@ namespace hsqp {
 
 constexpr int RIC_ACL = 0;                     // [58][58] closed-loop transition
 constexpr int RIC_BCL = RIC_ACL + NX * NX;     // [58]
-constexpr int RIC_U = RIC_BCL + NX;            // [23][23] upper Cholesky factor of Lam (U^T U = Lam)
-constexpr int RIC_Z = RIC_U + NUT * NUT;       // [23][58] L^-1 G
-constexpr int RIC_ZV = RIC_Z + NUT * NX;       // [23]     L^-1 g
-constexpr int RIC_SIZE = ((RIC_ZV + NUT + 7) / 8) * 8;
+constexpr int RIC_K = RIC_BCL + NX;            // [23][58] feedback gain  K = -Lam^-1 G
+constexpr int RIC_KV = RIC_K + NUT * NX;       // [23]     feed-forward   k = -Lam^-1 g
+constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
 constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices
+constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
 constexpr int EM_G = NUT, EM_GV = NUT + NX, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns
 
 struct RicWS {
-  double S[NX][NX], A2[2][NX][NX], SA[NX][NX];   // A2: double-buffered A~ (stage k uses A2[k & 1])
-  double B[NX][LDB], SB[NX][LDB];
-  double Em[NUT][LDE];                         // [Lam | G | g | B^T], factorised in place
+  union {
+    double S[NX][NX];
+    struct {                                   // scratch of the factorisation (S is dead between P2 and P5)
+      double Ef[LDB][LDF];                     // [Lam | 0 | I] -> [U-ish | . | unit-lower inverse] -> columns 24.. scaled to L^-1
+      double LinvT[LDB][LDB];                  // (L^-1)^T
+    } fac;
+  };
+  double A2[2][NX][NX], SA[NX][NX];            // A2: double-buffered A~ (stage k uses A2[k & 1])
+  double B[NX][LDB];
+  union {
+    double SB[NX][LDB];
+    double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam is formed)
+  };
+  double Em[NUT][LDE];                         // [Lam | G -> K | g | B^T]
   double dsq[LDB];
-  double sv[NX], sn[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX];
+  double sv[NX], sn[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];
   double part[NX * 4];
   int ok;
 };
@@ -77,7 +88,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
     {
       const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
-                              xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.Em[0][0], LDE, q + QP_R, NUT)};
+                              xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
       constexpr int na = nbatches(NX * NX, 8);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
@@ -89,68 +100,99 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
           else { const int j = it - NUT, r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
         }
+        WG_FOR(hc, it, NUT * (LDF - NUT)) { const int r = it / (LDF - NUT), c = NUT + it % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
       }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
-    // ---- P4: right-looking elimination of Lam carried through the augmented columns.  Rows stay UNSCALED during the
-    // sweep (row j holds d_j * L^-1[...]), so a step needs no pivot broadcast phase: one barrier per column.  The
-    // Cholesky scaling U = D^-1/2 (...) is applied to all rows at the end.
+    // ---- P4a: Gaussian elimination of [Lam | I] on full rows (rows stay unscaled, so a step needs no pivot broadcast
+    //      phase: one barrier per column).  Fixed (row, 3 strided columns) grid; every load is unconditional, so the
+    //      step is one LDS round trip + the reciprocal chain.  The multiplier is read from the (symmetric) upper part.
     for (int j = 0; j < NUT - 1; ++j) {
-      constexpr int NCH = (LDE + 7) / 8;   // 8 strided columns per item: fixed (row, chunk) grid, masked
-      WG_FOR(ctx, it, NUT * NCH) {
-        const int i = it / NCH, c0 = it % NCH;
+      WG_FOR(ctx, it, NUT * 16) {
+        const int i = it >> 4, c0 = it & 15;
         if (i <= j) continue;
-        const double f = w.Em[j][i] * fast_rcp(w.Em[j][j]);
-        double ej[8], ei[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { const int c = c0 + t * NCH; const bool on = c < LDE && c >= i; ej[t] = on ? w.Em[j][c] : 0.0; ei[t] = on ? w.Em[i][c] : 0.0; }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { const int c = c0 + t * NCH; if (c < LDE && c >= i) w.Em[i][c] = ei[t] - f * ej[t]; }
+        const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
+        const double ej0 = w.fac.Ef[j][c0], ej1 = w.fac.Ef[j][c0 + 16], ej2 = w.fac.Ef[j][c0 + 32];
+        const double ei0 = w.fac.Ef[i][c0], ei1 = w.fac.Ef[i][c0 + 16], ei2 = w.fac.Ef[i][c0 + 32];
+        const double f = fji * fast_rcp(pj);
+        w.fac.Ef[i][c0] = ei0 - f * ej0;
+        w.fac.Ef[i][c0 + 16] = ei1 - f * ej1;
+        w.fac.Ef[i][c0 + 32] = ei2 - f * ej2;
       }
       WG_SYNC(ctx);
     }
-    WG_FOR(ctx, it, NUT * LDE) {
-      const int j = it / LDE, c = it % LDE;
-      double dj = w.Em[j][j];
+    // ---- P4b: Cholesky scaling: L^-1 = D^-1/2 Mi (in place) and its transpose
+    WG_FOR(ctx, it, NUT * LDB) {
+      const int r = it / LDB, c = it % LDB;
+      double dj = w.fac.Ef[r][r];
       if (!(dj > 0.0)) { dj = 1.0; if (c == 0) w.ok = 0; }
-      const double rs = inv_sqrt(dj);
-      if (c == j) w.dsq[j] = dj * rs;
-      else if (c > j) w.Em[j][c] = w.Em[j][c] * rs;
+      const double v = c <= r ? w.fac.Ef[r][EF_MI + c] * inv_sqrt(dj) : 0.0;
+      w.fac.Ef[r][EF_MI + c] = v;
+      w.fac.LinvT[c][r] = v;
+    }
+    WG_SYNC(ctx);
+    // ---- P4c: Z = L^-1 G (matrix cores), z = L^-1 g
+    {
+      const XtyJob job = xty_job(NUT, NX, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
+      if (is_helper_half(ctx)) {
+        const Ctx hc = helper_ctx(ctx);
+        WG_FOR(hc, r, NUT) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < NUT; ++l) s += w.fac.Ef[r][EF_MI + l] * w.Em[l][EM_GV];
+          w.zv[r] = s;
+        }
+      }
+    }
+    WG_SYNC(ctx);
+    // ---- P4d: K = -L^-T Z (matrix cores, over the G block), k = -L^-T z; both also to the record
+    {
+      const XtyJob job = xty_job(NUT, NX, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0);
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
+      if (is_helper_half(ctx)) {
+        const Ctx hc = helper_ctx(ctx);
+        WG_FOR(hc, r, NUT) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < NUT; ++l) s += w.fac.LinvT[r][l] * w.zv[l];
+          w.kv[r] = -s;
+          rk[RIC_KV + r] = -s;
+        }
+      }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 4);
-    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A - Y^T Z, s <- q + A^T sb - Z^T z, bcl = b - Y^T z ; factors -> global;
+    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A + B K, s <- q + A^T sb - Z^T z, bcl = b + B k ; K -> record;
     //          prefetch of the next stage's B~, b~ (B is dead since P3)
     {
       XtyJob js = xty_job(NX, NX, NX, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
-      js.L2 = NUT; js.X2 = &w.Em[0][EM_G]; js.ldx2 = LDE; js.Y2 = &w.Em[0][EM_G]; js.ldy2 = LDE; js.sign2 = -1.0;
-      const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX, -1.0)};
+      js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
+      const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX)};
       constexpr int nbb = nbatches(NX * LDB, 8);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, 2 * NX + NUT * (NUT + NX + 1)) {
+        WG_FOR(hc, it, 2 * NX + NUT * NX) {
           if (it < NX) {
             const int r = it;
             double s = q[QP_QV + r] + dot_strided<NX>(&A[0][r], NX, w.sb);
 #pragma unroll
-            for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_G + r] * w.Em[l][EM_GV];
+            for (int l = 0; l < NUT; ++l) s -= w.Zs[l][r] * w.zv[l];
             w.sn[r] = s;
           } else if (it < 2 * NX) {
             const int r = it - NX;
             double s = w.bt[r];
 #pragma unroll
-            for (int l = 0; l < NUT; ++l) s -= w.Em[l][EM_BT + r] * w.Em[l][EM_GV];
+            for (int l = 0; l < NUT; ++l) s += w.Em[l][EM_BT + r] * w.kv[l];
             rk[RIC_BCL + r] = s;
           } else {
-            const int j = it - 2 * NX, r = j / (NUT + NX + 1), c = j % (NUT + NX + 1);
-            if (c < NUT) rk[RIC_U + r * NUT + c] = c > r ? w.Em[r][c] : (c == r ? w.dsq[r] : 0.0);
-            else if (c < NUT + NX) rk[RIC_Z + r * NX + (c - NUT)] = w.Em[r][EM_G + (c - NUT)];
-            else rk[RIC_ZV + r] = w.Em[r][EM_GV];
+            const int j = it - 2 * NX;
+            rk[RIC_K + j] = w.Em[j / NX][EM_G + j % NX];
           }
         }
-        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage (B is dead since P3)
+        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage
           if (k > 0) {
             if (bb < nbb) {
               double t[8];
@@ -204,7 +246,7 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
 }
 
 // Per-node recovery of the inputs and the step of length alpha (parallel over all nodes of all instances):
-//   ut = -U^-1 (Z dx + z),  du = Px dx + Pu ut + Pe,  x_new = x + alpha dx,  u_new = u + alpha du.
+//   ut = K dx + k,  du = Px dx + Pu ut + Pe,  x_new = x + alpha dx,  u_new = u + alpha du.
 struct StepWS {
   double dx[NX], t[NUT], ut[NUT];
   double part[(NX + NU) * 4];
@@ -213,17 +255,9 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
                        double alpha, double* ut_out, double* du_out, double* x_new, double* u_new) {
   WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
   WG_SYNC(ctx);
-  WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_Z + (it >> 2) * NX, w.dx, it & 3);
+  WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_K + (it >> 2) * NX, w.dx, it & 3);
   WG_SYNC(ctx);
-  WG_FOR(ctx, i, NUT) w.t[i] = -(rk[RIC_ZV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3])));
-  WG_SYNC(ctx);
-  WG_FOR(ctx, it, 1) {  // back substitution U ut = t
-    for (int i = NUT - 1; i >= 0; --i) {
-      double s = w.t[i];
-      for (int c = i + 1; c < NUT; ++c) s -= rk[RIC_U + i * NUT + c] * w.ut[c];
-      w.ut[i] = s / rk[RIC_U + i * NUT + i];
-    }
-  }
+  WG_FOR(ctx, i, NUT) w.ut[i] = rk[RIC_KV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
   WG_SYNC(ctx);
   WG_FOR(ctx, it, NU * 4 + NUT) {
     if (it < NU * 4) {
