@@ -22,14 +22,24 @@ void emu_destroy(void* h) { delete static_cast<DevModel*>(h); }
 // base acceleration and its Jacobian (6 x 93) at (x, u)
 void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double* ab, double* G) {
   const DevModel& dm = *static_cast<DevModel*>(h);
-  auto ws = std::make_unique<StageWS>();
   Ctx ctx{0, 1, nullptr};
-  for (int i = 0; i < NV; ++i) { ws->q[i] = x[i]; ws->v[i] = x[NV + i]; }
-  for (int i = 0; i < 12; ++i) ws->W[i] = u[i];
-  for (int i = 0; i < NJ; ++i) ws->qddj[i] = u[12 + i];
-  if (deriv) stage_eval<true>(ctx, dm, *ws); else stage_eval<false>(ctx, dm, *ws);
-  for (int i = 0; i < 6; ++i) ab[i] = ws->ab[i];
-  if (deriv && G) for (int r = 0; r < 6; ++r) for (int c = 0; c < NZ; ++c) G[r * NZ + c] = ws->G[r][c];
+  auto run = [&](auto& ws) {
+    for (int i = 0; i < NV; ++i) { ws.q[i] = x[i]; ws.v[i] = x[NV + i]; }
+    for (int i = 0; i < 12; ++i) ws.W[i] = u[i];
+    for (int i = 0; i < NJ; ++i) ws.qddj[i] = u[12 + i];
+  };
+  if (deriv) {
+    auto ws = std::make_unique<StageWST<true>>();
+    run(*ws);
+    stage_eval<true>(ctx, dm, *ws);
+    for (int i = 0; i < 6; ++i) ab[i] = ws->ab[i];
+    if (G) for (int r = 0; r < 6; ++r) for (int c = 0; c < NZ; ++c) G[r * NZ + c] = ws->G[r][c];
+  } else {
+    auto ws = std::make_unique<StageWST<false>>();
+    run(*ws);
+    stage_eval<false>(ctx, dm, *ws);
+    for (int i = 0; i < 6; ++i) ab[i] = ws->ab[i];
+  }
 }
 
 
@@ -37,9 +47,9 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 int emu_rec_size() { return REC_SIZE; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
-  auto w = std::make_unique<LqWS>();
   Ctx ctx{0, 1, nullptr};
-  if (deriv) lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); else lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC);
+  if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
+  else { auto w = std::make_unique<LqWST<false>>(); lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
 }
 // dense blocks from a record: AB[58*93], H[93*93], g[93], CDe[14*94]
 void emu_expand(const double* rec, double dt, double* AB, double* H, double* g, double* CDe) {
@@ -71,7 +81,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
   std::vector<double> rec((size_t)N * REC_SIZE), qp((size_t)N * QP_SIZE), ric((size_t)N * RIC_SIZE), ut((size_t)N * NUT);
-  auto lw = std::make_unique<LqWS>();
+  auto lw = std::make_unique<LqWST<true>>();
+  auto lwv = std::make_unique<LqWST<false>>();
   auto pw = std::make_unique<ProjWS>();
   auto rw = std::make_unique<RicWS>();
   double pb[3] = {0, 0, 0};
@@ -96,7 +107,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {
-    lq_node<false>(ctx, dm, *lw, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
+    lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
     pa[0] += r2[REC_MISC + 1]; pa[1] += r2[REC_MISC + 3]; pa[2] += r2[REC_MISC + 2];
   }
   pa[0] += terminal(x_new);

@@ -18,16 +18,17 @@ namespace {
 constexpr int LQ_THREADS = 256;
 constexpr int PROJ_THREADS = 512;
 constexpr int RIC_THREADS = 512;
+constexpr int LQV_THREADS = 128;   // value-only LQ pass: 31 KB workspace, 5 workgroups per CU
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 
 // ---- LQ approximation: one workgroup per (instance, node)
 template <bool DERIV>
-__global__ __launch_bounds__(LQ_THREADS, 3) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
+__global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, 3) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
                                                    const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
                                                    double* __restrict__ rec, double* __restrict__ misc, long long* prof) {
   const int node = blockIdx.x, b = node / N, k = node % N;
-  LqWS& w = *reinterpret_cast<LqWS*>(hsqp_smem);
+  LqWST<DERIV>& w = *reinterpret_cast<LqWST<DERIV>*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
@@ -213,7 +214,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (hipMemset(h->d_prof, 0, 4 * 128 * sizeof(long long)) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
-  hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
+  hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
   hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -263,7 +264,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (want_kkt)
       hipLaunchKernelGGL(k_kkt, dim3(B), dim3(128), 0, h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dx, h->d_ut, N, h->d_kkt);
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
-    hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+    hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
                        N, (double*)nullptr, h->d_misc, h->d_prof + 384);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after);

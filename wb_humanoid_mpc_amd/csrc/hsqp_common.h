@@ -33,6 +33,7 @@ constexpr int NJC = 26;        // revolute generalized coordinates: euler z,y,x 
 constexpr int NE_MAX = 14;     // max active equality rows (flight: 6+1+6+1)
 constexpr int NUT = 23;        // max projected input dimension nu - ne (padded with identity when ne > 12)
 constexpr int NR = 60;         // residual-row slots of the Gauss-Newton / penalty model (see hsqp_node.h)
+constexpr int NANC = 8;        // longest path of moving bodies from the base to a leaf
 constexpr int NLEVELS = 8;     // depth of the body tree incl. the base
 
 struct Ctx {
@@ -93,19 +94,16 @@ struct DevModel {
   // kinematic tree, bodies in depth-first order (subtree of i = [i, i + subtree_size[i]))
   int parent[NB];
   int subtree_size[NB];
-  int level[NB];
-  int level_start[NLEVELS + 1];   // bodies sorted by level: level_bodies[level_start[l] .. level_start[l+1])
-  int level_bodies[NB];
   double Rfix[NB][9];
   double pfix[NB][3];
   double axis[NB][3];
   double axis_p[NB][3];            // Rfix * axis: joint axis in the parent body frame
-  // chains: maximal single-child paths; a chain is walked by ONE work item with the parent state in registers
-  int n_chains, n_chain_phases;
-  int chain_start[NB], chain_len[NB], chain_phase[NB];
-  // children lists and the 'heavy' bodies (large subtrees) for the two-step composite sums
-  int child_start[NB + 1], child_list[NB];
-  int n_heavy, heavy[NB];         // in decreasing index order
+  // chains: maximal single-child paths (the placement walk runs per chain end)
+  int n_chains;
+  int chain_start[NB], chain_len[NB];
+  // ancestor path of every body (root-most moving body first, the body itself last; the base is not listed)
+  int n_anc[NB];
+  unsigned char anc[NB][NANC];
   double mass[NB];
   double com[NB][3];
   double inertia[NB][9];          // about com, body axes

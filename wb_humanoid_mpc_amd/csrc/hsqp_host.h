@@ -26,8 +26,6 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
     memcpy(dm.inertia[i], b.inertia, sizeof(b.inertia));
     dm.total_mass += b.mass;
     if (i > 0) { dm.q_lo[i - 1] = b.q_lo; dm.q_hi[i - 1] = b.q_hi; }
-    dm.level[i] = i == 0 ? 0 : dm.level[b.parent] + 1;
-    if (dm.level[i] >= NLEVELS) return "kinematic tree deeper than NLEVELS";
     if (i > 0) {
       const double n = b.axis[0] * b.axis[0] + b.axis[1] * b.axis[1] + b.axis[2] * b.axis[2];
       if (fabs(n - 1.0) > 1e-9) return "joint axes must be unit vectors";
@@ -44,19 +42,13 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
     for (int a = p; a >= 0; a = dm.parent[a])
       if (!(i >= a && i < a + dm.subtree_size[a])) return "bodies are not in depth-first order";
   }
-  // chains, children, heavy bodies
+  // chains (maximal single-child paths), ancestor paths, joint axes in the parent frame
   {
     int nchild[NB] = {0};
     for (int i = 1; i < NB; ++i) nchild[dm.parent[i]]++;
-    int cpos = 0;
-    for (int i = 0; i < NB; ++i) {
-      dm.child_start[i] = cpos;
-      for (int c = i + 1; c < NB; ++c) if (dm.parent[c] == i) dm.child_list[cpos++] = c;
-    }
-    dm.child_start[NB] = cpos;
     int chain_of[NB];
     chain_of[0] = -1;
-    dm.n_chains = 0; dm.n_chain_phases = 0;
+    dm.n_chains = 0;
     for (int i = 1; i < NB; ++i) {
       const int p = dm.parent[i];
       if (p != 0 && nchild[p] == 1 && i == p + 1) {
@@ -66,24 +58,20 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
         const int c = dm.n_chains++;
         chain_of[i] = c;
         dm.chain_start[c] = i; dm.chain_len[c] = 1;
-        dm.chain_phase[c] = p == 0 ? 0 : dm.chain_phase[chain_of[p]] + 1;
-        if (dm.chain_phase[c] + 1 > dm.n_chain_phases) dm.n_chain_phases = dm.chain_phase[c] + 1;
       }
     }
-    dm.n_heavy = 0;
-    for (int i = NB - 1; i >= 0; --i) if (dm.subtree_size[i] > 8) dm.heavy[dm.n_heavy++] = i;
+    for (int i = 0; i < NB; ++i) {
+      int path[NB], n = 0;
+      for (int a = i; a > 0; a = dm.parent[a]) path[n++] = a;
+      if (n > NANC) return "kinematic tree deeper than NANC moving bodies";
+      dm.n_anc[i] = n;
+      for (int k = 0; k < NANC; ++k) dm.anc[i][k] = (unsigned char)(k < n ? path[n - 1 - k] : i);   // padded with the body itself (valid index)
+    }
     for (int i = 1; i < NB; ++i) {
       const hsqp_body& b = md.bodies[i];
       for (int r = 0; r < 3; ++r) dm.axis_p[i][r] = b.R[3 * r] * b.axis[0] + b.R[3 * r + 1] * b.axis[1] + b.R[3 * r + 2] * b.axis[2];
     }
   }
-  int pos = 0;
-  for (int l = 0; l < NLEVELS; ++l) {
-    dm.level_start[l] = pos;
-    for (int i = 0; i < NB; ++i)
-      if (dm.level[i] == l) dm.level_bodies[pos++] = i;
-  }
-  dm.level_start[NLEVELS] = pos;
   dm.gravity = md.gravity;
   for (int f = 0; f < 2; ++f) {
     dm.contact_body[f] = md.contact[f].body;

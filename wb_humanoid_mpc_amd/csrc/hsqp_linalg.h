@@ -129,6 +129,7 @@ struct XtyJob {
   double scale;                   // C = scale * acc + Add
   const double* Add; int ldadd;   // optional (may be global memory)
   double* C; int ldc;             // destination (LDS or global)
+  int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
 };
 
 HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, double* C, int ldc,
@@ -136,7 +137,7 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0;
   return j;
 }
 
@@ -191,39 +192,65 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r0[t] + kk + 4 * r;
-        if (row < j.M) j.C[row * j.ldc + c] = j.scale * acc[t][r] + addv[t][r];
+        if (row < j.M) {
+          const double v = j.scale * acc[t][r] + addv[t][r];
+          j.C[row * j.ldc + c] = v;
+          if (j.sym && r0[t] != c0[t]) j.C[c * j.ldc + row] = v;
+        }
       }
     }
   }
 }
 #endif
 
+// symmetric jobs enumerate the tiles on/above the diagonal row by row
+HSQP_HD int xty_tile_id(int sym, int tn, int t) {
+  if (!sym) return t;
+  int tr = 0;
+  while (t >= tn - tr) { t -= tn - tr; ++tr; }
+  return tr * tn + tr + t;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// tiles are numbered globally (base + t) and dealt round-robin to the waves; a wave takes its tiles two at a time
+HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane) {
+  const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
+  const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
+  const int sym = j.sym;
+  int t = (wave - base % nwaves + nwaves) % nwaves;
+  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2>(j, pair, lane); }
+  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1>(j, &one, lane); }
+  return nt;
+}
+#endif
+
 // Executes `njobs` independent products; must be called by every thread of the workgroup (no barrier inside).
-// `wave_offset` rotates the tile -> wave assignment so that other work of the phase can be placed on the idle waves.
+// UNROLL: the loop over the jobs is unrolled so that each job gets code specialised for its (constant) shape and the
+// descriptors stay in registers — pays off for long contractions in throughput kernels, not inside the Riccati stage loop.
+template <bool UNROLL = false>
 HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wave = ctx.tid >> 6, nwaves = ctx.nthreads >> 6, lane = ctx.tid & 63;
   int base = 0;
-  for (int jn = 0; jn < njobs; ++jn) {
-    const XtyJob& j = jobs[jn];
-    const int nt = ((j.M + 15) >> 4) * ((j.N + 15) >> 4);
-    // tiles are numbered globally (base + t) and dealt round-robin; a wave takes its tiles two at a time
-    int t = (wave - base % nwaves + nwaves) % nwaves;
-    for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {t, t + nwaves}; xty_job_tiles_mfma<2>(j, pair, lane); }
-    if (t < nt) xty_job_tiles_mfma<1>(j, &t, lane);
-    base += nt;
+  if constexpr (UNROLL) {
+#pragma unroll
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job(jobs[jn], base, wave, nwaves, lane);
+  } else {
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job(jobs[jn], base, wave, nwaves, lane);
   }
 #else
   for (int jn = 0; jn < njobs; ++jn) {
     const XtyJob& j = jobs[jn];
     WG_FOR(ctx, e, j.M * j.N) {
       const int r = e / j.N, c = e % j.N;
+      if (j.sym && (c >> 4) < (r >> 4)) continue;   // mirrored from the tile above the diagonal
       double acc = 0.0;
       for (int l = 0; l < j.L1; ++l) acc += j.X1[l * j.ldx1 + r] * j.Y1[l * j.ldy1 + c];
       for (int l = 0; l < j.L2; ++l) acc += j.sign2 * j.X2[l * j.ldx2 + r] * j.Y2[l * j.ldy2 + c];
       double v = j.scale * acc;
       if (j.Add) v += j.Add[r * j.ldadd + c];
       j.C[r * j.ldc + c] = v;
+      if (j.sym && (c >> 4) != (r >> 4)) j.C[c * j.ldc + r] = v;
     }
   }
 #endif

@@ -28,24 +28,27 @@ constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
 constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel)
 constexpr int REC_SIZE = REC_GS + 4 * 6 * LDJ;
 
-struct LqWS {
+template <bool D>
+struct LqWST {
   DevModel dml;        // the model constants, copied to LDS once per workgroup (they are read on every serial path)
   union {
-    StageWS st;
+    StageWST<D> st;
     struct {
-      double Gs[3][6][LDJ];   // stage Jacobians of stages 2..4 (stage 1 is Ab[0])
-      double Ab[4][6][LDJ];
+      double Gs[D ? 3 : 1][D ? 6 : 1][LDJ];   // stage Jacobians of stages 2..4 (stage 1 is Ab[0])
+      double Ab[D ? 4 : 1][D ? 6 : 1][LDJ];
     } ch;              // RK4 chain workspace: aliases the stage workspace, which is dead after stage 4
   };
-  NodeWS nw;
+  NodeWST<D> nw;
   double vs[4][NV];    // velocity part of the stage states
   double as[4][6];     // base accelerations of the stages
   double xnext[NX];
   double bvec[64];
 };
+using LqWS = LqWST<true>;
 
 // set up the model evaluation inputs of RK4 stage s (0..3)
-HSQP_HD void rk4_stage_inputs(const Ctx& ctx, LqWS& w, int s, double dt) {
+template <class LW>
+HSQP_HD void rk4_stage_inputs(const Ctx& ctx, LW& w, int s, double dt) {
   const double c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt);
   WG_FOR(ctx, i, NV + NV + NJ + 12) {
     if (i < NV) {
@@ -78,7 +81,7 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
 // Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory); misc[0..3] = {ne, dt*cost, dt*|eq|^2, dt*|b|^2}.
 // DERIV = false: values only (performance index); rec is not touched and may be null.
 template <bool DERIV>
-HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const double* x, const double* u, const double* xnext,
+HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w, const double* x, const double* u, const double* xnext,
                      const double* par, double dt, double* rec, double* misc) {
   {
     constexpr int nw = (int)(sizeof(DevModel) / sizeof(double));
@@ -111,7 +114,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
       PH_TICK(ctx, 4);
       node_scalars(ctx, dm, w.st, w.nw);
       PH_TICK(ctx, 5);
-      if (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J, rec + REC_CDE);
+      if constexpr (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J, rec + REC_CDE);
       PH_TICK(ctx, 6);
       if (DERIV) WG_FOR(ctx, i, 64 + NRS) {
         if (i < 64) {
@@ -151,7 +154,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
     misc[2] = dt * eq;
     misc[3] = dt * dyn;
   }
-  if (!DERIV) return;
+  if constexpr (DERIV) {
   // ---- write d, gd (the equality rows went straight to the record)
   WG_FOR(ctx, i, 2 * LDJ) {
     if (i < LDJ) rec[REC_D + i] = w.nw.d[i];
@@ -193,6 +196,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWS& w, const d
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 9);
+  }
 }
 
 // Expand the structured record into the dense [A|B] (58 x 93) — used by the debug/parity path and by tests.

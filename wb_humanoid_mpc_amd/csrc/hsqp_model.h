@@ -21,7 +21,9 @@
 
 namespace hsqp {
 
-struct StageWS {
+// D = false: value-only evaluation (performance index pass) — the derivative arrays shrink to one element.
+template <bool D>
+struct StageWST {
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
   double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
@@ -30,16 +32,16 @@ struct StageWS {
   double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
   double Einv[9];
   // ---- revolute coordinates jc = 0..25 (euler z,y,x, then joints); generalized coordinate = 3 + jc
-  double S[NJC][6], Sd[NJC][6], Sdd[NJC][6];
+  double S[NJC][6], Sd[NJC][6], Sdd[D ? NJC : 1][6];
   double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
   // ---- bodies
   double R[NB][9], r[NB][3];       // world rotation, origin relative to the base origin O
   double In[NB][10], f[NB][6];
   union {
-    double BB[NB][36];             // per-body BB (dead once the composites are formed)
-    double G[6][96];               // d ab / d[x;u], columns 0..92 used (written after the composites)
+    double BB[D ? NB : 1][36];     // per-body BB (dead once the composites are formed)
+    double G[D ? 6 : 1][96];       // d ab / d[x;u], columns 0..92 used (written after the composites)
   };
-  double Ic[NB][10], fc[NB][6], BBc[NB][36];
+  double Ic[D ? NB : 1][10], fc[D ? NB : 1][6], BBc[D ? NB : 1][36];
   double rP[2][3];                 // contact points relative to O
   // ---- results
   double Ftil[6];                  // F_ext - F  {moment, force}
@@ -47,6 +49,7 @@ struct StageWS {
   double y[3];                     // E a_ang
   double ab[6];                    // base acceleration {lin, euler-rate acc}
 };
+using StageWS = StageWST<true>;
 
 HSQP_HD void rot_axis(const double* ax, double q, double* Rm) {
   const double c = cos(q), s = sin(q), t = 1.0 - c, x = ax[0], y = ax[1], z = ax[2];
@@ -95,78 +98,131 @@ HSQP_HD void rot_axis_cs(const double* ax, double c, double s, double* Rm) {
 
 // One evaluation of a_b (and, if DERIV, of G = d a_b / d[x;u]) at ws.q, ws.v, ws.qddj, ws.W.
 //
-// Serial depth: the kinematic tree is walked chain by chain (DevModel::chain_*): one work item per chain keeps the
-// parent state in registers, so a 6-body leg costs 6 dependent body updates and no barrier; chains hanging off
-// another chain (the arms) run in the next phase.  Everything that is not needed by a child (Sdd, inertia, net
-// force, BB) is deferred to fully parallel phases.
+// Serial depth: only the placements (R_i, r_i, w_i) are propagated along the tree, row by row (three independent
+// items per chain, DevModel::chain_* / anc); velocities and accelerations are sums over the ancestor path, one item
+// per component.  Everything else (Sdd, inertia, net force, BB) runs in fully parallel phases.
 template <bool DERIV>
-HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
-  // ---- phase T0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
+HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws) {
+  // ---- phase F0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
   WG_FOR(ctx, it, NB + 2) {
-    if (it < 3) { ws.ecs[it][0] = cos(ws.q[3 + it]); ws.ecs[it][1] = sin(ws.q[3 + it]); continue; }
+    double sn, cs;
+    if (it < 3) { sincos(ws.q[3 + it], &sn, &cs); ws.ecs[it][0] = cs; ws.ecs[it][1] = sn; continue; }
     const int i = it - 2;
     double Rq[9];
-    const double qi = ws.q[5 + i];
-    rot_axis_cs(dm.axis[i], cos(qi), sin(qi), Rq);
+    sincos(ws.q[5 + i], &sn, &cs);
+    rot_axis_cs(dm.axis[i], cs, sn, Rq);
     m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
   }
   WG_SYNC(ctx);
-  // ---- phase T1: the base chain (one item)
-  WG_FOR(ctx, it, 1) {
+  // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
+  // only on row r of R_p, so every chain is walked by three independent items (one per row), each from the base
+  // down its whole ancestor path (the shared waist bodies are recomputed, not exchanged): no barrier inside the tree.
+  WG_FOR(ctx, it, dm.n_chains * 3 + 4) {
     const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
-    const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
-    for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
-    m3_inverse(ws.E, ws.Einv);
-    double* R0 = ws.R[0];   // R0 = Rz Ry Rx
-    R0[0] = cz * cy; R0[1] = cz * sy * sx - sz * cx; R0[2] = cz * sy * cx + sz * sx;
-    R0[3] = sz * cy; R0[4] = sz * sy * sx + cz * cx; R0[5] = sz * sy * cx - cz * sx;
-    R0[6] = -sy;     R0[7] = cy * sx;                R0[8] = cy * cx;
-    ws.r[0][0] = ws.r[0][1] = ws.r[0][2] = 0.0;
-    double vP[6] = {0.0, 0.0, 0.0, ws.v[0], ws.v[1], ws.v[2]};
-    double aP[6] = {0.0, 0.0, 0.0, 0.0, 0.0, dm.gravity};
-    const double* ax[3] = {wz, wy, wx};
-    const double* vpar = vP;
-    const double* apar = aP;
-    for (int e = 0; e < 3; ++e) {
-      for (int k = 0; k < 3; ++k) { ws.S[e][k] = ax[e][k]; ws.S[e][3 + k] = 0.0; }
-      joint_motion(vpar, apar, ws.S[e], ws.v[3 + e], 0.0, ws.vl[e], ws.al[e], ws.Sd[e], ws.Sdd[e]);
-      vpar = ws.vl[e];
-      apar = ws.al[e];
+    if (it == dm.n_chains * 3 + 3) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
+      const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
+      for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
+      m3_inverse(ws.E, ws.Einv);
+      for (int k = 0; k < 3; ++k) {
+        ws.S[0][k] = wz[k]; ws.S[1][k] = wy[k]; ws.S[2][k] = wx[k];
+        ws.S[0][3 + k] = 0.0; ws.S[1][3 + k] = 0.0; ws.S[2][3 + k] = 0.0;
+      }
+      continue;
+    }
+    const int r = it % 3, ch = it / 3;
+    double Rp[3];   // row r of R0 = Rz Ry Rx
+    if (r == 0) { Rp[0] = cz * cy; Rp[1] = cz * sy * sx - sz * cx; Rp[2] = cz * sy * cx + sz * sx; }
+    else if (r == 1) { Rp[0] = sz * cy; Rp[1] = sz * sy * sx + cz * cx; Rp[2] = sz * sy * cx - cz * sx; }
+    else { Rp[0] = -sy; Rp[1] = cy * sx; Rp[2] = cy * cx; }
+    if (ch == dm.n_chains) {           // the base itself
+      for (int c = 0; c < 3; ++c) ws.R[0][3 * r + c] = Rp[c];
+      ws.r[0][r] = 0.0;
+      continue;
+    }
+    const int b0 = dm.chain_start[ch], end = b0 + dm.chain_len[ch] - 1, na = dm.n_anc[end];
+    double rp = 0.0;
+    // fully unrolled over the (padded) path: the index and operand loads do not depend on the running row, only the
+    // multiply-adds are chained
+#pragma unroll
+    for (int n = 0; n < NANC; ++n) {
+      const int i = dm.anc[end][n];
+      const double* M = ws.Mq[i];
+      const double rn0 = Rp[0] * M[0] + Rp[1] * M[3] + Rp[2] * M[6];
+      const double rn1 = Rp[0] * M[1] + Rp[1] * M[4] + Rp[2] * M[7];
+      const double rn2 = Rp[0] * M[2] + Rp[1] * M[5] + Rp[2] * M[8];
+      const double rr = rp + Rp[0] * dm.pfix[i][0] + Rp[1] * dm.pfix[i][1] + Rp[2] * dm.pfix[i][2];
+      const double w = Rp[0] * dm.axis_p[i][0] + Rp[1] * dm.axis_p[i][1] + Rp[2] * dm.axis_p[i][2];
+      if (n < na) {
+        if (i >= b0) { ws.R[i][3 * r] = rn0; ws.R[i][3 * r + 1] = rn1; ws.R[i][3 * r + 2] = rn2; ws.r[i][r] = rr; ws.S[i + 2][r] = w; }
+        Rp[0] = rn0; Rp[1] = rn1; Rp[2] = rn2; rp = rr;
+      }
     }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 20);
-  // ---- chain phases: one work item per chain, parent state carried in registers
-  for (int ph = 0; ph < dm.n_chain_phases; ++ph) {
-    WG_FOR(ctx, ch, dm.n_chains) {
-      if (dm.chain_phase[ch] != ph) continue;
-      const int b0 = dm.chain_start[ch], pb = dm.parent[b0];
-      double Rp[9], rp[3], vp[6], ap[6];
-      for (int k = 0; k < 9; ++k) Rp[k] = ws.R[pb][k];
-      for (int k = 0; k < 3; ++k) rp[k] = ws.r[pb][k];
-      for (int k = 0; k < 6; ++k) { vp[k] = ws.vl[pb + 2][k]; ap[k] = ws.al[pb + 2][k]; }
-      for (int n = 0; n < dm.chain_len[ch]; ++n) {
-        const int i = b0 + n, jc = i + 2;
-        double Rn[9], rr[3], Sx[6], vl[6], al[6], Sd[6];
-        m3_mul(Rp, ws.Mq[i], Rn);
-        m3_mulv(Rp, dm.pfix[i], rr);
-        m3_mulv(Rp, dm.axis_p[i], Sx);
-        for (int k = 0; k < 3; ++k) rr[k] += rp[k];
-        v3_cross(rr, Sx, Sx + 3);
-        const double qd = ws.v[5 + i], qdd = ws.qddj[i - 1];
-        for (int k = 0; k < 6; ++k) vl[k] = vp[k] + Sx[k] * qd;
-        mxm(vl, Sx, Sd);
-        for (int k = 0; k < 6; ++k) al[k] = ap[k] + Sx[k] * qdd + Sd[k] * qd;
-        for (int k = 0; k < 9; ++k) { ws.R[i][k] = Rn[k]; Rp[k] = Rn[k]; }
-        for (int k = 0; k < 3; ++k) { ws.r[i][k] = rr[k]; rp[k] = rr[k]; }
-        for (int k = 0; k < 6; ++k) { ws.S[jc][k] = Sx[k]; ws.vl[jc][k] = vl[k]; ws.al[jc][k] = al[k]; ws.Sd[jc][k] = Sd[k]; vp[k] = vl[k]; ap[k] = al[k]; }
+  // ---- phase F2: linear part of the joint axes S_i = {w_i, r_i x w_i} and the link velocities as sums over the
+  // ancestor path, v_i = v_base + sum_a S_a qd_a (one item per component)
+  WG_FOR(ctx, it, NJC * 6) {
+    const int jc = it / 6, k = it % 6, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    double s;
+    if (k < 3) { s = ws.S[0][k] * ws.v[3]; if (jc >= 1) s += ws.S[1][k] * ws.v[4]; if (jc >= 2) s += ws.S[2][k] * ws.v[5]; }
+    else s = ws.v[k - 3];
+    if (jc >= 3) {
+      const int i = jc - 2, na = dm.n_anc[i];
+      double sa = 0.0;
+#pragma unroll
+      for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself: the last term is always the own axis
+        const int a = dm.anc[i][n];
+        sa = k < 3 ? ws.S[a + 2][k] : ws.r[a][k1] * ws.S[a + 2][k2] - ws.r[a][k2] * ws.S[a + 2][k1];
+        s += (n < na ? ws.v[5 + a] : 0.0) * sa;
+      }
+      if (k >= 3) ws.S[jc][k] = sa;
+    }
+    ws.vl[jc][k] = s;
+  }
+  WG_SYNC(ctx);
+  // ---- phase F3: Sd_i = v_i x S_i
+  WG_FOR(ctx, it, NJC * 6) {
+    const int jc = it / 6, k = it % 6, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    const double* vv = ws.vl[jc];
+    const double* Sx = ws.S[jc];
+    double s = vv[k1] * Sx[(k < 3 ? 0 : 3) + k2] - vv[k2] * Sx[(k < 3 ? 0 : 3) + k1];
+    if (k >= 3) s += vv[3 + k1] * Sx[k2] - vv[3 + k2] * Sx[k1];
+    ws.Sd[jc][k] = s;
+  }
+  WG_SYNC(ctx);
+  // ---- phase F4: link accelerations (gravity trick, base acceleration unknown -> 0):
+  // a_i = a_0 + sum_a (S_a qdd_a + Sd_a qd_a); the euler joints enter with zero acceleration
+  WG_FOR(ctx, it, NJC * 6) {
+    const int jc = it / 6, k = it % 6;
+    double s = k == 5 ? dm.gravity : 0.0;
+    s += ws.Sd[0][k] * ws.v[3];
+    if (jc >= 1) s += ws.Sd[1][k] * ws.v[4];
+    if (jc >= 2) s += ws.Sd[2][k] * ws.v[5];
+    if (jc >= 3) {
+      const int i = jc - 2, na = dm.n_anc[i];
+#pragma unroll
+      for (int n = 0; n < NANC; ++n) {
+        const int a = dm.anc[i][n];
+        const double t = ws.S[a + 2][k] * ws.qddj[a - 1] + ws.Sd[a + 2][k] * ws.v[5 + a];
+        s += n < na ? t : 0.0;
       }
     }
-    WG_SYNC(ctx);
+    ws.al[jc][k] = s;
   }
+  WG_SYNC(ctx);
   PH_TICK(ctx, 21);
   // ---- per-body spatial inertia about O and net force
-  WG_FOR(ctx, i, NB) {
+  WG_FOR(ctx, it, NB + (DERIV ? NJC : 0)) {
+    if (it >= NB) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
+      const int jc = it - NB;
+      double t1[6], t2[6];
+      mxm(ws.al[jc], ws.S[jc], t1);
+      mxm(ws.vl[jc], ws.Sd[jc], t2);
+      for (int k = 0; k < 6; ++k) ws.Sdd[jc][k] = t1[k] + t2[k];
+      continue;
+    }
+    const int i = it;
     const double* Rb = ws.R[i];
     double c[3], t[9], Iw[9];
     m3_mulv(Rb, dm.com[i], c);
@@ -185,12 +241,6 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     inertia_apply(In, ws.al[jc], fa);
     mxf(ws.vl[jc], h, fv);
     for (int k = 0; k < 6; ++k) ws.f[i][k] = fa[k] + fv[k];
-    if (DERIV && i > 0) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
-      double t1[6], t2[6];
-      mxm(ws.al[jc], ws.S[jc], t1);
-      mxm(ws.vl[jc], ws.Sd[jc], t2);
-      for (int k = 0; k < 6; ++k) ws.Sdd[jc][k] = t1[k] + t2[k];
-    }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 22);
@@ -204,28 +254,18 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWS& ws) {
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 23);
-    // composites over subtrees: direct sums for the light bodies (subtrees are contiguous in depth-first order) ...
+    // composites over subtrees: direct sums (subtrees are contiguous in depth-first order), one item per quantity
     WG_FOR(ctx, it, NB * 52) {
       const int i = it / 52, e = it % 52;
-      if (dm.subtree_size[i] > 8) continue;
       const int end = i + dm.subtree_size[i];
-      double s = 0.0;
-      if (e < 10) { for (int d = i; d < end; ++d) s += ws.In[d][e]; ws.Ic[i][e] = s; }
-      else if (e < 16) { for (int d = i; d < end; ++d) s += ws.f[d][e - 10]; ws.fc[i][e - 10] = s; }
-      else { for (int d = i; d < end; ++d) s += ws.BB[d][e - 16]; ws.BBc[i][e - 16] = s; }
-    }
-    WG_SYNC(ctx);
-    // ... then own + children for the heavy ones, leaves-first, one item per quantity
-    WG_FOR(ctx, e, 52) {
-      for (int hb = 0; hb < dm.n_heavy; ++hb) {
-        const int i = dm.heavy[hb];
-        double s = e < 10 ? ws.In[i][e] : (e < 16 ? ws.f[i][e - 10] : ws.BB[i][e - 16]);
-        for (int cc = dm.child_start[i]; cc < dm.child_start[i + 1]; ++cc) {
-          const int c = dm.child_list[cc];
-          s += e < 10 ? ws.Ic[c][e] : (e < 16 ? ws.fc[c][e - 10] : ws.BBc[c][e - 16]);
-        }
-        if (e < 10) ws.Ic[i][e] = s; else if (e < 16) ws.fc[i][e - 10] = s; else ws.BBc[i][e - 16] = s;
-      }
+      const double* src = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
+      const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
+      double s0 = 0.0, s1 = 0.0;
+      int d = i;
+      for (; d + 1 < end; d += 2) { s0 += src[d * st]; s1 += src[(d + 1) * st]; }
+      if (d < end) s0 += src[d * st];
+      const double sum = s0 + s1;
+      if (e < 10) ws.Ic[i][e] = sum; else if (e < 16) ws.fc[i][e - 10] = sum; else ws.BBc[i][e - 16] = sum;
     }
   } else {
     WG_FOR(ctx, e, 16) {

@@ -19,7 +19,8 @@ constexpr int NRS = 64;          // residual row slots
 constexpr int ROW_FOOT = 0, ROW_FRIC = 30, ROW_MXY = 38, ROW_COLL = 46;
 constexpr int LDJ = 96;          // leading dimension of J rows / CDe rows in memory (cols 0..92 used; CDe col 93 = e)
 
-struct NodeWS {
+template <bool D>
+struct NodeWST {
   double x[NX], u[NU], par[NP];
   double xnom[NX], unom[NU];
   int contact[2];
@@ -32,11 +33,12 @@ struct NodeWS {
   double hfric[2], hmxy[2][4], hcoll[16];
   double scale[NRS];             // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive
   double rho[NRS];
-  double d[LDJ], gd[LDJ];
+  double d[D ? LDJ : 1], gd[D ? LDJ : 1];   // Hessian / gradient diagonals (derivative pass only)
   double eqv[NE_MAX];
   double terms[208], tsum[16];   // stage-cost terms and their partial sums
   double cost;
 };
+using NodeWS = NodeWST<true>;
 
 // orientation error wrt the ground plane (oracle ASSUMPTION A2): e = (n x a)/sqrt(2(1+a.n)), a = R e_z, n = e_z
 HSQP_HD void ori_error(const double* R, double* e) {
@@ -61,7 +63,8 @@ HSQP_HD bool supports(const DevModel& dm, int jc, int b) {
 }
 
 // Values of everything that does not need derivatives.  Requires stage_eval() results in ws for (x,u).
-HSQP_HD void node_values(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw) {
+template <class SW, class NW>
+HSQP_HD void node_values(const Ctx& ctx, const DevModel& dm, const SW& ws, NW& nw) {
   // ---- nominal state / input, contact flags, equality row layout (one item)
   WG_FOR(ctx, it, 1) {
     // StateInputQuadraticCost::getStateInputDeviation (humanoid_common_mpc/src/cost/StateInputQuadraticCost.cpp:67-78)
@@ -124,7 +127,8 @@ HSQP_HD void coll_pair(int row, int& a, int& b) {
 }
 
 // Constraint values, penalties, row scalings, equality values, cost.  After node_values().
-HSQP_HD void node_scalars(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw) {
+template <class SW, class NW>
+HSQP_HD void node_scalars(const Ctx& ctx, const DevModel& dm, const SW& ws, NW& nw) {
   WG_FOR(ctx, it, 2 + 8 + 16) {
     if (it < 2) {  // friction cone value (FrictionForceConeConstraint.cpp:180-185)
       const int f = it;

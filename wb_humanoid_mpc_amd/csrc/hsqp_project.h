@@ -41,44 +41,52 @@ struct ProjWS {
       double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double V[NE_MAX][NU + 1];  // Householder vectors
-      double beta[NE_MAX], Rdiag[NE_MAX];
+      double beta[NE_MAX], Rdiag[NE_MAX], rinv[LDR];
       double part[LDR][4], yk[LDR];   // per-step scratch: partial dots, row k of R
     } qr;
     double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
   };
   int ne, nut, ok;
   double Tm[NU][LDTM];           // [Px (58) | Pu (23) | Pe | 0 0]
-  double PV[2][6][LDJ];
+  double PV[2][6][LDJ];          // PV, bvec and rho, d, gd mirror two contiguous pieces of the LQ record (one batched copy each)
   double bvec[64];
-  double d[LDJ], gd[LDJ], rho[NRS];
+  double rho[NRS], d[LDJ], gd[LDJ];
   double Jt[NRX][LDTM];          // rows 0..63: J T with rho' in column 81; rows 64..98: sqrt(d_u) [Px|Pu|Pe]; row 99: 0
 };
 
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp) {
-  // ---- load
-  WG_FOR(ctx, i, NE_MAX * LDJ + 2 * 6 * LDJ + 64 + 2 * LDJ + NRS + 1) {
-    int j = i;
-    if (j < NE_MAX * LDJ) { w.qr.CDe[j / LDJ][j % LDJ] = rec[REC_CDE + j]; continue; }
-    j -= NE_MAX * LDJ;
-    if (j < 2 * 6 * LDJ) { w.PV[j / (6 * LDJ)][(j / LDJ) % 6][j % LDJ] = rec[REC_PV + j]; continue; }
-    j -= 2 * 6 * LDJ;
-    if (j < 64) { w.bvec[j] = rec[REC_B + j]; continue; }
-    j -= 64;
-    if (j < LDJ) { w.d[j] = rec[REC_D + j]; continue; }
-    j -= LDJ;
-    if (j < LDJ) { w.gd[j] = rec[REC_GD + j]; continue; }
-    j -= LDJ;
-    if (j < NRS) { w.rho[j] = rec[REC_RHO + j]; continue; }
-    w.ne = (int)rec[REC_MISC];
-    w.nut = NU - w.ne;
-    w.ok = 1;
+  // ---- load: record pieces [REC_PV, REC_J) -> PV, bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
+  {
+    static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
+    static_assert(REC_D == REC_RHO + NRS && REC_GD == REC_D + LDJ && REC_CDE == REC_GD + LDJ && REC_MISC == REC_CDE + NE_MAX * LDJ, "record layout");
+    constexpr int n1 = 2 * 6 * LDJ + 64, n2 = NRS + 2 * LDJ, n3 = NE_MAX * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
+    double* dst1 = &w.PV[0][0][0];
+    double* dst2 = &w.rho[0];
+    double* dst3 = &w.qr.CDe[0][0];
+    WG_FOR(ctx, b, nb) {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int idx = b + j * nb; t[j] = idx < nld ? rec[idx < n1 ? REC_PV + idx : REC_RHO + (idx - n1)] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = b + j * nb;
+        if (idx < n1) dst1[idx] = t[j];
+        else if (idx < n1 + n2) dst2[idx - n1] = t[j];
+        else if (idx < nld) dst3[idx - n1 - n2] = t[j];
+      }
+    }
+    WG_FOR(ctx, i, 1) {
+      w.ne = (int)rec[REC_MISC];
+      w.nut = NU - w.ne;
+      w.ok = 1;
+    }
   }
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut;
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
   // left untouched: its final diagonal goes to Rdiag, the vector to V).
-  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; }
+  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; if (r == 0) w.qr.rinv[c] = 0.0; }
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
   // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
@@ -105,13 +113,15 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       const double q0 = w.qr.part[c][0], q1 = w.qr.part[c][1], q2 = w.qr.part[c][2], q3 = w.qr.part[c][3], ykc = w.qr.yk[c];
       const double xi = w.qr.Rm[i][k], rc = w.qr.Rm[i][c];
       const double nrm2 = (p0 + p1) + (p2 + p3);
-      const double nrm = nrm2 * inv_sqrt(nrm2 > 1e-300 ? nrm2 : 1e-300);
+      const double rs = inv_sqrt(nrm2 > 1e-300 ? nrm2 : 1e-300);
+      const double nrm = nrm2 * rs;
       const double alpha = rkk >= 0.0 ? -nrm : nrm;
       const double hv = nrm2 - alpha * rkk;      // = |v|^2 / 2
       const double beta = hv > 1e-300 ? fast_rcp(hv) : 0.0;
       if (it == 0) {
         w.qr.beta[k] = beta;
         w.qr.Rdiag[k] = alpha;
+        w.qr.rinv[k] = rkk >= 0.0 ? -rs : rs;
         if (!(nrm >= 1e-12)) w.ok = 0;
       }
       const double vi = i < k ? 0.0 : (xi - (i == k ? alpha : 0.0));
@@ -140,12 +150,16 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 2);
-  // ---- W = R1^-T [C | e]: forward substitution per column
+  // ---- W = R1^-T [C | e]: forward substitution per column, the column kept in registers (rows >= ne: rinv = 0 -> 0)
   WG_FOR(ctx, c, NX + 1) {
-    for (int i = 0; i < ne; ++i) {
+    double wc[NE_MAX];
+#pragma unroll
+    for (int i = 0; i < NE_MAX; ++i) {
       double s = c < NX ? w.qr.CDe[i][c] : w.qr.CDe[i][NZ];
-      for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * w.qr.Wm[j][c];
-      w.qr.Wm[i][c] = s / w.qr.Rdiag[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * wc[j];
+      wc[i] = s * w.qr.rinv[i];
+      w.qr.Wm[i][c] = wc[i];
     }
   }
   WG_SYNC(ctx);
@@ -153,7 +167,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
   {
     const XtyJob job = xty_job(NU, NX, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
-    wg_xty_jobs(ctx, &job, 1);
+    wg_xty_jobs<true>(ctx, &job, 1);
     WG_FOR(ctx, i, NU * (NUT + 3)) {
       const int r = i / (NUT + 3), cc = i % (NUT + 3);
       if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ne + cc][r] : 0.0;
@@ -164,9 +178,18 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);  // QR data dead from here: JuT aliases it
   PH_TICK(ctx, 4);
   // ---- stage the (transposed) input block of the residual rows, write the projection
-  WG_FOR(ctx, i, NRS * NU + NU * (NX + NUT + 1) + 1) {
-    if (i < NRS * NU) { const int r = i / NU, k = i % NU; w.JuT[k][r] = rec[REC_J + r * LDJ + NX + k]; continue; }
-    int j = i - NRS * NU;
+  {
+    constexpr int nj = NRS * NU, nbj = nbatches(nj, 8);
+    WG_FOR(ctx, b, nbj) {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int e = b + j * nbj; t[j] = e < nj ? rec[REC_J + (e / NU) * LDJ + NX + e % NU] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int e = b + j * nbj; if (e < nj) w.JuT[e % NU][e / NU] = t[j]; }
+    }
+  }
+  WG_FOR(ctx, i, NU * (NX + NUT + 1) + 1) {
+    int j = i;
     if (j < NU * NX) { qp[QP_PX + j] = w.Tm[j / NX][j % NX]; continue; }
     j -= NU * NX;
     if (j < NU * NUT) { qp[QP_PU + j] = w.Tm[j / NUT][NX + j % NUT]; continue; }
@@ -204,7 +227,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   {
     const XtyJob jobs[2] = {xty_job(NRS, NX, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J, LDJ),
                             xty_job(NRS, NUT, NU, &w.JuT[0][0], NRS, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
-    wg_xty_jobs(ctx, jobs, 2);
+    wg_xty_jobs<true>(ctx, jobs, 2);
     WG_FOR(ctx, i, NRS + (NU + 1) * LDTM) {
       if (i < NRS) {
         double sdot = w.rho[i];
@@ -225,7 +248,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     const XtyJob jobs[3] = {xty_job(NX, NX, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX),
                             xty_job(NUT, NX, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX),
                             xty_job(NUT, NUT, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT)};
-    wg_xty_jobs(ctx, jobs, 3);
+    wg_xty_jobs<true>(ctx, jobs, 3);
     WG_FOR(ctx, a, NTW) {
       double s = 0.0;
 #pragma unroll 10

@@ -169,6 +169,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     {
       XtyJob js = xty_job(NX, NX, NX, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
       js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
+      js.sym = 1;   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
       const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX)};
       constexpr int nbb = nbatches(NX * LDB, 8);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
@@ -209,14 +210,14 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
-    // ---- P6: symmetrise S (round-off only), roll s and b~
-    WG_FOR(ctx, i, NX * NX + NX) {
-      if (i < NX * NX) {
-        const int r = i / NX, c = i % NX;
-        if (c > r) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
+    // ---- P6: symmetrise S inside the diagonal tiles (the off-diagonal tiles were mirrored), roll s and b~
+    WG_FOR(ctx, i, 4 * 256 + NX) {
+      if (i < 4 * 256) {
+        const int r = 16 * (i >> 8) + ((i >> 4) & 15), c = 16 * (i >> 8) + (i & 15);
+        if (c > r && c < NX) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
       } else {
-        w.sv[i - NX * NX] = w.sn[i - NX * NX];
-        if (k > 0) w.bt[i - NX * NX] = w.btn[i - NX * NX];
+        w.sv[i - 4 * 256] = w.sn[i - 4 * 256];
+        if (k > 0) w.bt[i - 4 * 256] = w.btn[i - 4 * 256];
       }
     }
     WG_SYNC(ctx);
