@@ -31,12 +31,14 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
   if (deriv) {
     auto ws = std::make_unique<StageWST<true>>();
     run(*ws);
+    stage_topology(ctx, dm, *ws);
     stage_eval<true>(ctx, dm, *ws);
     for (int i = 0; i < 6; ++i) ab[i] = ws->ab[i];
     if (G) for (int r = 0; r < 6; ++r) for (int c = 0; c < NZ; ++c) G[r * NZ + c] = ws->G[r][c];
   } else {
     auto ws = std::make_unique<StageWST<false>>();
     run(*ws);
+    stage_topology(ctx, dm, *ws);
     stage_eval<false>(ctx, dm, *ws);
     for (int i = 0; i < 6; ++i) ab[i] = ws->ab[i];
   }

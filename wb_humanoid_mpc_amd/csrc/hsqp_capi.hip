@@ -15,16 +15,29 @@ using namespace hsqp;
 
 namespace {
 
-constexpr int LQ_THREADS = 256;
+// launch shapes of the LQ kernels (overridable for tuning builds: tools/build_variants.py)
+#ifndef HSQP_LQ_THREADS
+#define HSQP_LQ_THREADS 128   /* 40 KB workspace: 4 workgroups of 2 waves per CU, no register spills */
+#endif
+#ifndef HSQP_LQ_WPE
+#define HSQP_LQ_WPE 2
+#endif
+#ifndef HSQP_LQV_THREADS
+#define HSQP_LQV_THREADS 128
+#endif
+#ifndef HSQP_LQV_WPE
+#define HSQP_LQV_WPE 3
+#endif
+constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 constexpr int PROJ_THREADS = 512;
 constexpr int RIC_THREADS = 512;
-constexpr int LQV_THREADS = 128;   // value-only LQ pass: 31 KB workspace, 5 workgroups per CU
+constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (22 KB workspace)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 
 // ---- LQ approximation: one workgroup per (instance, node)
 template <bool DERIV>
-__global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, 3) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
+__global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_WPE : HSQP_LQV_WPE) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
                                                    const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
                                                    double* __restrict__ rec, double* __restrict__ misc, long long* prof) {
   const int node = blockIdx.x, b = node / N, k = node % N;

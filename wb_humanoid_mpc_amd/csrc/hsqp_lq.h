@@ -28,9 +28,19 @@ constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
 constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel)
 constexpr int REC_SIZE = REC_GS + 4 * 6 * LDJ;
 
+// Model constants: read from global memory through the vector L1 (every workgroup of a CU reads the same 9 KB), or,
+// with -DHSQP_DM_LDS=1, from a per-workgroup LDS copy (costs 9 KB of LDS = one workgroup of occupancy per CU).
+#ifndef HSQP_DM_LDS
+#define HSQP_DM_LDS 0
+#endif
+struct NoDevModelCopy {};
 template <bool D>
 struct LqWST {
-  DevModel dml;        // the model constants, copied to LDS once per workgroup (they are read on every serial path)
+#if HSQP_DM_LDS
+  DevModel dml;
+#else
+  NoDevModelCopy dml;
+#endif
   union {
     StageWST<D> st;
     struct {
@@ -83,6 +93,7 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
 template <bool DERIV>
 HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w, const double* x, const double* u, const double* xnext,
                      const double* par, double dt, double* rec, double* misc) {
+#if HSQP_DM_LDS
   {
     constexpr int nw = (int)(sizeof(DevModel) / sizeof(double));
     static_assert(sizeof(DevModel) % sizeof(double) == 0, "DevModel must be a whole number of doubles");
@@ -91,6 +102,10 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     WG_FOR(ctx, i, nw) dst[i] = src[i];
   }
   const DevModel& dm = w.dml;
+#else
+  const DevModel& dm = dm_global;
+#endif
+  stage_topology(ctx, dm, w.st);
   WG_FOR(ctx, i, NX + NU + NP + NX) {
     if (i < NX) w.nw.x[i] = x[i];
     else if (i < NX + NU) w.nw.u[i - NX] = u[i - NX];

@@ -24,6 +24,10 @@ namespace hsqp {
 // D = false: value-only evaluation (performance index pass) — the derivative arrays shrink to one element.
 template <bool D>
 struct StageWST {
+  // ---- tree topology used by the placement walk and the ancestor sums (copied from DevModel once per workgroup:
+  //      these indices sit in front of dependent loads)
+  unsigned char anc[NB][NANC], n_anc[NB], chain_start[NB], chain_len[NB];
+  int n_chains;
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
   double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
@@ -101,6 +105,15 @@ HSQP_HD void rot_axis_cs(const double* ax, double c, double s, double* Rm) {
 // Serial depth: only the placements (R_i, r_i, w_i) are propagated along the tree, row by row (three independent
 // items per chain, DevModel::chain_* / anc); velocities and accelerations are sums over the ancestor path, one item
 // per component.  Everything else (Sdd, inertia, net force, BB) runs in fully parallel phases.
+template <class SW>
+HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
+  WG_FOR(ctx, i, NB * NANC + NB) {
+    if (i < NB * NANC) ws.anc[i / NANC][i % NANC] = dm.anc[i / NANC][i % NANC];
+    else { const int b = i - NB * NANC; ws.n_anc[b] = (unsigned char)dm.n_anc[b]; ws.chain_start[b] = (unsigned char)dm.chain_start[b]; ws.chain_len[b] = (unsigned char)dm.chain_len[b]; if (b == 0) ws.n_chains = dm.n_chains; }
+  }
+  WG_SYNC(ctx);
+}
+
 template <bool DERIV>
 HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws) {
   // ---- phase F0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
@@ -117,9 +130,9 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
   // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
   // only on row r of R_p, so every chain is walked by three independent items (one per row), each from the base
   // down its whole ancestor path (the shared waist bodies are recomputed, not exchanged): no barrier inside the tree.
-  WG_FOR(ctx, it, dm.n_chains * 3 + 4) {
+  WG_FOR(ctx, it, ws.n_chains * 3 + 4) {
     const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
-    if (it == dm.n_chains * 3 + 3) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
+    if (it == ws.n_chains * 3 + 3) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
       const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
       for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
       m3_inverse(ws.E, ws.Einv);
@@ -134,18 +147,18 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
     if (r == 0) { Rp[0] = cz * cy; Rp[1] = cz * sy * sx - sz * cx; Rp[2] = cz * sy * cx + sz * sx; }
     else if (r == 1) { Rp[0] = sz * cy; Rp[1] = sz * sy * sx + cz * cx; Rp[2] = sz * sy * cx - cz * sx; }
     else { Rp[0] = -sy; Rp[1] = cy * sx; Rp[2] = cy * cx; }
-    if (ch == dm.n_chains) {           // the base itself
+    if (ch == ws.n_chains) {           // the base itself
       for (int c = 0; c < 3; ++c) ws.R[0][3 * r + c] = Rp[c];
       ws.r[0][r] = 0.0;
       continue;
     }
-    const int b0 = dm.chain_start[ch], end = b0 + dm.chain_len[ch] - 1, na = dm.n_anc[end];
+    const int b0 = ws.chain_start[ch], end = b0 + ws.chain_len[ch] - 1, na = ws.n_anc[end];
     double rp = 0.0;
     // fully unrolled over the (padded) path: the index and operand loads do not depend on the running row, only the
     // multiply-adds are chained
 #pragma unroll
     for (int n = 0; n < NANC; ++n) {
-      const int i = dm.anc[end][n];
+      const int i = ws.anc[end][n];
       const double* M = ws.Mq[i];
       const double rn0 = Rp[0] * M[0] + Rp[1] * M[3] + Rp[2] * M[6];
       const double rn1 = Rp[0] * M[1] + Rp[1] * M[4] + Rp[2] * M[7];
@@ -168,11 +181,11 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
     if (k < 3) { s = ws.S[0][k] * ws.v[3]; if (jc >= 1) s += ws.S[1][k] * ws.v[4]; if (jc >= 2) s += ws.S[2][k] * ws.v[5]; }
     else s = ws.v[k - 3];
     if (jc >= 3) {
-      const int i = jc - 2, na = dm.n_anc[i];
+      const int i = jc - 2, na = ws.n_anc[i];
       double sa = 0.0;
 #pragma unroll
       for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself: the last term is always the own axis
-        const int a = dm.anc[i][n];
+        const int a = ws.anc[i][n];
         sa = k < 3 ? ws.S[a + 2][k] : ws.r[a][k1] * ws.S[a + 2][k2] - ws.r[a][k2] * ws.S[a + 2][k1];
         s += (n < na ? ws.v[5 + a] : 0.0) * sa;
       }
@@ -200,10 +213,10 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
     if (jc >= 1) s += ws.Sd[1][k] * ws.v[4];
     if (jc >= 2) s += ws.Sd[2][k] * ws.v[5];
     if (jc >= 3) {
-      const int i = jc - 2, na = dm.n_anc[i];
+      const int i = jc - 2, na = ws.n_anc[i];
 #pragma unroll
       for (int n = 0; n < NANC; ++n) {
-        const int a = dm.anc[i][n];
+        const int a = ws.anc[i][n];
         const double t = ws.S[a + 2][k] * ws.qddj[a - 1] + ws.Sd[a + 2][k] * ws.v[5 + a];
         s += n < na ? t : 0.0;
       }

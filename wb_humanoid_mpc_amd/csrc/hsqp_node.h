@@ -33,9 +33,11 @@ struct NodeWST {
   double hfric[2], hmxy[2][4], hcoll[16];
   double scale[NRS];             // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive
   double rho[NRS];
-  double d[D ? LDJ : 1], gd[D ? LDJ : 1];   // Hessian / gradient diagonals (derivative pass only)
   double eqv[NE_MAX];
-  double terms[208], tsum[16];   // stage-cost terms and their partial sums
+  union {
+    struct { double terms[208], tsum[16]; };          // stage-cost terms and their partial sums (node_scalars) ...
+    struct { double d[D ? LDJ : 1], gd[D ? LDJ : 1]; };   // ... then the Hessian / gradient diagonals (node_derivatives)
+  };
   double cost;
 };
 using NodeWS = NodeWST<true>;
