@@ -29,7 +29,13 @@ namespace {
 #define HSQP_LQV_WPE 3
 #endif
 constexpr int LQ_THREADS = HSQP_LQ_THREADS;
-constexpr int PROJ_THREADS = 512;
+#ifndef HSQP_PROJ_THREADS
+#define HSQP_PROJ_THREADS 256
+#endif
+#ifndef HSQP_PROJ_WPE
+#define HSQP_PROJ_WPE 2
+#endif
+constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 77 KB workspace: two workgroups per CU
 constexpr int RIC_THREADS = 512;
 constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (22 KB workspace)
 
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
 }
 
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof) {
+__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)

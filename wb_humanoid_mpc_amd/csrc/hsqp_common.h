@@ -104,6 +104,10 @@ struct DevModel {
   // ancestor path of every body (root-most moving body first, the body itself last; the base is not listed)
   int n_anc[NB];
   unsigned char anc[NB][NANC];
+  // composite (subtree) sums run chain by chain from the leaves: comp_i = own_i + comp_{i+1 in the same chain} + comp of
+  // the chains hanging off body i (xchild, 255 = none).  Chain n_chains is the base alone.  cphase: 0 = leaf chains.
+  int n_cphases;
+  unsigned char cphase[NB], xchild[NB][3];
   double mass[NB];
   double com[NB][3];
   double inertia[NB][9];          // about com, body axes

@@ -129,6 +129,7 @@ struct XtyJob {
   double scale;                   // C = scale * acc + Add
   const double* Add; int ldadd;   // optional (may be global memory)
   double* C; int ldc;             // destination (LDS or global)
+  int sx1, sx2;                   // element stride of X along the output-row index (1 = row-major X[l][r]; ld = 1, sx = ld' reads X'[r][l])
   int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
 };
 
@@ -137,7 +138,7 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1;
   return j;
 }
 
@@ -170,7 +171,7 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
     const bool ok = k < j.L1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const double a = ok ? j.X1[k * j.ldx1 + xr[t]] : 0.0;
+      const double a = ok ? j.X1[k * j.ldx1 + xr[t] * j.sx1] : 0.0;
       const double b = ok ? j.Y1[k * j.ldy1 + yc[t]] : 0.0;
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
@@ -180,7 +181,7 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
     const bool ok = k < j.L2;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr[t]] : 0.0;
+      const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr[t] * j.sx2] : 0.0;
       const double b = ok ? j.Y2[k * j.ldy2 + yc[t]] : 0.0;
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
@@ -245,8 +246,8 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
       const int r = e / j.N, c = e % j.N;
       if (j.sym && (c >> 4) < (r >> 4)) continue;   // mirrored from the tile above the diagonal
       double acc = 0.0;
-      for (int l = 0; l < j.L1; ++l) acc += j.X1[l * j.ldx1 + r] * j.Y1[l * j.ldy1 + c];
-      for (int l = 0; l < j.L2; ++l) acc += j.sign2 * j.X2[l * j.ldx2 + r] * j.Y2[l * j.ldy2 + c];
+      for (int l = 0; l < j.L1; ++l) acc += j.X1[l * j.ldx1 + r * j.sx1] * j.Y1[l * j.ldy1 + c];
+      for (int l = 0; l < j.L2; ++l) acc += j.sign2 * j.X2[l * j.ldx2 + r * j.sx2] * j.Y2[l * j.ldy2 + c];
       double v = j.scale * acc;
       if (j.Add) v += j.Add[r * j.ldadd + c];
       j.C[r * j.ldc + c] = v;

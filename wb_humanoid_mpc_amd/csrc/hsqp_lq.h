@@ -187,17 +187,29 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
   for (int s = 1; s < 4; ++s) {
     const double c = s == 1 ? c2 : (s == 2 ? c3 : c4);
     const double cprev = s == 2 ? c2 : c3;  // coefficient of stage s-1 (used for s >= 2)
+    // direct part: G_s composed with the selection structure of d z_s / d z
     WG_FOR(ctx, i, 6 * LDJ) {
       const int r = i / LDJ, col = i % LDJ;
+      const double* G = w.ch.Gs[s - 1][r];
       double val = 0.0;
       if (col < NZ) {
-        if (col < NV) val = w.ch.Gs[s - 1][r][col];
-        else if (col < NX) val = c * w.ch.Gs[s - 1][r][col - NV] + w.ch.Gs[s - 1][r][col];
-        else val = w.ch.Gs[s - 1][r][col];
-        val += c * times_vd(w.ch.Gs[s - 1], NV, w.ch.Ab[s - 1], r, col);                       // c_s G_v Vd_{s-1}
-        if (s >= 2) val += c * cprev * times_vd(w.ch.Gs[s - 1], 0, w.ch.Ab[s - 2], r, col);     // c_s c_{s-1} G_q Vd_{s-2}
+        val = G[col];
+        if (col >= NV && col < NX) val += c * G[col - NV];
+        if (col >= NX + 12) {
+          val += c * G[NV + 6 + (col - NX - 12)];
+          if (s >= 2) val += c * cprev * G[6 + (col - NX - 12)];
+        }
       }
       w.ch.Ab[s][r][col] = val;
+    }
+    WG_SYNC(ctx);
+    // chained part on the matrix cores: Ab_s += c G_s[:, v_b] Ab_{s-1} + c c_{s-1} G_s[:, q_b] Ab_{s-2}  (6x6 by 6x96 products;
+    // X^T Y with X read through an element stride: X[l][r] = G_s[r][c0 + l])
+    {
+      XtyJob job = xty_job(6, LDJ, 6, &w.ch.Gs[s - 1][0][NV], 1, &w.ch.Ab[s - 1][0][0], LDJ, &w.ch.Ab[s][0][0], LDJ, &w.ch.Ab[s][0][0], LDJ, c);
+      job.sx1 = LDJ;
+      if (s >= 2) { job.L2 = 6; job.X2 = &w.ch.Gs[s - 1][0][0]; job.ldx2 = 1; job.sx2 = LDJ; job.Y2 = &w.ch.Ab[s - 2][0][0]; job.ldy2 = LDJ; job.sign2 = cprev; }
+      wg_xty_jobs<true>(ctx, &job, 1);
     }
     WG_SYNC(ctx);
   }

@@ -26,8 +26,8 @@ template <bool D>
 struct StageWST {
   // ---- tree topology used by the placement walk and the ancestor sums (copied from DevModel once per workgroup:
   //      these indices sit in front of dependent loads)
-  unsigned char anc[NB][NANC], n_anc[NB], chain_start[NB], chain_len[NB];
-  int n_chains;
+  unsigned char anc[NB][NANC], n_anc[NB], chain_start[NB], chain_len[NB], cphase[NB], xchild[NB][3];
+  int n_chains, n_cphases;
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
   double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
@@ -109,7 +109,13 @@ template <class SW>
 HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
   WG_FOR(ctx, i, NB * NANC + NB) {
     if (i < NB * NANC) ws.anc[i / NANC][i % NANC] = dm.anc[i / NANC][i % NANC];
-    else { const int b = i - NB * NANC; ws.n_anc[b] = (unsigned char)dm.n_anc[b]; ws.chain_start[b] = (unsigned char)dm.chain_start[b]; ws.chain_len[b] = (unsigned char)dm.chain_len[b]; if (b == 0) ws.n_chains = dm.n_chains; }
+    else {
+      const int b = i - NB * NANC;
+      ws.n_anc[b] = (unsigned char)dm.n_anc[b]; ws.chain_start[b] = (unsigned char)dm.chain_start[b]; ws.chain_len[b] = (unsigned char)dm.chain_len[b];
+      ws.cphase[b] = dm.cphase[b];
+      for (int k = 0; k < 3; ++k) ws.xchild[b][k] = dm.xchild[b][k];
+      if (b == 0) { ws.n_chains = dm.n_chains; ws.n_cphases = dm.n_cphases; }
+    }
   }
   WG_SYNC(ctx);
 }
@@ -267,18 +273,28 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 23);
-    // composites over subtrees: direct sums (subtrees are contiguous in depth-first order), one item per quantity
-    WG_FOR(ctx, it, NB * 52) {
-      const int i = it / 52, e = it % 52;
-      const int end = i + dm.subtree_size[i];
-      const double* src = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
-      const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
-      double s0 = 0.0, s1 = 0.0;
-      int d = i;
-      for (; d + 1 < end; d += 2) { s0 += src[d * st]; s1 += src[(d + 1) * st]; }
-      if (d < end) s0 += src[d * st];
-      const double sum = s0 + s1;
-      if (e < 10) ws.Ic[i][e] = sum; else if (e < 16) ws.fc[i][e - 10] = sum; else ws.BBc[i][e - 16] = sum;
+    // composites over subtrees, chain by chain from the leaves (item = chain x quantity, running sum in a register):
+    // comp_i = own_i + comp_{i+1} + comp of the chains hanging off body i
+    for (int ph = 0; ph < ws.n_cphases; ++ph) {
+      WG_FOR(ctx, it, (ws.n_chains + 1) * 52) {
+        const int ch = it / 52, e = it % 52;
+        if (ws.cphase[ch] != ph) continue;
+        const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
+        double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
+        const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
+        const int b0 = ws.chain_start[ch];
+        double s = 0.0;
+        for (int i = b0 + ws.chain_len[ch] - 1; i >= b0; --i) {
+          const int c0 = ws.xchild[i][0], c1 = ws.xchild[i][1], c2 = ws.xchild[i][2];
+          double t = own[i * st];
+          if (c0 != 255) t += comp[c0 * st];
+          if (c1 != 255) t += comp[c1 * st];
+          if (c2 != 255) t += comp[c2 * st];
+          s += t;
+          comp[i * st] = s;
+        }
+      }
+      if (ph + 1 < ws.n_cphases) WG_SYNC(ctx);
     }
   } else {
     WG_FOR(ctx, e, 16) {

@@ -30,7 +30,11 @@ constexpr int QP_SIZE = ((QP_NUT + 1 + 7) / 8) * 8;
 
 constexpr int NTW = NX + NUT;                  // 81: projected stage variable [dx; ut]
 constexpr int LDTM = 84;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
-constexpr int NRX = 100;                       // residual rows after projection: 64 slots + 35 input-weight rows + 1 zero row
+// The projected residual rows (64 slots + 35 input-weight rows sqrt(d_u) [Px|Pu|Pe]) are processed in two passes so that
+// the workspace stays under 80 KB (two workgroups per CU): pass A = slots 0..47, pass B = slots 48..63 + weight rows.
+constexpr int NRA = 48;                        // residual row slots of pass A
+constexpr int NRB = (NRS - NRA) + NU + 1;      // 16 slots + 35 input-weight rows + 1 zero row = 52
+static_assert(NRA % 4 == 0 && NRB % 4 == 0 && NRB >= NRA, "pass sizes");
 
 constexpr int LDR = 16;
 struct ProjWS {
@@ -43,30 +47,31 @@ struct ProjWS {
       double V[NE_MAX][NU + 1];  // Householder vectors
       double beta[NE_MAX], Rdiag[NE_MAX], rinv[LDR];
       double part[LDR][4], yk[LDR];   // per-step scratch: partial dots, row k of R
-    } qr;
-    double JuT[NU][NRS];         // transposed input block of the residual rows (staged after the QR data is dead)
+    } qr;                        // live until Tm is formed
+    double PV[2][6][LDJ];        // then the non-trivial rows of [A|B] (loaded when the QR data is dead) ...
+    double Jt[NRB][LDTM];        // ... then the projected residual rows of the current pass (column 81 = rho')
   };
+  double JuT[NU][NRA];           // transposed input block of the residual rows of the current pass
   int ne, nut, ok;
   double Tm[NU][LDTM];           // [Px (58) | Pu (23) | Pe | 0 0]
-  double PV[2][6][LDJ];          // PV, bvec and rho, d, gd mirror two contiguous pieces of the LQ record (one batched copy each)
   double bvec[64];
-  double rho[NRS], d[LDJ], gd[LDJ];
-  double Jt[NRX][LDTM];          // rows 0..63: J T with rho' in column 81; rows 64..98: sqrt(d_u) [Px|Pu|Pe]; row 99: 0
+  double rho[NRS], d[LDJ], gd[LDJ];   // mirror one contiguous piece of the LQ record
+  double gacc[LDTM];             // gradient partial sums of pass A
 };
 
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp) {
-  // ---- load: record pieces [REC_PV, REC_J) -> PV, bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
+  // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
     static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
     static_assert(REC_D == REC_RHO + NRS && REC_GD == REC_D + LDJ && REC_CDE == REC_GD + LDJ && REC_MISC == REC_CDE + NE_MAX * LDJ, "record layout");
-    constexpr int n1 = 2 * 6 * LDJ + 64, n2 = NRS + 2 * LDJ, n3 = NE_MAX * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
-    double* dst1 = &w.PV[0][0][0];
+    constexpr int n1 = 64, n2 = NRS + 2 * LDJ, n3 = NE_MAX * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
+    double* dst1 = &w.bvec[0];
     double* dst2 = &w.rho[0];
     double* dst3 = &w.qr.CDe[0][0];
     WG_FOR(ctx, b, nb) {
       double t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int idx = b + j * nb; t[j] = idx < nld ? rec[idx < n1 ? REC_PV + idx : REC_RHO + (idx - n1)] : 0.0; }
+      for (int j = 0; j < 8; ++j) { const int idx = b + j * nb; t[j] = idx < nld ? rec[idx < n1 ? REC_B + idx : REC_RHO + (idx - n1)] : 0.0; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int idx = b + j * nb;
@@ -175,19 +180,30 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       else w.Tm[r][NTW + (cc - NUT)] = 0.0;
     }
   }
-  WG_SYNC(ctx);  // QR data dead from here: JuT aliases it
+  WG_SYNC(ctx);  // QR data dead from here: PV, then Jt alias it
   PH_TICK(ctx, 4);
-  // ---- stage the (transposed) input block of the residual rows, write the projection
-  {
-    constexpr int nj = NRS * NU, nbj = nbatches(nj, 8);
-    WG_FOR(ctx, b, nbj) {
+  // ---- stage the (transposed) input block of the residual rows r0 .. r0+nr and, in pass A, the [A|B] rows
+  auto stage_inputs = [&](int r0, int nr, bool with_pv) {
+    const int nj = nr * NU, ntot = nj + (with_pv ? 2 * 6 * LDJ : 0), nb = (ntot + 7) / 8;
+    double* pv = &w.PV[0][0][0];
+    WG_FOR(ctx, b, nb) {
       double t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int e = b + j * nbj; t[j] = e < nj ? rec[REC_J + (e / NU) * LDJ + NX + e % NU] : 0.0; }
+      for (int j = 0; j < 8; ++j) {
+        const int e = b + j * nb;
+        t[j] = e < nj ? rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU] : (e < ntot ? rec[REC_PV + (e - nj)] : 0.0);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int e = b + j * nbj; if (e < nj) w.JuT[e % NU][e / NU] = t[j]; }
+      for (int j = 0; j < 8; ++j) {
+        const int e = b + j * nb;
+        if (e < nj) w.JuT[e % NU][e / NU] = t[j];
+        else if (e < ntot) pv[e - nj] = t[j];
+      }
     }
-  }
+  };
+  stage_inputs(0, NRA, true);
+  WG_SYNC(ctx);
+  // ---- write the projection
   WG_FOR(ctx, i, NU * (NX + NUT + 1) + 1) {
     int j = i;
     if (j < NU * NX) { qp[QP_PX + j] = w.Tm[j / NX][j % NX]; continue; }
@@ -221,45 +237,59 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       qp[QP_BV + r] = w.bvec[r] + s;
     }
   }
-  WG_SYNC(ctx);
+  WG_SYNC(ctx);  // PV dead: Jt aliases it
   PH_TICK(ctx, 5);
-  // ---- residual rows after projection: J T (+ rho' in column 81), then the input-weight rows sqrt(d_u) [Px|Pu|Pe]
-  {
-    const XtyJob jobs[2] = {xty_job(NRS, NX, NU, &w.JuT[0][0], NRS, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J, LDJ),
-                            xty_job(NRS, NUT, NU, &w.JuT[0][0], NRS, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
-    wg_xty_jobs<true>(ctx, jobs, 2);
-    WG_FOR(ctx, i, NRS + (NU + 1) * LDTM) {
-      if (i < NRS) {
-        double sdot = w.rho[i];
+  // ---- two passes over the residual rows: J~ = J T (+ rho' in column 81), then H~ (+)= J~^T J~ on the matrix cores (blocks
+  //      Q~, P~, R~ straight to the QP record; pass B adds to what the same lanes wrote in pass A) and the gradient
+  //      g~ = T^T gd + J~^T rho'
 #pragma unroll
-        for (int k = 0; k < NU; ++k) sdot += w.JuT[k][i] * w.Tm[k][NTW];
-        w.Jt[i][NTW] = sdot;
-      } else {
-        const int k = (i - NRS) / LDTM, a = (i - NRS) % LDTM;
-        w.Jt[NRS + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r0 = pass == 0 ? 0 : NRA, nr = pass == 0 ? NRA : NRS - NRA, nrows = pass == 0 ? NRA : NRB;
+    if (pass == 1) { stage_inputs(NRA, NRS - NRA, false); WG_SYNC(ctx); }
+    {
+      const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.JuT[0][0], NRA, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
+                              xty_job(nr, NUT, NU, &w.JuT[0][0], NRA, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
+      wg_xty_jobs<true>(ctx, jobs, 2);
+      WG_FOR(ctx, i, nr + (pass == 1 ? (NU + 1) * LDTM : 0)) {
+        if (i < nr) {
+          double sdot = w.rho[r0 + i];
+#pragma unroll
+          for (int k = 0; k < NU; ++k) sdot += w.JuT[k][i] * w.Tm[k][NTW];
+          w.Jt[i][NTW] = sdot;
+        } else {   // pass B: the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the zero row
+          const int k = (i - nr) / LDTM, a = (i - nr) % LDTM;
+          w.Jt[nr + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
+        }
       }
     }
-  }
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 6);
-  // ---- projected Hessian H~ = diag(d_x, 0) + J~ext^T J~ext on the matrix cores (blocks Q~, P~, R~ straight to the QP
-  //      record) and gradient g~ = T^T gd + J~ext^T rho'
-  {
-    const XtyJob jobs[3] = {xty_job(NX, NX, NRX, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX),
-                            xty_job(NUT, NX, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX),
-                            xty_job(NUT, NUT, NRX, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT)};
-    wg_xty_jobs<true>(ctx, jobs, 3);
-    WG_FOR(ctx, a, NTW) {
-      double s = 0.0;
-#pragma unroll 10
-      for (int r = 0; r < NRX; ++r) s += w.Jt[r][a] * w.Jt[r][NTW];
-      if (a < NX) s += w.gd[a];
+    WG_SYNC(ctx);
+    PH_TICK(ctx, 6);
+    {
+      const double* addq = pass == 0 ? nullptr : qp + QP_Q;
+      const double* addp = pass == 0 ? nullptr : qp + QP_P;
+      const double* addr = pass == 0 ? nullptr : qp + QP_R;
+      const XtyJob jobs[3] = {xty_job(NX, NX, nrows, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX, addq, NX),
+                              xty_job(NUT, NX, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX, addp, NX),
+                              xty_job(NUT, NUT, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT, addr, NUT)};
+      wg_xty_jobs<true>(ctx, jobs, 3);
+      WG_FOR(ctx, a, NTW) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < nrows; ++r) s += w.Jt[r][a] * w.Jt[r][NTW];
+        if (pass == 0) {
+          if (a < NX) s += w.gd[a];
 #pragma unroll
-      for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
-      if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
+          for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
+          w.gacc[a] = s;
+        } else {
+          s += w.gacc[a];
+          if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
+        }
+      }
     }
+    WG_SYNC(ctx);
+    PH_TICK(ctx, 7);
   }
-  WG_SYNC(ctx);
   // diagonal of Q~ and the identity padding of the unused projected inputs (read-modify-write of this node's own record)
   WG_FOR(ctx, i, NX + NUT * NUT) {
     if (i < NX) qp[QP_Q + i * NX + i] += w.d[i];
@@ -269,7 +299,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
   }
   WG_SYNC(ctx);
-  PH_TICK(ctx, 7);
+  PH_TICK(ctx, 10);
 }
 
 }  // namespace hsqp
