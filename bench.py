@@ -39,6 +39,18 @@ PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 --pmc passes of this same command
+    (tools/gpu_pmc.sh -> profiles/r01_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"][kernel_key]
+        return k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, n_nodes, seed):
     """The CPU oracle (oracle/oracle.cpp, kind 'port') on a bounded sample of the same workload."""
     from hsqp_oracle import Oracle
@@ -123,9 +135,11 @@ def main():
         value = aggregate_throughput([B] * world, args.steps, elapsed)
         nodes = B * N
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
-        kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN), "projection(k_project)": (kms[1], F_PROJ), "riccati(k_riccati)": (kms[2], F_RIC)}
+        kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN, "k_lq<true>"), "projection(k_project)": (kms[1], F_PROJ, "k_project"),
+                "riccati(k_riccati)": (kms[2], F_RIC, "k_riccati")}
         dom = max(kern, key=lambda n: kern[n][0])
-        dom_ms, dom_flops = kern[dom]
+        dom_ms, dom_flops, dom_key = kern[dom]
+        traffic = pmc_traffic(dom_key) if (B, N) == (256, 100) else None
         ach_tf = nodes * dom_flops / (dom_ms * 1e-3) / 1e12
         step_tf = nodes * F_NODE / (elapsed / args.steps) / 1e12
         step_tbs = nodes * BYTES_NODE / (elapsed / args.steps) / 1e12
@@ -137,7 +151,9 @@ def main():
                                    "1 SQP iteration per step (LQ + projection + Riccati + full step + performance index), cold-start trajectory",
                        "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE) from the committed rocprofv3 --pmc "
+                                         "passes of this command (profiles/r01_pmc_summary.json); null for other shapes",
                          "note": "achieved = ALGORITHMIC (dense-count) flops of the dominant kernel / its HIP-event duration; the kernels exploit "
                                  "the flow map's structure and execute fewer flops than the dense count (DESIGN.md)",
                          "whole_step_algorithmic_TFLOPs": step_tf, "whole_step_frac_fp64": step_tf / PEAK_FP64_TFLOPS,
