@@ -116,11 +116,13 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
   for (int s = 0; s < 4; ++s) {
     PH_TICK(ctx, 1);
     rk4_stage_inputs(ctx, w, s, dt);
-    stage_eval<DERIV>(ctx, dm, w.st);
+    // the stage Jacobians of stages 2..4 go straight to the record (they are only chained later); stage 1 stays in LDS
+    // for the node terms and is copied out
+    stage_eval<DERIV>(ctx, dm, w.st, (DERIV && s > 0) ? rec + REC_GS + s * 6 * LDJ : nullptr);
     PH_TICK(ctx, 2);
-    WG_FOR(ctx, i, 6 + (DERIV ? 6 * LDJ : 0)) {
+    WG_FOR(ctx, i, 6 + ((DERIV && s == 0) ? 6 * LDJ : 0)) {
       if (i < 6) w.as[s][i] = w.st.ab[i];
-      else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; rec[REC_GS + (s * 6 + r) * LDJ + c] = c < NZ ? w.st.G[r][c] : 0.0; }
+      else { const int r = (i - 6) / LDJ, c = (i - 6) % LDJ; rec[REC_GS + r * LDJ + c] = c < NZ ? w.st.G[r][c] : 0.0; }
     }
     WG_SYNC(ctx);
     if (s == 0) {
@@ -178,10 +180,14 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
   WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
   // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
   const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
-  WG_FOR(ctx, i, 4 * 6 * LDJ) {   // stage Jacobians back from the record (written by this workgroup, L2-resident)
-    const double g = rec[REC_GS + i];
-    if (i < 6 * LDJ) w.ch.Ab[0][i / LDJ][i % LDJ] = g;
-    else w.ch.Gs[i / (6 * LDJ) - 1][(i / LDJ) % 6][i % LDJ] = g;
+  {   // stage Jacobians back from the record (written by this workgroup, L2-resident), 9 loads in flight per item
+    constexpr int ng = 4 * 6 * LDJ, nbg = nbatches(ng, 9);
+    WG_FOR(ctx, b, nbg) {
+      copy_batch<9>(b, ng, rec + REC_GS, [&](int i, double g) {
+        if (i < 6 * LDJ) w.ch.Ab[0][i / LDJ][i % LDJ] = g;
+        else w.ch.Gs[i / (6 * LDJ) - 1][(i / LDJ) % 6][i % LDJ] = g;
+      });
+    }
   }
   WG_SYNC(ctx);
   for (int s = 1; s < 4; ++s) {

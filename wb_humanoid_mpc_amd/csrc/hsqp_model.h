@@ -120,8 +120,10 @@ HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
   WG_SYNC(ctx);
 }
 
+// Gout (optional, row stride LDJ, may be global memory): if given, the Jacobian goes there instead of ws.G (columns
+// NZ..LDJ-1 are written as zero).
 template <bool DERIV>
-HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws) {
+HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws, double* Gout = nullptr) {
   // ---- phase F0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
   WG_FOR(ctx, it, NB + 2) {
     double sn, cs;
@@ -404,12 +406,15 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws)
     double t[3], ang[3];
     m3_mulv(ws.Iinv, rhs, t);
     m3_mulv(ws.Einv, t, ang);
-    for (int k = 0; k < 3; ++k) { ws.G[k][col] = lin[k]; ws.G[3 + k][col] = ang[k]; }
+    if (Gout) for (int k = 0; k < 3; ++k) { Gout[k * LDJ + col] = lin[k]; Gout[(3 + k) * LDJ + col] = ang[k]; }
+    else for (int k = 0; k < 3; ++k) { ws.G[k][col] = lin[k]; ws.G[3 + k][col] = ang[k]; }
   }
   // columns with identically zero derivative: base position (0..2) and base linear velocity (29..31)
-  WG_FOR(ctx, it, 36) {
-    const int r = it / 6, c = it % 6;
-    ws.G[r][c < 3 ? c : NV + (c - 3)] = 0.0;
+  WG_FOR(ctx, it, 6 * 9) {
+    const int r = it / 9, c = it % 9;
+    const int col = c < 3 ? c : (c < 6 ? NV + (c - 3) : NZ + (c - 6));
+    if (Gout) Gout[r * LDJ + col] = 0.0;
+    else if (col < NZ) ws.G[r][col] = 0.0;
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 26);

@@ -17,7 +17,6 @@ namespace hsqp {
 
 constexpr int NRS = 64;          // residual row slots
 constexpr int ROW_FOOT = 0, ROW_FRIC = 30, ROW_MXY = 38, ROW_COLL = 46;
-constexpr int LDJ = 96;          // leading dimension of J rows / CDe rows in memory (cols 0..92 used; CDe col 93 = e)
 
 template <bool D>
 struct NodeWST {

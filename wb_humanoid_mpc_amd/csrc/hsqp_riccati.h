@@ -108,6 +108,26 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     // ---- P4a: Gaussian elimination of [Lam | I] on full rows (rows stay unscaled, so a step needs no pivot broadcast
     //      phase: one barrier per column).  Fixed (row, 3 strided columns) grid; every load is unconditional, so the
     //      step is one LDS round trip + the reciprocal chain.  The multiplier is read from the (symmetric) upper part.
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ctx.nthreads >= NUT * 16) {
+      // device path: every lane keeps its three elements of [Lam | I] in registers for the whole sweep; only the pivot
+      // row goes through LDS (row j+1 is published by its owners at the end of step j, when it is final)
+      const int i = ctx.tid >> 4, c0 = ctx.tid & 15;
+      const bool mine = ctx.tid < NUT * 16;
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+      if (mine) { e0 = w.fac.Ef[i][c0]; e1 = w.fac.Ef[i][c0 + 16]; e2 = w.fac.Ef[i][c0 + 32]; }
+      for (int j = 0; j < NUT - 1; ++j) {
+        if (mine && i > j) {
+          const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
+          const double ej0 = w.fac.Ef[j][c0], ej1 = w.fac.Ef[j][c0 + 16], ej2 = w.fac.Ef[j][c0 + 32];
+          const double f = fji * fast_rcp(pj);
+          e0 -= f * ej0; e1 -= f * ej1; e2 -= f * ej2;
+          if (i == j + 1) { w.fac.Ef[i][c0] = e0; w.fac.Ef[i][c0 + 16] = e1; w.fac.Ef[i][c0 + 32] = e2; }
+        }
+        WG_SYNC(ctx);
+      }
+    } else
+#endif
     for (int j = 0; j < NUT - 1; ++j) {
       WG_FOR(ctx, it, NUT * 16) {
         const int i = it >> 4, c0 = it & 15;
