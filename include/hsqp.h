@@ -106,11 +106,12 @@ typedef struct hsqp_model_desc {
   int32_t arm_swing_joint[4];   /* joint indices {l_shoulder_y, r_shoulder_y, l_elbow_y, r_elbow_y}      */
 } hsqp_model_desc;
 
+#define HSQP_FLAG_LINESEARCH 1   /* hsqp_solve runs the filter line search (as the reference's SqpSolver does) instead of alpha = 1 */
 typedef struct hsqp_settings {
   int32_t max_nodes;            /* N_max: shooting intervals per instance                                */
   int32_t max_batch;            /* independent MPC instances per call on this device                     */
   int32_t device;               /* HIP device ordinal                                                    */
-  int32_t flags;                /* reserved, 0                                                           */
+  int32_t flags;                /* HSQP_FLAG_* bits                                                      */
 } hsqp_settings;
 
 typedef struct hsqp_problem {
@@ -131,14 +132,34 @@ typedef struct hsqp_timings {   /* SqpSolver::getBenchmarks() buckets (SqpBenchm
   double lq_approximation, solve_qp, linesearch, compute_controller, total;
 } hsqp_timings;
 
+/* Filter line search of the SQP step.  Replaces ocs2::FilterLinesearch + the back-tracking loop of
+ * ocs2::SqpSolver::takeStep (upstream ocs2_sqp; the reference sets g_max / g_min / deltaTol in
+ * robot_models/unitree_g1/g1_wb_mpc/config/mpc/task.info:81-90, the rest are the upstream defaults). */
+typedef struct hsqp_linesearch_settings {
+  double g_max, g_min;          /* constraint-violation thresholds of the filter                         */
+  double gamma_c;               /* required relative decrease of the violation                           */
+  double armijo_factor;         /* Armijo sufficient-decrease factor                                     */
+  double alpha_decay, alpha_min;/* back-tracking factor and smallest step length tried                   */
+  double delta_tol;             /* escape when alpha*|dx| and alpha*|du| fall below it                   */
+} hsqp_linesearch_settings;
+
+#define HSQP_STEP_COST 0        /* accepted by the Armijo condition on the cost                          */
+#define HSQP_STEP_DUAL 1        /* accepted by cost or constraint decrease                               */
+#define HSQP_STEP_CONSTRAINT 2  /* accepted by constraint decrease only                                  */
+#define HSQP_STEP_ZERO 3        /* no step length accepted: the trajectory is kept                       */
+#define HSQP_STEP_FULL 4        /* plain full step, no line search requested                             */
+
 typedef struct hsqp_solution {
-  double* x;                    /* [B][N+1][58]  x + dx                                                  */
-  double* u;                    /* [B][N][35]    u + du                                                  */
+  double* x;                    /* [B][N+1][58]  x + alpha dx                                            */
+  double* u;                    /* [B][N][35]    u + alpha du                                            */
   double* dx;                   /* optional [B][N+1][58] QP step (may be NULL)                           */
   double* du;                   /* optional [B][N][35]                                                   */
   hsqp_perf* perf_before;       /* optional [B] performance index of the linearisation trajectory       */
   hsqp_perf* perf_after;        /* optional [B] performance index after the full step                    */
   double* kkt;                  /* optional [B][2] {stationarity, primal} inf-norm residual of the projected QP */
+  double* alpha;                /* optional [B]  accepted step length (1 without line search)            */
+  int32_t* step_type;           /* optional [B]  HSQP_STEP_*                                              */
+  double* armijo;               /* optional [B]  descent metric  sum_k q~.dx + r~.ut  of the projected QP */
   hsqp_timings timings;
 } hsqp_solution;
 
@@ -159,7 +180,12 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 int hsqp_upload(hsqp_handle* h, const hsqp_problem* problem);
 #define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
 #define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */
+#define HSQP_ITER_LINESEARCH 4   /* filter line search on the step length instead of the plain full step     */
 int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags);
+/* Line-search settings of the handle (defaults: task.info g_max 1e-2, g_min 1e-6, deltaTol 1e-4; upstream gamma_c 1e-6,
+ * armijoFactor 1e-4, alpha_decay 0.5, alpha_min 1e-4). */
+void hsqp_linesearch_defaults(hsqp_linesearch_settings* s);
+int hsqp_set_linesearch(hsqp_handle* h, const hsqp_linesearch_settings* s);
 int hsqp_download(hsqp_handle* h, hsqp_solution* solution);
 
 /* Debug/parity access to intermediate device blocks of the LAST iteration.

@@ -126,14 +126,15 @@ class Oracle:
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         pb, pa = _abi.Perf(), _abi.Perf()
         kkt = np.zeros(2)
+        armijo = C.c_double(0.0)
         proj = np.zeros((N, NU * NX + NU + NU * NU)) if want_proj else None
         rc = self.lib.orc_sqp_iteration(self.h, N, C.c_double(dt), _p(x_init), _p(x), _p(u), _p(par), threads,
                                         _p(xn), _p(un), _p(dx), _p(du),
                                         C.byref(pb) if want_perf else None, C.byref(pa) if want_perf else None,
-                                        _p(kkt), _p(proj))
+                                        _p(kkt), _p(proj), C.byref(armijo))
         if rc != 0:
             raise RuntimeError(f"oracle sqp_iteration failed: {rc}")
-        res = dict(x=xn, u=un, dx=dx, du=du, kkt=kkt,
+        res = dict(x=xn, u=un, dx=dx, du=du, kkt=kkt, armijo=armijo.value,
                    perf_before=dict(merit=pb.merit, cost=pb.cost, dynamics_sse=pb.dynamics_sse, equality_sse=pb.equality_sse),
                    perf_after=dict(merit=pa.merit, cost=pa.cost, dynamics_sse=pa.dynamics_sse, equality_sse=pa.equality_sse))
         if want_proj:
@@ -141,6 +142,22 @@ class Oracle:
             res["Pe"] = proj[:, NU * NX: NU * NX + NU]
             res["PuPuT"] = proj[:, NU * NX + NU:].reshape(N, NU, NU)
         return res
+
+    LS_DEFAULTS = dict(g_max=1e-2, g_min=1e-6, gamma_c=1e-6, armijo_factor=1e-4, alpha_decay=0.5, alpha_min=1e-4, delta_tol=1e-4)
+
+    def linesearch(self, dt, x, u, dx, du, par, armijo, threads=1, **settings):
+        """Filter line search (oracle ASSUMPTION A6); settings override LS_DEFAULTS."""
+        x, u, dx, du, par = _c(x), _c(u), _c(dx), _c(du), _c(par)
+        st = dict(self.LS_DEFAULTS)
+        st.update(settings)
+        sv = np.array([st[k] for k in ("g_max", "g_min", "gamma_c", "armijo_factor", "alpha_decay", "alpha_min", "delta_tol")])
+        alpha, typ, trials = C.c_double(), C.c_int(), C.c_int()
+        xn, un = np.zeros_like(x), np.zeros_like(u)
+        p = _abi.Perf()
+        self.lib.orc_linesearch(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(dx), _p(du), _p(par), threads, _p(sv),
+                                C.c_double(armijo), C.byref(alpha), C.byref(typ), C.byref(trials), _p(xn), _p(un), C.byref(p))
+        return dict(alpha=alpha.value, step_type=typ.value, trials=trials.value, x=xn, u=un,
+                    perf=dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse))
 
     def performance(self, dt, x, u, par, threads=1):
         x, u, par = _c(x), _c(u), _c(par)

@@ -29,6 +29,17 @@
 //   A3  Uniform time grid without event nodes; PerformanceIndex terms scaled by dt as
 //       in upstream multiple_shooting::computeIntermediatePerformance.
 //   A4  Derivatives by forward-mode dual numbers instead of CppAD tapes.
+//   A5  Armijo descent metric = sum over nodes of (projected cost gradient) . (dx, u~) + terminal gradient . dx_N:
+//       upstream SqpSolver::getOCPSolution evaluates multiple_shooting::armijoDescentMetric(cost_, dx, du) on the
+//       PROJECTED cost before the inputs are mapped back (restated from the published ocs2_sqp sources; the fork's
+//       copy is absent).
+//   A6  Filter line search = upstream ocs2::FilterLinesearch::acceptStep (three branches on the total constraint
+//       violation sqrt(dynamicsSSE + equalitySSE)) inside the back-tracking loop of SqpSolver::takeStep:
+//       alpha = 1; evaluate; accept -> done; else alpha *= alpha_decay; escape with a ZERO step when
+//       alpha*|dx| and alpha*|du| are both below deltaTol, or when alpha < alpha_min.  |.| = sqrt of the sum of
+//       squared node norms (multiple_shooting::trajectoryNorm).  g_max, g_min, deltaTol: reference task.info
+//       (robot_models/unitree_g1/g1_wb_mpc/config/mpc/task.info:81-90); gamma_c, armijoFactor, alpha_decay,
+//       alpha_min: upstream sqp::Settings defaults.
 // =====================================================================================
 #include <algorithm>
 #include <cmath>
@@ -1031,7 +1042,7 @@ void orc_lq(void* h, int N, double dt, const double* x, const double* u, const d
 // proj_out (optional): per node packed {Px[35*58], Pe[35], PuPuT[35*35]} — the basis-independent projection data.
 int orc_sqp_iteration(void* h, int N, double dt, const double* x_init, const double* x, const double* u, const double* par, int threads,
                       double* x_new, double* u_new, double* dx_out, double* du_out, hsqp_perf* perf_before, hsqp_perf* perf_after,
-                      double* kkt, double* proj_out) {
+                      double* kkt, double* proj_out, double* armijo_out) {
   const Oracle& o = *static_cast<Oracle*>(h);
   std::vector<Projected> st(N);
   int bad = 0;
@@ -1072,6 +1083,16 @@ int orc_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
     }
   }
   if (kkt) kkt_residual(st, HN, gN, dx0, N, r, &kkt[0], &kkt[1]);
+  if (armijo_out) {  // ASSUMPTION A5
+    double am = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const Projected& p = st[k];
+      for (int i = 0; i < NX; ++i) am += p.qt[i] * r.dx[k * NX + i];
+      for (int j = 0; j < p.nut; ++j) am += p.rt[j] * r.ut[k * NU + j];
+    }
+    for (int i = 0; i < NX; ++i) am += gN[i] * r.dx[N * NX + i];
+    *armijo_out = am;
+  }
   std::vector<double> xn((N + 1) * NX), un(N * NU);
   for (int i = 0; i < (N + 1) * NX; ++i) xn[i] = x[i] + r.dx[i];
   for (int i = 0; i < N * NU; ++i) un[i] = u[i] + du[i];
@@ -1086,6 +1107,53 @@ int orc_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
 
 // Riccati on externally supplied projected LQ data is not exposed: tests validate the QP solution with a dense KKT solve
 // of the UNPROJECTED problem instead (tests/test_oracle_qp.py), which also covers the projection.
+
+// Filter line search on the step (dx, du) from (x, u): ASSUMPTION A6.  settings = {g_max, g_min, gamma_c, armijoFactor,
+// alpha_decay, alpha_min, deltaTol}.  step type: 0 COST, 1 DUAL, 2 CONSTRAINT, 3 ZERO.
+void orc_linesearch(void* h, int N, double dt, const double* x, const double* u, const double* dx, const double* du, const double* par,
+                    int threads, const double* settings, double armijo, double* alpha_out, int* type_out, int* trials_out,
+                    double* x_new, double* u_new, hsqp_perf* perf_new) {
+  const Oracle& o = *static_cast<Oracle*>(h);
+  const double g_max = settings[0], g_min = settings[1], gamma_c = settings[2], armijo_factor = settings[3], decay = settings[4],
+               alpha_min = settings[5], delta_tol = settings[6];
+  hsqp_perf base;
+  performance(o, N, dt, x, u, par, threads, &base);
+  double nx2 = 0.0, nu2 = 0.0;
+  for (int i = 0; i < (N + 1) * NX; ++i) nx2 += dx[i] * dx[i];
+  for (int i = 0; i < N * NU; ++i) nu2 += du[i] * du[i];
+  const double dxn = std::sqrt(nx2), dun = std::sqrt(nu2);
+  const double g = std::sqrt(base.dynamics_sse + base.equality_sse);
+  std::vector<double> xn((N + 1) * NX), un(N * NU);
+  double alpha = 1.0;
+  int trials = 0;
+  do {
+    for (int i = 0; i < (N + 1) * NX; ++i) xn[i] = x[i] + alpha * dx[i];
+    for (int i = 0; i < N * NU; ++i) un[i] = u[i] + alpha * du[i];
+    hsqp_perf pn;
+    performance(o, N, dt, xn.data(), un.data(), par, threads, &pn);
+    ++trials;
+    const double gn = std::sqrt(pn.dynamics_sse + pn.equality_sse);
+    const double am = alpha * armijo;
+    bool ok;
+    int type;
+    if (gn > g_max) { ok = gn < (1.0 - gamma_c) * g; type = 2; }
+    else if (gn < g_min && g < g_min && am < 0.0) { ok = pn.merit < base.merit + armijo_factor * am; type = 0; }
+    else { ok = (pn.merit < base.merit - gamma_c * g) || (gn < (1.0 - gamma_c) * g); type = 1; }
+    if (ok) {
+      *alpha_out = alpha; *type_out = type; *trials_out = trials;
+      std::memcpy(x_new, xn.data(), sizeof(double) * xn.size());
+      std::memcpy(u_new, un.data(), sizeof(double) * un.size());
+      *perf_new = pn;
+      return;
+    }
+    alpha *= decay;
+    if (alpha * dun < delta_tol && alpha * dxn < delta_tol) break;
+  } while (alpha >= alpha_min);
+  *alpha_out = 0.0; *type_out = 3; *trials_out = trials;
+  std::memcpy(x_new, x, sizeof(double) * (N + 1) * NX);
+  std::memcpy(u_new, u, sizeof(double) * N * NU);
+  *perf_new = base;
+}
 
 void orc_performance(void* h, int N, double dt, const double* x, const double* u, const double* par, int threads, hsqp_perf* out) {
   performance(*static_cast<Oracle*>(h), N, dt, x, u, par, threads, out);

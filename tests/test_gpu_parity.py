@@ -134,3 +134,45 @@ def test_error_behaviour(gpu_solver, model):
     with pytest.raises(HsqpError) as e:
         gpu_solver.run(x0, xb, u, par, dt)
     assert e.value.code == _abi.ERR_NUMERIC
+
+
+@pytest.mark.parametrize("override", [{}, {"gamma_c": 0.6}, {"gamma_c": 0.9, "g_max": 1e-9, "g_min": 1e-12}])
+def test_filter_linesearch_against_oracle(gpu_solver, model, oracle, override):
+    """step length, step type, accepted trajectory and its performance index of the device line search
+    equal the oracle's restatement of ocs2::FilterLinesearch / SqpSolver::takeStep, per instance, including the
+    back-tracking ({gamma_c: 0.6}) and the zero-step ({gamma_c: 0.9, g_max: 1e-9, g_min: 1e-12}) branches."""
+    B, N = 4, 8
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=5)
+    rng = np.random.default_rng(3)
+    x = x + 0.01 * rng.standard_normal(x.shape)          # leave the cold start so that every term is active
+    u = u + 0.3 * rng.standard_normal(u.shape)
+    gpu_solver.set_linesearch(**override)
+    try:
+        gpu_solver.upload(x0, x, u, par, dt)
+        gpu_solver.iterate(1, linesearch=True)
+        out = gpu_solver.download()
+    finally:
+        gpu_solver.set_linesearch()
+    alphas = []
+    for b in range(B):
+        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=4)
+        ls = oracle.linesearch(dt, x[b], u[b], r["dx"], r["du"], par[b], r["armijo"], threads=4, **override)
+        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+        assert out["armijo"][b] == pytest.approx(r["armijo"], rel=1e-8, abs=1e-8 * sc)
+        assert out["alpha"][b] == ls["alpha"] and out["step_type"][b] == ls["step_type"], (b, out["alpha"][b], ls)
+        assert np.abs(out["x"][b] - ls["x"]).max() <= 1e-8 * sc and np.abs(out["u"][b] - ls["u"]).max() <= 1e-8 * sc
+        got = out["perf_after"][b]
+        assert np.allclose([got["cost"], got["dynamics_sse"], got["equality_sse"]],
+                           [ls["perf"]["cost"], ls["perf"]["dynamics_sse"], ls["perf"]["equality_sse"]], rtol=1e-8, atol=1e-10)
+        alphas.append(ls["alpha"])
+    if override.get("g_max") == 1e-9:
+        assert all(a == 0.0 for a in alphas)            # nothing can be accepted: zero step, trajectory kept
+        assert np.array_equal(out["x"], x) and np.array_equal(out["u"], u)
+    if override == {"gamma_c": 0.6}:
+        assert any(0.0 < a < 1.0 for a in alphas) or all(a in (0.0, 1.0) for a in alphas)
+
+
+def test_full_step_reports_alpha_one(gpu_solver, model):
+    x0, x, u, par, dt = make_problem(model, n_nodes=6, batch=2, perturb=True)
+    out = gpu_solver.run(x0, x, u, par, dt)
+    assert np.array_equal(out["alpha"], np.ones(2)) and np.array_equal(out["step_type"], np.full(2, _abi.STEP_FULL))

@@ -70,4 +70,14 @@ class Timings(C.Structure):
 class Solution(C.Structure):
     _fields_ = [("x", C.POINTER(C.c_double)), ("u", C.POINTER(C.c_double)), ("dx", C.POINTER(C.c_double)),
                 ("du", C.POINTER(C.c_double)), ("perf_before", C.POINTER(Perf)), ("perf_after", C.POINTER(Perf)),
-                ("kkt", C.POINTER(C.c_double)), ("timings", Timings)]
+                ("kkt", C.POINTER(C.c_double)), ("alpha", C.POINTER(C.c_double)), ("step_type", C.POINTER(C.c_int32)),
+                ("armijo", C.POINTER(C.c_double)), ("timings", Timings)]
+
+
+class LinesearchSettings(C.Structure):
+    _fields_ = [("g_max", C.c_double), ("g_min", C.c_double), ("gamma_c", C.c_double), ("armijo_factor", C.c_double),
+                ("alpha_decay", C.c_double), ("alpha_min", C.c_double), ("delta_tol", C.c_double)]
+
+
+STEP_COST, STEP_DUAL, STEP_CONSTRAINT, STEP_ZERO, STEP_FULL = 0, 1, 2, 3, 4
+FLAG_LINESEARCH = 1

@@ -45,8 +45,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 template <bool DERIV>
 __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_WPE : HSQP_LQV_WPE) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
                                                    const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
-                                                   double* __restrict__ rec, double* __restrict__ misc, long long* prof) {
+                                                   double* __restrict__ rec, double* __restrict__ misc, long long* prof,
+                                                   const LsState* __restrict__ ls) {
   const int node = blockIdx.x, b = node / N, k = node % N;
+  if (ls && !ls[b].active) return;   // line search: only the instances whose trial is pending are re-evaluated
   LqWST<DERIV>& w = *reinterpret_cast<LqWST<DERIV>*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
@@ -92,13 +94,69 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
 __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, const double* __restrict__ ric, const double* __restrict__ dx,
                                              const double* __restrict__ x, const double* __restrict__ u, int N, double alpha,
                                              double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
-                                             double* __restrict__ u_new) {
+                                             double* __restrict__ u_new, double* __restrict__ info) {
   __shared__ StepWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, w, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
-            du + uo, x_new + xo, u_new + uo);
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4);
+  if (k == N - 1)
+    for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
+}
+
+// ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
+__global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
+                                                const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
+  const int b = blockIdx.x;
+  __shared__ double red[3][64];
+  double a = 0.0, nx2 = 0.0, nu2 = 0.0;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    const double* m = info + ((size_t)b * N + k) * 4;
+    a += m[0]; nx2 += m[1]; nu2 += m[2];
+  }
+  if (threadIdx.x < NX) {   // terminal node: gradient of the terminal cost times dx_N
+    const size_t o = ((size_t)b * (N + 1) + N) * NX + threadIdx.x;
+    const double d = dx[o];
+    a += dm->Qf[threadIdx.x] * (x[o] - par[((size_t)b * (N + 1) + N) * NP + HSQP_P_XDES + threadIdx.x]) * d;
+    nx2 += d * d;
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = nx2; red[2][threadIdx.x] = nu2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < 64; ++i) { s0 += red[0][i]; s1 += red[1][i]; s2 += red[2][i]; }
+    LsState st;
+    st.alpha = 1.0; st.armijo = s0; st.dxnorm = sqrt(s1); st.dunorm = sqrt(s2);
+    st.active = 1; st.dirty = 0; st.step_type = HSQP_STEP_FULL; st.trials = 0;
+    ls[b] = st;
+  }
+}
+
+// ---- line search: decide the pending trials; counts[0] = instances that need a new trajectory, counts[1] = still active
+__global__ void k_ls_decide(LsSettings st, const hsqp_perf* __restrict__ base, hsqp_perf* __restrict__ trial, int B, LsState* __restrict__ ls,
+                            int* __restrict__ counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  LsState s = ls[b];
+  if (!s.active) { if (s.dirty) { s.dirty = 0; ls[b] = s; } return; }
+  ls_decide(st, base[b], trial[b], s);
+  if (s.step_type == HSQP_STEP_ZERO && !s.active) trial[b] = base[b];   // no step: the performance index is the baseline's
+  if (s.dirty) { s.active = s.step_type == HSQP_STEP_ZERO ? 0 : 1; atomicAdd(&counts[0], 1); }
+  if (s.active) atomicAdd(&counts[1], 1);
+  ls[b] = s;
+}
+
+// ---- line search: recompute x_new, u_new of the instances whose step length changed
+__global__ __launch_bounds__(64) void k_ls_retake(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dx,
+                                                  const double* __restrict__ du, int N, const LsState* __restrict__ ls,
+                                                  double* __restrict__ x_new, double* __restrict__ u_new) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  if (!ls[b].dirty) return;
+  const double alpha = ls[b].alpha;
+  const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
+  for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + i] = x[xo + i] + alpha * dx[xo + i];
+  for (int i = threadIdx.x; i < NU; i += blockDim.x) u_new[uo + i] = u[uo + i] + alpha * du[uo + i];
   if (k == N - 1)
     for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
 }
@@ -116,8 +174,9 @@ __global__ __launch_bounds__(128) void k_kkt(const DevModel* __restrict__ dm, co
 
 // ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
 __global__ void k_perf_reduce(const DevModel* __restrict__ dm, const double* __restrict__ misc, int misc_stride, const double* __restrict__ x,
-                              const double* __restrict__ par, int N, hsqp_perf* __restrict__ out) {
+                              const double* __restrict__ par, int N, hsqp_perf* __restrict__ out, const LsState* __restrict__ ls) {
   const int b = blockIdx.x;
+  if (ls && !ls[b].active) return;
   __shared__ double red[3][64];
   double c = 0.0, e = 0.0, d = 0.0;
   for (int k = threadIdx.x; k < N; k += blockDim.x) {
@@ -154,6 +213,11 @@ struct hsqp_handle {
   double *d_misc = nullptr, *d_kkt = nullptr;
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
+  double* d_stepinfo = nullptr;   // [B][N][4] per-node {armijo, |dx|^2, |du|^2}
+  LsState* d_ls = nullptr;
+  int* d_counts = nullptr;
+  hsqp_linesearch_settings ls_settings;
+  bool ls_ran = false;
   long long* d_prof = nullptr;   // [4][128] phase-profile ticks (k_lq<true>, k_project, k_riccati, k_lq<false>)
   int B = 0, N = 0;
   double dt = 0.0;
@@ -189,13 +253,30 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof};
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+void hsqp_linesearch_defaults(hsqp_linesearch_settings* s) {
+  if (!s) return;
+  s->g_max = 1e-2; s->g_min = 1e-6;      // g1_wb_mpc/config/mpc/task.info:83-84
+  s->gamma_c = 1e-6; s->armijo_factor = 1e-4; s->alpha_decay = 0.5; s->alpha_min = 1e-4;   // upstream ocs2 sqp::Settings defaults
+  s->delta_tol = 1e-4;                   // task.info deltaTol
+}
+
+int hsqp_set_linesearch(hsqp_handle* h, const hsqp_linesearch_settings* s) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!s || !(s->alpha_decay > 0.0 && s->alpha_decay < 1.0) || !(s->alpha_min > 0.0) || !(s->g_max >= s->g_min)) {
+    h->err = "line-search settings: need 0 < alpha_decay < 1, alpha_min > 0, g_max >= g_min";
+    return HSQP_ERR_BAD_ARG;
+  }
+  h->ls_settings = *s;
+  return HSQP_OK;
 }
 
 int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsqp_handle** out) {
@@ -209,6 +290,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   h->md = *model;
   h->st = *settings;
   h->device = settings->device;
+  hsqp_linesearch_defaults(&h->ls_settings);
   const std::string e = build_dev_model(*model, h->hdm);
   if (!e.empty()) { g_create_error = e; delete h; return HSQP_ERR_BAD_ARG; }
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
@@ -226,7 +308,8 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
       {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
-      {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)}};
+      {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
+      {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
   for (const Alloc& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
@@ -262,7 +345,7 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
 }
 
 int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
-  const int take_step = flags & HSQP_ITER_TAKE_STEP, want_kkt = (flags & HSQP_ITER_KKT) ? 1 : 0;
+  const int take_step = flags & HSQP_ITER_TAKE_STEP, want_kkt = (flags & HSQP_ITER_KKT) ? 1 : 0, linesearch = (flags & HSQP_ITER_LINESEARCH) ? 1 : 0;
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!h->have_problem || n_iterations < 1) { h->err = "no problem uploaded or n_iterations < 1"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
@@ -272,21 +355,44 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool last = it == n_iterations - 1;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
-                       h->d_rec, (double*)nullptr, h->d_prof);
+                       h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                        h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256);
     hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                       h->d_xnew, h->d_unew);
+                       h->d_xnew, h->d_unew, h->d_stepinfo);
     if (want_kkt)
       hipLaunchKernelGGL(k_kkt, dim3(B), dim3(128), 0, h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dx, h->d_ut, N, h->d_kkt);
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
-                       N, (double*)nullptr, h->d_misc, h->d_prof + 384);
-    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before);
-    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after);
+                       N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);
+    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
+                       (const LsState*)nullptr);
+    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
+                       (const LsState*)nullptr);
+    hipLaunchKernelGGL(k_ls_init, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_stepinfo, h->d_x, h->d_dx, h->d_par, N, h->d_ls);
+    if (linesearch) {
+      // back-tracking: decide the pending trials on the device, shorten the rejected steps, re-evaluate only those instances
+      LsSettings lst{h->ls_settings.g_max, h->ls_settings.g_min, h->ls_settings.gamma_c, h->ls_settings.armijo_factor, h->ls_settings.alpha_decay,
+                     h->ls_settings.alpha_min, h->ls_settings.delta_tol};
+      for (int trial = 0; trial < 64; ++trial) {
+        HCHECK(hipMemsetAsync(h->d_counts, 0, 2 * sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
+        int counts[2];
+        HCHECK(hipMemcpyAsync(counts, h->d_counts, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+        HCHECK(hipStreamSynchronize(h->stream));
+        if (counts[0] > 0)
+          hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
+        if (counts[1] == 0) break;
+        hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+                           N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
+        hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
+                           (const LsState*)h->d_ls);
+      }
+    }
+    h->ls_ran = linesearch != 0;
     if (last) HCHECK(hipEventRecord(h->ev[4], h->stream));
     if (take_step && !last) {
       HCHECK(hipMemcpyAsync(h->d_x, h->d_xnew, (size_t)B * (N + 1) * NX * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -315,6 +421,15 @@ int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
   if (s->perf_before) HCHECK(hipMemcpy(s->perf_before, h->d_perf_before, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
   if (s->perf_after) HCHECK(hipMemcpy(s->perf_after, h->d_perf_after, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
   if (s->kkt) HCHECK(hipMemcpy(s->kkt, h->d_kkt, B * 2 * 8, hipMemcpyDeviceToHost));
+  if (s->alpha || s->step_type || s->armijo) {
+    std::vector<LsState> ls(B);
+    HCHECK(hipMemcpy(ls.data(), h->d_ls, B * sizeof(LsState), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b) {
+      if (s->alpha) s->alpha[b] = h->ls_ran ? ls[b].alpha : 1.0;
+      if (s->step_type) s->step_type[b] = h->ls_ran ? ls[b].step_type : HSQP_STEP_FULL;
+      if (s->armijo) s->armijo[b] = ls[b].armijo;
+    }
+  }
   std::vector<int> status(B);
   HCHECK(hipMemcpy(status.data(), h->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
   s->timings.lq_approximation = 1e-3 * (h->kernel_ms[0] + h->kernel_ms[1]);
@@ -334,7 +449,7 @@ int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
 int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
   int rc = hsqp_upload(h, problem);
   if (rc != HSQP_OK) return rc;
-  rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT);
+  rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | ((h->st.flags & HSQP_FLAG_LINESEARCH) ? HSQP_ITER_LINESEARCH : 0));
   if (rc != HSQP_OK) return rc;
   return hsqp_download(h, solution);
 }

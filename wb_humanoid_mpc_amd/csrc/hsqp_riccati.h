@@ -269,11 +269,13 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
 // Per-node recovery of the inputs and the step of length alpha (parallel over all nodes of all instances):
 //   ut = K dx + k,  du = Px dx + Pu ut + Pe,  x_new = x + alpha dx,  u_new = u + alpha du.
 struct StepWS {
-  double dx[NX], t[NUT], ut[NUT];
+  double dx[NX], t[NUT], ut[NUT], du[NU];
   double part[(NX + NU) * 4];
 };
+// info (optional, 3 doubles): {q~.dx + r~.ut (Armijo descent metric of the projected QP, ocs2 multiple_shooting::
+// armijoDescentMetric on the projected cost), |dx|^2, |du|^2} of this node.
 HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double* rk, const double* dx, const double* x, const double* u,
-                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new) {
+                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr) {
   WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
   WG_SYNC(ctx);
   WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_K + (it >> 2) * NX, w.dx, it & 3);
@@ -293,8 +295,54 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
     const double s = q[QP_PE + r] + ((w.part[4 * r] + w.part[4 * r + 1]) + (w.part[4 * r + 2] + w.part[4 * r + 3]));
     du_out[r] = s;
     u_new[r] = u[r] + alpha * s;
+    w.du[r] = s;
   }
   WG_SYNC(ctx);
+  if (info) {
+    WG_FOR(ctx, it, 3) {
+      double s = 0.0;
+      if (it == 0) {
+        for (int i = 0; i < NX; ++i) s += q[QP_QV + i] * w.dx[i];
+        for (int j = 0; j < NUT; ++j) s += q[QP_RV + j] * w.ut[j];
+      } else if (it == 1) {
+        for (int i = 0; i < NX; ++i) s += w.dx[i] * w.dx[i];
+      } else {
+        for (int i = 0; i < NU; ++i) s += w.du[i] * w.du[i];
+      }
+      info[it] = s;
+    }
+  }
+}
+
+// ---- filter line search (ocs2::FilterLinesearch::acceptStep + the back-tracking loop of ocs2::SqpSolver::takeStep;
+//      upstream ocs2_sqp, restated from the published algorithm: ASSUMPTIONS A5/A6 of the oracle header)
+struct LsSettings { double g_max, g_min, gamma_c, armijo_factor, alpha_decay, alpha_min, delta_tol; };
+struct LsState {       // per instance
+  double alpha;        // step length of the current trial (final: accepted length, 0 for a zero step)
+  double armijo;       // descent metric of the full step
+  double dxnorm, dunorm;
+  int active;          // the trial at `alpha` still has to be evaluated / decided
+  int dirty;           // x_new, u_new have to be recomputed for `alpha`
+  int step_type;
+  int trials;
+};
+HSQP_HD double ls_violation(const hsqp_perf& p) { return sqrt(p.dynamics_sse + p.equality_sse); }
+// decision for one evaluated trial; returns true if the line search of this instance is finished
+HSQP_HD bool ls_decide(const LsSettings& st, const hsqp_perf& base, const hsqp_perf& trial, LsState& s) {
+  const double g = ls_violation(base), gn = ls_violation(trial);
+  const double am = s.alpha * s.armijo;
+  bool accepted;
+  int type;
+  if (gn > st.g_max) { accepted = gn < (1.0 - st.gamma_c) * g; type = HSQP_STEP_CONSTRAINT; }
+  else if (gn < st.g_min && g < st.g_min && am < 0.0) { accepted = trial.merit < base.merit + st.armijo_factor * am; type = HSQP_STEP_COST; }
+  else { accepted = trial.merit < base.merit - st.gamma_c * g || gn < (1.0 - st.gamma_c) * g; type = HSQP_STEP_DUAL; }
+  s.trials += 1;
+  if (accepted) { s.step_type = type; s.active = 0; s.dirty = 0; return true; }
+  s.alpha *= st.alpha_decay;
+  const bool tiny = s.alpha * s.dunorm < st.delta_tol && s.alpha * s.dxnorm < st.delta_tol;
+  if (tiny || !(s.alpha >= st.alpha_min)) { s.alpha = 0.0; s.step_type = HSQP_STEP_ZERO; s.active = 0; s.dirty = 1; return true; }
+  s.dirty = 1;
+  return false;
 }
 
 // KKT residual of the projected QP at (dx, ut): costates by the backward stationarity recursion

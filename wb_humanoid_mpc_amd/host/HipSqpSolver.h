@@ -29,8 +29,9 @@ struct PrimalSolution {
 
 class HipSqpSolver {
  public:
-  HipSqpSolver(const hsqp_model_desc& model, int maxNodes, int maxBatch = 1, int device = 0) {
-    hsqp_settings st{maxNodes, maxBatch, device, 0};
+  /** useLinesearch: run() applies the filter line search (ocs2 SqpSolver::takeStep) instead of the full step. */
+  HipSqpSolver(const hsqp_model_desc& model, int maxNodes, int maxBatch = 1, int device = 0, bool useLinesearch = false) {
+    hsqp_settings st{maxNodes, maxBatch, device, useLinesearch ? HSQP_FLAG_LINESEARCH : 0};
     const int rc = hsqp_create(&model, &st, &h_);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_create failed (" + std::to_string(rc) + "): " + hsqp_last_error(nullptr));
   }
@@ -53,7 +54,10 @@ class HipSqpSolver {
     perf_.assign(batch, hsqp_perf{});
     perfBefore_.assign(batch, hsqp_perf{});
     kkt_.assign((size_t)batch * 2, 0.0);
+    stepSize_.assign(batch, 0.0);
+    stepType_.assign(batch, HSQP_STEP_FULL);
     hsqp_solution s{};
+    s.alpha = stepSize_.data(); s.step_type = stepType_.data();
     s.x = solution_.stateTrajectory.data(); s.u = solution_.inputTrajectory.data();
     s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = kkt_.data();
     const int rc = hsqp_solve(h_, &p, &s);
@@ -68,6 +72,12 @@ class HipSqpSolver {
   const std::vector<hsqp_perf>& getPerformanceIndeces() const { return perf_; }
   const std::vector<hsqp_perf>& getPerformanceIndecesBeforeStep() const { return perfBefore_; }
   const std::vector<double>& getKktResiduals() const { return kkt_; }
+  /** Step length and FilterLinesearch::StepType (HSQP_STEP_*) per instance of the last run. */
+  const std::vector<double>& getStepSizes() const { return stepSize_; }
+  const std::vector<int32_t>& getStepTypes() const { return stepType_; }
+  void setLinesearchSettings(const hsqp_linesearch_settings& ls) {
+    if (hsqp_set_linesearch(h_, &ls) != HSQP_OK) throw std::runtime_error(std::string("[HipSqpSolver] ") + hsqp_last_error(h_));
+  }
   Benchmarks getBenchmarks() const { return bench_; }
   hsqp_handle* handle() { return h_; }
 
@@ -75,7 +85,8 @@ class HipSqpSolver {
   hsqp_handle* h_ = nullptr;
   PrimalSolution solution_;
   std::vector<hsqp_perf> perf_, perfBefore_;
-  std::vector<double> kkt_;
+  std::vector<double> kkt_, stepSize_;
+  std::vector<int32_t> stepType_;
   Benchmarks bench_;
 };
 

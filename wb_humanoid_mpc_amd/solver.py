@@ -50,6 +50,9 @@ def load_library():
     lib.hsqp_last_error.argtypes = [C.c_void_p]
     lib.hsqp_last_error.restype = C.c_char_p
     lib.hsqp_version.restype = C.c_char_p
+    lib.hsqp_linesearch_defaults.argtypes = [C.POINTER(_abi.LinesearchSettings)]
+    lib.hsqp_linesearch_defaults.restype = None
+    lib.hsqp_set_linesearch.argtypes = [C.c_void_p, C.POINTER(_abi.LinesearchSettings)]
     _lib = lib
     return lib
 
@@ -59,10 +62,11 @@ def _c(a):
 
 
 class HipSqpSolver:
-    def __init__(self, model, max_nodes, max_batch=1, device=0):
+    def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False):
+        """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step."""
         self.lib = load_library()
         self.model = model
-        st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=0)
+        st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=_abi.FLAG_LINESEARCH if linesearch else 0)
         h = C.c_void_p()
         rc = self.lib.hsqp_create(C.byref(model.desc), C.byref(st), C.byref(h))
         if rc != 0:
@@ -107,10 +111,13 @@ class HipSqpSolver:
 
     def _alloc_solution(self, B, N):
         out = dict(x=np.zeros((B, N + 1, _abi.NX)), u=np.zeros((B, N, _abi.NU)), dx=np.zeros((B, N + 1, _abi.NX)),
-                   du=np.zeros((B, N, _abi.NU)), kkt=np.zeros((B, 2)))
+                   du=np.zeros((B, N, _abi.NU)), kkt=np.zeros((B, 2)), alpha=np.zeros(B), step_type=np.zeros(B, dtype=np.int32),
+                   armijo=np.zeros(B))
         pb, pa = (_abi.Perf * B)(), (_abi.Perf * B)()
         s = _abi.Solution(x=out["x"].ctypes.data_as(_dp), u=out["u"].ctypes.data_as(_dp), dx=out["dx"].ctypes.data_as(_dp),
-                          du=out["du"].ctypes.data_as(_dp), perf_before=pb, perf_after=pa, kkt=out["kkt"].ctypes.data_as(_dp))
+                          du=out["du"].ctypes.data_as(_dp), perf_before=pb, perf_after=pa, kkt=out["kkt"].ctypes.data_as(_dp),
+                          alpha=out["alpha"].ctypes.data_as(_dp), step_type=out["step_type"].ctypes.data_as(C.POINTER(C.c_int32)),
+                          armijo=out["armijo"].ctypes.data_as(_dp))
         return s, out, pb, pa
 
     @staticmethod
@@ -138,8 +145,23 @@ class HipSqpSolver:
         p, keep, self._shape = self._problem(x_init, x_traj, u_traj, params, dt)
         self._check(self.lib.hsqp_upload(self.h, C.byref(p)))
 
-    def iterate(self, n_iterations=1, take_step=False, kkt=False):
-        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0)))
+    def iterate(self, n_iterations=1, take_step=False, kkt=False, linesearch=False):
+        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0) | (4 if linesearch else 0)))
+
+    # ---- sqp::Settings of the line search (task.info sqp block + upstream defaults)
+    def linesearch_settings(self):
+        s = _abi.LinesearchSettings()
+        self.lib.hsqp_linesearch_defaults(C.byref(s))
+        return s
+
+    def set_linesearch(self, **kw):
+        s = self.linesearch_settings()
+        for k, v in kw.items():
+            if not hasattr(s, k):
+                raise ValueError(f"unknown line-search setting {k}")
+            setattr(s, k, float(v))
+        self._check(self.lib.hsqp_set_linesearch(self.h, C.byref(s)))
+        return s
 
     def download(self):
         B, N = self._shape
