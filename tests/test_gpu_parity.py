@@ -176,3 +176,26 @@ def test_full_step_reports_alpha_one(gpu_solver, model):
     x0, x, u, par, dt = make_problem(model, n_nodes=6, batch=2, perturb=True)
     out = gpu_solver.run(x0, x, u, par, dt)
     assert np.array_equal(out["alpha"], np.ones(2)) and np.array_equal(out["step_type"], np.full(2, _abi.STEP_FULL))
+
+
+def test_multi_iteration_sqp_with_linesearch(model):
+    """sqpIteration > 1 with the filter line search, device resident: equal to repeated hsqp_solve calls
+    of a line-search solver, and the constraint violation of a perturbed walk problem decreases monotonically."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=10, batch=3, perturb=True, seed=9)
+    s = HipSqpSolver(model, max_nodes=10, max_batch=3, linesearch=True)
+    try:
+        xs, us, viol = x, u, []
+        for _ in range(3):
+            out = s.run(x0, xs, us, par, dt)
+            assert np.all(out["step_type"] != _abi.STEP_FULL)
+            viol.append([np.sqrt(p["dynamics_sse"] + p["equality_sse"]) for p in out["perf_after"]])
+            xs, us = out["x"], out["u"]
+        s.upload(x0, x, u, par, dt)
+        s.iterate(3, take_step=True, linesearch=True)
+        res = s.download()
+        assert np.array_equal(res["x"], xs) and np.array_equal(res["u"], us)
+        viol = np.array(viol)
+        assert np.all(viol[1:] <= viol[:-1] * (1 + 1e-12))
+    finally:
+        s.close()
