@@ -124,6 +124,30 @@ typedef struct hsqp_problem {
   const double* node_params;    /* [B][N+1][HSQP_NODE_PARAMS]                                            */
 } hsqp_problem;
 
+/* ---- device-side parameter generation ------------------------------------
+ * Instead of sampling the reference's ReferenceManager / SwingTrajectoryPlanner on the host for every node and
+ * uploading the table, the adaptor hands over the compact per-instance reference and the table is built on the device. */
+typedef struct hsqp_swing_config {      /* SwingTrajectoryPlanner::Config (task.info swing_trajectory_config)       */
+  double lift_off_velocity, touch_down_velocity, swing_height, touch_down_height_offset, swing_time_scale;
+  double impact_mid, impact_lift_velocity, impact_touch_velocity;   /* impactProximityFactor{MidPointValue,LiftOffVelocity,TouchDownVelocity} */
+} hsqp_swing_config;
+
+typedef struct hsqp_reference {
+  int32_t batch, n_nodes;
+  double t0, dt;                        /* node k sits at t0 + k dt                                               */
+  int32_t max_events;                   /* row length of event_times; mode_sequence rows have max_events + 1      */
+  const int32_t* n_events;              /* [B]        events of each instance's ocs2::ModeSchedule                */
+  const double* event_times;            /* [B][max_events]                                                        */
+  const int32_t* mode_sequence;         /* [B][max_events + 1]   0 FLY, 1 RF, 2 LF, 3 STANCE (MotionPhaseDefinition.h:47-56) */
+  int32_t n_knots;                      /* knots of the TargetTrajectories (>= 1)                                  */
+  const double* target_times;           /* [B][n_knots]                                                           */
+  const double* target_states;          /* [B][n_knots][58]                                                       */
+  hsqp_swing_config swing;
+  double terrain_height;
+  int32_t arm_swing;                    /* 0 disables the arm-swing reference                                     */
+  int32_t reserved;
+} hsqp_reference;
+
 typedef struct hsqp_perf {      /* ocs2::PerformanceIndex subset, per instance                           */
   double merit, cost, dynamics_sse, equality_sse;
 } hsqp_perf;
@@ -178,6 +202,10 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 /* Same, but the problem is already resident on the device from the previous
  * hsqp_solve/hsqp_upload and the result is left there (bench / multi-iteration use). */
 int hsqp_upload(hsqp_handle* h, const hsqp_problem* problem);
+/* Like hsqp_upload, but hsqp_problem::node_params may be NULL: the per-node table is generated on the device from `ref`
+ * (batch, n_nodes, dt must agree).  Fails with HSQP_ERR_BAD_ARG if a swing phase has no lift-off / touch-down inside
+ * the schedule (the reference's SwingTrajectoryPlanner throws there). */
+int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* problem, const hsqp_reference* ref);
 #define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
 #define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */
 #define HSQP_ITER_LINESEARCH 4   /* filter line search on the step length instead of the plain full step     */
@@ -201,6 +229,7 @@ int hsqp_download(hsqp_handle* h, hsqp_solution* solution);
 #define HSQP_BLK_DX 8           /* [B][N+1][58]                                                            */
 #define HSQP_BLK_DU 9           /* [B][N][35]                                                              */
 #define HSQP_BLK_FLOW 10        /* [B][N][58]       xdot at (x_k,u_k)                                      */
+#define HSQP_BLK_PARAMS 11      /* [B][N+1][72]     the per-node parameter table resident on the device    */
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes);
 
 /* Elapsed device time (ms) of the kernels of the last hsqp_iterate_device call,

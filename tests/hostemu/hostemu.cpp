@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE: compiles the kernel sources of wb_humanoid_mpc_amd/csrc for the HOST with a
 // one-thread execution context (hsqp_common.h) so that the arithmetic of the HIP kernels can be
 // checked against the oracle in the GPU-less build container.  Never loaded by the product.
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_params.h"
 #include <vector>
 #include <memory>
 
@@ -67,6 +68,16 @@ void emu_expand(const double* rec, double dt, double* AB, double* H, double* g, 
     }
   }
   for (int r = 0; r < NE_MAX; ++r) for (int c = 0; c <= NZ; ++c) CDe[r * (NZ + 1) + c] = rec[REC_CDE + r * LDJ + c];
+}
+
+// per-node parameter table of one instance through the device-side generator (hsqp_params.h); returns 0 if every swing
+// phase was bracketed
+int emu_node_params(const hsqp_swing_config* cfg, double terrain, int arm_swing, int n_ev, const double* ev, const int* seq, int n_knots,
+                    const double* tt, const double* ts, double t0, double dt, int N, double* par) {
+  int bad = 0;
+  for (int k = 0; k <= N; ++k)
+    if (!node_params_eval(*cfg, terrain, arm_swing, n_ev, ev, seq, n_knots, tt, ts, t0 + k * dt, par + (size_t)k * NP)) bad = 1;
+  return bad;
 }
 
 int emu_qp_size() { return QP_SIZE; }

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
     assert _header_functions() == sorted([
         "hsqp_create", "hsqp_destroy", "hsqp_solve", "hsqp_upload", "hsqp_iterate_device", "hsqp_download",
         "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_version", "hsqp_device_count",
-        "hsqp_linesearch_defaults", "hsqp_set_linesearch"])
+        "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference"])
 
 
 def test_library_exports_every_declared_symbol():
@@ -34,14 +34,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_c_compiler(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "hsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "hsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(hsqp_body),sizeof(hsqp_frame),sizeof(hsqp_model_desc),sizeof(hsqp_settings),sizeof(hsqp_problem),"
-                   "sizeof(hsqp_perf),sizeof(hsqp_timings),sizeof(hsqp_solution),sizeof(hsqp_linesearch_settings));return 0;}\n")
+                   "sizeof(hsqp_perf),sizeof(hsqp_timings),sizeof(hsqp_solution),sizeof(hsqp_linesearch_settings),sizeof(hsqp_swing_config),sizeof(hsqp_reference));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(s) for s in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(t) for t in (_abi.Body, _abi.Frame, _abi.ModelDesc, _abi.Settings, _abi.Problem, _abi.Perf,
-                                           _abi.Timings, _abi.Solution, _abi.LinesearchSettings)]
+                                           _abi.Timings, _abi.Solution, _abi.LinesearchSettings, _abi.SwingConfig, _abi.Reference)]
 
 
 def test_linesearch_defaults_follow_task_info():

@@ -74,6 +74,19 @@ class Solution(C.Structure):
                 ("armijo", C.POINTER(C.c_double)), ("timings", Timings)]
 
 
+class SwingConfig(C.Structure):
+    _fields_ = [("lift_off_velocity", C.c_double), ("touch_down_velocity", C.c_double), ("swing_height", C.c_double),
+                ("touch_down_height_offset", C.c_double), ("swing_time_scale", C.c_double), ("impact_mid", C.c_double),
+                ("impact_lift_velocity", C.c_double), ("impact_touch_velocity", C.c_double)]
+
+
+class Reference(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n_nodes", C.c_int32), ("t0", C.c_double), ("dt", C.c_double), ("max_events", C.c_int32),
+                ("n_events", C.POINTER(C.c_int32)), ("event_times", C.POINTER(C.c_double)), ("mode_sequence", C.POINTER(C.c_int32)),
+                ("n_knots", C.c_int32), ("target_times", C.POINTER(C.c_double)), ("target_states", C.POINTER(C.c_double)),
+                ("swing", SwingConfig), ("terrain_height", C.c_double), ("arm_swing", C.c_int32), ("reserved", C.c_int32)]
+
+
 class LinesearchSettings(C.Structure):
     _fields_ = [("g_max", C.c_double), ("g_min", C.c_double), ("gamma_c", C.c_double), ("armijo_factor", C.c_double),
                 ("alpha_decay", C.c_double), ("alpha_min", C.c_double), ("delta_tol", C.c_double)]
@@ -81,3 +94,4 @@ class LinesearchSettings(C.Structure):
 
 STEP_COST, STEP_DUAL, STEP_CONSTRAINT, STEP_ZERO, STEP_FULL = 0, 1, 2, 3, 4
 FLAG_LINESEARCH = 1
+BLK_PARAMS = 11

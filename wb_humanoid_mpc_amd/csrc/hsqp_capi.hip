@@ -10,6 +10,7 @@
 
 #include "hsqp_host.h"
 #include "hsqp_riccati.h"
+#include "hsqp_params.h"
 
 using namespace hsqp;
 
@@ -170,6 +171,19 @@ __global__ __launch_bounds__(128) void k_kkt(const DevModel* __restrict__ dm, co
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, par + ((size_t)b * (N + 1) + N) * NP,
                qp + (size_t)b * N * QP_SIZE, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT, N, kkt + 2 * b);
+}
+
+// ---- per-node parameter table from the compact per-instance reference: one thread per (instance, node)
+__global__ __launch_bounds__(64) void k_params(hsqp_swing_config cfg, double terrain, int arm_swing, int max_events, const int* __restrict__ n_events,
+                                               const double* __restrict__ ev, const int* __restrict__ seq, int n_knots,
+                                               const double* __restrict__ tt, const double* __restrict__ ts, double t0, double dt, int N, int B,
+                                               double* __restrict__ par, int* __restrict__ bad) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * (N + 1)) return;
+  const int b = id / (N + 1), k = id % (N + 1);
+  const bool ok = node_params_eval(cfg, terrain, arm_swing, n_events[b], ev + (size_t)b * max_events, seq + (size_t)b * (max_events + 1), n_knots,
+                                   tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, t0 + k * dt, par + (size_t)id * NP);
+  if (!ok) atomicExch(bad, 1);
 }
 
 // ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
@@ -344,6 +358,62 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
   return HSQP_OK;
 }
 
+int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_reference* r) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!p || !r || !p->x_init || !p->x_traj || !p->u_traj || !r->n_events || !r->event_times || !r->mode_sequence || !r->target_times || !r->target_states) {
+    h->err = "null problem / reference pointer";
+    return HSQP_ERR_BAD_ARG;
+  }
+  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || !(p->dt > 0.0)) {
+    h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
+    return HSQP_ERR_BAD_ARG;
+  }
+  if (r->batch != p->batch || r->n_nodes != p->n_nodes || r->dt != p->dt || r->max_events < 1 || r->n_knots < 1) {
+    h->err = "reference does not match the problem (batch, n_nodes, dt) or is empty";
+    return HSQP_ERR_BAD_ARG;
+  }
+  for (int b = 0; b < r->batch; ++b)
+    if (r->n_events[b] < 1 || r->n_events[b] > r->max_events) { h->err = "n_events outside [1, max_events]"; return HSQP_ERR_BAD_ARG; }
+  HCHECK(hipSetDevice(h->device));
+  const size_t B = p->batch, N = p->n_nodes, E = r->max_events, K = r->n_knots;
+  // staging buffers for the compact reference (a few KB per instance)
+  int *d_ne = nullptr, *d_seq = nullptr, *d_bad = nullptr;
+  double *d_ev = nullptr, *d_tt = nullptr, *d_ts = nullptr;
+  auto release = [&]() { for (void* q : {(void*)d_ne, (void*)d_seq, (void*)d_bad, (void*)d_ev, (void*)d_tt, (void*)d_ts}) if (q) (void)hipFree(q); };
+  if (hipMalloc(&d_ne, B * 4) != hipSuccess || hipMalloc(&d_seq, B * (E + 1) * 4) != hipSuccess || hipMalloc(&d_bad, 4) != hipSuccess ||
+      hipMalloc(&d_ev, B * E * 8) != hipSuccess || hipMalloc(&d_tt, B * K * 8) != hipSuccess || hipMalloc(&d_ts, B * K * NX * 8) != hipSuccess) {
+    release();
+    h->err = "hipMalloc failed (reference staging)";
+    return HSQP_ERR_OOM;
+  }
+  int rc = HSQP_OK;
+  auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
+  step(hipMemcpyAsync(d_ne, r->n_events, B * 4, hipMemcpyHostToDevice, h->stream), "upload n_events");
+  step(hipMemcpyAsync(d_seq, r->mode_sequence, B * (E + 1) * 4, hipMemcpyHostToDevice, h->stream), "upload mode_sequence");
+  step(hipMemcpyAsync(d_ev, r->event_times, B * E * 8, hipMemcpyHostToDevice, h->stream), "upload event_times");
+  step(hipMemcpyAsync(d_tt, r->target_times, B * K * 8, hipMemcpyHostToDevice, h->stream), "upload target_times");
+  step(hipMemcpyAsync(d_ts, r->target_states, B * K * NX * 8, hipMemcpyHostToDevice, h->stream), "upload target_states");
+  step(hipMemsetAsync(d_bad, 0, 4, h->stream), "memset");
+  step(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, hipMemcpyHostToDevice, h->stream), "upload x_init");
+  step(hipMemcpyAsync(h->d_x, p->x_traj, B * (N + 1) * NX * 8, hipMemcpyHostToDevice, h->stream), "upload x");
+  step(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, hipMemcpyHostToDevice, h->stream), "upload u");
+  if (rc == HSQP_OK) {
+    const int total = (int)(B * (N + 1));
+    hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
+                       (int)K, d_tt, d_ts, r->t0, r->dt, (int)N, (int)B, h->d_par, d_bad);
+    step(hipGetLastError(), "k_params");
+  }
+  int bad = 0;
+  step(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream), "download status");
+  step(hipStreamSynchronize(h->stream), "sync");
+  release();
+  if (rc != HSQP_OK) return rc;
+  if (bad) { h->err = "a swing phase has no lift-off / touch-down inside the mode schedule"; return HSQP_ERR_BAD_ARG; }
+  h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
+  h->have_problem = true; h->have_solution = false;
+  return HSQP_OK;
+}
+
 int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
   const int take_step = flags & HSQP_ITER_TAKE_STEP, want_kkt = (flags & HSQP_ITER_KKT) ? 1 : 0, linesearch = (flags & HSQP_ITER_LINESEARCH) ? 1 : 0;
   if (!h) return HSQP_ERR_BAD_ARG;
@@ -462,6 +532,13 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
 
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
   if (!h) return HSQP_ERR_BAD_ARG;
+  if (what == HSQP_BLK_PARAMS) {   // available as soon as a problem is resident
+    if (!h->have_problem) { h->err = "no problem uploaded"; return HSQP_ERR_BAD_ARG; }
+    if (hipSetDevice(h->device) != hipSuccess) return HSQP_ERR_HIP;
+    const long long size = (long long)h->B * (h->N + 1) * NP * 8;
+    if (dst && bytes > 0 && hipMemcpy(dst, h->d_par, (size_t)(bytes < size ? bytes : size), hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP;
+    return size;
+  }
   if (!h->have_solution) { h->err = "no iteration has run"; return HSQP_ERR_BAD_ARG; }
   if (hipSetDevice(h->device) != hipSuccess) return HSQP_ERR_HIP;
   const size_t B = h->B, N = h->N, nodes = B * N;

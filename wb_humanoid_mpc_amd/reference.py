@@ -255,6 +255,34 @@ def build_node_params(model, schedule, targets, t0, dt, n_nodes, arm_swing=True)
     return par
 
 
+def swing_config(model):
+    """hsqp_swing_config from task.info's swing_trajectory_config."""
+    c = model.swing
+    return _abi.SwingConfig(lift_off_velocity=c["liftOffVelocity"], touch_down_velocity=c["touchDownVelocity"], swing_height=c["swingHeight"],
+                            touch_down_height_offset=c["touchDownHeightOffset"], swing_time_scale=c["swingTimeScale"],
+                            impact_mid=c["impactProximityFactorMidPointValue"], impact_lift_velocity=c["impactProximityFactorLiftOffVelocity"],
+                            impact_touch_velocity=c["impactProximityFactorTouchDownVelocity"])
+
+
+def pack_reference(schedules, targets):
+    """Compact per-instance reference for hsqp_upload_reference: (n_events[B], event_times[B,E], mode_sequence[B,E+1],
+    target_times[B,K], target_states[B,K,58]) from ModeSchedule / TargetTrajectories objects."""
+    B = len(schedules)
+    E = max(len(s.event_times) for s in schedules)
+    K = len(targets[0].times)
+    n_events = np.array([len(s.event_times) for s in schedules], dtype=np.int32)
+    ev = np.zeros((B, E))
+    seq = np.full((B, E + 1), STANCE, dtype=np.int32)
+    for b, s in enumerate(schedules):
+        ev[b, :n_events[b]] = s.event_times
+        ev[b, n_events[b]:] = s.event_times[-1]
+        seq[b, :n_events[b] + 1] = s.mode_sequence
+    tt = np.stack([t.times for t in targets])
+    ts = np.stack([t.states for t in targets])
+    assert tt.shape == (B, K) and ts.shape[:2] == (B, K)
+    return n_events, ev, seq, tt, ts
+
+
 def cold_start(model, x0, par):
     """WeightCompInitializer: x_k = x0, u_k = weight compensation for the node's contact flags."""
     n_nodes = par.shape[0] - 1
@@ -268,10 +296,11 @@ BENCH_SEED = 20250808
 
 
 def make_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.7925, 0.0), dt=None, perturb=False,
-                 seed=BENCH_SEED, t0=0.0):
+                 seed=BENCH_SEED, t0=0.0, with_reference=False):
     """Synthetic inputs of BASELINE.md configs 3-5: (x_init[B,58], x[B,N+1,58], u[B,N,35], params[B,N+1,72], dt).
 
     perturb=False: every instance starts at task.info's initialState with gait phase offset 0 (config 3).
+    with_reference=True additionally returns (schedules, targets, t0) for the device-side parameter generation.
     perturb=True : x0 + N(0, sigma^2) (0.02 m base position, 0.05 rad euler/joints, 0.1 velocities; joints clipped to
                    limits - 0.05 rad) and a per-instance gait phase offset U[0, 1.4 s) from numpy PCG64(seed) (configs 4-5).
     """
@@ -280,6 +309,7 @@ def make_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.79
     rng = np.random.Generator(np.random.PCG64(seed))
     nj = model.nj
     xs, us, ps, x0s = [], [], [], []
+    schedules, targets_all = [], []
     for _ in range(batch):
         x0 = model.initial_state.copy()
         offset = 0.0
@@ -295,4 +325,7 @@ def make_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.79
         par = build_node_params(model, schedule, targets, t0, dt, n_nodes)
         x, u = cold_start(model, x0, par)
         xs.append(x); us.append(u); ps.append(par); x0s.append(x0)
+        schedules.append(schedule); targets_all.append(targets)
+    if with_reference:
+        return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt, (schedules, targets_all, t0)
     return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt

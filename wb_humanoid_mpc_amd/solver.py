@@ -42,6 +42,7 @@ def load_library():
     lib.hsqp_destroy.argtypes = [C.c_void_p]
     lib.hsqp_solve.argtypes = [C.c_void_p, C.POINTER(_abi.Problem), C.POINTER(_abi.Solution)]
     lib.hsqp_upload.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
+    lib.hsqp_upload_reference.argtypes = [C.c_void_p, C.POINTER(_abi.Problem), C.POINTER(_abi.Reference)]
     lib.hsqp_iterate_device.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.hsqp_download.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
     lib.hsqp_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
@@ -144,6 +145,39 @@ class HipSqpSolver:
     def upload(self, x_init, x_traj, u_traj, params, dt):
         p, keep, self._shape = self._problem(x_init, x_traj, u_traj, params, dt)
         self._check(self.lib.hsqp_upload(self.h, C.byref(p)))
+
+    def upload_reference(self, x_init, x_traj, u_traj, dt, t0, n_events, event_times, mode_sequence, target_times, target_states,
+                         swing, terrain_height=0.0, arm_swing=True):
+        """hsqp_upload_reference: the per-node parameter table is generated on the device from the compact reference
+        (mode schedule + target knots per instance; see reference.pack_reference)."""
+        x_traj, u_traj, x_init = _c(x_traj), _c(u_traj), _c(x_init)
+        if x_traj.ndim == 2:
+            x_traj, u_traj, x_init = x_traj[None], u_traj[None], x_init[None]
+        B, N = u_traj.shape[0], u_traj.shape[1]
+        n_events = np.ascontiguousarray(n_events, dtype=np.int32)
+        mode_sequence = np.ascontiguousarray(mode_sequence, dtype=np.int32)
+        event_times, target_times, target_states = _c(event_times), _c(target_times), _c(target_states)
+        if event_times.shape[0] != B or mode_sequence.shape != (B, event_times.shape[1] + 1) or target_states.shape != (B, target_times.shape[1], _abi.NX):
+            raise ValueError("inconsistent reference array shapes")
+        ip = C.POINTER(C.c_int32)
+        p = _abi.Problem(batch=B, n_nodes=N, dt=dt, x_init=x_init.ctypes.data_as(_dp), x_traj=x_traj.ctypes.data_as(_dp),
+                         u_traj=u_traj.ctypes.data_as(_dp), node_params=None)
+        r = _abi.Reference(batch=B, n_nodes=N, t0=t0, dt=dt, max_events=event_times.shape[1], n_events=n_events.ctypes.data_as(ip),
+                           event_times=event_times.ctypes.data_as(_dp), mode_sequence=mode_sequence.ctypes.data_as(ip),
+                           n_knots=target_times.shape[1], target_times=target_times.ctypes.data_as(_dp),
+                           target_states=target_states.ctypes.data_as(_dp), swing=swing, terrain_height=terrain_height,
+                           arm_swing=1 if arm_swing else 0, reserved=0)
+        self._check(self.lib.hsqp_upload_reference(self.h, C.byref(p), C.byref(r)))
+        self._shape = (B, N)
+
+    def device_params(self):
+        """The per-node parameter table resident on the device ([B][N+1][72])."""
+        B, N = self._shape
+        a = np.zeros((B, N + 1, _abi.NODE_PARAMS))
+        n = self.lib.hsqp_debug_read(self.h, _abi.BLK_PARAMS, a.ctypes.data_as(C.c_void_p), a.nbytes)
+        if n < 0:
+            raise HsqpError(n, self.lib.hsqp_last_error(self.h).decode())
+        return a
 
     def iterate(self, n_iterations=1, take_step=False, kkt=False, linesearch=False):
         self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0) | (4 if linesearch else 0)))
