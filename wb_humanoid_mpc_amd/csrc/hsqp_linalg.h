@@ -121,6 +121,7 @@ constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nb
 //   A[i][k] = X[k0 + (lane >> 4)][r0 + (lane & 15)],  B[k][j] = Y[k0 + (lane >> 4)][c0 + (lane & 15)],
 //   D: lane holds rows (lane >> 4) + 4 reg, column lane & 15  (reg = 0..3).
 // A job list is executed cooperatively: 16x16 output tiles are dealt round-robin to the waves of the workgroup.
+constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2;
 struct XtyJob {
   int M, N;                       // output size
   int L1; const double* X1; int ldx1; const double* Y1; int ldy1;
@@ -144,9 +145,14 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(1))) * hsqp_gcptr;
+typedef double __attribute__((address_space(1))) * hsqp_gptr;
 // NT = 1 or 2 output tiles of one job processed together: two independent accumulator chains keep the FP64 matrix
 // pipe busy from a single wave (a dependent v_mfma_f64 chain alone leaves it half idle).
-template <int NT>
+// SPACES (XTY_ADD_GLOBAL | XTY_C_GLOBAL): the additive term / the destination of every job of the call is known to be in
+// GLOBAL memory -> address-space-qualified accesses.  A generic pointer compiles to FLAT instructions, whose loads also
+// count on lgkmcnt and make the LDS operand waits of the MFMA loop wait for the L2/HBM round trip.
+template <int NT, int SPACES>
 HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
   const int tn = (j.N + 15) >> 4;
   const int i = lane & 15, kk = lane >> 4;
@@ -159,12 +165,26 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
     xr[t] = r0[t] + i < j.M ? r0[t] + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
     yc[t] = c0[t] + i < j.N ? c0[t] + i : j.N - 1;
     acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
-    // the additive term may live in HBM: issue its loads before the MFMA loop, consume them in the epilogue
+  }
+  // the additive term may live in HBM: its loads are issued before the MFMA loop and consumed in the epilogue.  They are
+  // UNCONDITIONAL (clamped indices, one uniform test of the pointer): a per-lane conditional load becomes an exec-masked
+  // branch per element and the compiler drains vmcnt at every join, i.e. one L2 round trip after the other.
+  if (j.Add) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0[t] + kk + 4 * r;
-      addv[t][r] = (j.Add && c0[t] + i < j.N && row < j.M) ? j.Add[row * j.ldadd + c0[t] + i] : 0.0;
+    for (int t = 0; t < NT; ++t) {
+      const int cc = c0[t] + i < j.N ? c0[t] + i : j.N - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0[t] + kk + 4 * r, rc = row < j.M ? row : j.M - 1;
+        if (SPACES & XTY_ADD_GLOBAL) addv[t][r] = ((hsqp_gcptr)j.Add)[rc * j.ldadd + cc];
+        else addv[t][r] = j.Add[rc * j.ldadd + cc];
+      }
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) addv[t][r] = 0.0;
   }
   for (int k0 = 0; k0 < j.L1; k0 += 4) {
     const int k = k0 + kk;
@@ -195,8 +215,13 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
         const int row = r0[t] + kk + 4 * r;
         if (row < j.M) {
           const double v = j.scale * acc[t][r] + addv[t][r];
-          j.C[row * j.ldc + c] = v;
-          if (j.sym && r0[t] != c0[t]) j.C[c * j.ldc + row] = v;
+          if (SPACES & XTY_C_GLOBAL) {
+            ((hsqp_gptr)j.C)[row * j.ldc + c] = v;
+            if (j.sym && r0[t] != c0[t]) ((hsqp_gptr)j.C)[c * j.ldc + row] = v;
+          } else {
+            j.C[row * j.ldc + c] = v;
+            if (j.sym && r0[t] != c0[t]) j.C[c * j.ldc + row] = v;
+          }
         }
       }
     }
@@ -214,13 +239,14 @@ HSQP_HD int xty_tile_id(int sym, int tn, int t) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // tiles are numbered globally (base + t) and dealt round-robin to the waves; a wave takes its tiles two at a time
+template <int SPACES>
 HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane) {
   const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
   const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
   const int sym = j.sym;
   int t = (wave - base % nwaves + nwaves) % nwaves;
-  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2>(j, pair, lane); }
-  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1>(j, &one, lane); }
+  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane); }
+  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane); }
   return nt;
 }
 #endif
@@ -228,16 +254,16 @@ HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane
 // Executes `njobs` independent products; must be called by every thread of the workgroup (no barrier inside).
 // UNROLL: the loop over the jobs is unrolled so that each job gets code specialised for its (constant) shape and the
 // descriptors stay in registers — pays off for long contractions in throughput kernels, not inside the Riccati stage loop.
-template <bool UNROLL = false>
+template <bool UNROLL = false, int SPACES = 0>
 HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wave = ctx.tid >> 6, nwaves = ctx.nthreads >> 6, lane = ctx.tid & 63;
   int base = 0;
   if constexpr (UNROLL) {
 #pragma unroll
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job(jobs[jn], base, wave, nwaves, lane);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane);
   } else {
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job(jobs[jn], base, wave, nwaves, lane);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane);
   }
 #else
   for (int jn = 0; jn < njobs; ++jn) {

@@ -91,7 +91,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
   // left untouched: its final diagonal goes to Rdiag, the vector to V).
-  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; if (r == 0) w.qr.rinv[c] = 0.0; }
+  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; if (r == 0) w.qr.rinv[c] = 0.0; if (i < NU) w.d[NX + i] = sqrt(w.d[NX + i]); }   // d_u -> sqrt(d_u) (only used for the weight rows)
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
   // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
@@ -245,11 +245,11 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int r0 = pass == 0 ? 0 : NRA, nr = pass == 0 ? NRA : NRS - NRA, nrows = pass == 0 ? NRA : NRB;
-    if (pass == 1) { stage_inputs(NRA, NRS - NRA, false); WG_SYNC(ctx); }
+    if (pass == 1) { stage_inputs(NRA, NRS - NRA, false); WG_SYNC(ctx); PH_TICK(ctx, 13); }
     {
       const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.JuT[0][0], NRA, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
                               xty_job(nr, NUT, NU, &w.JuT[0][0], NRA, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
-      wg_xty_jobs<true>(ctx, jobs, 2);
+      wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
       WG_FOR(ctx, i, nr + (pass == 1 ? (NU + 1) * LDTM : 0)) {
         if (i < nr) {
           double sdot = w.rho[r0 + i];
@@ -258,12 +258,12 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
           w.Jt[i][NTW] = sdot;
         } else {   // pass B: the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the zero row
           const int k = (i - nr) / LDTM, a = (i - nr) % LDTM;
-          w.Jt[nr + k][a] = (k < NU && a <= NTW) ? sqrt(w.d[NX + k]) * w.Tm[k][a] : 0.0;
+          w.Jt[nr + k][a] = (k < NU && a <= NTW) ? w.d[NX + k] * w.Tm[k][a] : 0.0;
         }
       }
     }
     WG_SYNC(ctx);
-    PH_TICK(ctx, 6);
+    PH_TICK(ctx, pass == 0 ? 6 : 11);
     {
       const double* addq = pass == 0 ? nullptr : qp + QP_Q;
       const double* addp = pass == 0 ? nullptr : qp + QP_P;
@@ -271,7 +271,8 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       const XtyJob jobs[3] = {xty_job(NX, NX, nrows, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX, addq, NX),
                               xty_job(NUT, NX, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX, addp, NX),
                               xty_job(NUT, NUT, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT, addr, NUT)};
-      wg_xty_jobs<true>(ctx, jobs, 3);
+      wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_C_GLOBAL>(ctx, jobs, 3);
+      PH_TICK(ctx, pass == 0 ? 14 : 15);
       WG_FOR(ctx, a, NTW) {
         double s = 0.0;
 #pragma unroll 4
@@ -288,7 +289,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       }
     }
     WG_SYNC(ctx);
-    PH_TICK(ctx, 7);
+    PH_TICK(ctx, pass == 0 ? 7 : 12);
   }
   // diagonal of Q~ and the identity padding of the unused projected inputs (read-modify-write of this node's own record)
   WG_FOR(ctx, i, NX + NUT * NUT) {
