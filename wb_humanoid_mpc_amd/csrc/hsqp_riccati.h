@@ -81,7 +81,16 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const XtyJob jobs[2] = {xty_job(NX, NX, NX, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
                               xty_job(NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
-      if (is_helper_half(ctx)) { const Ctx hc = helper_ctx(ctx); WG_FOR(hc, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt); }
+      if (is_helper_half(ctx)) {
+        const Ctx hc = helper_ctx(ctx);
+        WG_FOR(hc, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt);
+        // first half of the next stage's A~ into the other buffer (second half in P3): one batch of loads per phase, so the
+        // L2/HBM round trip hides behind this phase's matrix-core work
+        constexpr int nh = (NX * NX) / 2, na = nbatches(nh, 7);
+        WG_FOR(hc, it, na) {
+          if (k > 0) copy_batch<7>(it, nh, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+        }
+      }
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
@@ -89,12 +98,12 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     {
       const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
                               xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
-      constexpr int na = nbatches(NX * NX, 8);
+      constexpr int nh = (NX * NX) / 2, na = nbatches(NX * NX - nh, 7);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         WG_FOR(hc, it, na) {
-          if (k > 0) copy_batch<8>(it, NX * NX, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+          if (k > 0) copy_batch<7>(it, NX * NX - nh, qn + QP_A + nh, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
         }
         WG_FOR(hc, it, NUT + NUT * NX) {
           if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
@@ -105,6 +114,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
+    bool prefetched_b = false;
     // ---- P4a: Gaussian elimination of [Lam | I] on full rows (rows stay unscaled, so a step needs no pivot broadcast
     //      phase: one barrier per column).  Fixed (row, 3 strided columns) grid; every load is unconditional, so the
     //      step is one LDS round trip + the reciprocal chain.  The multiplier is read from the (symmetric) upper part.
@@ -116,6 +126,15 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const bool mine = ctx.tid < NUT * 16;
       double e0 = 0.0, e1 = 0.0, e2 = 0.0;
       if (mine) { e0 = w.fac.Ef[i][c0]; e1 = w.fac.Ef[i][c0 + 16]; e2 = w.fac.Ef[i][c0 + 32]; }
+      // the two waves without elimination work fetch the next stage's B~, b~ meanwhile (B is dead since P3): the loads are
+      // issued here, travel while the barriers of the elimination go by, and land in LDS after the sweep
+      constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
+      const int pt = ctx.tid - 384;
+      double pb[NPB];
+      if (pt >= 0 && k > 0) {
+#pragma unroll
+        for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
+      }
       for (int j = 0; j < NUT - 1; ++j) {
         if (mine && i > j) {
           const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
@@ -126,6 +145,15 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         }
         WG_SYNC(ctx);
       }
+      if (pt >= 0 && k > 0) {
+#pragma unroll
+        for (int t = 0; t < NPB; ++t) {
+          const int idx = pt + 128 * t;
+          if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
+          else if (idx < NX * NUT + NX) w.btn[idx - NX * NUT] = pb[t];
+        }
+      }
+      prefetched_b = true;
     } else
 #endif
     for (int j = 0; j < NUT - 1; ++j) {
@@ -213,8 +241,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
             rk[RIC_K + j] = w.Em[j / NX][EM_G + j % NX];
           }
         }
-        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage
-          if (k > 0) {
+        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage (unless the elimination phase already did)
+          if (k > 0 && !prefetched_b) {
             if (bb < nbb) {
               double t[8];
 #pragma unroll
