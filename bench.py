@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="MPC instances per GPU")
     ap.add_argument("--nodes", type=int, default=100)
+    ap.add_argument("--gait", default="walk", help="gait of the synthetic schedule (config 5: slow_walk)")
+    ap.add_argument("--no-perturb", action="store_true", help="config 3: the unperturbed initial state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,7 +123,7 @@ def main():
 
     model = load_model()
     B, N = args.batch, args.nodes
-    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=shard_seed(BENCH_SEED, rank))
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=args.gait, perturb=not args.no_perturb, seed=shard_seed(BENCH_SEED, rank))
     solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank)
     solver.upload(x0, x, u, par, dt)      # inputs resident in HBM before the timed region
 
@@ -155,6 +157,7 @@ def main():
 
     if rank == 0:
         value = aggregate_throughput([B] * world, args.steps, elapsed)
+        cfg = {(100, 256): "4", (100, 1): "3", (200, 1024): "5"}.get((N, B), "4-like")
         nodes = B * N
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
         kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN, "k_lq<true>"), "projection(k_project)": (kms[1], F_PROJ, "k_project"),
@@ -169,7 +172,7 @@ def main():
             "metric": "SQP iters/sec (G1 WB-MPC, N=100)", "value": value, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4: G1 whole-body MPC, N={N}, dt={dt}, gait walk, {B} perturbed instances per GPU, "
+            "config": {"workload": f"BASELINE config {cfg}: G1 whole-body MPC, N={N}, dt={dt}, gait {args.gait}, {B} {'perturbed ' if not args.no_perturb else ''}instances per GPU, "
                                    "1 SQP iteration per step (LQ + projection + Riccati + full step + performance index), cold-start trajectory",
                        "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",

@@ -199,3 +199,23 @@ def test_multi_iteration_sqp_with_linesearch(model):
         assert np.all(viol[1:] <= viol[:-1] * (1 + 1e-12))
     finally:
         s.close()
+
+
+def test_instances_of_a_large_batch_equal_their_solo_solves(model):
+    """Independence of the batch axis under full occupancy: with several workgroups resident per CU every instance must get
+    bit-identical results to the same instance solved alone, and the batch must be repeatable (catches intra-workgroup races
+    that lock-step execution of a lone workgroup hides)."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 96, 60
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=77)
+    s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+    try:
+        a = s.run(x0, x, u, par, dt)
+        b = s.run(x0, x, u, par, dt)
+        assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["du"], b["du"])
+        for i in range(0, B, 7):
+            solo = s.run(x0[i], x[i], u[i], par[i], dt)
+            assert np.array_equal(solo["dx"][0], a["dx"][i]) and np.array_equal(solo["du"][0], a["du"][i]), i
+            assert solo["perf_after"][0] == a["perf_after"][i]
+    finally:
+        s.close()

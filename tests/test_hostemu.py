@@ -72,3 +72,13 @@ def test_full_iteration_matches_oracle(model, oracle, emu, gait, n):
     assert kkt[0] <= 1e-9 * sc and kkt[1] <= 1e-10 * sc
     for got, want in ((pb, r["perf_before"]), (pa, r["perf_after"])):
         assert np.allclose(got, [want["cost"], want["dynamics_sse"], want["equality_sse"]], rtol=1e-9, atol=1e-12)
+
+
+def test_composite_sum_schedule_orders_every_chain_after_its_children(emu):
+    """The subtree sums run chain by chain in barrier-separated phases; a chain must come strictly after every chain hanging
+    off it (a same-phase dependency is a data race on the device that a sequential emulation cannot see).  G1: legs and arms
+    first, then the waist chain, then the base."""
+    lib, h = emu
+    n = C.c_int(0)
+    assert lib.emu_check_composite_schedule(h, C.byref(n)) == 0
+    assert n.value == 3

@@ -78,7 +78,10 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
       dm.xchild[p][k] = (unsigned char)dm.chain_start[c];
     }
     dm.n_cphases = 0;
-    for (int c = dm.n_chains; c >= 0; --c) {   // chains are numbered in depth-first order: children have larger indices
+    // chains are numbered in depth-first order (children have larger indices), the base — chain n_chains — comes last:
+    // every chain's phase is computed after the phases of all chains hanging off it
+    for (int cc_ = dm.n_chains; cc_ >= 0; --cc_) {
+      const int c = cc_ == 0 ? dm.n_chains : cc_ - 1;
       int ph = 0;
       for (int i = dm.chain_start[c]; i < dm.chain_start[c] + dm.chain_len[c]; ++i)
         for (int k = 0; k < 3; ++k)
