@@ -219,3 +219,20 @@ def test_instances_of_a_large_batch_equal_their_solo_solves(model):
             assert solo["perf_after"][0] == a["perf_after"][i]
     finally:
         s.close()
+
+
+def test_config4_instances_against_oracle_at_full_size(model, oracle):
+    """BASELINE config 4 at full size (N = 100, 256 perturbed instances, every CU busy): two instances of the batch against the
+    CPU oracle; step max-abs <= 1e-8 * scale."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 256, 100
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True)
+    s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+    try:
+        out = s.run(x0, x, u, par, dt)
+    finally:
+        s.close()
+    for b in (37, 255):
+        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4, want_perf=False)
+        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+        assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc

@@ -1,27 +1,21 @@
-"""Probe (GPU box): which stage differs between an instance solved inside a large batch and the same instance solved alone."""
+"""Accuracy probe (GPU box): steps of the HIP path vs the CPU oracle for selected instances of a long-horizon batch."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
 import numpy as np
 import torch  # noqa: F401
-from wb_humanoid_mpc_amd import load_model, _abi
+from wb_humanoid_mpc_amd import load_model
 from wb_humanoid_mpc_amd.reference import make_problem, BENCH_SEED
 from wb_humanoid_mpc_amd.solver import HipSqpSolver
+from hsqp_oracle import Oracle
 m = load_model()
-N, gait, B = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+o = Oracle(m)
+N, gait, B = 200, "slow_walk", 64
 x0, x, u, par, dt = make_problem(m, n_nodes=N, batch=B, gait=gait, perturb=True, seed=BENCH_SEED)
 s = HipSqpSolver(m, max_nodes=N, max_batch=B)
 out = s.run(x0, x, u, par, dt)
-blocks = {k: s.debug_read(getattr(_abi, "BLK_" + k)) for k in ("AB", "BVEC", "H", "G", "CDE", "COST", "FLOW")}
-out2 = s.run(x0, x, u, par, dt)
-print("batch run repeatable:", np.array_equal(out["dx"], out2["dx"]), "max diff", np.abs(out["dx"] - out2["dx"]).max())
-nbad = 0
-for b in range(B):
-    o1 = s.run(x0[b], x[b], u[b], par[b], dt)
-    d = np.abs(o1["dx"][0] - out["dx"][b]).max()
-    if d > 1e-9 * max(1, np.abs(o1["dx"]).max()):
-        nbad += 1
-        if nbad <= 4:
-            diffs = {k: float(np.abs(s.debug_read(getattr(_abi, "BLK_" + k))[0] - blocks[k][b]).max()) for k in blocks}
-            node = np.abs(o1["dx"][0] - out["dx"][b]).max(axis=1)
-            print("instance", b, "dx diff %.3e" % d, "first node with diff > 1e-9:", int(np.argmax(node > 1e-9)), "LQ block diffs", diffs)
-print("bad instances:", nbad, "of", B)
+print("kkt stat: max %.3e median %.3e" % (out["kkt"][:, 0].max(), np.median(out["kkt"][:, 0])))
+for b in (int(out["kkt"][:, 0].argmax()), 0, 13, 49):
+    r = o.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=64)
+    sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+    print(b, "scale %.1f dx rel %.2e du rel %.2e" % (sc, np.abs(out["dx"][b] - r["dx"]).max() / sc, np.abs(out["du"][b] - r["du"]).max() / sc),
+          "kkt gpu", out["kkt"][b], "oracle", r["kkt"])
