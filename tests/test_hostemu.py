@@ -19,7 +19,7 @@ P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
 
 @pytest.fixture(scope="module")
 def emu(model):
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu"), "all"])
     lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
     lib.emu_create.restype = C.c_void_p
     err = C.create_string_buffer(256)
@@ -82,3 +82,25 @@ def test_composite_sum_schedule_orders_every_chain_after_its_children(emu):
     n = C.c_int(0)
     assert lib.emu_check_composite_schedule(h, C.byref(n)) == 0
     assert n.value == 3
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14)])
+def test_phases_are_free_of_intra_phase_dependencies(model, emu, gait, n):
+    """Race check: the same kernel sources built with every phase executing its work items in REVERSE order
+    (-DHSQP_EMU_REVERSE) must give bit-identical results — the items of a barrier-separated phase may not depend on each
+    other, whatever order the hardware runs them in."""
+    lib, h = emu
+    rev = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu_rev.so"))
+    rev.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    hr = C.c_void_p(rev.emu_create(C.byref(model.desc), err, 256))
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=5)
+    res = []
+    for L, hh in ((lib, h), (rev, hr)):
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        qp = np.zeros((n, L.emu_qp_size()))
+        assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp)) == 0
+        res.append((dx, du, qp, pb, pa))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)

@@ -62,7 +62,13 @@ struct Ctx {
 #else
 #define WG_SYNC(ctx) ((void)0)
 #endif
+#if defined(HSQP_EMU_REVERSE) && !defined(__HIP_DEVICE_COMPILE__)
+// host emulation, race check: the items of a phase are executed in REVERSE order.  Phases are race-free iff their items are
+// independent, i.e. iff this build produces bit-identical results to the forward build (tests/test_hostemu.py).
+#define WG_FOR(ctx, i, n) for (int i = (n) - 1 - (ctx).tid; i >= 0; i -= (ctx).nthreads)
+#else
 #define WG_FOR(ctx, i, n) for (int i = (ctx).tid; i < (n); i += (ctx).nthreads)
+#endif
 
 // Wave-local section: code executed by ONE wave (wave 0) needs no workgroup barrier between its dependent steps — the
 // LDS processes a wave's instructions in order; WV_SYNC only has to stop the compiler from reordering across the step
