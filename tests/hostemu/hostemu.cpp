@@ -2,6 +2,7 @@
 // one-thread execution context (hsqp_common.h) so that the arithmetic of the HIP kernels can be
 // checked against the oracle in the GPU-less build container.  Never loaded by the product.
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_params.h"
+#include <algorithm>
 #include <vector>
 #include <memory>
 
@@ -124,7 +125,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   }
   auto terminal = [&](const double* xx) { double c = 0; for (int i = 0; i < NX; ++i) { const double d = xx[N * NX + i] - par[N * NP + HSQP_P_XDES + i]; c += 0.5 * dm.Qf[i] * d * d; } return c; };
   pb[0] += terminal(x);
-  riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N);
+  std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
+  riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
   riccati_forward(ctx, *rw, x_init, x, ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();
@@ -133,7 +135,15 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
               du + k * NU, x_new + k * NX, u_new + k * NU);
   for (int i = 0; i < NX; ++i) x_new[N * NX + i] = x[N * NX + i] + dx[N * NX + i];
   auto kw = std::make_unique<KktWS>();
-  kkt_residual(ctx, *kw, dm.Qf, x_init, x, par + N * NP, qp.data(), dx, ut.data(), N, kkt);
+  kkt[0] = kkt[1] = 0.0;
+  std::vector<double> dx0(NX);
+  for (int i = 0; i < NX; ++i) dx0[i] = x_init[i] - x[i];
+  for (int k = 0; k < N; ++k) {
+    double r2[2];
+    kkt_node(ctx, *kw, &qp[(size_t)k * QP_SIZE], &vf[(size_t)k * VF_SIZE], &vf[(size_t)(k + 1) * VF_SIZE], dx + k * NX, dx + (k + 1) * NX,
+             &ut[(size_t)k * NUT], k == 0 ? dx0.data() : nullptr, r2);
+    kkt[0] = std::max(kkt[0], r2[0]); kkt[1] = std::max(kkt[1], r2[1]);
+  }
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {

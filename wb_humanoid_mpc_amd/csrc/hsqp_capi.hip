@@ -71,7 +71,8 @@ __global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const d
 __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
                                                          const double* __restrict__ x, const double* __restrict__ par,
                                                          const double* __restrict__ qp, double* __restrict__ ric, int N,
-                                                         double* __restrict__ dx, int* __restrict__ status, long long* prof) {
+                                                         double* __restrict__ dx, int* __restrict__ status, long long* prof,
+                                                         double* __restrict__ vf) {
   const int b = blockIdx.x;
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   for (int k = threadIdx.x; k < N; k += blockDim.x)
     if (qpb[(size_t)k * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
   const int bad = __syncthreads_or(mybad);
-  riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N);
+  riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
   PH_TICK(ctx, 0);
   riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
@@ -162,15 +163,24 @@ __global__ __launch_bounds__(64) void k_ls_retake(const double* __restrict__ x, 
     for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
 }
 
-// ---- KKT residual of the projected QP: one workgroup per instance (reporting only, not part of an SQP step)
-__global__ __launch_bounds__(128) void k_kkt(const DevModel* __restrict__ dm, const double* __restrict__ x_init, const double* __restrict__ x,
-                                             const double* __restrict__ par, const double* __restrict__ qp, const double* __restrict__ dx,
-                                             const double* __restrict__ ut, int N, double* __restrict__ kkt) {
+// ---- KKT residual of the projected QP (reporting only, not part of an SQP step): one workgroup per (instance, node), the
+//      per-instance maxima by atomic max on the bit patterns of the (non-negative) residuals
+__global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+                                             const double* __restrict__ vf, const double* __restrict__ dx, const double* __restrict__ ut, int N,
+                                             double* __restrict__ kkt) {
   __shared__ KktWS w;
-  const int b = blockIdx.x;
+  __shared__ double dx0[NX], r2[2];
+  const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
-  kkt_residual(ctx, w, dm->Qf, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, par + ((size_t)b * (N + 1) + N) * NP,
-               qp + (size_t)b * N * QP_SIZE, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT, N, kkt + 2 * b);
+  if (k == 0) {
+    for (int i = threadIdx.x; i < NX; i += blockDim.x) dx0[i] = x_init[(size_t)b * NX + i] - x[(size_t)b * (N + 1) * NX + i];
+    __syncthreads();
+  }
+  const double* vfb = vf + (size_t)b * (N + 1) * VF_SIZE;
+  const double* dxb = dx + (size_t)b * (N + 1) * NX;
+  kkt_node(ctx, w, qp + (size_t)node * QP_SIZE, vfb + (size_t)k * VF_SIZE, vfb + (size_t)(k + 1) * VF_SIZE, dxb + (size_t)k * NX,
+           dxb + (size_t)(k + 1) * NX, ut + (size_t)node * NUT, k == 0 ? dx0 : nullptr, r2);
+  if (threadIdx.x < 2) atomicMax(reinterpret_cast<unsigned long long*>(kkt + 2 * b + threadIdx.x), (unsigned long long)__double_as_longlong(r2[threadIdx.x]));
 }
 
 // ---- per-node parameter table from the compact per-instance reference: one thread per (instance, node)
@@ -225,6 +235,7 @@ struct hsqp_handle {
   double *d_rec = nullptr, *d_qp = nullptr, *d_ric = nullptr;
   double *d_dx = nullptr, *d_du = nullptr, *d_ut = nullptr, *d_xnew = nullptr, *d_unew = nullptr;
   double *d_misc = nullptr, *d_kkt = nullptr;
+  double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   double* d_stepinfo = nullptr;   // [B][N][4] per-node {armijo, |dx|^2, |du|^2}
@@ -267,7 +278,7 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts};
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -429,12 +440,18 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
+    if (want_kkt && !h->d_vf) {
+      const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
+      if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+    }
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                       h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256);
+                       h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
     hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                        h->d_xnew, h->d_unew, h->d_stepinfo);
-    if (want_kkt)
-      hipLaunchKernelGGL(k_kkt, dim3(B), dim3(128), 0, h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dx, h->d_ut, N, h->d_kkt);
+    if (want_kkt) {
+      HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
+      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt);
+    }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
                        N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);

@@ -64,7 +64,7 @@ struct Ctx {
 #endif
 #if defined(HSQP_EMU_REVERSE) && !defined(__HIP_DEVICE_COMPILE__)
 // host emulation, race check: the items of a phase are executed in REVERSE order.  Phases are race-free iff their items are
-// independent, i.e. iff this build produces bit-identical results to the forward build (tests/test_hostemu.py).
+// independent, i.e. iff this build produces bit-identical results to the forward build (tests/hostemu, race check).
 #define WG_FOR(ctx, i, n) for (int i = (n) - 1 - (ctx).tid; i >= 0; i -= (ctx).nthreads)
 #else
 #define WG_FOR(ctx, i, n) for (int i = (ctx).tid; i < (n); i += (ctx).nthreads)

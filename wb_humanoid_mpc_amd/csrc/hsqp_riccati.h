@@ -49,14 +49,19 @@ struct RicWS {
 };
 
 // qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
+// vf (optional, [N+1][VF_SIZE]): the value function S_k, s_k of every node, for the KKT check (lam_k = S_k dx_k + s_k).
+constexpr int VF_SIZE = NX * NX + NX;
 HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const double* xN, const double* parN, const double* qp,
-                              double* ric, int N) {
+                              double* ric, int N, double* vf = nullptr) {
   WG_FOR(ctx, i, NX * NX + NX + 1) {
     if (i < NX * NX) { const int r = i / NX, c = i % NX; w.S[r][c] = r == c ? Qf[r] : 0.0; }
     else if (i < NX * NX + NX) { const int r = i - NX * NX; w.sv[r] = Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]); }
     else w.ok = 1;
   }
   WG_SYNC(ctx);
+  if (vf) {
+    WG_FOR(ctx, i, VF_SIZE) vf[(size_t)N * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : w.sv[i - NX * NX];
+  }
   // stage N-1 data -> LDS (the later stages are prefetched while the previous one is being processed)
   {
     const double* q = qp + (size_t)(N - 1) * QP_SIZE;
@@ -269,6 +274,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       }
     }
     WG_SYNC(ctx);
+    if (vf) {
+      WG_FOR(ctx, i, VF_SIZE) vf[(size_t)k * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : w.sv[i - NX * NX];
+    }
     PH_TICK(ctx, 6);
   }
 }
@@ -373,52 +381,58 @@ HSQP_HD bool ls_decide(const LsSettings& st, const hsqp_perf& base, const hsqp_p
   return false;
 }
 
-// KKT residual of the projected QP at (dx, ut): costates by the backward stationarity recursion
-//   lam_N = Qf dx_N + g_N,  lam_k = Q~ dx + P~^T ut + q~ + A~^T lam+   (x-stationarity holds by construction)
-// reported: max | R~ ut + P~ dx + r~ + B~^T lam+ |  and  max | dx+ - A~ dx - B~ ut - b~ |, | dx_0 - (x_init - x_0) |.
+// KKT residual of the projected QP at (dx, ut) for one node k (parallel over the nodes), with the costates of the Riccati
+// value function lam_k = S_k dx_k + s_k (the oracle's definition):
+//   stationarity: | Q~ dx + P~^T ut + q~ + A~^T lam+ - lam |_inf ,  | R~ ut + P~ dx + r~ + B~^T lam+ |_inf
+//   primal:       | dx+ - A~ dx - B~ ut - b~ |_inf   (node 0 also | dx_0 - (x_init - x_0) |)
+// out2 = {stationarity, primal} of this node.
 struct KktWS {
-  double lam[NX], lamn[NX], pr[NX], st[NUT];
+  double dx[NX], dxn[NX], ut[NUT], lam[NX], lamn[NX], res[2 * NX + NUT];
 };
-HSQP_HD void kkt_residual(const Ctx& ctx, KktWS& w, const double* Qf, const double* x_init, const double* x, const double* parN,
-                          const double* qp, const double* dx, const double* ut, int N, double* out2) {
-  WG_FOR(ctx, i, NX) {
-    const double dN = dx[(size_t)N * NX + i];
-    w.lam[i] = Qf[i] * dN + Qf[i] * (x[(size_t)N * NX + i] - parN[HSQP_P_XDES + i]);
-    w.pr[i] = fabs(dx[i] - (x_init[i] - x[i]));
-    if (i < NUT) w.st[i] = 0.0;
+HSQP_HD void kkt_node(const Ctx& ctx, KktWS& w, const double* q, const double* vfk, const double* vfn, const double* dxk, const double* dxn,
+                      const double* utk, const double* dx0 /*null unless k == 0*/, double* out2) {
+  WG_FOR(ctx, i, 2 * NX + NUT) {
+    if (i < NX) w.dx[i] = dxk[i];
+    else if (i < 2 * NX) w.dxn[i - NX] = dxn[i - NX];
+    else w.ut[i - 2 * NX] = utk[i - 2 * NX];
   }
   WG_SYNC(ctx);
-  for (int k = N - 1; k >= 0; --k) {
-    const double* q = qp + (size_t)k * QP_SIZE;
-    const double* dxk = dx + (size_t)k * NX;
-    const double* dxn = dx + (size_t)(k + 1) * NX;
-    const double* utk = ut + (size_t)k * NUT;
-    WG_FOR(ctx, i, NX + NUT) {
-      if (i < NX) {
-        double l = q[QP_QV + i];
-        double pr = dxn[i] - q[QP_BV + i];
-        for (int j = 0; j < NX; ++j) { l += q[QP_Q + i * NX + j] * dxk[j] + q[QP_A + j * NX + i] * w.lam[j]; pr -= q[QP_A + i * NX + j] * dxk[j]; }
-        for (int j = 0; j < NUT; ++j) { l += q[QP_P + j * NX + i] * utk[j]; pr -= q[QP_B + i * NUT + j] * utk[j]; }
-        w.lamn[i] = l;
-        w.pr[i] = fmax(w.pr[i], fabs(pr));
-      } else {
-        const int r = i - NX;
-        double s = q[QP_RV + r];
-        for (int j = 0; j < NX; ++j) s += q[QP_P + r * NX + j] * dxk[j] + q[QP_B + j * NUT + r] * w.lam[j];
-        for (int j = 0; j < NUT; ++j) s += q[QP_R + r * NUT + j] * utk[j];
-        w.st[r] = fmax(w.st[r], fabs(s));
-      }
-    }
-    WG_SYNC(ctx);
-    WG_FOR(ctx, i, NX) w.lam[i] = w.lamn[i];
-    WG_SYNC(ctx);
+  WG_FOR(ctx, i, 2 * NX) {
+    const bool nxt = i >= NX;
+    const int r = nxt ? i - NX : i;
+    const double* vf = nxt ? vfn : vfk;
+    const double* d = nxt ? w.dxn : w.dx;
+    double l = vf[NX * NX + r];
+    for (int j = 0; j < NX; ++j) l += vf[r * NX + j] * d[j];
+    if (nxt) w.lamn[r] = l; else w.lam[r] = l;
   }
-  WG_FOR(ctx, it, 1) {
-    double st = 0.0, pr = 0.0;
-    for (int i = 0; i < NX; ++i) pr = fmax(pr, w.pr[i]);
-    for (int i = 0; i < NUT; ++i) st = fmax(st, w.st[i]);
-    out2[0] = st;
-    out2[1] = pr;
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, 2 * NX + NUT) {
+    double a;
+    if (i < NX) {              // x-stationarity
+      a = q[QP_QV + i] - w.lam[i];
+      for (int j = 0; j < NX; ++j) a += q[QP_Q + i * NX + j] * w.dx[j] + q[QP_A + j * NX + i] * w.lamn[j];
+      for (int j = 0; j < NUT; ++j) a += q[QP_P + j * NX + i] * w.ut[j];
+    } else if (i < NX + NUT) { // u-stationarity
+      const int r = i - NX;
+      a = q[QP_RV + r];
+      for (int j = 0; j < NX; ++j) a += q[QP_P + r * NX + j] * w.dx[j] + q[QP_B + j * NUT + r] * w.lamn[j];
+      for (int j = 0; j < NUT; ++j) a += q[QP_R + r * NUT + j] * w.ut[j];
+    } else {                   // dynamics
+      const int r = i - NX - NUT;
+      a = w.dxn[r] - q[QP_BV + r];
+      for (int j = 0; j < NX; ++j) a -= q[QP_A + r * NX + j] * w.dx[j];
+      for (int j = 0; j < NUT; ++j) a -= q[QP_B + r * NUT + j] * w.ut[j];
+      if (dx0) a = fmax(fabs(a), fabs(w.dx[r] - dx0[r]));
+    }
+    w.res[i] = fabs(a);
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, it, 2) {
+    double m = 0.0;
+    if (it == 0) { for (int i = 0; i < NX + NUT; ++i) m = fmax(m, w.res[i]); }
+    else { for (int i = NX + NUT; i < 2 * NX + NUT; ++i) m = fmax(m, w.res[i]); }
+    out2[it] = m;
   }
   WG_SYNC(ctx);
 }
