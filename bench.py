@@ -91,6 +91,47 @@ def cpu_baseline(model, n_nodes, seed):
             "value_4_threads": done4 / wall4, "sample_4_threads": f"{done4} iterations in {wall4:.1f} s on 4 threads (the reference's nThreads)"}
 
 
+def cpu_kernel_sources_on_host(model, n_nodes, seed):
+    """Second, stronger CPU figure (reported beside `cpu_baseline`, never instead of it): the SAME kernel sources
+    (wb_humanoid_mpc_amd/csrc/*.h: analytic derivatives, structured RK4 chain, projection, Riccati) compiled for the host
+    with a one-thread context (tests/hostemu, g++ -O2), one instance per host thread, all cores."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from wb_humanoid_mpc_amd.reference import make_problem
+    path = os.path.join(ROOT, "tests", "hostemu", "libhsqp_hostemu.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(model.desc), err, 256))
+    if not h.value:
+        return None
+    cores = os.cpu_count() or 1
+    n_inst = 8
+    x0, x, u, par, dt = make_problem(model, n_nodes=n_nodes, batch=n_inst, perturb=True, seed=seed)
+    dp = C.POINTER(C.c_double)
+    t0 = time.perf_counter()
+
+    def work(wid):
+        P = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+        xn, un, dx, du = np.zeros_like(x[0]), np.zeros_like(u[0]), np.zeros_like(x[0]), np.zeros_like(u[0])
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        done = 0
+        while done < 1 or time.perf_counter() - t0 < 8.0:
+            b = (wid + done) % n_inst
+            lib.emu_sqp_iteration(h, n_nodes, C.c_double(dt), P(x0[b]), P(x[b]), P(u[b]), P(par[b]), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), None)
+            done += 1
+        return done
+
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    wall = time.perf_counter() - t0
+    return {"value": done / wall, "unit": "SQP iters/s", "cores": cores, "kind": "kernel sources compiled for the host (tests/hostemu)",
+            "sample": f"{done} single-instance iterations (N={n_nodes}) in {wall:.1f} s, one instance per thread on {cores} threads, "
+                      "each iteration incl. the KKT check and the performance pass"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +232,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, N, BENCH_SEED)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+            host = cpu_kernel_sources_on_host(model, N, BENCH_SEED)
+            if host:
+                res["cpu_kernel_sources_on_host"] = host
+                res["speedup_vs_kernel_sources_on_host"] = value / host["value"]
         print(json.dumps(res))
     solver.close()
     group.close()
