@@ -170,6 +170,9 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     misc[1] = dt * w.nw.cost;
     misc[2] = dt * eq;
     misc[3] = dt * dyn;
+    // structure of the equality rows for the projection: a swing foot's zero-wrench rows are unit rows of D (and have C = 0)
+    misc[4] = (double)w.nw.contact[0]; misc[5] = (double)w.nw.contact[1];
+    misc[6] = (double)w.nw.eq_off[0]; misc[7] = (double)w.nw.eq_off[1];
   }
   if constexpr (DERIV) {
   // ---- write d, gd (the equality rows went straight to the record)

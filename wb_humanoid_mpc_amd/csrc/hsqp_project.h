@@ -45,7 +45,7 @@ struct ProjWS {
       double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double V[NE_MAX][NU + 1];  // Householder vectors
-      double beta[NE_MAX], Rdiag[NE_MAX], rinv[LDR];
+      double beta[NE_MAX], Rdiag[NE_MAX], rinv[LDR], ep[LDR];   // ep: e of the dense rows after the eliminated inputs are substituted
       double part[LDR][4], yk[LDR];   // per-step scratch: partial dots, row k of R
     } qr;                        // live until Tm is formed
     double PV[2][6][LDJ];        // then the non-trivial rows of [A|B] (loaded when the QR data is dead) ...
@@ -53,6 +53,12 @@ struct ProjWS {
   };
   double JuT[NU][NRA];           // transposed input block of the residual rows of the current pass
   int ne, nut, ok;
+  // deflation of the unit rows of D (a swing foot's zero-wrench constraints W_f = 0 fix six inputs outright): the Householder
+  // QR only sees the dense rows (ned of them) restricted to the free inputs (nub of them)
+  int ned, nub;
+  int ub[NU];                    // free input indices, then the eliminated ones (positions nub..NU-1)
+  int urow[NU];                  // for an eliminated input: its unit constraint row; -1 for a free input
+  int rd[NE_MAX];                // dense constraint rows
   double Tm[NU][LDTM];           // [Px (58) | Pu (23) | Pe | 0 0]
   double bvec[64];
   double rho[NRS], d[LDJ], gd[LDJ];   // mirror one contiguous piece of the LQ record
@@ -80,23 +86,57 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         else if (idx < nld) dst3[idx - n1 - n2] = t[j];
       }
     }
-    WG_FOR(ctx, i, 1) {
-      w.ne = (int)rec[REC_MISC];
-      w.nut = NU - w.ne;
-      w.ok = 1;
+    // structure of the equality rows (closed forms, one item per input / row): a swing foot f contributes the unit rows
+    // off[f] .. off[f]+5 on the inputs 6f .. 6f+5
+    WG_FOR(ctx, i, NU + NE_MAX + 1) {
+      const int ne_ = (int)rec[REC_MISC];
+      const int sw0 = rec[REC_MISC + 4] == 0.0 ? 1 : 0, sw1 = rec[REC_MISC + 5] == 0.0 ? 1 : 0;
+      const int off0 = (int)rec[REC_MISC + 6], off1 = (int)rec[REC_MISC + 7];
+      const int nel = 6 * (sw0 + sw1);
+      auto clamp6 = [](int v) { return v < 0 ? 0 : (v > 6 ? 6 : v); };
+      if (i < NU) {
+        const int u = i;
+        const int before = sw0 * clamp6(u) + sw1 * clamp6(u - 6);          // eliminated inputs below u
+        const bool elim = (u < 6 && sw0) || (u >= 6 && u < 12 && sw1);
+        w.urow[u] = elim ? (u < 6 ? off0 + u : off1 + u - 6) : -1;
+        if (elim) w.ub[NU - nel + before] = u; else w.ub[u - before] = u;
+      } else if (i < NU + NE_MAX) {
+        const int r = i - NU;
+        const int before = sw0 * clamp6(r - off0) + sw1 * clamp6(r - off1);  // unit rows below r
+        const bool unit = (sw0 && r >= off0 && r < off0 + 6) || (sw1 && r >= off1 && r < off1 + 6);
+        if (r < ne_ && !unit) w.rd[r - before] = r;
+        if (r >= ne_ - nel) w.rd[r] = 0;                                      // padding of the dense-row list
+      } else {
+        w.ne = ne_;
+        w.nut = NU - ne_;
+        w.ok = 1;
+        w.ned = ne_ - nel;
+        w.nub = NU - nel;
+      }
     }
   }
   WG_SYNC(ctx);
-  const int ne = w.ne, nut = w.nut;
+  const int ne = w.ne, nut = w.nut, ned = w.ned, nub = w.nub;
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
   // left untouched: its final diagonal goes to Rdiag, the vector to V).
-  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ne && r < NU) ? w.qr.CDe[c][NX + r] : 0.0; if (r == 0) w.qr.rinv[c] = 0.0; if (i < NU) w.d[NX + i] = sqrt(w.d[NX + i]); }   // d_u -> sqrt(d_u) (only used for the weight rows)
+  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ned && r < nub) ? w.qr.CDe[w.rd[c]][NX + w.ub[r]] : 0.0; if (r == 0) {
+      w.qr.rinv[c] = 0.0;
+      // e' = e - D_a e_U: the eliminated inputs are fixed at -e_U (the unit rows have C = 0)
+      double ep = 0.0;
+      if (c < ned) {
+        const int ri = w.rd[c];
+        ep = w.qr.CDe[ri][NZ];
+        for (int t = nub; t < NU; ++t) { const int ue = w.ub[t]; ep -= w.qr.CDe[ri][NX + ue] * w.qr.CDe[w.urow[ue]][NZ]; }
+      }
+      w.qr.ep[c] = ep;
+    }
+    if (i < NU) w.d[NX + i] = sqrt(w.d[NX + i]); }   // d_u -> sqrt(d_u) (only used for the weight rows)
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
   // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
   // phase is one LDS round trip; masks are applied to values, not to control flow.
-  for (int k = 0; k < ne; ++k) {
+  for (int k = 0; k < ned; ++k) {
     // (a) partial dots x . R(:,c) of the pivot column x = R(k:,k) with every column (item = column c, row residue p mod 4)
     WG_FOR(ctx, it, LDR * 4) {
       const int c = it >> 2, p = it & 3;
@@ -137,12 +177,13 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     WG_SYNC(ctx);
   }
   PH_TICK(ctx, 9);
-  // Q^T = H_{ne-1} ... H_0: one column per item, the column lives in registers while the reflectors are applied
+  // Q^T = H_{ned-1} ... H_0 of the free inputs: one column per item, the column lives in registers while the reflectors are
+  // applied; it is stored at the ORIGINAL input index (column ub[c]); the columns of the eliminated inputs are zero
   WG_FOR(ctx, c, NU) {
     double col[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) col[i] = i == c ? 1.0 : 0.0;
-    for (int k = 0; k < ne; ++k) {
+    for (int i = 0; i < NU; ++i) col[i] = (i == c && c < nub) ? 1.0 : 0.0;
+    for (int k = 0; k < (c < nub ? ned : 0); ++k) {
       double sdot = 0.0;
 #pragma unroll
       for (int i = 0; i < NU; ++i) sdot += w.qr.V[k][i] * col[i];
@@ -150,17 +191,20 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
 #pragma unroll
       for (int i = 0; i < NU; ++i) col[i] -= sdot * w.qr.V[k][i];
     }
+    const int uc = w.ub[c];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) w.qr.QT[i][c] = col[i];
+    for (int i = 0; i < NU; ++i) w.qr.QT[i][uc] = col[i];
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 2);
-  // ---- W = R1^-T [C | e]: forward substitution per column, the column kept in registers (rows >= ne: rinv = 0 -> 0)
+  // ---- W = R1^-T [C | e'] over the dense rows: forward substitution per column, the column kept in registers (rows >= ned:
+  //      rinv = 0 -> 0)
   WG_FOR(ctx, c, NX + 1) {
     double wc[NE_MAX];
 #pragma unroll
     for (int i = 0; i < NE_MAX; ++i) {
-      double s = c < NX ? w.qr.CDe[i][c] : w.qr.CDe[i][NZ];
+      const int ri = w.rd[i];
+      double s = c < NX ? w.qr.CDe[ri][c] : w.qr.ep[i];
 #pragma unroll
       for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * wc[j];
       wc[i] = s * w.qr.rinv[i];
@@ -171,12 +215,16 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   PH_TICK(ctx, 3);
   // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
   {
-    const XtyJob job = xty_job(NU, NX, ne, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
+    const XtyJob job = xty_job(NU, NX, ned, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
     wg_xty_jobs<true>(ctx, &job, 1);
     WG_FOR(ctx, i, NU * (NUT + 3)) {
       const int r = i / (NUT + 3), cc = i % (NUT + 3);
-      if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ne + cc][r] : 0.0;
-      else if (cc == NUT) { double sdot = 0.0; for (int j = 0; j < ne; ++j) sdot += w.qr.QT[j][r] * w.qr.Wm[j][NX]; w.Tm[r][NTW] = -sdot; }
+      if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ned + cc][r] : 0.0;
+      else if (cc == NUT) {
+        double sdot = 0.0;
+        for (int j = 0; j < ned; ++j) sdot += w.qr.QT[j][r] * w.qr.Wm[j][NX];
+        w.Tm[r][NTW] = (w.urow[r] >= 0 ? -w.qr.CDe[w.urow[r]][NZ] : 0.0) - sdot;   // an eliminated input is fixed at -e of its unit row
+      }
       else w.Tm[r][NTW + (cc - NUT)] = 0.0;
     }
   }
