@@ -161,7 +161,10 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
   double addv[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    r0[t] = (tiles[t] / tn) << 4; c0[t] = (tiles[t] % tn) << 4;
+    // tile row / column without an integer division (a runtime div or mod costs ~40 instructions; tile ids are < 40)
+    int tr = 0, tc = tiles[t];
+    while (tc >= tn) { tc -= tn; ++tr; }
+    r0[t] = tr << 4; c0[t] = tc << 4;
     xr[t] = r0[t] + i < j.M ? r0[t] + i : j.M - 1;   // clamped: the duplicate rows / columns are never stored
     yc[t] = c0[t] + i < j.N ? c0[t] + i : j.N - 1;
     acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
@@ -244,7 +247,7 @@ HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane
   const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
   const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
   const int sym = j.sym;
-  int t = (wave - base % nwaves + nwaves) % nwaves;
+  int t = (wave - base) & (nwaves - 1);   // round-robin over the waves (their number is a power of two)
   for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane); }
   if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane); }
   return nt;
