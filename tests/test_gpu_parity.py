@@ -236,3 +236,35 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4, want_perf=False)
         sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
         assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc
+
+
+def test_edge_sizes_and_settings_errors(model, oracle):
+    """Smallest problem (one interval, one instance), handle capacity limits, invalid line-search settings, a reference whose
+    schedule ends in the air (the reference's swing planner throws there)."""
+    from wb_humanoid_mpc_amd.reference import pack_reference, swing_config, ModeSchedule, TargetTrajectories
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver, HsqpError
+    s = HipSqpSolver(model, max_nodes=3, max_batch=2)
+    try:
+        x0, x, u, par, dt = make_problem(model, n_nodes=1, batch=1, perturb=True, seed=4)
+        out = s.run(x0, x, u, par, dt)
+        r = oracle.sqp_iteration(dt, x0[0], x[0], u[0], par[0])
+        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+        assert np.abs(out["dx"][0] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][0] - r["du"]).max() <= 1e-8 * sc
+        with pytest.raises(HsqpError) as e:                                # batch larger than the handle
+            s.run(*make_problem(model, n_nodes=2, batch=3))
+        assert e.value.code == _abi.ERR_BAD_ARG
+        for bad in ({"alpha_decay": 1.5}, {"alpha_min": 0.0}, {"g_max": 1e-9, "g_min": 1e-3}):
+            with pytest.raises(HsqpError) as e:
+                s.set_linesearch(**bad)
+            assert e.value.code == _abi.ERR_BAD_ARG
+        with pytest.raises(ValueError):
+            s.set_linesearch(no_such_setting=1.0)
+        # a schedule that ends in flight has no touch-down for the last swing phase
+        x0, x, u, par, dt = make_problem(model, n_nodes=3, batch=1)
+        sched = ModeSchedule([0.0, 0.05], [3, 2, 0])                      # STANCE, LF, FLY
+        tgt = TargetTrajectories([0.0], [par[0, 0, :_abi.NX]])
+        with pytest.raises(HsqpError) as e:
+            s.upload_reference(x0, x, u, dt, 0.0, *pack_reference([sched], [tgt]), swing_config(model))
+        assert e.value.code == _abi.ERR_BAD_ARG
+    finally:
+        s.close()
