@@ -236,6 +236,15 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes);
  * measured with HIP events on the handle's stream: {lq, project, riccati, step, total}. */
 int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]);
 
+/* ---- the step after the solve -------------------------------------------------------------
+ * Joint torques as the reference's computeJointTorques (humanoid_common_mpc/src/pinocchio_model/DynamicsHelperFunctions.cpp:
+ * 233-270): tau_j = M_j [a_b; qdd_j] + nle_j - (sum J^T W)_j with a_b from the flow map's base solve, for n (x, u) pairs. */
+int hsqp_joint_torques(hsqp_handle* h, int n, const double* x /*[n][58]*/, const double* u /*[n][35]*/, double* tau /*[n][23]*/);
+/* Feed-forward policy of the solution resident on the device (MPC_MRT_Interface::evaluatePolicy as used in
+ * humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:136-147): clamped linear interpolation of the optimal state / input
+ * trajectories at s[b] seconds after the first node, and the joint torques there.  Any output may be NULL. */
+int hsqp_evaluate_policy(hsqp_handle* h, const double* s /*[B]*/, double* x /*[B][58]*/, double* u /*[B][35]*/, double* tau /*[B][23]*/);
+
 const char* hsqp_last_error(const hsqp_handle* h);   /* h may be NULL: last creation error */
 const char* hsqp_version(void);
 int hsqp_device_count(void);

@@ -2,6 +2,7 @@
 // one-thread execution context (hsqp_common.h) so that the arithmetic of the HIP kernels can be
 // checked against the oracle in the GPU-less build container.  Never loaded by the product.
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_params.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_policy.h"
 #include <algorithm>
 #include <vector>
 #include <memory>
@@ -96,6 +97,18 @@ int emu_node_params(const hsqp_swing_config* cfg, double terrain, int arm_swing,
   for (int k = 0; k <= N; ++k)
     if (!node_params_eval(*cfg, terrain, arm_swing, n_ev, ev, seq, n_knots, tt, ts, t0 + k * dt, par + (size_t)k * NP)) bad = 1;
   return bad;
+}
+
+// joint torques of one (x, u) pair through the device code path (hsqp_policy.h)
+void emu_joint_torques(void* h, const double* x, const double* u, double* tau) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  Ctx ctx{0, 1, nullptr};
+  auto ws = std::make_unique<StageWST<false>>();
+  policy_node(ctx, dm, *ws, x, u, tau);
+}
+void emu_policy_interpolate(const double* xt, const double* ut, int N, double dt, double s, double* x, double* u) {
+  Ctx ctx{0, 1, nullptr};
+  policy_interpolate(ctx, xt, ut, N, dt, s, x, u);
 }
 
 int emu_qp_size() { return QP_SIZE; }

@@ -11,6 +11,7 @@
 #include "hsqp_host.h"
 #include "hsqp_riccati.h"
 #include "hsqp_params.h"
+#include "hsqp_policy.h"
 
 using namespace hsqp;
 
@@ -194,6 +195,26 @@ __global__ __launch_bounds__(64) void k_params(hsqp_swing_config cfg, double ter
   const bool ok = node_params_eval(cfg, terrain, arm_swing, n_events[b], ev + (size_t)b * max_events, seq + (size_t)b * (max_events + 1), n_knots,
                                    tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, t0 + k * dt, par + (size_t)id * NP);
   if (!ok) atomicExch(bad, 1);
+}
+
+// ---- policy evaluation / joint torques: one workgroup per (x, u) pair.  xt != null: interpolate the trajectories of
+//      instance blockIdx.x at s[blockIdx.x] first; otherwise take the pair from xin / uin.
+struct PolicyWS { StageWST<false> st; double x[NX], u[NU]; };
+__global__ __launch_bounds__(128) void k_policy(const DevModel* __restrict__ dm, const double* __restrict__ xt, const double* __restrict__ ut, int N,
+                                                double dt, const double* __restrict__ s, const double* __restrict__ xin,
+                                                const double* __restrict__ uin, double* __restrict__ xout, double* __restrict__ uout,
+                                                double* __restrict__ tau) {
+  PolicyWS& w = *reinterpret_cast<PolicyWS*>(hsqp_smem);
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  if (xt) {
+    policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], w.x, w.u);
+  } else {
+    for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) w.x[i] = xin[(size_t)b * NX + i]; else w.u[i - NX] = uin[(size_t)b * NU + i - NX]; }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) xout[(size_t)b * NX + i] = w.x[i]; else uout[(size_t)b * NU + i - NX] = w.u[i - NX]; }
+  policy_node(ctx, *dm, w.st, w.x, w.u, tau + (size_t)b * NJ);
 }
 
 // ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
@@ -539,6 +560,52 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
   rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | ((h->st.flags & HSQP_FLAG_LINESEARCH) ? HSQP_ITER_LINESEARCH : 0));
   if (rc != HSQP_OK) return rc;
   return hsqp_download(h, solution);
+}
+
+static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s_or_x, const double* u_in, double* x_out, double* u_out, double* tau) {
+  HCHECK(hipSetDevice(h->device));
+  double *d_in = nullptr, *d_x = nullptr, *d_u = nullptr, *d_tau = nullptr;
+  const size_t nin = from_solution ? (size_t)n : (size_t)n * (NX + NU);
+  auto release = [&]() { for (double* q : {d_in, d_x, d_u, d_tau}) if (q) (void)hipFree(q); };
+  if (hipMalloc(&d_in, nin * 8) != hipSuccess || hipMalloc(&d_x, (size_t)n * NX * 8) != hipSuccess || hipMalloc(&d_u, (size_t)n * NU * 8) != hipSuccess ||
+      hipMalloc(&d_tau, (size_t)n * NJ * 8) != hipSuccess) { release(); h->err = "hipMalloc failed (policy evaluation)"; return HSQP_ERR_OOM; }
+  int rc = HSQP_OK;
+  auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
+  if (from_solution) {
+    step(hipMemcpyAsync(d_in, s_or_x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream), "upload s");
+  } else {
+    step(hipMemcpyAsync(d_in, s_or_x, (size_t)n * NX * 8, hipMemcpyHostToDevice, h->stream), "upload x");
+    step(hipMemcpyAsync(d_in + (size_t)n * NX, u_in, (size_t)n * NU * 8, hipMemcpyHostToDevice, h->stream), "upload u");
+  }
+  if (rc == HSQP_OK) {
+    step(hipFuncSetAttribute((const void*)k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicyWS)), "hipFuncSetAttribute");
+    if (from_solution)
+      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->N, h->dt, d_in, (const double*)nullptr,
+                         (const double*)nullptr, d_x, d_u, d_tau);
+    else
+      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)nullptr, (const double*)nullptr, 0, 0.0,
+                         (const double*)nullptr, d_in, d_in + (size_t)n * NX, d_x, d_u, d_tau);
+    step(hipGetLastError(), "k_policy");
+  }
+  if (x_out) step(hipMemcpyAsync(x_out, d_x, (size_t)n * NX * 8, hipMemcpyDeviceToHost, h->stream), "download x");
+  if (u_out) step(hipMemcpyAsync(u_out, d_u, (size_t)n * NU * 8, hipMemcpyDeviceToHost, h->stream), "download u");
+  if (tau) step(hipMemcpyAsync(tau, d_tau, (size_t)n * NJ * 8, hipMemcpyDeviceToHost, h->stream), "download tau");
+  step(hipStreamSynchronize(h->stream), "sync");
+  release();
+  return rc;
+}
+
+int hsqp_joint_torques(hsqp_handle* h, int n, const double* x, const double* u, double* tau) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (n < 1 || !x || !u || !tau) { h->err = "hsqp_joint_torques: n < 1 or null pointer"; return HSQP_ERR_BAD_ARG; }
+  return run_policy(h, n, false, x, u, nullptr, nullptr, tau);
+}
+
+int hsqp_evaluate_policy(hsqp_handle* h, const double* s, double* x, double* u, double* tau) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!h->have_solution) { h->err = "no solution on the device"; return HSQP_ERR_BAD_ARG; }
+  if (!s) { h->err = "hsqp_evaluate_policy: null time offsets"; return HSQP_ERR_BAD_ARG; }
+  return run_policy(h, h->B, true, s, nullptr, x, u, tau);
 }
 
 int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {

@@ -51,6 +51,8 @@ def load_library():
     lib.hsqp_last_error.argtypes = [C.c_void_p]
     lib.hsqp_last_error.restype = C.c_char_p
     lib.hsqp_version.restype = C.c_char_p
+    lib.hsqp_joint_torques.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    lib.hsqp_evaluate_policy.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     lib.hsqp_linesearch_defaults.argtypes = [C.POINTER(_abi.LinesearchSettings)]
     lib.hsqp_linesearch_defaults.restype = None
     lib.hsqp_set_linesearch.argtypes = [C.c_void_p, C.POINTER(_abi.LinesearchSettings)]
@@ -207,6 +209,21 @@ class HipSqpSolver:
         ms = np.zeros(5)
         self._check(self.lib.hsqp_last_kernel_ms(self.h, ms.ctypes.data_as(_dp)))
         return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
+
+    # ---- the step after the solve: MPC_MRT_Interface::evaluatePolicy + computeJointTorques (WBMpcMrtJointController.cpp:136-147)
+    def evaluate_policy(self, s):
+        """Feed-forward policy of the device-resident solution at s[b] seconds after the first node: (x[B,58], u[B,35], tau[B,23])."""
+        B, _ = self._shape
+        s = _c(np.broadcast_to(s, (B,)))
+        x, u, tau = np.zeros((B, _abi.NX)), np.zeros((B, _abi.NU)), np.zeros((B, _abi.NJ))
+        self._check(self.lib.hsqp_evaluate_policy(self.h, s.ctypes.data_as(_dp), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), tau.ctypes.data_as(_dp)))
+        return x, u, tau
+
+    def joint_torques(self, x, u):
+        x, u = _c(np.atleast_2d(x)), _c(np.atleast_2d(u))
+        tau = np.zeros((x.shape[0], _abi.NJ))
+        self._check(self.lib.hsqp_joint_torques(self.h, x.shape[0], x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), tau.ctypes.data_as(_dp)))
+        return tau
 
     # ---- reference-named accessors
     def getPrimalSolution(self):
