@@ -268,3 +268,34 @@ def test_edge_sizes_and_settings_errors(model, oracle):
         assert e.value.code == _abi.ERR_BAD_ARG
     finally:
         s.close()
+
+
+def test_receding_horizon_loop_with_device_parameters(model):
+    """A short closed MPC loop the way the reference runs it (advanceMpc every control tick): device-generated parameters
+    for the shifted grid, warm start from the previous solution (shifted by one node, tail repeated), one SQP iteration with
+    line search, policy evaluation.  The constraint violation at the start of every cycle keeps falling (one real-time
+    iteration per cycle), and everything stays finite."""
+    from wb_humanoid_mpc_amd.reference import pack_reference, swing_config
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 2, 20
+    x0, x, u, par, dt, (schedules, targets, t0) = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=12, with_reference=True)
+    ref = pack_reference(schedules, targets)
+    s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+    try:
+        viol = []
+        for cycle in range(4):
+            s.upload_reference(x0, x, u, dt, t0 + cycle * dt, *ref, swing_config(model))
+            s.iterate(1, take_step=True, linesearch=True)
+            out = s.download()
+            assert np.all(np.isfinite(out["x"])) and np.all(np.isfinite(out["u"])) and np.all(out["alpha"] > 0.0)
+            viol.append([np.sqrt(p["dynamics_sse"] + p["equality_sse"]) for p in out["perf_before"]])
+            xp, up, tau = s.evaluate_policy(np.full(B, 0.005))
+            assert np.all(np.isfinite(tau)) and np.abs(tau).max() < 500.0
+            # next cycle: the plant follows the plan for one node; warm start = shifted solution
+            x0 = out["x"][:, 1].copy()
+            x = np.concatenate([out["x"][:, 1:], out["x"][:, -1:]], axis=1)
+            u = np.concatenate([out["u"][:, 1:], out["u"][:, -1:]], axis=1)
+        viol = np.array(viol)
+        assert np.all(viol[1:] < viol[:-1]) and np.all(viol[-1] < 0.6 * viol[0])
+    finally:
+        s.close()

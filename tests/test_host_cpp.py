@@ -20,6 +20,16 @@ int main() {
   try {
     hsqp_host::HipSqpSolver s(md, 8, 1, 0);
     std::printf("constructed\n");
+    // the rest of the surface must compile (never reached without a valid model / device)
+    hsqp_reference ref;
+    std::memset(&ref, 0, sizeof(ref));
+    s.runWithReference(8, 0.035, nullptr, nullptr, nullptr, ref, true);
+    std::vector<double> t(1, 0.005), x, u, tau;
+    s.evaluatePolicy(t, x, u, tau);
+    hsqp_linesearch_settings ls;
+    hsqp_linesearch_defaults(&ls);
+    s.setLinesearchSettings(ls);
+    (void)s.getStepSizes(); (void)s.getStepTypes();
     return 0;
   } catch (const std::runtime_error& e) {
     std::printf("runtime_error: %s\n", e.what());

@@ -68,6 +68,45 @@ class HipSqpSolver {
     bench_.computeControllerTime = s.timings.compute_controller;
   }
 
+  /**
+   * Same as run(), but the per-node parameter table is generated on the device from the compact reference — the adaptor hands
+   * over the ocs2::ModeSchedule (event times, mode sequence) and the TargetTrajectories knots instead of sampling the reference
+   * manager and the swing planner for every node (hsqp_upload_reference).
+   */
+  void runWithReference(int nodes, double dt, const double* xInit, const double* xTraj, const double* uTraj, const hsqp_reference& ref,
+                        bool takeStepWithLinesearch = false) {
+    const int batch = ref.batch;
+    hsqp_problem p{batch, nodes, dt, xInit, xTraj, uTraj, nullptr};
+    int rc = hsqp_upload_reference(h_, &p, &ref);
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_upload_reference failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+    rc = hsqp_iterate_device(h_, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0));
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_iterate_device failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+    solution_.batch = batch; solution_.nodes = nodes;
+    solution_.stateTrajectory.assign((size_t)batch * (nodes + 1) * HSQP_NX, 0.0);
+    solution_.inputTrajectory.assign((size_t)batch * nodes * HSQP_NU, 0.0);
+    perf_.assign(batch, hsqp_perf{}); perfBefore_.assign(batch, hsqp_perf{});
+    kkt_.assign((size_t)batch * 2, 0.0); stepSize_.assign(batch, 0.0); stepType_.assign(batch, HSQP_STEP_FULL);
+    hsqp_solution s{};
+    s.x = solution_.stateTrajectory.data(); s.u = solution_.inputTrajectory.data();
+    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = kkt_.data();
+    s.alpha = stepSize_.data(); s.step_type = stepType_.data();
+    rc = hsqp_download(h_, &s);
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_download failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+    bench_.linearQuadraticApproximationTime = s.timings.lq_approximation;
+    bench_.solveQpTime = s.timings.solve_qp;
+    bench_.linesearchTime = s.timings.linesearch;
+    bench_.computeControllerTime = s.timings.compute_controller;
+  }
+
+  /** MPC_MRT_Interface::evaluatePolicy + computeJointTorques for the solution of the last run: per instance, at `secondsAfterStart`. */
+  void evaluatePolicy(const std::vector<double>& secondsAfterStart, std::vector<double>& state, std::vector<double>& input, std::vector<double>& jointTorques) {
+    const size_t B = (size_t)solution_.batch;
+    if (secondsAfterStart.size() != B) throw std::runtime_error("[HipSqpSolver] evaluatePolicy: one time per instance expected");
+    state.assign(B * HSQP_NX, 0.0); input.assign(B * HSQP_NU, 0.0); jointTorques.assign(B * HSQP_NJ, 0.0);
+    const int rc = hsqp_evaluate_policy(h_, secondsAfterStart.data(), state.data(), input.data(), jointTorques.data());
+    if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_evaluate_policy failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+  }
+
   const PrimalSolution& getPrimalSolution() const { return solution_; }
   const std::vector<hsqp_perf>& getPerformanceIndeces() const { return perf_; }
   const std::vector<hsqp_perf>& getPerformanceIndecesBeforeStep() const { return perfBefore_; }
