@@ -34,6 +34,7 @@ constexpr int NE_MAX = 14;     // max active equality rows (flight: 6+1+6+1)
 constexpr int NUT = 23;        // max projected input dimension nu - ne (padded with identity when ne > 12)
 constexpr int NR = 60;         // residual-row slots of the Gauss-Newton / penalty model (see hsqp_node.h)
 constexpr int LDJ = 96;        // leading dimension of Jacobian rows over z = [x;u] in memory (cols 0..92 used; CDe col 93 = e)
+constexpr int MAXCHAIN = 6;    // longest chain (maximal single-child path) of the kinematic tree
 constexpr int NANC = 8;        // longest path of moving bodies from the base to a leaf
 constexpr int NLEVELS = 8;     // depth of the body tree incl. the base
 

@@ -60,6 +60,7 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
         dm.chain_start[c] = i; dm.chain_len[c] = 1;
       }
     }
+    for (int c = 0; c < dm.n_chains; ++c) if (dm.chain_len[c] > MAXCHAIN) return "a chain of the kinematic tree is longer than MAXCHAIN bodies";
     for (int i = 0; i < NB; ++i) {
       int path[NB], n = 0;
       for (int a = i; a > 0; a = dm.parent[a]) path[n++] = a;

@@ -30,7 +30,6 @@ struct StageWST {
   int n_chains, n_cphases;
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
-  double Mq[NB][9];                // Rfix * Rot(axis, q): joint rotation in the parent body frame
   double ecs[3][2];                // cos, sin of the euler angles z, y, x
   // ---- base
   double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
@@ -40,7 +39,13 @@ struct StageWST {
   double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
   // ---- bodies
   double R[NB][9], r[NB][3];       // world rotation, origin relative to the base origin O
-  double In[NB][10], f[NB][6];
+  union {
+    struct {                       // placement walk (phases F0-F1):
+      double Mq[NB][9];            //   Rfix * Rot(axis, q): joint rotation in the parent body frame
+      double pa[NB][6];            //   joint offset and joint axis in the parent body frame (copied next to Mq: they sit on the walk's serial path)
+    };
+    struct { double In[NB][10], f[NB][6]; };   // spatial inertia about O and net force per body (from the inertia phase on)
+  };
   union {
     double BB[D ? NB : 1][36];     // per-body BB (dead once the composites are formed)
     double G[D ? 6 : 1][96];       // d ab / d[x;u], columns 0..92 used (written after the composites)
@@ -133,6 +138,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     sincos(ws.q[5 + i], &sn, &cs);
     rot_axis_cs(dm.axis[i], cs, sn, Rq);
     m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
+    for (int k = 0; k < 3; ++k) { ws.pa[i][k] = dm.pfix[i][k]; ws.pa[i][3 + k] = dm.axis_p[i][k]; }
   }
   WG_SYNC(ctx);
   // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
@@ -168,11 +174,12 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     for (int n = 0; n < NANC; ++n) {
       const int i = ws.anc[end][n];
       const double* M = ws.Mq[i];
+      const double* pa = ws.pa[i];
       const double rn0 = Rp[0] * M[0] + Rp[1] * M[3] + Rp[2] * M[6];
       const double rn1 = Rp[0] * M[1] + Rp[1] * M[4] + Rp[2] * M[7];
       const double rn2 = Rp[0] * M[2] + Rp[1] * M[5] + Rp[2] * M[8];
-      const double rr = rp + Rp[0] * dm.pfix[i][0] + Rp[1] * dm.pfix[i][1] + Rp[2] * dm.pfix[i][2];
-      const double w = Rp[0] * dm.axis_p[i][0] + Rp[1] * dm.axis_p[i][1] + Rp[2] * dm.axis_p[i][2];
+      const double rr = rp + Rp[0] * pa[0] + Rp[1] * pa[1] + Rp[2] * pa[2];
+      const double w = Rp[0] * pa[3] + Rp[1] * pa[4] + Rp[2] * pa[5];
       if (n < na) {
         if (i >= b0) { ws.R[i][3 * r] = rn0; ws.R[i][3 * r + 1] = rn1; ws.R[i][3 * r + 2] = rn2; ws.r[i][r] = rr; ws.S[i + 2][r] = w; }
         Rp[0] = rn0; Rp[1] = rn1; Rp[2] = rn2; rp = rr;
@@ -193,9 +200,13 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
       double sa = 0.0;
 #pragma unroll
       for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself: the last term is always the own axis
+        // branch-free: sa = p1 S[j1] - p2 S[j2] with (p1, j1, p2, j2) = (1, k, 0, k) for the angular rows, (r[k1], k2, r[k2], k1) for the linear
         const int a = ws.anc[i][n];
-        sa = k < 3 ? ws.S[a + 2][k] : ws.r[a][k1] * ws.S[a + 2][k2] - ws.r[a][k2] * ws.S[a + 2][k1];
-        s += (n < na ? ws.v[5 + a] : 0.0) * sa;
+        const double r1 = ws.r[a][k1], r2 = ws.r[a][k2];
+        const double s1 = ws.S[a + 2][k < 3 ? k : k2], s2 = ws.S[a + 2][k < 3 ? k : k1];
+        const double qa = ws.v[5 + a];
+        sa = (k < 3 ? 1.0 : r1) * s1 - (k < 3 ? 0.0 : r2) * s2;
+        s += (n < na ? qa : 0.0) * sa;
       }
       if (k >= 3) ws.S[jc][k] = sa;
     }
@@ -284,16 +295,20 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
         const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
         double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
         const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
-        const int b0 = ws.chain_start[ch];
+        const int b0 = ws.chain_start[ch], len = ws.chain_len[ch];
         double s = 0.0;
-        for (int i = b0 + ws.chain_len[ch] - 1; i >= b0; --i) {
+        // fixed trip count (chains have at most MAXCHAIN bodies), clamped indices, masks on the VALUES: the index and operand
+        // loads of all iterations are independent of the running sum
+#pragma unroll
+        for (int n = 0; n < MAXCHAIN; ++n) {
+          const bool valid = n < len;
+          const int i = valid ? b0 + len - 1 - n : b0;
           const int c0 = ws.xchild[i][0], c1 = ws.xchild[i][1], c2 = ws.xchild[i][2];
-          double t = own[i * st];
-          if (c0 != 255) t += comp[c0 * st];
-          if (c1 != 255) t += comp[c1 * st];
-          if (c2 != 255) t += comp[c2 * st];
-          s += t;
-          comp[i * st] = s;
+          const double o = own[i * st];
+          const double v0 = comp[(c0 != 255 ? c0 : i) * st], v1 = comp[(c1 != 255 ? c1 : i) * st], v2 = comp[(c2 != 255 ? c2 : i) * st];
+          const double t = o + (c0 != 255 ? v0 : 0.0) + (c1 != 255 ? v1 : 0.0) + (c2 != 255 ? v2 : 0.0);
+          s += valid ? t : 0.0;
+          if (valid) comp[i * st] = s;
         }
       }
       if (ph + 1 < ws.n_cphases) WG_SYNC(ctx);
