@@ -263,6 +263,8 @@ struct hsqp_handle {
   LsState* d_ls = nullptr;
   int* d_counts = nullptr;
   hsqp_linesearch_settings ls_settings;
+  void* d_stage = nullptr;        // grow-only staging area for the small per-call inputs (reference, policy queries)
+  size_t stage_bytes = 0;
   bool ls_ran = false;
   long long* d_prof = nullptr;   // [4][128] phase-profile ticks (k_lq<true>, k_project, k_riccati, k_lq<false>)
   int B = 0, N = 0;
@@ -283,6 +285,18 @@ static std::string g_create_error;
     }                                                                                                  \
   } while (0)
 
+// grow-only device staging area of the handle (256-byte aligned carving by the callers)
+static void* stage_area(hsqp_handle* h, size_t bytes) {
+  if (bytes > h->stage_bytes) {
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    h->d_stage = nullptr; h->stage_bytes = 0;
+    if (hipMalloc(&h->d_stage, bytes) != hipSuccess) return nullptr;
+    h->stage_bytes = bytes;
+  }
+  return h->d_stage;
+}
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
 extern "C" {
 
 const char* hsqp_version(void) { return "hsqp-hip 0.1 (gfx950, f64)"; }
@@ -299,7 +313,7 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf};
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -408,16 +422,18 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
     if (r->n_events[b] < 1 || r->n_events[b] > r->max_events) { h->err = "n_events outside [1, max_events]"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes, E = r->max_events, K = r->n_knots;
-  // staging buffers for the compact reference (a few KB per instance)
-  int *d_ne = nullptr, *d_seq = nullptr, *d_bad = nullptr;
-  double *d_ev = nullptr, *d_tt = nullptr, *d_ts = nullptr;
-  auto release = [&]() { for (void* q : {(void*)d_ne, (void*)d_seq, (void*)d_bad, (void*)d_ev, (void*)d_tt, (void*)d_ts}) if (q) (void)hipFree(q); };
-  if (hipMalloc(&d_ne, B * 4) != hipSuccess || hipMalloc(&d_seq, B * (E + 1) * 4) != hipSuccess || hipMalloc(&d_bad, 4) != hipSuccess ||
-      hipMalloc(&d_ev, B * E * 8) != hipSuccess || hipMalloc(&d_tt, B * K * 8) != hipSuccess || hipMalloc(&d_ts, B * K * NX * 8) != hipSuccess) {
-    release();
-    h->err = "hipMalloc failed (reference staging)";
-    return HSQP_ERR_OOM;
-  }
+  // staging area for the compact reference (a few KB per instance)
+  const size_t o_ne = 0, o_seq = o_ne + align256(B * 4), o_bad = o_seq + align256(B * (E + 1) * 4), o_ev = o_bad + 256,
+               o_tt = o_ev + align256(B * E * 8), o_ts = o_tt + align256(B * K * 8), total = o_ts + align256(B * K * NX * 8);
+  char* base = static_cast<char*>(stage_area(h, total));
+  if (!base) { h->err = "hipMalloc failed (reference staging)"; return HSQP_ERR_OOM; }
+  int* d_ne = reinterpret_cast<int*>(base + o_ne);
+  int* d_seq = reinterpret_cast<int*>(base + o_seq);
+  int* d_bad = reinterpret_cast<int*>(base + o_bad);
+  double* d_ev = reinterpret_cast<double*>(base + o_ev);
+  double* d_tt = reinterpret_cast<double*>(base + o_tt);
+  double* d_ts = reinterpret_cast<double*>(base + o_ts);
+  auto release = []() {};
   int rc = HSQP_OK;
   auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
   step(hipMemcpyAsync(d_ne, r->n_events, B * 4, hipMemcpyHostToDevice, h->stream), "upload n_events");
@@ -564,11 +580,16 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 
 static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s_or_x, const double* u_in, double* x_out, double* u_out, double* tau) {
   HCHECK(hipSetDevice(h->device));
-  double *d_in = nullptr, *d_x = nullptr, *d_u = nullptr, *d_tau = nullptr;
   const size_t nin = from_solution ? (size_t)n : (size_t)n * (NX + NU);
-  auto release = [&]() { for (double* q : {d_in, d_x, d_u, d_tau}) if (q) (void)hipFree(q); };
-  if (hipMalloc(&d_in, nin * 8) != hipSuccess || hipMalloc(&d_x, (size_t)n * NX * 8) != hipSuccess || hipMalloc(&d_u, (size_t)n * NU * 8) != hipSuccess ||
-      hipMalloc(&d_tau, (size_t)n * NJ * 8) != hipSuccess) { release(); h->err = "hipMalloc failed (policy evaluation)"; return HSQP_ERR_OOM; }
+  const size_t o_in = 0, o_x = o_in + align256(nin * 8), o_u = o_x + align256((size_t)n * NX * 8), o_tau = o_u + align256((size_t)n * NU * 8),
+               total = o_tau + align256((size_t)n * NJ * 8);
+  char* base = static_cast<char*>(stage_area(h, total));
+  if (!base) { h->err = "hipMalloc failed (policy evaluation staging)"; return HSQP_ERR_OOM; }
+  double* d_in = reinterpret_cast<double*>(base + o_in);
+  double* d_x = reinterpret_cast<double*>(base + o_x);
+  double* d_u = reinterpret_cast<double*>(base + o_u);
+  double* d_tau = reinterpret_cast<double*>(base + o_tau);
+  auto release = []() {};
   int rc = HSQP_OK;
   auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
   if (from_solution) {
