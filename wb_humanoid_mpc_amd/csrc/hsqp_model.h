@@ -297,18 +297,15 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
         const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
         const int b0 = ws.chain_start[ch], len = ws.chain_len[ch];
         double s = 0.0;
-        // fixed trip count (chains have at most MAXCHAIN bodies), clamped indices, masks on the VALUES: the index and operand
-        // loads of all iterations are independent of the running sum
-#pragma unroll
-        for (int n = 0; n < MAXCHAIN; ++n) {
-          const bool valid = n < len;
-          const int i = valid ? b0 + len - 1 - n : b0;
+        // trip count = chain length (uniform over the active items of the later phases: the waist chain, the base); clamped
+        // child indices with masks on the VALUES keep the loads of an iteration independent of each other
+        for (int n = 0; n < len; ++n) {
+          const int i = b0 + len - 1 - n;
           const int c0 = ws.xchild[i][0], c1 = ws.xchild[i][1], c2 = ws.xchild[i][2];
           const double o = own[i * st];
           const double v0 = comp[(c0 != 255 ? c0 : i) * st], v1 = comp[(c1 != 255 ? c1 : i) * st], v2 = comp[(c2 != 255 ? c2 : i) * st];
-          const double t = o + (c0 != 255 ? v0 : 0.0) + (c1 != 255 ? v1 : 0.0) + (c2 != 255 ? v2 : 0.0);
-          s += valid ? t : 0.0;
-          if (valid) comp[i * st] = s;
+          s += o + (c0 != 255 ? v0 : 0.0) + (c1 != 255 ? v1 : 0.0) + (c2 != 255 ? v2 : 0.0);
+          comp[i * st] = s;
         }
       }
       if (ph + 1 < ws.n_cphases) WG_SYNC(ctx);
