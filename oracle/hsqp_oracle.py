@@ -169,3 +169,32 @@ class Oracle:
         d1, d2 = C.c_double(), C.c_double()
         p = self.lib.orc_penalty(kind, C.c_double(mu), C.c_double(delta), C.c_double(h), C.byref(d1), C.byref(d2))
         return p, d1.value, d2.value
+
+    # ---- groundwork for the centroidal formulation (oracle/centroidal.hpp; no product path yet)
+    # index layout of humanoid_centroidal_mpc/common/CentroidalMpcRobotModel.h:89-95
+    CENT_NX, CENT_NU = 12 + _abi.NJ, 12 + _abi.NJ
+    CENT_BASE_START, CENT_JOINT_START, CENT_JOINT_VEL_START = 6, 12, 12
+
+    def cent_momentum_matrix(self, q):
+        q = _c(q)
+        A, com = np.zeros((6, NV)), np.zeros(3)
+        self.lib.orc_cent_momentum_matrix(self.h, _p(q), _p(A), _p(com))
+        return A, com
+
+    def cent_momentum_rate(self, q, u):
+        q, u = _c(q), _c(u)
+        out = np.zeros(6)
+        self.lib.orc_cent_momentum_rate(self.h, _p(q), _p(u), _p(out))
+        return out
+
+    def cent_flow_map(self, x, u):
+        x, u = _c(x), _c(u)
+        out = np.zeros(self.CENT_NX)
+        self.lib.orc_cent_flow_map(self.h, _p(x), _p(u), _p(out))
+        return out
+
+    def cent_flow_map_jac(self, x, u):
+        x, u = _c(x), _c(u)
+        out, J = np.zeros(self.CENT_NX), np.zeros((self.CENT_NX, self.CENT_NX + self.CENT_NU))
+        self.lib.orc_cent_flow_map_jac(self.h, _p(x), _p(u), _p(out), _p(J))
+        return out, J

@@ -1167,3 +1167,5 @@ double orc_penalty(int kind, double mu, double delta, double hval, double* d1, d
 }
 
 }  // extern "C"
+
+#include "centroidal.hpp"   // groundwork for the centroidal formulation: flow map only
