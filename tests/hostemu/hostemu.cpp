@@ -22,23 +22,6 @@ void* emu_create(const hsqp_model_desc* md, char* err, int errlen) {
 }
 void emu_destroy(void* h) { delete static_cast<DevModel*>(h); }
 
-// composite-sum schedule of the kinematic tree: returns 0 if every chain is summed in a later phase than all chains hanging
-// off it (the device relies on this ordering: the phases are separated by barriers)
-int emu_check_composite_schedule(void* h, int* n_phases) {
-  const DevModel& dm = *static_cast<DevModel*>(h);
-  *n_phases = dm.n_cphases;
-  int chain_of[NB];
-  for (int c = 0; c <= dm.n_chains; ++c)
-    for (int i = dm.chain_start[c]; i < dm.chain_start[c] + dm.chain_len[c]; ++i) chain_of[i] = c;
-  for (int c = 0; c <= dm.n_chains; ++c) {
-    if (dm.cphase[c] >= dm.n_cphases) return 2;
-    for (int i = dm.chain_start[c]; i < dm.chain_start[c] + dm.chain_len[c]; ++i)
-      for (int k = 0; k < 3; ++k)
-        if (dm.xchild[i][k] != 255 && dm.cphase[chain_of[dm.xchild[i][k]]] >= dm.cphase[c]) return 1;
-  }
-  return 0;
-}
-
 // base acceleration and its Jacobian (6 x 93) at (x, u)
 void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double* ab, double* G) {
   const DevModel& dm = *static_cast<DevModel*>(h);

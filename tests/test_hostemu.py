@@ -74,16 +74,6 @@ def test_full_iteration_matches_oracle(model, oracle, emu, gait, n):
         assert np.allclose(got, [want["cost"], want["dynamics_sse"], want["equality_sse"]], rtol=1e-9, atol=1e-12)
 
 
-def test_composite_sum_schedule_orders_every_chain_after_its_children(emu):
-    """The subtree sums run chain by chain in barrier-separated phases; a chain must come strictly after every chain hanging
-    off it (a same-phase dependency is a data race on the device that a sequential emulation cannot see).  G1: legs and arms
-    first, then the waist chain, then the base."""
-    lib, h = emu
-    n = C.c_int(0)
-    assert lib.emu_check_composite_schedule(h, C.byref(n)) == 0
-    assert n.value == 3
-
-
 @pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14)])
 def test_phases_are_free_of_intra_phase_dependencies(model, emu, gait, n):
     """Race check: the same kernel sources built with every phase executing its work items in REVERSE order

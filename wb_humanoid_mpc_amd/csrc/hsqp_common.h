@@ -106,16 +106,13 @@ struct DevModel {
   double pfix[NB][3];
   double axis[NB][3];
   double axis_p[NB][3];            // Rfix * axis: joint axis in the parent body frame
-  // chains: maximal single-child paths (the placement walk runs per chain end)
+  // chains: maximal single-child paths of consecutive bodies (the placement walk runs per chain end, the composite sums per
+  // chain); chain n_chains is the base alone
   int n_chains;
   int chain_start[NB], chain_len[NB];
   // ancestor path of every body (root-most moving body first, the body itself last; the base is not listed)
   int n_anc[NB];
   unsigned char anc[NB][NANC];
-  // composite (subtree) sums run chain by chain from the leaves: comp_i = own_i + comp_{i+1 in the same chain} + comp of
-  // the chains hanging off body i (xchild, 255 = none).  Chain n_chains is the base alone.  cphase: 0 = leaf chains.
-  int n_cphases;
-  unsigned char cphase[NB], xchild[NB][3];
   double mass[NB];
   double com[NB][3];
   double inertia[NB][9];          // about com, body axes

@@ -68,28 +68,7 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
       dm.n_anc[i] = n;
       for (int k = 0; k < NANC; ++k) dm.anc[i][k] = (unsigned char)(k < n ? path[n - 1 - k] : i);   // padded with the body itself (valid index)
     }
-    // chains hanging off a body, and the leaves-first order of the chains (the base is chain n_chains)
-    for (int i = 0; i < NB; ++i) for (int k = 0; k < 3; ++k) dm.xchild[i][k] = 255;
-    dm.chain_start[dm.n_chains] = 0; dm.chain_len[dm.n_chains] = 1;
-    for (int c = 0; c < dm.n_chains; ++c) {
-      const int p = dm.parent[dm.chain_start[c]];
-      int k = 0;
-      while (k < 3 && dm.xchild[p][k] != 255) ++k;
-      if (k == 3) return "a body carries more than three chains";
-      dm.xchild[p][k] = (unsigned char)dm.chain_start[c];
-    }
-    dm.n_cphases = 0;
-    // chains are numbered in depth-first order (children have larger indices), the base — chain n_chains — comes last:
-    // every chain's phase is computed after the phases of all chains hanging off it
-    for (int cc_ = dm.n_chains; cc_ >= 0; --cc_) {
-      const int c = cc_ == 0 ? dm.n_chains : cc_ - 1;
-      int ph = 0;
-      for (int i = dm.chain_start[c]; i < dm.chain_start[c] + dm.chain_len[c]; ++i)
-        for (int k = 0; k < 3; ++k)
-          if (dm.xchild[i][k] != 255) { const int cc = chain_of[dm.xchild[i][k]]; if (dm.cphase[cc] + 1 > ph) ph = dm.cphase[cc] + 1; }
-      dm.cphase[c] = (unsigned char)ph;
-      if (ph + 1 > dm.n_cphases) dm.n_cphases = ph + 1;
-    }
+    dm.chain_start[dm.n_chains] = 0; dm.chain_len[dm.n_chains] = 1;   // the base
     for (int i = 1; i < NB; ++i) {
       const hsqp_body& b = md.bodies[i];
       for (int r = 0; r < 3; ++r) dm.axis_p[i][r] = b.R[3 * r] * b.axis[0] + b.R[3 * r + 1] * b.axis[1] + b.R[3 * r + 2] * b.axis[2];

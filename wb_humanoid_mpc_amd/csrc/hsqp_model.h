@@ -26,8 +26,8 @@ template <bool D>
 struct StageWST {
   // ---- tree topology used by the placement walk and the ancestor sums (copied from DevModel once per workgroup:
   //      these indices sit in front of dependent loads)
-  unsigned char anc[NB][NANC], n_anc[NB], chain_start[NB], chain_len[NB], cphase[NB], xchild[NB][3];
-  int n_chains, n_cphases;
+  unsigned char anc[NB][NANC], n_anc[NB], chain_start[NB], chain_len[NB], sub[NB];   // sub: subtree size
+  int n_chains;
   // ---- inputs of one evaluation
   double q[NV], v[NV], qddj[NJ], W[12];
   double ecs[3][2];                // cos, sin of the euler angles z, y, x
@@ -117,9 +117,8 @@ HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
     else {
       const int b = i - NB * NANC;
       ws.n_anc[b] = (unsigned char)dm.n_anc[b]; ws.chain_start[b] = (unsigned char)dm.chain_start[b]; ws.chain_len[b] = (unsigned char)dm.chain_len[b];
-      ws.cphase[b] = dm.cphase[b];
-      for (int k = 0; k < 3; ++k) ws.xchild[b][k] = dm.xchild[b][k];
-      if (b == 0) { ws.n_chains = dm.n_chains; ws.n_cphases = dm.n_cphases; }
+      ws.sub[b] = (unsigned char)dm.subtree_size[b];
+      if (b == 0) ws.n_chains = dm.n_chains;
     }
   }
   WG_SYNC(ctx);
@@ -286,29 +285,30 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 23);
-    // composites over subtrees, chain by chain from the leaves (item = chain x quantity, running sum in a register):
-    // comp_i = own_i + comp_{i+1} + comp of the chains hanging off body i
-    for (int ph = 0; ph < ws.n_cphases; ++ph) {
-      WG_FOR(ctx, it, (ws.n_chains + 1) * 52) {
-        const int ch = it / 52, e = it % 52;
-        if (ws.cphase[ch] != ph) continue;
-        const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
-        double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
-        const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
-        const int b0 = ws.chain_start[ch], len = ws.chain_len[ch];
-        double s = 0.0;
-        // trip count = chain length (uniform over the active items of the later phases: the waist chain, the base); clamped
-        // child indices with masks on the VALUES keep the loads of an iteration independent of each other
-        for (int n = 0; n < len; ++n) {
-          const int i = b0 + len - 1 - n;
-          const int c0 = ws.xchild[i][0], c1 = ws.xchild[i][1], c2 = ws.xchild[i][2];
-          const double o = own[i * st];
-          const double v0 = comp[(c0 != 255 ? c0 : i) * st], v1 = comp[(c1 != 255 ? c1 : i) * st], v2 = comp[(c2 != 255 ? c2 : i) * st];
-          s += o + (c0 != 255 ? v0 : 0.0) + (c1 != 255 ? v1 : 0.0) + (c2 != 255 ? v2 : 0.0);
-          comp[i * st] = s;
+    // composites over subtrees, comp_i = sum of own_j over the depth-first range [i, i + sub_i), in ONE phase: an item
+    // (chain, quantity) runs down the whole range of the chain's first body and records the running sum at the bodies of
+    // the chain itself, which lead the range (the rest of the range are the subtrees of the chains hanging off it; their
+    // composites are formed by their own items from the same `own` data, so no item reads another item's result).  The
+    // loads have contiguous, sum-independent addresses; only the additions are chained.
+    WG_FOR(ctx, it, (ws.n_chains + 1) * 52) {
+      const int ch = it / 52, e = it % 52;
+      const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
+      double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
+      const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
+      const int b0 = ws.chain_start[ch], len = ws.chain_len[ch], sz = ws.sub[b0];
+      double s = 0.0;
+      // blocks of 8 from the far end of the range: the 8 loads of a block are issued together (clamped index, masked use)
+      for (int n0 = sz; n0 > 0; n0 -= 8) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int n = n0 - 1 - t; v[t] = own[(b0 + (n >= 0 ? n : 0)) * st]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int n = n0 - 1 - t;
+          s += n >= 0 ? v[t] : 0.0;
+          if (n >= 0 && n < len) comp[(b0 + n) * st] = s;
         }
       }
-      if (ph + 1 < ws.n_cphases) WG_SYNC(ctx);
     }
   } else {
     WG_FOR(ctx, e, 16) {
