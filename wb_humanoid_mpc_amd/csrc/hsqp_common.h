@@ -54,8 +54,18 @@ struct Ctx {
       (ctx).prof[127] = t_;                                                          \
     }                                                                                \
   } while (0)
+// per-wave arrival times at the barrier that ends a phase: PH_MARK after the barrier that starts it, PH_ARRIVE(slot 0..8)
+// before the one that ends it; lane 0 of every wave accumulates into prof[40 + 8 * slot + wave] (up to 8 waves)
+#define PH_MARK(ctx)                                                                                     \
+  do { if (((ctx).tid & 63) == 0 && (ctx).prof) (ctx).prof[112 + ((ctx).tid >> 6)] = clock64(); } while (0)
+#define PH_ARRIVE(ctx, slot)                                                                             \
+  do {                                                                                                   \
+    if (((ctx).tid & 63) == 0 && (ctx).prof) (ctx).prof[40 + 8 * (slot) + ((ctx).tid >> 6)] += clock64() - (ctx).prof[112 + ((ctx).tid >> 6)]; \
+  } while (0)
 #else
 #define PH_TICK(ctx, id) ((void)0)
+#define PH_MARK(ctx) ((void)0)
+#define PH_ARRIVE(ctx, slot) ((void)0)
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -110,6 +110,19 @@ HSQP_HD void copy_batch(int b, int count, const double* src, Dst dst) {
 #pragma unroll
   for (int j = 0; j < NBATCH; ++j) { const int idx = b + j * nb; if (idx < count) dst(idx, t[j]); }
 }
+// The two halves of copy_batch, for items that do other work between issuing the loads and storing the values.
+template <int NBATCH>
+HSQP_HD void load_batch(int b, int count, const double* src, double* t) {
+  const int nb = (count + NBATCH - 1) / NBATCH;
+#pragma unroll
+  for (int j = 0; j < NBATCH; ++j) { const int idx = b + j * nb; t[j] = (b < nb && idx < count) ? src[idx] : 0.0; }
+}
+template <int NBATCH, class Dst>
+HSQP_HD void store_batch(int b, int count, const double* t, Dst dst) {
+  const int nb = (count + NBATCH - 1) / NBATCH;
+#pragma unroll
+  for (int j = 0; j < NBATCH; ++j) { const int idx = b + j * nb; if (b < nb && idx < count) dst(idx, t[j]); }
+}
 constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nbatch; }
 
 
@@ -143,6 +156,11 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   return j;
 }
 
+#if defined(HSQP_PHASE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define XTY_PROF_T(name) const long long name = clock64()
+#else
+#define XTY_PROF_T(name) ((void)0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) * hsqp_gcptr;
@@ -153,7 +171,8 @@ typedef double __attribute__((address_space(1))) * hsqp_gptr;
 // GLOBAL memory -> address-space-qualified accesses.  A generic pointer compiles to FLAT instructions, whose loads also
 // count on lgkmcnt and make the LDS operand waits of the MFMA loop wait for the L2/HBM round trip.
 template <int NT, int SPACES>
-HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
+HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long long* prof = nullptr) {
+  XTY_PROF_T(t_begin);
   const int tn = (j.N + 15) >> 4;
   const int i = lane & 15, kk = lane >> 4;
   int r0[NT], c0[NT], xr[NT], yc[NT];
@@ -176,9 +195,11 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int cc = c0[t] + i < j.N ? c0[t] + i : j.N - 1;
+      const int rb = r0[t] + kk;
+      const bool inside = r0[t] + 16 <= j.M;   // uniform
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = r0[t] + kk + 4 * r, rc = row < j.M ? row : j.M - 1;
+        const int row = rb + 4 * r, rc = (inside || row < j.M) ? row : j.M - 1;
         if (SPACES & XTY_ADD_GLOBAL) addv[t][r] = ((hsqp_gcptr)j.Add)[rc * j.ldadd + cc];
         else addv[t][r] = j.Add[rc * j.ldadd + cc];
       }
@@ -189,6 +210,7 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) addv[t][r] = 0.0;
   }
+  XTY_PROF_T(t_loop);
   for (int k0 = 0; k0 < j.L1; k0 += 4) {
     const int k = k0 + kk;
     const bool ok = k < j.L1;
@@ -209,26 +231,43 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane) {
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
+  XTY_PROF_T(t_epi);
+  // epilogue: one address per tile (rows r0 + kk + 4 r are 4 ldc apart: constant offsets), a uniform fast path for tiles that
+  // lie inside the matrix in the row direction (no per-element predicate), no arithmetic when there is nothing to add
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int c = c0[t] + i;
     if (c < j.N) {
+      const int rb = r0[t] + kk;
+      const bool mirror = j.sym && r0[t] != c0[t];
+      const int o1 = rb * j.ldc + c, o2 = c * j.ldc + rb;
+      double v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0[t] + kk + 4 * r;
-        if (row < j.M) {
-          const double v = j.scale * acc[t][r] + addv[t][r];
-          if (SPACES & XTY_C_GLOBAL) {
-            ((hsqp_gptr)j.C)[row * j.ldc + c] = v;
-            if (j.sym && r0[t] != c0[t]) ((hsqp_gptr)j.C)[c * j.ldc + row] = v;
-          } else {
-            j.C[row * j.ldc + c] = v;
-            if (j.sym && r0[t] != c0[t]) j.C[c * j.ldc + row] = v;
-          }
+      for (int r = 0; r < 4; ++r) v[r] = j.Add ? j.scale * acc[t][r] + addv[t][r] : j.scale * acc[t][r];
+      auto put = [&](int r) {
+        if (SPACES & XTY_C_GLOBAL) {
+          ((hsqp_gptr)j.C)[o1 + 4 * r * j.ldc] = v[r];
+          if (mirror) ((hsqp_gptr)j.C)[o2 + 4 * r] = v[r];
+        } else {
+          j.C[o1 + 4 * r * j.ldc] = v[r];
+          if (mirror) j.C[o2 + 4 * r] = v[r];
         }
+      };
+      if (r0[t] + 16 <= j.M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put(r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (rb + 4 * r < j.M) put(r);
       }
     }
   }
+#if defined(HSQP_PHASE_PROFILE)
+  if (prof && lane == 0) {   // wave 0 of workgroup 0: prologue / matrix loop / epilogue ticks, number of calls, matrix instructions
+    const long long t_end = clock64();
+    prof[90] += t_loop - t_begin; prof[91] += t_epi - t_loop; prof[92] += t_end - t_epi; prof[93] += 1; prof[94] += NT * (((j.L1 + 3) >> 2) + ((j.L2 + 3) >> 2));
+  }
+#endif
 }
 #endif
 
@@ -243,13 +282,13 @@ HSQP_HD int xty_tile_id(int sym, int tn, int t) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // tiles are numbered globally (base + t) and dealt round-robin to the waves; a wave takes its tiles two at a time
 template <int SPACES>
-HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane) {
+HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane, long long* prof = nullptr) {
   const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
   const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
   const int sym = j.sym;
   int t = (wave - base) & (nwaves - 1);   // round-robin over the waves (their number is a power of two)
-  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane); }
-  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane); }
+  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane, prof); }
+  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane, prof); }
   return nt;
 }
 #endif
@@ -262,11 +301,16 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wave = ctx.tid >> 6, nwaves = ctx.nthreads >> 6, lane = ctx.tid & 63;
   int base = 0;
+#if defined(HSQP_PHASE_PROFILE)
+  long long* prof = wave == 0 ? ctx.prof : nullptr;
+#else
+  long long* prof = nullptr;
+#endif
   if constexpr (UNROLL) {
 #pragma unroll
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane, prof);
   } else {
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane, prof);
   }
 #else
   for (int jn = 0; jn < njobs; ++jn) {

@@ -25,8 +25,9 @@ constexpr int RIC_KV = RIC_K + NUT * NX;       // [23]     feed-forward   k = -L
 constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
 constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
-constexpr int EM_G = NUT, EM_GV = NUT + NX, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns
+constexpr int EM_GVP = 0, EM_G = NUT, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns; 0..3: partial sums of g
 
+constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
   union {
     double S[NX][NX];
@@ -41,10 +42,10 @@ struct RicWS {
     double SB[NX][LDB];
     double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam is formed)
   };
-  double Em[NUT][LDE];                         // [Lam | G -> K | g | B^T]
+  double Em[NUT][LDE];                         // [g partials (4) . | G -> K | . | B^T]
   double dsq[LDB];
-  double sv[NX], sn[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];
-  double part[NX * 4];
+  double sv[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];
+  double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of Acl dx (forward sweep)
   int ok;
 };
 
@@ -81,6 +82,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     double(*A)[NX] = w.A2[k & 1];
     double(*An)[NX] = w.A2[(k + 1) & 1];
     PH_TICK(ctx, 1);
+    PH_MARK(ctx);
     // ---- P2: SA = S A, SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
     {
       const XtyJob jobs[2] = {xty_job(NX, NX, NX, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
@@ -88,17 +90,22 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, r, NX) w.sb[r] = w.sv[r] + dot_strided<NX>(&w.S[0][r], NX, w.bt);
-        // first half of the next stage's A~ into the other buffer (second half in P3): one batch of loads per phase, so the
-        // L2/HBM round trip hides behind this phase's matrix-core work
+        // first half of the next stage's A~ into the other buffer (second half in P3).  One item = one batch of global loads,
+        // issued FIRST; the item's LDS-only work (a row of sb) runs under their L2/HBM round trip; the stores come last.
         constexpr int nh = (NX * NX) / 2, na = nbatches(nh, 7);
-        WG_FOR(hc, it, na) {
-          if (k > 0) copy_batch<7>(it, nh, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
+        static_assert(na <= RIC_HELPERS && NX <= RIC_HELPERS, "one pass");
+        WG_FOR(hc, it, RIC_HELPERS) {
+          double t[7];
+          if (k > 0) load_batch<7>(it, nh, qn + QP_A, t);
+          if (it < NX) w.sb[it] = w.sv[it] + dot_strided<NX>(&w.S[0][it], NX, w.bt);
+          if (k > 0) store_batch<7>(it, nh, t, [&](int i, double v) { An[i / NX][i % NX] = v; });
         }
       }
     }
+    PH_ARRIVE(ctx, 0);
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
+    PH_MARK(ctx);
     // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
     {
       const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
@@ -107,16 +114,28 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, na) {
-          if (k > 0) copy_batch<7>(it, NX * NX - nh, qn + QP_A + nh, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
+        // same structure as in P2: global loads (second half of the next A~, r~) first, then the LDS-only work of the item
+        // (row of g, a slice of B^T and of the identity block of [Lam | I]), then the stores of the loaded values
+        static_assert(na <= RIC_HELPERS && 4 * NUT <= RIC_HELPERS, "one pass");
+        WG_FOR(hc, it, RIC_HELPERS) {
+          double t[7];
+          if (k > 0) load_batch<7>(it, NX * NX - nh, qn + QP_A + nh, t);
+          const double rv = (it < 4 * NUT && (it & 3) == 0) ? q[QP_RV + (it >> 2)] : 0.0;
+          for (int j = it; j < NUT * NX; j += RIC_HELPERS) { const int r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
+          for (int j = it; j < NUT * (LDF - NUT); j += RIC_HELPERS) { const int r = j / (LDF - NUT), c = NUT + j % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
+          if (it < 4 * NUT) {   // g = r~ + B^T sb in four partial sums per row (columns 0..3 of Em, added where g is used)
+            const int r = it >> 2, p = it & 3;
+            constexpr int LA = (NX + 3) / 4;
+            double sg = rv;
+#pragma unroll
+            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NX ? ll : NX - 1; const double a = w.B[lc][r], b = w.sb[lc]; sg += ll < NX ? a * b : 0.0; }
+            w.Em[r][EM_GVP + p] = sg;
+          }
+          if (k > 0) store_batch<7>(it, NX * NX - nh, t, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
         }
-        WG_FOR(hc, it, NUT + NUT * NX) {
-          if (it < NUT) w.Em[it][EM_GV] = q[QP_RV + it] + dot_strided<NX>(&w.B[0][it], LDB, w.sb);
-          else { const int j = it - NUT, r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
-        }
-        WG_FOR(hc, it, NUT * (LDF - NUT)) { const int r = it / (LDF - NUT), c = NUT + it % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
       }
     }
+    PH_ARRIVE(ctx, 1);
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
     bool prefetched_b = false;
@@ -194,7 +213,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         WG_FOR(hc, r, NUT) {
           double s = 0.0;
 #pragma unroll
-          for (int l = 0; l < NUT; ++l) s += w.fac.Ef[r][EF_MI + l] * w.Em[l][EM_GV];
+          for (int l = 0; l < NUT; ++l) s += w.fac.Ef[r][EF_MI + l] * ((w.Em[l][EM_GVP] + w.Em[l][EM_GVP + 1]) + (w.Em[l][EM_GVP + 2] + w.Em[l][EM_GVP + 3]));
           w.zv[r] = s;
         }
       }
@@ -217,6 +236,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 4);
+    PH_MARK(ctx);
     // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A + B K, s <- q + A^T sb - Z^T z, bcl = b + B k ; K -> record;
     //          prefetch of the next stage's B~, b~ (B is dead since P3)
     {
@@ -228,21 +248,24 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, 2 * NX + NUT * NX) {
-          if (it < NX) {
-            const int r = it;
-            double s = q[QP_QV + r] + dot_strided<NX>(&A[0][r], NX, w.sb);
+        WG_FOR(hc, it, 5 * NX + NUT * NX) {
+          if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in P6): short chains, 232 lanes
+            const int r = it >> 2, p = it & 3;
+            constexpr int LA = (NX + 3) / 4, LZ = (NUT + 3) / 4;
+            double s = p == 0 ? q[QP_QV + r] : 0.0;
 #pragma unroll
-            for (int l = 0; l < NUT; ++l) s -= w.Zs[l][r] * w.zv[l];
-            w.sn[r] = s;
-          } else if (it < 2 * NX) {
-            const int r = it - NX;
+            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NX ? ll : NX - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NX ? a * b : 0.0; }
+#pragma unroll
+            for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
+            w.part[it] = s;
+          } else if (it < 5 * NX) {
+            const int r = it - 4 * NX;
             double s = w.bt[r];
 #pragma unroll
             for (int l = 0; l < NUT; ++l) s += w.Em[l][EM_BT + r] * w.kv[l];
             rk[RIC_BCL + r] = s;
           } else {
-            const int j = it - 2 * NX;
+            const int j = it - 5 * NX;
             rk[RIC_K + j] = w.Em[j / NX][EM_G + j % NX];
           }
         }
@@ -261,6 +284,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         }
       }
     }
+    PH_ARRIVE(ctx, 2);
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
     // ---- P6: symmetrise S inside the diagonal tiles (the off-diagonal tiles were mirrored), roll s and b~
@@ -269,7 +293,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         const int r = 16 * (i >> 8) + ((i >> 4) & 15), c = 16 * (i >> 8) + (i & 15);
         if (c > r && c < NX) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
       } else {
-        w.sv[i - 4 * 256] = w.sn[i - 4 * 256];
+        const double* sp = &w.part[4 * (i - 4 * 256)];
+        w.sv[i - 4 * 256] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
         if (k > 0) w.bt[i - 4 * 256] = w.btn[i - 4 * 256];
       }
     }
