@@ -198,3 +198,19 @@ class Oracle:
         out, J = np.zeros(self.CENT_NX), np.zeros((self.CENT_NX, self.CENT_NX + self.CENT_NU))
         self.lib.orc_cent_flow_map_jac(self.h, _p(x), _p(u), _p(out), _p(J))
         return out, J
+
+    def cent_foot_kinematics(self, x, u):
+        x, u = _c(x), _c(u)
+        out = np.zeros((2, 12))
+        self.lib.orc_cent_foot_kinematics(self.h, _p(x), _p(u), _p(out))
+        return out
+
+    def cent_equalities(self, x, u, contact, zpos=(0.0, 0.0), zvel=(0.0, 0.0), gain_pos_z=0.0, gain_ori=0.0, jac=False):
+        x, u = _c(x), _c(u)
+        cf = (C.c_int * 2)(*[int(c) for c in contact])
+        zp, zv = _c(zpos), _c(zvel)
+        eq = np.zeros(NE_MAX)
+        J = np.zeros((NE_MAX, self.CENT_NX + self.CENT_NU)) if jac else None
+        ne = self.lib.orc_cent_equalities(self.h, _p(x), _p(u), cf, _p(zp), _p(zv), C.c_double(gain_pos_z), C.c_double(gain_ori),
+                                          _p(eq), _p(J))
+        return (eq[:ne].copy(), J[:ne].copy()) if jac else eq[:ne].copy()

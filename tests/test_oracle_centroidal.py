@@ -114,3 +114,74 @@ def test_flow_map_jacobian_matches_central_differences(model, oracle, rng):
     assert np.allclose(J[12:, 35 + 12:], np.eye(23)) and np.allclose(J[12:, :35 + 12], 0.0)
     assert np.allclose(J[:6, :6], 0.0) and np.allclose(J[:6, 35 + 12:], 0.0)
     assert np.allclose(J[:, 6:9], 0.0, atol=1e-12)
+
+
+# ---- velocity-level foot kinematics and the equality constraints
+G1C_GAIN_POS_Z, G1C_GAIN_ORI = 5.0, 20.0    # robot_models/unitree_g1/g1_centroidal_mpc/config/mpc/task.info:16-17
+
+
+def test_foot_twist_is_the_time_derivative_of_the_foot_placement_along_the_flow(model, oracle, rng):
+    x, u = cent_state_input(model, rng)
+    xd = oracle.cent_flow_map(x, u)
+    fk = oracle.cent_foot_kinematics(x, u)
+    eps = 1e-6
+    xp, xm = x.copy(), x.copy()
+    xp[6:] += eps * xd[6:]
+    xm[6:] -= eps * xd[6:]
+    fp, fm = oracle.cent_foot_kinematics(xp, u), oracle.cent_foot_kinematics(xm, u)
+    for f in range(2):
+        assert np.allclose((fp[f, :3] - fm[f, :3]) / (2 * eps), fk[f, 6:9], atol=1e-6)
+    # positions and orientation errors agree with the whole-body restatement at the same configuration
+    xw = np.concatenate([x[6:], np.zeros(29)])
+    out, _R = oracle.foot_kinematics(xw, np.zeros(model.nu))
+    assert np.allclose(out[:, :6], fk[:, :6], atol=1e-13)
+    # and the twist with the whole-body one at the generalized velocity the centroidal mapping yields
+    xw[29:] = xd[6:]
+    out, _R = oracle.foot_kinematics(xw, np.zeros(model.nu))
+    assert np.allclose(out[:, 6:12], fk[:, 6:12], atol=1e-12)
+
+
+def test_equality_rows_follow_the_contact_pattern(model, oracle, rng):
+    x, u = cent_state_input(model, rng)
+    fk = oracle.cent_foot_kinematics(x, u)
+    zpos, zvel = (0.01, 0.05), (0.2, -0.3)
+    for contact, ne in (((1, 1), 12), ((1, 0), 13), ((0, 1), 13), ((0, 0), 14)):
+        eq = oracle.cent_equalities(x, u, contact, zpos, zvel, G1C_GAIN_POS_Z, G1C_GAIN_ORI)
+        assert eq.size == ne
+        row = 0
+        for f in range(2):
+            if contact[f]:
+                want = np.concatenate([fk[f, 6:9], fk[f, 9:12] + G1C_GAIN_ORI * fk[f, 3:6]])
+                want[2] += G1C_GAIN_POS_Z * (fk[f, 2] - zpos[f])
+                assert np.allclose(eq[row:row + 6], want, atol=1e-13)
+                row += 6
+            else:
+                assert np.array_equal(eq[row:row + 6], u[6 * f:6 * f + 6])
+                assert np.isclose(eq[row + 6], fk[f, 8] - zvel[f] + G1C_GAIN_POS_Z * (fk[f, 2] - zpos[f]), atol=1e-13)
+                row += 7
+        assert row == ne
+
+
+def test_stance_constraint_vanishes_at_rest_on_the_ground(model, oracle):
+    # nominal stance, zero momentum, zero joint velocity, reference height = the foot's own height: nothing to correct
+    x = np.concatenate([np.zeros(6), model.initial_state[:29]])
+    u = np.zeros(35)
+    fk = oracle.cent_foot_kinematics(x, u)
+    eq = oracle.cent_equalities(x, u, (1, 1), fk[:, 2], (0.0, 0.0), G1C_GAIN_POS_Z, G1C_GAIN_ORI)
+    assert np.allclose(fk[:, 6:], 0.0, atol=1e-13)
+    assert np.allclose(eq.reshape(2, 6)[:, :3], 0.0, atol=1e-13)
+    assert np.allclose(eq.reshape(2, 6)[:, 3:], G1C_GAIN_ORI * fk[:, 3:6], atol=1e-13)   # feet of the nominal pose are flat
+    assert np.abs(fk[:, 3:6]).max() < 1e-6
+
+
+def test_equality_jacobian_matches_central_differences(model, oracle, rng):
+    x, u = cent_state_input(model, rng)
+    args = ((1, 0), (0.0, 0.04), (0.0, 0.3), G1C_GAIN_POS_Z, G1C_GAIN_ORI)
+    eq, J = oracle.cent_equalities(x, u, *args, jac=True)
+    assert np.allclose(eq, oracle.cent_equalities(x, u, *args), atol=1e-13)
+    Jfd = fd_jac(lambda z: oracle.cent_equalities(z[:35], z[35:], *args), np.concatenate([x, u]))
+    assert np.abs(J - Jfd).max() <= 1e-6 * max(1.0, np.abs(J).max())
+    # the swing foot's zero-wrench rows are unit rows of D (what the projection kernel deflates in the whole-body problem)
+    assert np.array_equal(J[6:12, 35 + 6:35 + 12], np.eye(6)) and np.count_nonzero(J[6:12]) == 6
+    # D = d eq / du has full row rank
+    assert np.linalg.matrix_rank(J[:, 35:]) == eq.size
