@@ -316,9 +316,11 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       const double* addq = pass == 0 ? nullptr : qp + QP_Q;
       const double* addp = pass == 0 ? nullptr : qp + QP_P;
       const double* addr = pass == 0 ? nullptr : qp + QP_R;
-      const XtyJob jobs[3] = {xty_job(NX, NX, nrows, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX, addq, NX),
-                              xty_job(NUT, NX, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX, addp, NX),
-                              xty_job(NUT, NUT, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT, addr, NUT)};
+      // Q~ and R~ are symmetric: only the tiles on/above the diagonal are computed (10 of 16, 3 of 4) and mirrored
+      XtyJob jq = xty_job(NX, NX, nrows, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX, addq, NX);
+      XtyJob jr = xty_job(NUT, NUT, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT, addr, NUT);
+      jq.sym = 1; jr.sym = 1;
+      const XtyJob jobs[3] = {jq, xty_job(NUT, NX, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX, addp, NX), jr};
       wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_C_GLOBAL>(ctx, jobs, 3);
       PH_TICK(ctx, pass == 0 ? 14 : 15);
       WG_FOR(ctx, a, NTW) {
