@@ -28,7 +28,10 @@ def _build(LIB, force, verbose, extra):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_HERE, "..", "include", "hsqp.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    # -amdgpu-sched-strategy=iterative-ilp: the kernels are chains of short dependent phases at an occupancy fixed by LDS and
+    # launch bounds, so scheduling for ILP instead of for occupancy pays (measured A/B in one run, tools/gpu_variants.sh:
+    # 9.53 vs 9.88 ms per iteration; max-ilp: no gain; iterative-minreg: 11.2 ms; any -unroll-threshold change: Riccati 2.5x slower)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-std=c++17", "-shared", "-fPIC",
            os.path.join(CSRC, "hsqp_capi.hip"), "-o", LIB, *extra]
     if verbose:
         print(" ".join(cmd))
