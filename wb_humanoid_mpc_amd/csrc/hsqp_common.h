@@ -13,6 +13,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/hsqp.h"
 

@@ -52,6 +52,7 @@ struct StageWST {
   };
   double Ic[D ? NB : 1][10], fc[D ? NB : 1][6], BBc[D ? NB : 1][36];
   double rP[2][3];                 // contact points relative to O
+  double Fx[2][6];                 // contact wrenches about O {moment, force}
   // ---- results
   double Ftil[6];                  // F_ext - F  {moment, force}
   double Iinv[9];                  // inverse of the total rotational inertia about O
@@ -110,6 +111,16 @@ HSQP_HD void rot_axis_cs(const double* ax, double c, double s, double* Rm) {
 // Serial depth: only the placements (R_i, r_i, w_i) are propagated along the tree, row by row (three independent
 // items per chain, DevModel::chain_* / anc); velocities and accelerations are sums over the ancestor path, one item
 // per component.  Everything else (Sdd, inertia, net force, BB) runs in fully parallel phases.
+// The ancestor path of a body is 8 byte indices: read as one 64-bit word (one LDS round trip instead of eight dependent
+// byte loads in front of the operand loads).
+static_assert(NANC == 8, "packed ancestor path");
+HSQP_HD unsigned long long anc_packed(const unsigned char* row) {
+  unsigned long long v;
+  memcpy(&v, row, 8);
+  return v;
+}
+HSQP_HD int anc_at(unsigned long long pk, int n) { return (int)((pk >> (8 * n)) & 0xffull); }
+
 template <class SW>
 HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
   WG_FOR(ctx, i, NB * NANC + NB) {
@@ -169,9 +180,10 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     double rp = 0.0;
     // fully unrolled over the (padded) path: the index and operand loads do not depend on the running row, only the
     // multiply-adds are chained
+    const unsigned long long pk1 = anc_packed(ws.anc[end]);
 #pragma unroll
     for (int n = 0; n < NANC; ++n) {
-      const int i = ws.anc[end][n];
+      const int i = anc_at(pk1, n);
       const double* M = ws.Mq[i];
       const double* pa = ws.pa[i];
       const double rn0 = Rp[0] * M[0] + Rp[1] * M[3] + Rp[2] * M[6];
@@ -197,10 +209,11 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     if (jc >= 3) {
       const int i = jc - 2, na = ws.n_anc[i];
       double sa = 0.0;
+      const unsigned long long pk2 = anc_packed(ws.anc[i]);
 #pragma unroll
       for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself: the last term is always the own axis
         // branch-free: sa = p1 S[j1] - p2 S[j2] with (p1, j1, p2, j2) = (1, k, 0, k) for the angular rows, (r[k1], k2, r[k2], k1) for the linear
-        const int a = ws.anc[i][n];
+        const int a = anc_at(pk2, n);
         const double r1 = ws.r[a][k1], r2 = ws.r[a][k2];
         const double s1 = ws.S[a + 2][k < 3 ? k : k2], s2 = ws.S[a + 2][k < 3 ? k : k1];
         const double qa = ws.v[5 + a];
@@ -232,9 +245,10 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     if (jc >= 2) s += ws.Sd[2][k] * ws.v[5];
     if (jc >= 3) {
       const int i = jc - 2, na = ws.n_anc[i];
+      const unsigned long long pk4 = anc_packed(ws.anc[i]);
 #pragma unroll
       for (int n = 0; n < NANC; ++n) {
-        const int a = ws.anc[i][n];
+        const int a = anc_at(pk4, n);
         const double t = ws.S[a + 2][k] * ws.qddj[a - 1] + ws.Sd[a + 2][k] * ws.v[5 + a];
         s += n < na ? t : 0.0;
       }
@@ -244,13 +258,22 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   WG_SYNC(ctx);
   PH_TICK(ctx, 21);
   // ---- per-body spatial inertia about O and net force
-  WG_FOR(ctx, it, NB + (DERIV ? NJC : 0)) {
-    if (it >= NB) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
-      const int jc = it - NB;
+  WG_FOR(ctx, it, NB + 2 + (DERIV ? NJC : 0)) {
+    if (it >= NB + 2) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
+      const int jc = it - NB - 2;
       double t1[6], t2[6];
       mxm(ws.al[jc], ws.S[jc], t1);
       mxm(ws.vl[jc], ws.Sd[jc], t2);
       for (int k = 0; k < 6; ++k) ws.Sdd[jc][k] = t1[k] + t2[k];
+      continue;
+    }
+    if (it >= NB) {   // contact point of foot f relative to O and its wrench about O {moment, force} (off the serial totals phase)
+      const int f = it - NB, b = dm.contact_body[f];
+      double rr[3], mom[3];
+      m3_mulv(ws.R[b], dm.contact_p[f], rr);
+      for (int k = 0; k < 3; ++k) { rr[k] += ws.r[b][k]; ws.rP[f][k] = rr[k]; }
+      v3_cross(rr, ws.W + 6 * f, mom);
+      for (int k = 0; k < 3; ++k) { ws.Fx[f][k] = ws.W[6 * f + 3 + k] + mom[k]; ws.Fx[f][3 + k] = ws.W[6 * f + k]; }
       continue;
     }
     const int i = it;
@@ -321,15 +344,8 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   PH_TICK(ctx, 24);
   // ---- totals and the block-diagonal base solve
   WG_FOR(ctx, it, 1) {
-    double Fext[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int f = 0; f < 2; ++f) {
-      const int b = dm.contact_body[f];
-      double rr[3], mom[3];
-      m3_mulv(ws.R[b], dm.contact_p[f], rr);
-      for (int k = 0; k < 3; ++k) { rr[k] += ws.r[b][k]; ws.rP[f][k] = rr[k]; }
-      v3_cross(rr, ws.W + 6 * f, mom);
-      for (int k = 0; k < 3; ++k) { Fext[k] += ws.W[6 * f + 3 + k] + mom[k]; Fext[3 + k] += ws.W[6 * f + k]; }
-    }
+    double Fext[6];
+    for (int k = 0; k < 6; ++k) Fext[k] = ws.Fx[0][k] + ws.Fx[1][k];
     for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ws.fc[0][k];
     const double* I6 = ws.Ic[0] + 4;
     const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
