@@ -47,6 +47,20 @@ extern "C" {
 #define HSQP_P_SWING 61         /* [2][3] per foot z*, zdot*, zddot* of the swing spline               */
 #define HSQP_P_IMPACT 67        /* [2]  impact proximity factor per foot                               */
 
+/* ---- centroidal formulation (hsqp_model_desc::formulation = HSQP_FORM_CENTROIDAL) ----------------
+ * x = [h/m (6: v_com, L/m) | p_b(3) eulerZYX(3) | q_j(23)], u = [W_left(6) W_right(6) | qd_j(23)]
+ * (humanoid_nmpc/humanoid_centroidal_mpc/include/humanoid_centroidal_mpc/common/CentroidalMpcRobotModel.h:49-71,89-95).
+ * Every array of this ABI keeps the whole-body row strides (58 per state, 35 per input, 72 per node-parameter row): the
+ * centroidal state occupies the first HSQP_CNX doubles of a state row, the remaining 23 are padding and must be zero on
+ * input (they come back zero).  Node-parameter rows: [0..34] desired state, [HSQP_PC_TORSO..+12] the torso task-space
+ * reference {position(3), quaternion x y z w, linear velocity(3), angular velocity(3)} — EndEffectorKinematicsQuadraticCost::
+ * getParameters (humanoid_common_mpc/src/cost/EndEffectorKinematicsQuadraticCost.cpp:80-104) —, the slots from
+ * HSQP_P_ARMSWING on as above with HSQP_P_SWING holding {z*, zdot*, unused} per foot. */
+#define HSQP_FORM_WB 0
+#define HSQP_FORM_CENTROIDAL 1
+#define HSQP_CNX 35
+#define HSQP_PC_TORSO 35
+
 /* ---- error codes ------------------------------------------------------------------------- */
 #define HSQP_OK 0
 #define HSQP_ERR_BAD_ARG (-1)
@@ -78,7 +92,7 @@ typedef struct hsqp_frame {
 typedef struct hsqp_barrier { double mu, delta; } hsqp_barrier;
 
 typedef struct hsqp_model_desc {
-  int32_t formulation;          /* 0 = whole-body acceleration-level (the only one implemented)         */
+  int32_t formulation;          /* HSQP_FORM_WB (whole-body acceleration-level) or HSQP_FORM_CENTROIDAL  */
   int32_t n_joints;             /* must equal HSQP_NJ                                                    */
   hsqp_body bodies[HSQP_NB];    /* bodies[0] = base; bodies[1+j] moved by joint j; parents before children */
   hsqp_frame contact[2];        /* foot_{l,r}_contact                                                    */
@@ -104,6 +118,14 @@ typedef struct hsqp_model_desc {
   double r_foot, r_knee;
   hsqp_barrier collision_barrier;     /* PieceWisePolynomialBarrierPenalty */
   int32_t arm_swing_joint[4];   /* joint indices {l_shoulder_y, r_shoulder_y, l_elbow_y, r_elbow_y}      */
+  /* ---- centroidal formulation only (ignored for HSQP_FORM_WB).  Q / R / Qf hold the 35 centroidal weights in their first
+   * entries (rest zero), gain_pos_z / gain_ori the foot_constraint gains of the centroidal task file. */
+  hsqp_frame torso;             /* task_space_costs.torso.link_name (mid360_link): body + translation     */
+  double torso_R[9];            /* ... and the frame's rotation in the body frame (row-major)             */
+  double torso_sqrt_w[12];      /* sqrt(EndEffectorKinematicsWeights) of the torso cost: pos, ori, lin vel, ang vel */
+  double cent_foot_sqrt_w[12];  /* sqrt(task_space_foot_cost_weights) of CentroidalMpcEndEffectorFootCost  */
+  double ext_torque_sqrt_w[2][6];   /* sqrt({left,right}_leg_torque_cost.weights)                          */
+  int32_t ext_torque_joint[2][6];   /* their activeJointNames as joint indices                              */
 } hsqp_model_desc;
 
 #define HSQP_FLAG_LINESEARCH 1   /* hsqp_solve runs the filter line search (as the reference's SqpSolver does) instead of alpha = 1 */

@@ -214,3 +214,56 @@ class Oracle:
         ne = self.lib.orc_cent_equalities(self.h, _p(x), _p(u), cf, _p(zp), _p(zv), C.c_double(gain_pos_z), C.c_double(gain_ori),
                                           _p(eq), _p(J))
         return (eq[:ne].copy(), J[:ne].copy()) if jac else eq[:ne].copy()
+
+    # ---- the centroidal OCP (oracle/centroidal.hpp): padded layout — state rows of 58 doubles, the first 35 used
+    def cent_stage_cost(self, x, u, par):
+        x, u, par = _c(x), _c(u), _c(par)
+        eq = np.zeros(NE_MAX)
+        ne = C.c_int(0)
+        self.lib.orc_cent_stage_cost.restype = C.c_double
+        c = self.lib.orc_cent_stage_cost(self.h, _p(x), _p(u), _p(par), _p(eq), C.byref(ne))
+        return c, eq[: ne.value].copy()
+
+    def cent_terms(self, x, u, par):
+        x, u, par = _c(x), _c(u), _c(par)
+        out = np.zeros(45)
+        self.lib.orc_cent_terms(self.h, _p(x), _p(u), _p(par), _p(out))
+        return dict(torso=out[:9].reshape(3, 3), coll=out[9:25], mxy=out[25:33].reshape(2, 4), tau=out[33:45].reshape(2, 6))
+
+    def cent_rk4(self, x, u, dt):
+        x, u = _c(x), _c(u)
+        out = np.zeros(self.CENT_NX)
+        self.lib.orc_cent_rk4(self.h, _p(x), _p(u), C.c_double(dt), _p(out))
+        return out
+
+    def cent_lq(self, dt, x, u, par, threads=1):
+        """LQ approximation of all nodes of ONE centroidal instance in the padded layout. x:(N+1,58) u:(N,35) par:(N+1,72)."""
+        x, u, par = _c(x), _c(u), _c(par)
+        N = u.shape[0]
+        out = dict(AB=np.zeros((N, NX, NZ)), b=np.zeros((N, NX)), H=np.zeros((N, NZ, NZ)), g=np.zeros((N, NZ)),
+                   CDe=np.zeros((N, NE_MAX, NZ + 1)), ne=np.zeros(N, dtype=np.int32), cost=np.zeros(N + 1),
+                   flow=np.zeros((N, NX)))
+        self.lib.orc_cent_lq(self.h, N, C.c_double(dt), _p(x), _p(u), _p(par), threads, _p(out["AB"]), _p(out["b"]),
+                             _p(out["H"]), _p(out["g"]), _p(out["CDe"]), out["ne"].ctypes.data_as(C.POINTER(C.c_int)),
+                             _p(out["cost"]), _p(out["flow"]))
+        return out
+
+    def cent_sqp_iteration(self, dt, x_init, x, u, par, threads=1):
+        x_init, x, u, par = _c(x_init), _c(x), _c(u), _c(par)
+        N = u.shape[0]
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        pb, pa = _abi.Perf(), _abi.Perf()
+        kkt = np.zeros(2)
+        rc = self.lib.orc_cent_sqp_iteration(self.h, N, C.c_double(dt), _p(x_init), _p(x), _p(u), _p(par), threads, _p(dx), _p(du),
+                                             _p(xn), _p(un), C.byref(pb), C.byref(pa), _p(kkt))
+        if rc != 0:
+            raise RuntimeError(f"oracle cent_sqp_iteration failed: {rc}")
+        return dict(x=xn, u=un, dx=dx, du=du, kkt=kkt,
+                    perf_before=dict(merit=pb.merit, cost=pb.cost, dynamics_sse=pb.dynamics_sse, equality_sse=pb.equality_sse),
+                    perf_after=dict(merit=pa.merit, cost=pa.cost, dynamics_sse=pa.dynamics_sse, equality_sse=pa.equality_sse))
+
+    def cent_performance(self, dt, x, u, par, threads=1):
+        x, u, par = _c(x), _c(u), _c(par)
+        p = _abi.Perf()
+        self.lib.orc_cent_performance(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(par), threads, C.byref(p))
+        return dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse)

@@ -201,9 +201,10 @@ def build_tree(links, joints, children, root_link):
     return bodies, frames
 
 
-def main(out_path):
-    task = parse_info(TASK)
-    ref = parse_info(REFERENCE)
+def main(out_path, formulation="wb"):
+    cent = formulation == "centroidal"
+    task = parse_info(TASK.replace("g1_wb_mpc", "g1_centroidal_mpc") if cent else TASK)
+    ref = parse_info(REFERENCE.replace("g1_wb_mpc", "g1_centroidal_mpc") if cent else REFERENCE)
     gait = parse_info(GAIT)
     ms = task["model_settings"]
     fixed = info_list(ms["fixedJointNames"])
@@ -244,7 +245,7 @@ def main(out_path):
     knees = [frame_on_joint(cc["knee"]["leftKneeFrame"], np.zeros(3)),
              frame_on_joint(cc["knee"]["rightKneeFrame"], np.zeros(3))]
 
-    nx, nu = 2 * (6 + nj), 12 + nj
+    nx, nu = (12 + nj if cent else 2 * (6 + nj)), 12 + nj
     Q = info_diag(task["Q"], nx)
     R = info_diag(task["R"], nu)
     Qf = info_diag(task["Q_final"], nx) * float(task["terminalCostScaling"])
@@ -259,6 +260,27 @@ def main(out_path):
               g("lin_acceleration_x"), g("lin_acceleration_y"), g("lin_acceleration_z"),
               g("ang_acceleration_x"), g("ang_acceleration_y"), g("ang_acceleration_z"),
               0.01, 0.01, 0.01, 0.01, 0.01, 0.01]
+    extra = {}
+    if cent:
+        # centroidal problem (humanoid_nmpc/humanoid_centroidal_mpc/src/CentroidalMpcInterface.cpp:139-215):
+        # EndEffectorKinematicsWeights::getWeights (humanoid_common_mpc/src/cost/EndEffectorKinematicCostHelpers.cpp:52-97) for the
+        # feet and the torso link, ExternalTorqueQuadraticCostAD::loadConfigFromFile (…/ExternalTorqueQuadraticCostAD.cpp:140-170)
+        kin_keys = ["pos_x", "pos_y", "pos_z", "orientation_x", "orientation_y", "orientation_z", "lin_velocity_x",
+                    "lin_velocity_y", "lin_velocity_z", "ang_velocity_x", "ang_velocity_y", "ang_velocity_z"]
+        torso = task["task_space_costs"]["torso"]
+        tb, tR, tp = frames[torso["link_name"]]
+        ext_w, ext_j = [], []
+        for side in ("left_leg_torque_cost", "right_leg_torque_cost"):
+            names = info_list(task[side]["activeJointNames"])
+            w = info_vec(task[side]["weights"], len(names)) * float(task[side]["weights"].get("scaling", 1.0))
+            ext_w.append(w.tolist())
+            ext_j.append([joint_names.index(n) for n in names])
+        extra = dict(cent_foot_cost_weights=[g(k) for k in kin_keys],
+                     torso=dict(link=torso["link_name"], body=tb, R=tR.reshape(-1).tolist(), p=tp.tolist(),
+                                weights=[float(torso["weights"][k]) for k in kin_keys]),
+                     ext_torque=dict(weights=ext_w, joints=ext_j),
+                     icp_weight=float(task["icp_cost_weights"]["icpErrorWeight"]),
+                     centroidal_model_type=int(task["centroidalModelType"]))
 
     fc = ms["foot_constraint"]
     fr = task["contacts"]["frictionForceConeSoftConstraint"]
@@ -276,7 +298,7 @@ def main(out_path):
 
     out = dict(
         _generated_by="tools/export_g1_model.py from manumerous/wb_humanoid_mpc @ 2025-08-08 (URDF + task.info + reference.info + gait.info)",
-        robot="g1", formulation="wb", nj=nj, nx=nx, nu=nu, gravity=9.81, total_mass=total_mass,
+        robot="g1", formulation=formulation, nj=nj, nx=nx, nu=nu, gravity=9.81, total_mass=total_mass,
         joint_names=joint_names,
         bodies=[dict(name=b["name"], joint=b["joint"], parent=b["parent"], R=b["R"].reshape(-1).tolist(),
                      p=b["p"].tolist(), axis=(b["axis"].tolist() if b["axis"] is not None else [0, 0, 0]),
@@ -305,6 +327,7 @@ def main(out_path):
         default_base_height=float(ref["defaultBaseHeight"]),
         phase_transition_stance_time=float(ms["phaseTransitionStanceTime"]),
         gaits=gaits,
+        **extra,
     )
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
@@ -313,4 +336,7 @@ def main(out_path):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "wb_humanoid_mpc_amd", "data", "g1_wb.json"))
+    if len(sys.argv) > 1 and sys.argv[1] == "--centroidal":
+        main(sys.argv[2] if len(sys.argv) > 2 else os.path.join(here, "..", "wb_humanoid_mpc_amd", "data", "g1_centroidal.json"), "centroidal")
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "wb_humanoid_mpc_amd", "data", "g1_wb.json"))

@@ -10,6 +10,8 @@ NZ = NX + NU
 NE_MAX = 14
 NODE_PARAMS = 72
 P_XDES, P_ARMSWING, P_CONTACT, P_SWING, P_IMPACT = 0, 58, 59, 61, 67
+FORM_WB, FORM_CENTROIDAL = 0, 1
+CNX, PC_TORSO = 35, 35
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_NUMERIC, ERR_HIP, ERR_NOT_CONVERGED = 0, -1, -2, -3, -4, -5, -6
 
@@ -44,7 +46,10 @@ class ModelDesc(C.Structure):
                 ("rect_x_min", C.c_double), ("rect_x_max", C.c_double), ("rect_y_min", C.c_double),
                 ("rect_y_max", C.c_double), ("moment_barrier", Barrier), ("joint_limit_barrier", Barrier),
                 ("r_foot", C.c_double), ("r_knee", C.c_double), ("collision_barrier", Barrier),
-                ("arm_swing_joint", C.c_int32 * 4)]
+                ("arm_swing_joint", C.c_int32 * 4),
+                ("torso", Frame), ("torso_R", C.c_double * 9), ("torso_sqrt_w", C.c_double * 12),
+                ("cent_foot_sqrt_w", C.c_double * 12), ("ext_torque_sqrt_w", (C.c_double * 6) * 2),
+                ("ext_torque_joint", (C.c_int32 * 6) * 2)]
 
 
 class Settings(C.Structure):

@@ -14,6 +14,7 @@ import numpy as np
 from . import _abi
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "g1_wb.json")
+_DATA_CENTROIDAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "g1_centroidal.json")
 
 
 class G1Model:
@@ -22,7 +23,8 @@ class G1Model:
             d = json.load(f)
         self.raw = d
         self.nj, self.nx, self.nu = d["nj"], d["nx"], d["nu"]
-        assert (self.nj, self.nx, self.nu) == (_abi.NJ, _abi.NX, _abi.NU)
+        self.centroidal = d.get("formulation", "wb") == "centroidal"
+        assert (self.nj, self.nx, self.nu) == (_abi.NJ, _abi.CNX if self.centroidal else _abi.NX, _abi.NU)
         self.joint_names = d["joint_names"]
         self.total_mass = d["total_mass"]
         self.initial_state = np.array(d["initial_state"])
@@ -36,7 +38,8 @@ class G1Model:
     @staticmethod
     def _build_desc(d):
         m = _abi.ModelDesc()
-        m.formulation = 0
+        cent = d.get("formulation", "wb") == "centroidal"
+        m.formulation = _abi.FORM_CENTROIDAL if cent else _abi.FORM_WB
         m.n_joints = d["nj"]
         for i, b in enumerate(d["bodies"]):
             mb = m.bodies[i]
@@ -55,9 +58,20 @@ class G1Model:
                 fr.body = d["frames"][name][i]["body"]
                 fr.p[:] = d["frames"][name][i]["p"]
         m.gravity = d["gravity"]
-        m.Q[:] = d["Q"]
+        pad = [0.0] * (_abi.NX - len(d["Q"]))   # centroidal: 35 weights, the padding states carry none
+        m.Q[:] = d["Q"] + pad
         m.R[:] = d["R"]
-        m.Qf[:] = d["Qf"]
+        m.Qf[:] = d["Qf"] + pad
+        if cent:
+            t = d["torso"]
+            m.torso.body = t["body"]
+            m.torso.p[:] = t["p"]
+            m.torso_R[:] = t["R"]
+            m.torso_sqrt_w[:] = [math.sqrt(w) for w in t["weights"]]
+            m.cent_foot_sqrt_w[:] = [math.sqrt(w) for w in d["cent_foot_cost_weights"]]
+            for f in range(2):
+                m.ext_torque_sqrt_w[f][:] = [math.sqrt(w) for w in d["ext_torque"]["weights"][f]]
+                m.ext_torque_joint[f][:] = d["ext_torque"]["joints"][f]
         m.foot_sqrt_w[:] = [math.sqrt(w) for w in d["foot_cost_weights"]]
         fc = d["foot_constraint"]
         m.gain_pos_z = fc["positionErrorGain_z"]
@@ -92,5 +106,8 @@ class G1Model:
         return np.array([b["hi"] for b in self.raw["bodies"][1:]])
 
 
-def load_model(path=None):
+def load_model(path=None, formulation="wb"):
+    """formulation: "wb" (whole-body acceleration-level, g1_wb_mpc) or "centroidal" (g1_centroidal_mpc)."""
+    if path is None and formulation == "centroidal":
+        path = _DATA_CENTROIDAL
     return G1Model(path)

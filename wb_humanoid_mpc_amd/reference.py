@@ -329,3 +329,177 @@ def make_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.79
     if with_reference:
         return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt, (schedules, targets_all, t0)
     return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt
+
+
+# ------------------------------------------------------------------------------------ centroidal formulation
+# Host-side parameter generation of the centroidal problem.  States are handled unpadded (35) in this section and padded to the
+# ABI's 58-double rows by make_centroidal_problem().
+def _rot_axis(axis, q):
+    a = np.asarray(axis, dtype=float)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(q) * K + (1.0 - math.cos(q)) * (K @ K)
+
+
+def body_placements(model, q):
+    """World placements (R[NB], p[NB]) of the MPC model's bodies at q = [p_b, eulerZYX, q_j] (composite Translation +
+    SphericalZYX base: createPinocchioModel.cpp:60-67)."""
+    bodies = model.raw["bodies"]
+    R, p = [None] * len(bodies), [None] * len(bodies)
+    R[0] = _rot_axis([0, 0, 1], q[3]) @ _rot_axis([0, 1, 0], q[4]) @ _rot_axis([1, 0, 0], q[5])
+    p[0] = np.array(q[:3], dtype=float)
+    for i in range(1, len(bodies)):
+        b = bodies[i]
+        par = b["parent"]
+        R[i] = R[par] @ np.array(b["R"]).reshape(3, 3) @ _rot_axis(b["axis"], q[5 + i])
+        p[i] = p[par] + R[par] @ np.array(b["p"])
+    return R, p
+
+
+def euler_rate_axes(q):
+    """World axes of the euler Z, Y, X rates: omega = E @ [zdot, ydot, xdot]."""
+    Rz = _rot_axis([0, 0, 1], q[3])
+    Rzy = Rz @ _rot_axis([0, 1, 0], q[4])
+    return np.stack([np.array([0.0, 0.0, 1.0]), Rz[:, 1], Rzy[:, 0]], axis=1)
+
+
+def centroidal_base_velocity(model, q, h_normalized, qd_j=None):
+    """v_b = A_b^-1 (m h - A_j qd_j): CentroidalModelPinocchioMapping::getPinocchioJointVelocity (upstream ocs2_centroidal_model,
+    FullCentroidalDynamics) evaluated from the composite inertia of the whole robot about its centre of mass."""
+    bodies = model.raw["bodies"]
+    R, p = body_placements(model, q)
+    m = model.total_mass
+    cs = [p[i] + R[i] @ np.array(b["com"]) for i, b in enumerate(bodies)]
+    com = sum(b["mass"] * c for b, c in zip(bodies, cs)) / m
+    Ic = np.zeros((3, 3))
+    for i, b in enumerate(bodies):
+        d = cs[i] - com
+        Ic += R[i] @ np.array(b["inertia"]).reshape(3, 3) @ R[i].T + b["mass"] * (d @ d * np.eye(3) - np.outer(d, d))
+    lin_j, ang_j = np.zeros(3), np.zeros(3)
+    if qd_j is not None:   # momentum of the joint motion about the centre of mass
+        om, v = [np.zeros(3)] * len(bodies), [np.zeros(3)] * len(bodies)
+        for i in range(1, len(bodies)):
+            b = bodies[i]
+            par = b["parent"]
+            w = R[par] @ np.array(b["R"]).reshape(3, 3) @ np.array(b["axis"])
+            om[i] = om[par] + w * qd_j[i - 1]
+            v[i] = v[par] + np.cross(om[par], p[i] - p[par])
+            vc = v[i] + np.cross(om[i], cs[i] - p[i])
+            lin_j = lin_j + b["mass"] * vc
+            ang_j = ang_j + R[i] @ np.array(b["inertia"]).reshape(3, 3) @ R[i].T @ om[i] + np.cross(cs[i] - com, b["mass"] * vc)
+    E = euler_rate_axes(q)
+    rhs_lin, rhs_ang = m * np.asarray(h_normalized[:3]) - lin_j, m * np.asarray(h_normalized[3:6]) - ang_j
+    euler_rates = np.linalg.solve(Ic @ E, rhs_ang)
+    omega = E @ euler_rates
+    vlin = rhs_lin / m - np.cross(omega, com - p[0])
+    return np.concatenate([vlin, euler_rates])
+
+
+def matrix_to_quaternion(R):
+    """x, y, z, w (Eigen coefficient order), w >= 0 branch first (oracle ASSUMPTION A8)."""
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0.0:
+        s = math.sqrt(tr + 1.0) * 2.0
+        return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2.0
+    qv = np.zeros(4)
+    qv[i] = 0.25 * s
+    qv[j] = (R[i, j] + R[j, i]) / s
+    qv[k] = (R[i, k] + R[k, i]) / s
+    qv[3] = (R[k, j] - R[j, k]) / s
+    return qv
+
+
+def torso_reference(model, x_ref):
+    """EndEffectorKinematicsQuadraticCost::getReferenceCostElement (EndEffectorKinematicsQuadraticCost.cpp:92-104): the torso
+    link's position, orientation quaternion and LOCAL_WORLD_ALIGNED velocities at (xRef, uRef = 0)."""
+    t = model.raw["torso"]
+    q = np.asarray(x_ref[6:35], dtype=float)
+    R, p = body_placements(model, q)
+    b = t["body"]
+    vb = centroidal_base_velocity(model, q, x_ref[:6])
+    omega = euler_rate_axes(q) @ vb[3:6]
+    r = R[b] @ np.array(t["p"])
+    pos = p[b] + r
+    vlin = vb[:3] + np.cross(omega, pos - p[0])
+    return np.concatenate([pos, matrix_to_quaternion(R[b] @ np.array(t["R"]).reshape(3, 3)), vlin, omega])
+
+
+def centroidal_velocity_command_targets(model, v_cmd, t0, x0, horizon):
+    """CentroidalMpcTargetTrajectoriesCalculator::commandedVelocityToTargetTrajectories
+    (humanoid_centroidal_mpc/src/command/CentroidalMpcTargetTrajectoriesCalculator.cpp:88-158), command filter at steady state."""
+    vx, vy, height, wz = v_cmd
+    pose = np.array(x0[6:12], dtype=float)
+    pose[4] = pose[5] = 0.0
+    yaw = pose[3]
+    gvx = math.cos(yaw) * vx - math.sin(yaw) * vy
+    gvy = math.sin(yaw) * vx + math.cos(yaw) * vy
+    target_momentum = np.array([gvx, gvy, 0.0, 0.0, 0.0, wz / model.total_mass])
+    base_vel = centroidal_base_velocity(model, np.asarray(x0[6:35]), x0[:6])   # "assumes no joint velocities"
+    # the reference reads baseVel[5] (the euler X rate) as the yaw rate here; reproduced
+    t_mid = 0.7 * horizon
+    pose[2] = height
+
+    def integrate(pp, v3, h, dt):
+        qq = pp.copy()
+        qq[0] += v3[0] * dt
+        qq[1] += v3[1] * dt
+        qq[2] = h
+        qq[3] += v3[2] * dt
+        qq[4] = qq[5] = 0.0
+        return qq
+
+    mid = integrate(pose, [(base_vel[0] + gvx) / 2, (base_vel[1] + gvy) / 2, (base_vel[5] + wz) / 2], height, t_mid)
+    fin = integrate(mid, [gvx, gvy, wz], height, horizon - t_mid)
+    jt = model.default_joint_state
+    mk = lambda pp: np.concatenate([target_momentum, pp, jt])
+    return TargetTrajectories([t0, t0 + t_mid, t0 + horizon], [mk(pose), mk(mid), mk(fin)])
+
+
+def build_centroidal_node_params(model, schedule, targets, t0, dt, n_nodes, arm_swing=True):
+    """[N+1][HSQP_NODE_PARAMS] table of the centroidal problem (layout: include/hsqp.h)."""
+    planner = SwingTrajectoryPlanner(model.swing, schedule)
+    par = np.zeros((n_nodes + 1, _abi.NODE_PARAMS))
+    for k in range(n_nodes + 1):
+        t = t0 + k * dt
+        flags = mode_to_contact_flags(schedule.mode_at(t))
+        xd = targets.desired_state(t)
+        par[k, _abi.P_XDES:_abi.P_XDES + _abi.CNX] = xd
+        par[k, _abi.PC_TORSO:_abi.PC_TORSO + 13] = torso_reference(model, xd)
+        par[k, _abi.P_ARMSWING] = math.sin(2.0 * math.pi * (phase_variable(schedule, t) - 0.15)) if arm_swing else 0.0
+        par[k, _abi.P_CONTACT:_abi.P_CONTACT + 2] = flags
+        for leg in range(2):
+            z, zd, _ = planner.z_refs(leg, t)
+            par[k, _abi.P_SWING + 3 * leg:_abi.P_SWING + 3 * leg + 3] = (z, zd, 0.0)
+            par[k, _abi.P_IMPACT + leg] = planner.impact_proximity(leg, t)
+    return par
+
+
+def make_centroidal_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.7925, 0.0), dt=None, perturb=False,
+                            seed=BENCH_SEED, t0=0.0):
+    """Synthetic inputs of BASELINE.md configs 1-2 in the ABI's padded layout: (x_init[B,58], x[B,N+1,58], u[B,N,35],
+    params[B,N+1,72], dt); only the first 35 entries of a state row are used.  Cold start as CentroidalWeightCompInitializer
+    (x_k = x0 with the momentum extended, u_k = weight compensation)."""
+    assert model.centroidal
+    dt = model.sqp["dt"] if dt is None else dt
+    horizon = n_nodes * dt
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nj = model.nj
+    xs, us, ps, x0s = [], [], [], []
+    for _ in range(batch):
+        x0 = model.initial_state.copy()
+        offset = 0.0
+        if perturb:
+            sig = np.concatenate([np.full(6, 0.1), np.full(3, 0.02), np.full(3 + nj, 0.05)])
+            x0 = x0 + sig * rng.standard_normal(model.nx)
+            x0[12:12 + nj] = np.clip(x0[12:12 + nj], model.q_lo + 0.05, model.q_hi - 0.05)
+            offset = rng.uniform(0.0, 1.4)
+        schedule = tile_gait(model.gaits[gait], t0 - offset - 1e-9, t0 + 2.0 * horizon + 3.0)
+        targets = centroidal_velocity_command_targets(model, v_cmd, t0, x0, horizon)
+        par = build_centroidal_node_params(model, schedule, targets, t0, dt, n_nodes)
+        x0p = np.zeros(_abi.NX)
+        x0p[:_abi.CNX] = x0
+        x, u = cold_start(model, x0p, par)
+        xs.append(x); us.append(u); ps.append(par); x0s.append(x0p)
+    return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt
