@@ -26,6 +26,18 @@ def oracle(model):
     return Oracle(model)
 
 
+@pytest.fixture(scope="session")
+def cmodel():
+    from wb_humanoid_mpc_amd import load_model
+    return load_model(formulation="centroidal")
+
+
+@pytest.fixture(scope="session")
+def coracle(cmodel):
+    from hsqp_oracle import Oracle
+    return Oracle(cmodel)
+
+
 @pytest.fixture()
 def rng():
     return np.random.default_rng(1234)
