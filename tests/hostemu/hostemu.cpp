@@ -9,6 +9,7 @@
 
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_host.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
 
 using namespace hsqp;
 
@@ -50,6 +51,7 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 
 // LQ record of one node (REC_SIZE doubles) + dense expansions for comparison with the oracle
 int emu_rec_size() { return REC_SIZE; }
+int emu_rec_misc_offset() { return REC_MISC; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
@@ -101,11 +103,20 @@ void emu_project_node(const double* rec, double dt, double* qp) {
   Ctx ctx{0, 1, nullptr};
   project_node(ctx, *w, rec, dt, qp);
 }
+// ---- centroidal formulation (hsqp_cent.h): padded layout, x rows of 58 doubles
+void emu_cent_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  Ctx ctx{0, 1, nullptr};
+  if (deriv) cent_lq_node(ctx, dm, x, u, xnext, par, dt, rec);
+  else cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC);
+}
+void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_AB(rec, dt, AB); }
 // one full SQP iteration of one instance through the kernel sources; returns 0 or HSQP_ERR_NUMERIC
 int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const double* x, const double* u, const double* par,
                       double* x_new, double* u_new, double* dx, double* du, double* kkt, double* perf_before /*3: cost,dyn,eq*/,
                       double* perf_after, double* qp_out) {
   const DevModel& dm = *static_cast<DevModel*>(h);
+  const bool cent = dm.formulation == HSQP_FORM_CENTROIDAL;
   Ctx ctx{0, 1, nullptr};
   std::vector<double> rec((size_t)N * REC_SIZE), qp((size_t)N * QP_SIZE), ric((size_t)N * RIC_SIZE), ut((size_t)N * NUT);
   auto lw = std::make_unique<LqWST<true>>();
@@ -114,8 +125,9 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto rw = std::make_unique<RicWS>();
   double pb[3] = {0, 0, 0};
   for (int k = 0; k < N; ++k) {
-    lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
-    project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE]);
+    if (cent) cent_lq_node(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);
+    else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
+    project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) return HSQP_ERR_NUMERIC;
     pb[0] += rec[(size_t)k * REC_SIZE + REC_MISC + 1]; pb[1] += rec[(size_t)k * REC_SIZE + REC_MISC + 3]; pb[2] += rec[(size_t)k * REC_SIZE + REC_MISC + 2];
   }
@@ -143,7 +155,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {
-    lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
+    if (cent) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, r2.data() + REC_MISC);
+    else lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
     pa[0] += r2[REC_MISC + 1]; pa[1] += r2[REC_MISC + 3]; pa[2] += r2[REC_MISC + 2];
   }
   pa[0] += terminal(x_new);

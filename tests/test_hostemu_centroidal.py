@@ -1,0 +1,116 @@
+"""Centroidal formulation: the kernel SOURCES (wb_humanoid_mpc_amd/csrc/hsqp_cent.h + projection / Riccati / step) compiled for
+the host against the oracle (oracle/centroidal.hpp).  The two evaluate the flow map differently (momentum balance with one
+tangent per lane vs. centroidal momentum matrix columns with 96-wide dual numbers), so agreement is a real check."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_oracle_centroidal_ocp import perturbed_centroidal_problem
+from wb_humanoid_mpc_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+CNX = _abi.CNX
+
+
+def _load(name, model):
+    lib = C.CDLL(os.path.join(HERE, "hostemu", name))
+    lib.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(model.desc), err, 256))
+    assert h.value, err.value
+    return lib, h
+
+
+@pytest.fixture(scope="module")
+def cemu(cmodel):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu"), "all"])
+    return _load("libhsqp_hostemu.so", cmodel)
+
+
+def _force_flight(par, nodes):
+    par = par.copy()
+    par[nodes, _abi.P_CONTACT:_abi.P_CONTACT + 2] = 0.0
+    return par
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 6), ("run", 12), ("flight", 4)])
+def test_lq_record_expands_to_the_oracle_blocks(cmodel, coracle, cemu, gait, n):
+    lib, h = cemu
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, "run" if gait == "flight" else gait, seed=5)
+    if gait == "flight":
+        par = _force_flight(par, slice(1, 3))
+    lq = coracle.cent_lq(dt, x, u, par)
+    RS = lib.emu_rec_size()
+    modes = set()
+    for k in range(n):
+        modes.add(tuple(par[k, _abi.P_CONTACT:_abi.P_CONTACT + 2] > 0.5))
+        rec = np.full(RS, np.nan)
+        lib.emu_cent_lq_node(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dt), 1, P(rec))
+        AB, H, g, CDe = np.zeros((58, 93)), np.zeros((93, 93)), np.zeros(93), np.zeros((14, 94))
+        lib.emu_expand(P(rec), C.c_double(dt), P(AB), P(H), P(g), P(CDe))
+        lib.emu_cent_expand_AB(P(rec), C.c_double(dt), P(AB))
+        for name, a, b in (("AB", AB, lq["AB"][k]), ("H", H, lq["H"][k]), ("g", g, lq["g"][k]), ("CDe", CDe, lq["CDe"][k])):
+            assert np.isfinite(a).all(), name
+            assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max()), (name, k)
+        # values: the value-only program (plain doubles) gives the same performance terms as the dual-number lanes
+        rec2 = np.zeros(RS)
+        lib.emu_cent_lq_node(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dt), 0, P(rec2))
+        mo = lib.emu_rec_misc_offset()
+        assert np.allclose(rec[mo:mo + 8], rec2[mo:mo + 8], rtol=1e-13, atol=1e-15)
+        assert np.isclose(rec[mo + 1], lq["cost"][k], rtol=1e-11) and rec[mo] == lq["ne"][k]
+    if gait == "flight":
+        assert (False, False) in modes and len(modes) >= 2
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14), ("flight", 8)])
+def test_full_iteration_matches_oracle(cmodel, coracle, cemu, gait, n):
+    lib, h = cemu
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, "run" if gait == "flight" else gait, seed=5)
+    if gait == "flight":
+        par = _force_flight(par, slice(3, 6))
+    r = coracle.cent_sqp_iteration(dt, x0, x, u, par)
+    xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+    kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+    qp = np.zeros((n, lib.emu_qp_size()))
+    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+    assert rc == 0
+    sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+    assert np.abs(dx - r["dx"]).max() <= 1e-9 * sc and np.abs(du - r["du"]).max() <= 1e-9 * sc
+    assert not dx[:, CNX:].any() and not xn[:, CNX:].any()        # padding states stay zero
+    assert kkt[0] <= 1e-9 * sc and kkt[1] <= 1e-10 * sc
+    for got, want in ((pb, r["perf_before"]), (pa, r["perf_after"])):
+        assert np.allclose(got, [want["cost"], want["dynamics_sse"], want["equality_sse"]], rtol=1e-9, atol=1e-12)
+
+
+def test_lanes_are_independent(cmodel, cemu):
+    """Race check as for the whole-body kernels: the build that runs the work items (= lanes) of every phase in reverse order must
+    reproduce the forward build bit for bit."""
+    lib, h = cemu
+    rev, hr = _load("libhsqp_hostemu_rev.so", cmodel)
+    n = 6
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, "walk", seed=5)
+    res = []
+    for L, hh in ((lib, h), (rev, hr)):
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        qp = np.zeros((n, L.emu_qp_size()))
+        assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp)) == 0
+        res.append((dx, du, qp, pb, pa))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+def test_whole_body_model_is_rejected_where_it_does_not_apply(cmodel):
+    """build_dev_model: non-zero position weights of the task-space costs are not carried by the centroidal kernels."""
+    import copy
+    lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
+    lib.emu_create.restype = C.c_void_p
+    d = copy.deepcopy(cmodel.desc) if False else type(cmodel.desc).from_buffer_copy(cmodel.desc)
+    d.torso_sqrt_w[0] = 1.0
+    err = C.create_string_buffer(256)
+    assert not lib.emu_create(C.byref(d), err, 256) and b"position weights" in err.value

@@ -1,0 +1,501 @@
+// Centroidal formulation of the humanoid MPC (BASELINE configs 1-2): LQ approximation of one shooting node.
+//
+//   x = [h/m (6) | p_b (3) eulerZYX (3) | q_j (23)],  u = [W_l (6) W_r (6) | qd_j (23)]
+//   (humanoid_nmpc/humanoid_centroidal_mpc/include/humanoid_centroidal_mpc/common/CentroidalMpcRobotModel.h:49-71,89-95)
+//
+// The problem is embedded in the whole-body array layout (include/hsqp.h): a state row keeps 58 doubles of which the first 35
+// are the centroidal state and the other 23 are decoupled padding states (A = I, no cost, dx = 0), so the projection, Riccati,
+// step, KKT and performance kernels run unchanged on the record this file writes; only the structured [A|B] differs
+// (project_node(..., cent = true)).
+//
+// First version of the device path: forward-mode derivatives with ONE tangent direction per lane.  Lane c of the workgroup
+// evaluates the whole scalar program of the node (4 RK4 stages of the flow map + every cost / constraint term) on dual numbers
+// whose tangent is d/dz_c, z = [x(35); u(35)]; lane 70 carries no tangent and writes the values; lanes 71..96 zero-fill the
+// padding columns of the record.  Lanes never exchange data: there are no barriers and no LDS traffic, the per-lane kinematic
+// arrays live in private memory.  The value-only pass (performance index, line search) runs the same program on plain doubles,
+// one lane per node.
+//
+// The flow map is NOT evaluated as the reference / the oracle write it (centroidal momentum matrix column by column,
+// ocs2_centroidal_model — oracle ASSUMPTION A7) but from the momentum balance directly:
+//   one tree pass with the joint rates only gives every body's placement, its velocity relative to the base (om_i, v_i), the
+//   momentum of the joint motion (lin_J, ang_J about the centre of mass), the centre of mass and the composite rotational
+//   inertia I_c of the whole robot about it; with E the euler-rate axes,
+//     A_b = [[m 1, -m [com - p_b]x E], [0, I_c E]],   A_j qd_j = [lin_J; ang_J]
+//   so   euler rates = (I_c E)^-1 (m h_ang - ang_J),   pdot = (m h_lin - lin_J)/m - (E euler rates) x (com - p_b),
+//   and  d(h/m)/dt = [g + sum f / m ;  sum ((p_c - com) x f + tau) / m].
+// Body velocities of the velocity-level model follow from the same pass plus the rigid base motion.
+#pragma once
+#include "hsqp_lq.h"
+
+namespace hsqp {
+
+constexpr int CNX = HSQP_CNX, CNZ = CNX + NU;    // 35, 70
+constexpr int CENT_LANES = 97;                   // 70 tangent lanes + 1 value lane + 26 zero-fill lanes (columns 35..57, 93..95)
+// residual row slots (NRS = 64).  Position rows of the foot / torso task-space costs are not carried: their weights are zero in
+// the G1 task file and build_dev_model() rejects non-zero ones.
+constexpr int CROW_FOOT = 0;     // 9 f + {ori(3), vlin(3), vang(3)}
+constexpr int CROW_TORSO = 18;   // ori(3), vlin(3), vang(3)
+constexpr int CROW_FRIC = 27;    // 4 f + k
+constexpr int CROW_MXY = 35;     // 4 f + k
+constexpr int CROW_COLL = 43;    // 16 rows (inactive in double support)
+// external-torque rows (6 per stance foot): double support -> the collision slots 43 + 6 f; single support -> the swing foot's
+// friction and moment slots (both inactive then)
+HSQP_HD int crow_ext(int f, bool both, int k) { return both ? CROW_COLL + 6 * f + k : (k < 4 ? CROW_FRIC + 4 * (1 - f) + k : CROW_MXY + 4 * (1 - f) + k - 4); }
+
+// ---- dual numbers with one tangent
+struct Dual1 { double v, d; };
+HSQP_HD Dual1 mk(double v, double d = 0.0) { Dual1 r; r.v = v; r.d = d; return r; }
+HSQP_HD Dual1 operator+(Dual1 a, Dual1 b) { return mk(a.v + b.v, a.d + b.d); }
+HSQP_HD Dual1 operator-(Dual1 a, Dual1 b) { return mk(a.v - b.v, a.d - b.d); }
+HSQP_HD Dual1 operator-(Dual1 a) { return mk(-a.v, -a.d); }
+HSQP_HD Dual1 operator*(Dual1 a, Dual1 b) { return mk(a.v * b.v, a.v * b.d + a.d * b.v); }
+HSQP_HD Dual1 operator*(Dual1 a, double b) { return mk(a.v * b, a.d * b); }
+HSQP_HD Dual1 operator*(double b, Dual1 a) { return mk(a.v * b, a.d * b); }
+HSQP_HD Dual1 operator+(Dual1 a, double b) { return mk(a.v + b, a.d); }
+HSQP_HD Dual1 operator-(Dual1 a, double b) { return mk(a.v - b, a.d); }
+HSQP_HD Dual1 operator/(Dual1 a, Dual1 b) { const double q = a.v / b.v; return mk(q, (a.d - q * b.d) / b.v); }
+HSQP_HD Dual1 dsqrt(Dual1 a) { const double s = sqrt(a.v); return mk(s, 0.5 * a.d / s); }
+HSQP_HD double dsqrt(double a) { return sqrt(a); }
+HSQP_HD void dsincos(Dual1 a, Dual1& s, Dual1& c) { const double sv = sin(a.v), cv = cos(a.v); s = mk(sv, cv * a.d); c = mk(cv, -sv * a.d); }
+HSQP_HD void dsincos(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+HSQP_HD double val(Dual1 a) { return a.v; }
+HSQP_HD double val(double a) { return a; }
+HSQP_HD void set_tan(Dual1& a) { a.d = 1.0; }
+HSQP_HD void set_tan(double&) {}
+template <class T> HSQP_HD T cst(double v);
+template <> HSQP_HD Dual1 cst<Dual1>(double v) { return mk(v); }
+template <> HSQP_HD double cst<double>(double v) { return v; }
+
+template <class T> HSQP_HD void t_cross(const T* a, const T* b, T* r) {
+  const T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class T> HSQP_HD T t_dot(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class T> HSQP_HD void t_mulc(const T* M, const double* v, T* r) {   // r = M v, v constant
+  for (int i = 0; i < 3; ++i) r[i] = M[3 * i] * v[0] + M[3 * i + 1] * v[1] + M[3 * i + 2] * v[2];
+}
+template <class T> HSQP_HD void t_mulv(const T* M, const T* v, T* r) {
+  for (int i = 0; i < 3; ++i) r[i] = M[3 * i] * v[0] + M[3 * i + 1] * v[1] + M[3 * i + 2] * v[2];
+}
+template <class T> HSQP_HD void t_tmulv(const T* M, const T* v, T* r) {       // r = M^T v
+  for (int i = 0; i < 3; ++i) r[i] = M[i] * v[0] + M[3 + i] * v[1] + M[6 + i] * v[2];
+}
+template <class T> HSQP_HD void t_inverse3(const T* a, T* c) {
+  c[0] = a[4] * a[8] - a[5] * a[7]; c[1] = a[2] * a[7] - a[1] * a[8]; c[2] = a[1] * a[5] - a[2] * a[4];
+  c[3] = a[5] * a[6] - a[3] * a[8]; c[4] = a[0] * a[8] - a[2] * a[6]; c[5] = a[2] * a[3] - a[0] * a[5];
+  c[6] = a[3] * a[7] - a[4] * a[6]; c[7] = a[1] * a[6] - a[0] * a[7]; c[8] = a[0] * a[4] - a[1] * a[3];
+  const T inv = cst<T>(1.0) / (a[0] * c[0] + a[1] * c[3] + a[2] * c[6]);
+  for (int i = 0; i < 9; ++i) c[i] = c[i] * inv;
+}
+
+// ---- per-lane kinematic state of one model pass
+template <class T>
+struct CentKin {
+  T R[NB][9], p[NB][3];
+  T w[NB][3];                    // joint axes, world
+  T om[NB][3], v[NB][3];         // angular / origin velocity of the bodies RELATIVE to the base (joint rates only)
+  T E[9];                        // E[3 r + e]: world axis of euler rate e (z, y, x)
+  T com[3];
+  T vb[6];                       // [pdot; euler rates]
+  T wb[3];                       // angular velocity of the base = E euler rates
+};
+
+// One pass over the kinematic tree at q = [p_b, euler, q_j] with joint rates qd, then the base velocity from the normalized
+// momentum h and the normalized momentum rate for the contact wrenches W.  xdot[0..11] = [d(h/m)/dt ; pdot ; euler rates].
+template <class T>
+HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, const T* qd, CentKin<T>& k, T* xdot) {
+  T sz, cz, sy, cy, sx, cx;
+  dsincos(q[3], sz, cz); dsincos(q[4], sy, cy); dsincos(q[5], sx, cx);
+  // R_0 = Rz Ry Rx
+  k.R[0][0] = cz * cy; k.R[0][1] = cz * sy * sx - sz * cx; k.R[0][2] = cz * sy * cx + sz * sx;
+  k.R[0][3] = sz * cy; k.R[0][4] = sz * sy * sx + cz * cx; k.R[0][5] = sz * sy * cx - cz * sx;
+  k.R[0][6] = -sy;     k.R[0][7] = cy * sx;                k.R[0][8] = cy * cx;
+  const T zero = cst<T>(0.0), one = cst<T>(1.0);
+  k.E[0] = zero; k.E[3] = zero; k.E[6] = one;            // z axis
+  k.E[1] = -sz;  k.E[4] = cz;   k.E[7] = zero;           // Rz e_y
+  k.E[2] = cz * cy; k.E[5] = sz * cy; k.E[8] = -sy;      // Rz Ry e_x
+  for (int r = 0; r < 3; ++r) { k.p[0][r] = q[r]; k.om[0][r] = zero; k.v[0][r] = zero; k.w[0][r] = zero; }
+  T mc[3] = {zero, zero, zero}, lin[3] = {zero, zero, zero}, angO[3] = {zero, zero, zero};
+  T IO[6] = {zero, zero, zero, zero, zero, zero};        // xx xy xz yy yz zz about the world origin
+  for (int i = 0; i < NB; ++i) {
+    if (i > 0) {
+      const int par = dm.parent[i];
+      T Rj[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          Rj[3 * r + c] = k.R[par][3 * r] * dm.Rfix[i][c] + k.R[par][3 * r + 1] * dm.Rfix[i][3 + c] + k.R[par][3 * r + 2] * dm.Rfix[i][6 + c];
+      T s, c;
+      dsincos(q[5 + i], s, c);
+      const double* a = dm.axis[i];
+      // Rodrigues: Rot = I + s K + (1 - c) K^2,  K = [a]x (unit axis)
+      const T omc = one - c;
+      T Rot[9];
+      Rot[0] = one + omc * (a[0] * a[0] - 1.0);     Rot[1] = omc * (a[0] * a[1]) - s * a[2];      Rot[2] = omc * (a[0] * a[2]) + s * a[1];
+      Rot[3] = omc * (a[0] * a[1]) + s * a[2];      Rot[4] = one + omc * (a[1] * a[1] - 1.0);     Rot[5] = omc * (a[1] * a[2]) - s * a[0];
+      Rot[6] = omc * (a[0] * a[2]) - s * a[1];      Rot[7] = omc * (a[1] * a[2]) + s * a[0];      Rot[8] = one + omc * (a[2] * a[2] - 1.0);
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) k.R[i][3 * r + cc] = Rj[3 * r] * Rot[cc] + Rj[3 * r + 1] * Rot[3 + cc] + Rj[3 * r + 2] * Rot[6 + cc];
+      T off[3], t[3];
+      t_mulc(k.R[par], dm.pfix[i], off);
+      t_mulc(Rj, dm.axis[i], k.w[i]);
+      t_cross(k.om[par], off, t);
+      for (int r = 0; r < 3; ++r) {
+        k.p[i][r] = k.p[par][r] + off[r];
+        k.om[i][r] = k.om[par][r] + k.w[i][r] * qd[i - 1];
+        k.v[i][r] = k.v[par][r] + t[r];
+      }
+    }
+    // body i: centre of mass, world inertia, momentum of the joint motion about the world origin
+    const double m = dm.mass[i];
+    T rc[3], c[3], t[3], vc[3];
+    t_mulc(k.R[i], dm.com[i], rc);
+    for (int r = 0; r < 3; ++r) c[r] = k.p[i][r] + rc[r];
+    t_cross(k.om[i], rc, t);
+    for (int r = 0; r < 3; ++r) vc[r] = k.v[i][r] + t[r];
+    // Iw = R I R^T (symmetric): RI = R I first
+    T RI[9], Iw[6];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) RI[3 * r + cc] = k.R[i][3 * r] * dm.inertia[i][cc] + k.R[i][3 * r + 1] * dm.inertia[i][3 + cc] + k.R[i][3 * r + 2] * dm.inertia[i][6 + cc];
+    {
+      int n = 0;
+      for (int r = 0; r < 3; ++r)
+        for (int cc = r; cc < 3; ++cc) Iw[n++] = RI[3 * r] * k.R[i][3 * cc] + RI[3 * r + 1] * k.R[i][3 * cc + 1] + RI[3 * r + 2] * k.R[i][3 * cc + 2];
+    }
+    const T c2 = t_dot(c, c);
+    IO[0] = IO[0] + Iw[0] + (c2 - c[0] * c[0]) * m; IO[1] = IO[1] + Iw[1] - (c[0] * c[1]) * m; IO[2] = IO[2] + Iw[2] - (c[0] * c[2]) * m;
+    IO[3] = IO[3] + Iw[3] + (c2 - c[1] * c[1]) * m; IO[4] = IO[4] + Iw[4] - (c[1] * c[2]) * m; IO[5] = IO[5] + Iw[5] + (c2 - c[2] * c[2]) * m;
+    T mv[3], cxmv[3];
+    for (int r = 0; r < 3; ++r) { mv[r] = vc[r] * m; mc[r] = mc[r] + c[r] * m; lin[r] = lin[r] + mv[r]; }
+    t_cross(c, mv, cxmv);
+    const T* o = k.om[i];
+    angO[0] = angO[0] + Iw[0] * o[0] + Iw[1] * o[1] + Iw[2] * o[2] + cxmv[0];
+    angO[1] = angO[1] + Iw[1] * o[0] + Iw[3] * o[1] + Iw[4] * o[2] + cxmv[1];
+    angO[2] = angO[2] + Iw[2] * o[0] + Iw[4] * o[1] + Iw[5] * o[2] + cxmv[2];
+  }
+  const double M = dm.total_mass, iM = 1.0 / M;
+  for (int r = 0; r < 3; ++r) k.com[r] = mc[r] * iM;
+  const T* cm = k.com;
+  const T cm2 = t_dot(cm, cm);
+  T Ic[9];
+  Ic[0] = IO[0] - (cm2 - cm[0] * cm[0]) * M; Ic[1] = IO[1] + (cm[0] * cm[1]) * M; Ic[2] = IO[2] + (cm[0] * cm[2]) * M;
+  Ic[4] = IO[3] - (cm2 - cm[1] * cm[1]) * M; Ic[5] = IO[4] + (cm[1] * cm[2]) * M; Ic[8] = IO[5] - (cm2 - cm[2] * cm[2]) * M;
+  Ic[3] = Ic[1]; Ic[6] = Ic[2]; Ic[7] = Ic[5];
+  T angJ[3], t[3];
+  t_cross(cm, lin, t);
+  for (int r = 0; r < 3; ++r) angJ[r] = angO[r] - t[r];
+  // euler rates = (Ic E)^-1 (M h_ang - angJ)
+  T A22[9], A22i[9], rhs[3];
+  for (int r = 0; r < 3; ++r)
+    for (int e = 0; e < 3; ++e) A22[3 * r + e] = Ic[3 * r] * k.E[e] + Ic[3 * r + 1] * k.E[3 + e] + Ic[3 * r + 2] * k.E[6 + e];
+  t_inverse3(A22, A22i);
+  for (int r = 0; r < 3; ++r) rhs[r] = h[3 + r] * M - angJ[r];
+  t_mulv(A22i, rhs, k.vb + 3);
+  t_mulv(k.E, k.vb + 3, k.wb);
+  T d[3];
+  for (int r = 0; r < 3; ++r) d[r] = cm[r] - k.p[0][r];
+  t_cross(k.wb, d, t);
+  for (int r = 0; r < 3; ++r) k.vb[r] = h[r] - lin[r] * iM - t[r];
+  // normalized momentum rate (getNormalizedCentroidalMomentumRate; gravity 9.81 hard-coded as upstream does)
+  T fs[3] = {zero, zero, cst<T>(-9.81 * M)}, ns[3] = {zero, zero, zero};
+  for (int f = 0; f < 2; ++f) {
+    const int b = dm.contact_body[f];
+    T rp[3], arm[3];
+    t_mulc(k.R[b], dm.contact_p[f], rp);
+    for (int r = 0; r < 3; ++r) arm[r] = k.p[b][r] + rp[r] - cm[r];
+    t_cross(arm, W + 6 * f, t);
+    for (int r = 0; r < 3; ++r) { fs[r] = fs[r] + W[6 * f + r]; ns[r] = ns[r] + t[r] + W[6 * f + 3 + r]; }
+  }
+  for (int r = 0; r < 3; ++r) { xdot[r] = fs[r] * iM; xdot[3 + r] = ns[r] * iM; }
+  for (int r = 0; r < 6; ++r) xdot[6 + r] = k.vb[r];
+}
+
+// world position and LOCAL_WORLD_ALIGNED velocity of a point fixed to body b (velocity-level model: base motion + joint motion)
+template <class T>
+HSQP_HD void cent_point(const CentKin<T>& k, int b, const double* pl, T* pos, T* vlin, T* vang) {
+  T rp[3], d[3], t1[3], t2[3];
+  t_mulc(k.R[b], pl, rp);
+  for (int r = 0; r < 3; ++r) { pos[r] = k.p[b][r] + rp[r]; d[r] = pos[r] - k.p[0][r]; vang[r] = k.wb[r] + k.om[b][r]; }
+  t_cross(k.wb, d, t1);          // rigid base motion of the point
+  t_cross(k.om[b], rp, t2);      // joint motion relative to the base
+  for (int r = 0; r < 3; ++r) vlin[r] = k.vb[r] + t1[r] + k.v[b][r] + t2[r];
+}
+
+// quaternion (x, y, z, w) of a rotation matrix, branch chosen on the values (oracle ASSUMPTION A8)
+template <class T>
+HSQP_HD void cent_quat(const T* R, T* q) {
+  const double tr = val(R[0]) + val(R[4]) + val(R[8]);
+  const T one = cst<T>(1.0);
+  if (tr > 0.0) {
+    const T s = dsqrt(R[0] + R[4] + R[8] + one) * 2.0;
+    q[3] = s * 0.25; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s;
+  } else if (val(R[0]) > val(R[4]) && val(R[0]) > val(R[8])) {
+    const T s = dsqrt(one + R[0] - R[4] - R[8]) * 2.0;
+    q[3] = (R[7] - R[5]) / s; q[0] = s * 0.25; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s;
+  } else if (val(R[4]) > val(R[8])) {
+    const T s = dsqrt(one + R[4] - R[0] - R[8]) * 2.0;
+    q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = s * 0.25; q[2] = (R[5] + R[7]) / s;
+  } else {
+    const T s = dsqrt(one + R[8] - R[0] - R[4]) * 2.0;
+    q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = s * 0.25;
+  }
+}
+
+// Everything one lane produces for its node.
+template <class T>
+struct CentOut {
+  T row[NRS];            // residual rows (unscaled: the quantity whose square / penalty is the cost term)
+  double sc[NRS];        // row scale: sqrt(w) (Gauss-Newton) or sqrt(p'') (penalty); 0 = inactive
+  double rho[NRS];       // sc * value (Gauss-Newton) or p' / sqrt(p'') (penalty)
+  double pen[NRS];       // cost contribution of the row: 0.5 rho^2 (Gauss-Newton) or the penalty value
+  T eq[NE_MAX];
+  int ne, contact[2], eq_off[2];
+  double hfric_d1[2];    // p' of the friction barrier per foot (0 if not in contact): Hessian diagonal shift
+};
+
+// Cost / constraint terms of the node from the stage-1 kinematics k at (x, u); order and sources as oracle/centroidal.hpp.
+template <class T>
+HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, const T* u, const double* par, CentOut<T>& o) {
+  const T zero = cst<T>(0.0);
+  const int c0 = par[HSQP_P_CONTACT] > 0.5, c1 = par[HSQP_P_CONTACT + 1] > 0.5;
+  const bool both = c0 && c1;
+  o.contact[0] = c0; o.contact[1] = c1;
+  o.eq_off[0] = 0; o.eq_off[1] = c0 ? 6 : 7;
+  o.ne = o.eq_off[1] + (c1 ? 6 : 7);
+  for (int s = 0; s < NRS; ++s) { o.row[s] = zero; o.sc[s] = 0.0; o.rho[s] = 0.0; o.pen[s] = 0.0; }
+  for (int r = 0; r < NE_MAX; ++r) o.eq[r] = zero;
+  auto gn = [&](int s, const T& r, double w) { o.row[s] = r; o.sc[s] = w; o.rho[s] = w * val(r); o.pen[s] = 0.5 * o.rho[s] * o.rho[s]; };
+  auto pen = [&](int s, const T& hh, const Pen3& p) {
+    o.row[s] = hh; o.pen[s] = p.p;
+    if (p.d2 > 0.0) { o.sc[s] = sqrt(p.d2); o.rho[s] = p.d1 / o.sc[s]; }
+  };
+  // ---- torso task-space cost: EndEffectorKinematicsQuadraticCost.cpp:110-138 (quaternionDistance, velocity differences)
+  {
+    const int b = dm.torso_body;
+    T Rt[9], qc[4], pos[3], vl[3], va[3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rt[3 * r + c] = k.R[b][3 * r] * dm.torso_R[c] + k.R[b][3 * r + 1] * dm.torso_R[3 + c] + k.R[b][3 * r + 2] * dm.torso_R[6 + c];
+    cent_quat(Rt, qc);
+    cent_point(k, b, dm.torso_p, pos, vl, va);
+    const double* ref = par + HSQP_PC_TORSO;
+    const T rv[3] = {cst<T>(ref[3]), cst<T>(ref[4]), cst<T>(ref[5])};
+    T cr[3];
+    t_cross(qc, rv, cr);
+    for (int c = 0; c < 3; ++c) {
+      gn(CROW_TORSO + c, rv[c] * qc[3] - qc[c] * ref[6] + cr[c], dm.torso_sqrt_w[3 + c]);
+      gn(CROW_TORSO + 3 + c, vl[c] - ref[7 + c], dm.torso_sqrt_w[6 + c]);
+      gn(CROW_TORSO + 6 + c, va[c] - ref[10 + c], dm.torso_sqrt_w[9 + c]);
+    }
+  }
+  // ---- foot collision (FootCollisionConstraint.cpp:92-144), inactive in double support
+  if (!both) {
+    T pts[10][3];
+    for (int p = 0; p < 10; ++p) {
+      T rp[3];
+      t_mulc(k.R[dm.coll_body[p]], dm.coll_p[p], rp);
+      for (int r = 0; r < 3; ++r) pts[p][r] = k.p[dm.coll_body[p]][r] + rp[r];
+    }
+    for (int r = 0; r < 16; ++r) {
+      int a, b;
+      coll_pair(r, a, b);
+      T dd[3];
+      for (int c = 0; c < 3; ++c) dd[c] = pts[a][c] - pts[b][c];
+      const T hh = dsqrt(t_dot(dd, dd)) - 2.0 * (r == 9 ? dm.r_knee : dm.r_foot);
+      pen(CROW_COLL + r, hh, pwp_barrier(dm.coll_bmu, dm.coll_bdelta, val(hh)));
+    }
+  }
+  // ---- per foot
+  o.hfric_d1[0] = o.hfric_d1[1] = 0.0;
+  for (int f = 0; f < 2; ++f) {
+    const int ct = o.contact[f], b = dm.contact_body[f];
+    T pos[3], vl[3], va[3], ori[3];
+    cent_point(k, b, dm.contact_p[f], pos, vl, va);
+    {  // orientation error to the ground plane (oracle ASSUMPTION A2): (n x a) / sqrt(2 (1 + a.n)), a = R e_z, n = e_z
+      const T s = dsqrt((k.R[b][8] + 1.0) * 2.0);
+      ori[0] = -k.R[b][5] / s; ori[1] = k.R[b][2] / s; ori[2] = zero;
+    }
+    const T* Wf = u + 6 * f;
+    if (ct) {
+      // friction cone (FrictionForceConeConstraint.cpp:78-224): relaxed barrier of h; its second-order term p' d2h as three rows
+      const T T2 = Wf[0] * Wf[0] + Wf[1] * Wf[1] + dm.friction_reg;
+      const T hh = (Wf[2] + dm.friction_grip) * dm.friction_mu - dsqrt(T2);
+      const Pen3 p = relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, val(hh));
+      pen(CROW_FRIC + 4 * f, hh, p);
+      o.hfric_d1[f] = p.d1;
+      const double T3 = val(T2) * sqrt(val(T2));
+      o.row[CROW_FRIC + 4 * f + 1] = Wf[0]; o.sc[CROW_FRIC + 4 * f + 1] = sqrt(-p.d1 * dm.friction_reg / T3);
+      o.row[CROW_FRIC + 4 * f + 2] = Wf[1]; o.sc[CROW_FRIC + 4 * f + 2] = sqrt(-p.d1 * dm.friction_reg / T3);
+      o.row[CROW_FRIC + 4 * f + 3] = Wf[0] * val(Wf[1]) - Wf[1] * val(Wf[0]); o.sc[CROW_FRIC + 4 * f + 3] = sqrt(-p.d1 / T3);
+      // contact moment XY (ContactMomentXYConstraintCppAd.cpp:77-104): wrench in the contact frame
+      T lf[3], lm[3];
+      t_tmulv(k.R[b], Wf, lf);
+      t_tmulv(k.R[b], Wf + 3, lm);
+      const T hm[4] = {lm[0] - lf[2] * dm.rect_y_min, lf[2] * dm.rect_y_max - lm[0], -lm[1] - lf[2] * dm.rect_x_min, lm[1] + lf[2] * dm.rect_x_max};
+      for (int r = 0; r < 4; ++r) pen(CROW_MXY + 4 * f + r, hm[r], relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, val(hm[r])));
+      // external torque cost (ExternalTorqueQuadraticCostAD.cpp:110-135): (J_ee^T W)[6 + j] .* sqrtW * (1 - impactProximity of the other foot)
+      const double mid = 1.0 - par[HSQP_P_IMPACT + (1 - f)];
+      for (int a = 0; a < 6; ++a) {
+        const int bj = 1 + dm.ext_joint[f][a];
+        T tau = zero;
+        if (b >= bj && b < bj + dm.subtree_size[bj]) {
+          T arm[3], t[3];
+          for (int r = 0; r < 3; ++r) arm[r] = pos[r] - k.p[bj][r];
+          t_cross(arm, Wf, t);
+          for (int r = 0; r < 3; ++r) t[r] = t[r] + Wf[3 + r];
+          tau = t_dot(k.w[bj], t);
+        }
+        gn(crow_ext(f, both, a), tau, dm.ext_sqrt_w[f][a] * mid);
+      }
+    }
+    // equalities: zeroWrench (swing), zeroVelocity (stance), normalVelocity (swing) — CentroidalMpcInterface.cpp:203-207,232-257
+    const int r0 = o.eq_off[f];
+    const double zp = par[HSQP_P_SWING + 3 * f], zv = par[HSQP_P_SWING + 3 * f + 1];
+    if (ct) {
+      for (int i = 0; i < 3; ++i) o.eq[r0 + i] = i == 2 ? vl[2] + (pos[2] - zp) * dm.gain_pos_z : vl[i];
+      for (int i = 0; i < 3; ++i) o.eq[r0 + 3 + i] = va[i] + ori[i] * dm.gain_ori;
+    } else {
+      for (int i = 0; i < 6; ++i) o.eq[r0 + i] = Wf[i];
+      o.eq[r0 + 6] = vl[2] - zv + (pos[2] - zp) * dm.gain_pos_z;
+    }
+    // foot task-space cost (CentroidalMpcEndEffectorFootCost.cpp:90-152): [oriErr, v * impactProximity, w] .* sqrtW
+    const double ip = par[HSQP_P_IMPACT + f];
+    for (int c = 0; c < 3; ++c) {
+      gn(CROW_FOOT + 9 * f + c, ori[c], dm.cent_foot_sqrt_w[3 + c]);
+      gn(CROW_FOOT + 9 * f + 3 + c, vl[c], dm.cent_foot_sqrt_w[6 + c] * ip);
+      gn(CROW_FOOT + 9 * f + 6 + c, va[c], dm.cent_foot_sqrt_w[9 + c]);
+    }
+  }
+}
+
+// nominal state / input of the quadratic cost (StateInputQuadraticCost.cpp:67-78 with the centroidal model's accessors)
+HSQP_HD void cent_nominal(const DevModel& dm, const double* x, const double* par, double* xnom, double* unom) {
+  for (int i = 0; i < CNX; ++i) xnom[i] = par[HSQP_P_XDES + i];
+  const double gcf = par[HSQP_P_ARMSWING] * (cos(x[9]) * xnom[0] + sin(x[9]) * xnom[1]);
+  xnom[12 + dm.arm_swing_joint[0]] += -0.15 * gcf;
+  xnom[12 + dm.arm_swing_joint[1]] += 0.15 * gcf;
+  xnom[12 + dm.arm_swing_joint[2]] += -0.15 * gcf;
+  xnom[12 + dm.arm_swing_joint[3]] += 0.15 * gcf;
+  const int c0 = par[HSQP_P_CONTACT] > 0.5, c1 = par[HSQP_P_CONTACT + 1] > 0.5;
+  for (int i = 0; i < NU; ++i) unom[i] = 0.0;
+  if (c0 + c1 > 0) {
+    const double fz = dm.total_mass * 9.81 / (c0 + c1);
+    if (c0) unom[2] = fz;
+    if (c1) unom[8] = fz;
+  }
+}
+
+// The whole scalar program of one node on the number type T with tangent direction `dir` (0..69, or -1 for none): RK4 of the
+// flow map (u held constant; joint rows q_j+ = q_j + dt qd_j exactly), the terms at (x, u).  Returns x_next (35), flow (12 rows).
+template <class T>
+HSQP_HD void cent_program(const DevModel& dm, const double* x, const double* u, const double* par, double dt, int dir, CentKin<T>& k, CentOut<T>& o,
+                          T* xn /*[CNX]*/, T* flow /*[12]*/) {
+  T xs[CNX], us[NU], k1[12], ks[12], acc[12];
+  for (int i = 0; i < CNX; ++i) xs[i] = cst<T>(x[i]);
+  for (int i = 0; i < NU; ++i) us[i] = cst<T>(u[i]);
+  if (dir >= 0 && dir < CNX) set_tan(xs[dir]);
+  else if (dir >= CNX && dir < CNZ) set_tan(us[dir - CNX]);
+  T x0[CNX];
+  for (int i = 0; i < CNX; ++i) x0[i] = xs[i];
+  cent_pass<T>(dm, xs, xs + 6, us, us + 12, k, k1);
+  cent_terms<T>(dm, k, xs, us, par, o);
+  for (int r = 0; r < 12; ++r) { flow[r] = k1[r]; acc[r] = k1[r]; }
+  // stages 2..4: x_s = x + c k_{s-1}; the joint rows of every k are qd_j
+  for (int s = 1; s < 4; ++s) {
+    const double c = s == 3 ? dt : 0.5 * dt;
+    const T* kp = s == 1 ? k1 : ks;
+    for (int r = 0; r < 12; ++r) xs[r] = x0[r] + kp[r] * c;
+    for (int j = 0; j < NJ; ++j) xs[12 + j] = x0[12 + j] + us[12 + j] * c;
+    T kn[12];
+    cent_pass<T>(dm, xs, xs + 6, us, us + 12, k, kn);
+    const double wgt = s == 3 ? 1.0 : 2.0;
+    for (int r = 0; r < 12; ++r) { ks[r] = kn[r]; acc[r] = acc[r] + kn[r] * wgt; }
+  }
+  for (int r = 0; r < 12; ++r) xn[r] = x0[r] + acc[r] * (dt / 6.0);
+  for (int j = 0; j < NJ; ++j) xn[12 + j] = x0[12 + j] + us[12 + j] * dt;
+}
+
+// value lane: cost, defect, misc; returns nothing, writes misc[0..7] and (if rec) the value pieces of the record
+template <class T>
+HSQP_HD void cent_write_values(const DevModel& dm, const CentOut<T>& o, const T* xn, const T* flow, const double* x, const double* u, const double* xnext,
+                               const double* par, double dt, double* rec, double* misc) {
+  double xnom[CNX], unom[NU];
+  cent_nominal(dm, x, par, xnom, unom);
+  const double sdt = sqrt(dt);
+  double cost = 0.0;
+  for (int i = 0; i < CNX; ++i) { const double d = x[i] - xnom[i]; cost += 0.5 * dm.Q[i] * d * d; }
+  for (int i = 0; i < NU; ++i) { const double d = u[i] - unom[i]; cost += 0.5 * dm.R[i] * d * d; }
+  for (int s = 0; s < NRS; ++s) cost += o.pen[s];
+  for (int j = 0; j < NJ; ++j)   // JointLimitsSoftConstraint.cpp:64-100
+    cost += pwp_barrier(dm.jl_bmu, dm.jl_bdelta, x[12 + j] - dm.q_lo[j]).p + pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - x[12 + j]).p;
+  double dyn = 0.0, eq = 0.0;
+  for (int i = 0; i < CNX; ++i) { const double b = val(xn[i]) - xnext[i]; dyn += b * b; if (rec) rec[REC_B + i] = b; }
+  for (int r = 0; r < o.ne; ++r) eq += val(o.eq[r]) * val(o.eq[r]);
+  misc[0] = (double)o.ne; misc[1] = dt * cost; misc[2] = dt * eq; misc[3] = dt * dyn;
+  misc[4] = (double)o.contact[0]; misc[5] = (double)o.contact[1]; misc[6] = (double)o.eq_off[0]; misc[7] = (double)o.eq_off[1];
+  if (!rec) return;
+  for (int i = CNX; i < 64; ++i) rec[REC_B + i] = 0.0;
+  for (int i = 0; i < 64; ++i) rec[REC_FLOW + i] = i < 12 ? val(flow[i]) : (i < CNX ? u[12 + i - 12] : 0.0);
+  for (int s = 0; s < NRS; ++s) rec[REC_RHO + s] = sdt * o.rho[s];
+  const double shift = -(o.hfric_d1[0] + o.hfric_d1[1]) * dm.friction_hess_shift;   // hessianDiagonalShift on every state and input
+  for (int i = 0; i < LDJ; ++i) {
+    double d = 0.0, g = 0.0;
+    if (i < CNX) { d = dm.Q[i] + shift; g = dm.Q[i] * (x[i] - xnom[i]); }
+    else if (i >= NX && i < NZ) { d = dm.R[i - NX] + shift; g = dm.R[i - NX] * (u[i - NX] - unom[i - NX]); }
+    if (i >= 12 && i < CNX) {
+      const int j = i - 12;
+      const Pen3 lo = pwp_barrier(dm.jl_bmu, dm.jl_bdelta, x[i] - dm.q_lo[j]), hi = pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - x[i]);
+      d += lo.d2 + hi.d2; g += lo.d1 - hi.d1;
+    }
+    rec[REC_D + i] = dt * d;
+    rec[REC_GD + i] = dt * g;
+  }
+  for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + NZ] = r < o.ne ? val(o.eq[r]) : 0.0;
+}
+
+// ---- the LQ kernel body: lane = tangent direction.  Workspace: none (private memory only).
+HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt,
+                          double* rec) {
+  WG_FOR(ctx, lane, CENT_LANES) {
+    if (lane > CNZ) {   // zero-fill lanes: padding columns 35..57 and 93..95 of every row of the record
+      const int col = lane - CNZ - 1 < NX - CNX ? CNX + (lane - CNZ - 1) : NZ + (lane - CNZ - 1 - (NX - CNX));
+      for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = 0.0;
+      for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = 0.0;
+      if (col != NZ) for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = 0.0;
+      continue;
+    }
+    CentKin<Dual1> k;
+    CentOut<Dual1> o;
+    Dual1 xn[CNX], flow[12];
+    cent_program<Dual1>(dm, x, u, par, dt, lane < CNZ ? lane : -1, k, o, xn, flow);
+    if (lane == CNZ) {
+      cent_write_values<Dual1>(dm, o, xn, flow, x, u, xnext, par, dt, rec, rec + REC_MISC);
+      continue;
+    }
+    const int col = lane < CNX ? lane : NX + (lane - CNX);
+    const double sdt = sqrt(dt);
+    // [A|B] - [I|0] on the 12 dense rows (the joint rows are q_j+ = q_j + dt qd_j: structure known to the projection)
+    for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = xn[r].d - (r == lane ? 1.0 : 0.0);
+    for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = sdt * o.sc[s] * o.row[s].d;
+    for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = r < o.ne ? o.eq[r].d : 0.0;
+  }
+  WG_SYNC(ctx);
+}
+
+// value-only evaluation of one node (performance index / line search): misc[0..7] as the LQ kernel's
+HSQP_HD void cent_value_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc) {
+  CentKin<double> k;
+  CentOut<double> o;
+  double xn[CNX], flow[12];
+  cent_program<double>(dm, x, u, par, dt, -1, k, o, xn, flow);
+  cent_write_values<double>(dm, o, xn, flow, x, u, xnext, par, dt, nullptr, misc);
+}
+
+// Expand the centroidal record into the dense padded [A|B] (58 x 93) — debug / parity path and tests.
+inline void cent_expand_AB(const double* rec, double dt, double* AB) {
+  for (int i = 0; i < NX * NZ; ++i) AB[i] = 0.0;
+  for (int i = 0; i < NX; ++i) AB[i * NZ + i] = 1.0;
+  for (int j = 0; j < NJ; ++j) AB[(12 + j) * NZ + NX + 12 + j] = dt;
+  for (int r = 0; r < 12; ++r)
+    for (int c = 0; c < NZ; ++c) AB[r * NZ + c] += rec[REC_PV + r * LDJ + c];
+}
+
+}  // namespace hsqp

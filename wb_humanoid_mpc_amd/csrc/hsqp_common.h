@@ -144,6 +144,10 @@ struct DevModel {
   double jl_bmu, jl_bdelta;
   double r_foot, r_knee, coll_bmu, coll_bdelta;
   int arm_swing_joint[4];
+  // centroidal formulation (hsqp_cent.h); unused by the whole-body kernels
+  int formulation, torso_body;
+  int ext_joint[2][6];
+  double torso_p[3], torso_R[9], torso_sqrt_w[12], cent_foot_sqrt_w[12], ext_sqrt_w[2][6];
 };
 
 // ------------------------------------------------------------------------------------------------

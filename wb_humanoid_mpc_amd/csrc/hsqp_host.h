@@ -11,7 +11,8 @@ namespace hsqp {
 // Returns an empty string on success, otherwise a description of what is wrong with the model.
 inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
   memset(&dm, 0, sizeof(dm));
-  if (md.formulation != 0) return "only formulation 0 (whole-body acceleration-level) is implemented";
+  if (md.formulation != HSQP_FORM_WB && md.formulation != HSQP_FORM_CENTROIDAL) return "formulation must be HSQP_FORM_WB or HSQP_FORM_CENTROIDAL";
+  dm.formulation = md.formulation;
   if (md.n_joints != NJ) return "n_joints must be " + std::to_string(NJ);
   dm.total_mass = 0.0;
   for (int i = 0; i < NB; ++i) {
@@ -105,6 +106,26 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
   for (int k = 0; k < 4; ++k) {
     if (md.arm_swing_joint[k] < 0 || md.arm_swing_joint[k] >= NJ) return "bad arm swing joint index";
     dm.arm_swing_joint[k] = md.arm_swing_joint[k];
+  }
+  if (md.formulation == HSQP_FORM_CENTROIDAL) {
+    if (md.torso.body < 0 || md.torso.body >= NB) return "bad torso frame body";
+    dm.torso_body = md.torso.body;
+    memcpy(dm.torso_p, md.torso.p, sizeof(double) * 3);
+    memcpy(dm.torso_R, md.torso_R, sizeof(md.torso_R));
+    memcpy(dm.torso_sqrt_w, md.torso_sqrt_w, sizeof(md.torso_sqrt_w));
+    memcpy(dm.cent_foot_sqrt_w, md.cent_foot_sqrt_w, sizeof(md.cent_foot_sqrt_w));
+    // the position rows of the task-space costs are not carried by the kernels (zero weight in the G1 task file; the reference's
+    // foot position reference is a placeholder (0,0,0): CentroidalMpcEndEffectorFootCost.cpp:139)
+    for (int k = 0; k < 3; ++k)
+      if (md.torso_sqrt_w[k] != 0.0 || md.cent_foot_sqrt_w[k] != 0.0) return "centroidal: non-zero position weights of the torso / foot task-space costs are not supported";
+    for (int i = HSQP_CNX; i < NX; ++i)
+      if (md.Q[i] != 0.0 || md.Qf[i] != 0.0) return "centroidal: Q / Qf beyond the 35 centroidal states must be zero";
+    for (int f = 0; f < 2; ++f)
+      for (int a = 0; a < 6; ++a) {
+        if (md.ext_torque_joint[f][a] < 0 || md.ext_torque_joint[f][a] >= NJ) return "bad external-torque joint index";
+        dm.ext_joint[f][a] = md.ext_torque_joint[f][a];
+        dm.ext_sqrt_w[f][a] = md.ext_torque_sqrt_w[f][a];
+      }
   }
   if (!(dm.total_mass > 0.0)) return "total mass must be positive";
   return "";

@@ -65,7 +65,9 @@ struct ProjWS {
   double gacc[LDTM];             // gradient partial sums of pass A
 };
 
-HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp) {
+// cent = true: the record comes from the centroidal LQ kernel (hsqp_cent.h): the dense rows of [A|B] - [I|0] are rows 0..11
+// (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
+HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false) {
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
     static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
@@ -265,19 +267,22 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_FOR(ctx, i, NX * (NTW + 1)) {
     const int r = i / (NTW + 1), c = i % (NTW + 1);
     double s = 0.0;
-    const bool base = (r < 6) || (r >= NV && r < NV + 6);
+    const bool base = cent ? r < 12 : ((r < 6) || (r >= NV && r < NV + 6));
+    const int pw = cent ? r / 6 : (r < 6 ? 0 : 1), pr = cent ? r % 6 : (r < 6 ? r : r - NV);   // block / row of PV (only used if base)
     if (base) {  // B row r applied to column c of [Px | Pu | Pe]
-      const double* Brow = &w.PV[r < 6 ? 0 : 1][r < 6 ? r : r - NV][NX];
+      const double* Brow = &w.PV[pw][pr][NX];
 #pragma unroll 5
       for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][c];
+    } else if (cent) {
+      s = r < HSQP_CNX ? dt * w.Tm[r][c] : 0.0;            // input 12 + (r - 12) = r
     } else {
       const int j = r < NV ? r - 6 : r - NV - 6;
       s = (r < NV ? 0.5 * dt * dt : dt) * w.Tm[12 + j][c];
     }
     if (c < NX) {
       double a = (r == c) ? 1.0 : 0.0;
-      if (r < NV && c == NV + r) a += dt;
-      if (base) a += w.PV[r < 6 ? 0 : 1][r < 6 ? r : r - NV][c];
+      if (!cent && r < NV && c == NV + r) a += dt;
+      if (base) a += w.PV[pw][pr][c];
       qp[QP_A + r * NX + c] = a + s;
     } else if (c < NTW) {
       qp[QP_B + r * NUT + (c - NX)] = s;
