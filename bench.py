@@ -27,14 +27,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 
 # algorithmic flops per node (SURVEY.md §8d / BASELINE.md §5; dense count, mul+add, no symmetry credit)
-NX, NU, NE, NUT, MROWS = 58, 35, 12, 23, 18
-F_RK4 = 6 * NX * NX * (NX + NU)
-F_GN = 2 * (2 * MROWS * (NX + NU) ** 2 + 2 * MROWS * (NX + NU))
-F_PROJ = (2 * NU * NE ** 2 + 2 * NX * NU * NUT + 2 * NX ** 2 * NU + 2 * NU ** 2 * NUT + 2 * NUT ** 2 * NU + 2 * NU ** 2 * NX +
-          2 * NUT * NU * NX + 4 * NX ** 2 * NU + 2 * NU ** 2 * NX)
-F_RIC = 7.0 / 3.0 * NX ** 3 + 4 * NX ** 2 * NUT + 2 * NX * NUT ** 2 + NUT ** 3 / 3.0
+def node_flops(NX, NU, NE, NUT, MROWS):
+    f_rk4 = 6 * NX * NX * (NX + NU)
+    f_gn = 2 * (2 * MROWS * (NX + NU) ** 2 + 2 * MROWS * (NX + NU))
+    f_proj = (2 * NU * NE ** 2 + 2 * NX * NU * NUT + 2 * NX ** 2 * NU + 2 * NU ** 2 * NUT + 2 * NUT ** 2 * NU + 2 * NU ** 2 * NX +
+              2 * NUT * NU * NX + 4 * NX ** 2 * NU + 2 * NU ** 2 * NX)
+    f_ric = 7.0 / 3.0 * NX ** 3 + 4 * NX ** 2 * NUT + 2 * NX * NUT ** 2 + NUT ** 3 / 3.0
+    return f_rk4, f_gn, f_proj, f_ric
+
+
+F_RK4, F_GN, F_PROJ, F_RIC = node_flops(58, 35, 12, 23, 18)      # whole-body double support: 4.62 Mflop per node
 F_NODE = F_RK4 + F_GN + F_PROJ + F_RIC
 BYTES_NODE = 404 * 1024          # unfused dataflow bytes per node
+CENT_F = node_flops(35, 35, 12, 23, 12)                          # centroidal stance: 1.65 Mflop per node
+CENT_BYTES_NODE = 201 * 1024
 PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355X_MICROARCH.md chip table; FP64 runs at half the FP32 rate)
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
 
@@ -49,6 +55,32 @@ def pmc_traffic(kernel_key):
         return k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]
     except Exception:
         return None
+
+
+def cpu_baseline_centroidal(model, n_nodes, seed):
+    """Centroidal workload: the CPU oracle's centroidal SQP iteration (oracle/centroidal.hpp, kind 'port'), node-parallel LQ on
+    OpenMP threads + serial Riccati, single instance, ~10 s; all host cores and 4 threads (the reference's nThreads)."""
+    from hsqp_oracle import Oracle
+    from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+    cores = os.cpu_count() or 1
+    x0, x, u, par, dt = make_centroidal_problem(model, n_nodes=n_nodes, batch=1)
+    oracle = Oracle(model)
+
+    def leg(threads, t_min):
+        oracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=threads)
+        t0, done = time.perf_counter(), 0
+        while done < 1 or time.perf_counter() - t0 < t_min:
+            oracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=threads)
+            done += 1
+        return done, time.perf_counter() - t0
+
+    omp = min(16, cores)
+    done, wall = leg(omp, 8.0)
+    done4, wall4 = leg(4, 5.0)
+    return {"value": done / wall, "unit": "SQP iters/s", "cores": omp, "kind": "port",
+            "sample": f"{done} single-instance iterations (centroidal, N={n_nodes}) in {wall:.1f} s on {omp} OpenMP threads (node-parallel LQ, "
+                      "serial Riccati on the padded 58-state layout); forward-mode dual-number oracle, not the reference's CppAD/HPIPM build",
+            "value_4_threads": done4 / wall4, "sample_4_threads": f"{done4} iterations in {wall4:.1f} s on 4 threads"}
 
 
 def cpu_baseline(model, n_nodes, seed):
@@ -137,7 +169,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="MPC instances per GPU")
+    ap.add_argument("--formulation", default="wb", choices=["wb", "centroidal"],
+                    help="wb: BASELINE configs 3-5 (default, the metric's workload); centroidal: configs 1-2 (default batch 1)")
+    ap.add_argument("--batch", type=int, default=None, help="MPC instances per GPU (default 256; centroidal: 1)")
     ap.add_argument("--nodes", type=int, default=100)
     ap.add_argument("--gait", default="walk", help="gait of the synthetic schedule (config 5: slow_walk)")
     ap.add_argument("--no-perturb", action="store_true", help="config 3: the unperturbed initial state")
@@ -162,9 +196,15 @@ def main():
     load_library()
     group = Group(world, backend="nccl", device=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
-    model = load_model()
-    B, N = args.batch, args.nodes
-    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=args.gait, perturb=not args.no_perturb, seed=shard_seed(BENCH_SEED, rank))
+    cent = args.formulation == "centroidal"
+    model = load_model(formulation=args.formulation)
+    B, N = args.batch if args.batch else (1 if cent else 256), args.nodes
+    if cent:
+        from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+        x0, x, u, par, dt = make_centroidal_problem(model, n_nodes=N, batch=B, gait=args.gait, perturb=B > 1 and not args.no_perturb,
+                                                    seed=shard_seed(BENCH_SEED, rank))
+    else:
+        x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=args.gait, perturb=not args.no_perturb, seed=shard_seed(BENCH_SEED, rank))
     solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank)
     solver.upload(x0, x, u, par, dt)      # inputs resident in HBM before the timed region
 
@@ -199,21 +239,25 @@ def main():
     if rank == 0:
         value = aggregate_throughput([B] * world, args.steps, elapsed)
         cfg = {(100, 256): "4", (100, 1): "3", (200, 1024): "5"}.get((N, B), "4-like")
+        if cent:
+            cfg = {(20, 1): "1", (100, 1): "2"}.get((N, B), "2-like")
         nodes = B * N
+        f_rk4, f_gn, f_proj, f_ric = CENT_F if cent else (F_RK4, F_GN, F_PROJ, F_RIC)
+        f_node, bytes_node = f_rk4 + f_gn + f_proj + f_ric, CENT_BYTES_NODE if cent else BYTES_NODE
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
-        kern = {"lq_approximation(k_lq)": (kms[0], F_RK4 + F_GN, "k_lq<true>"), "projection(k_project)": (kms[1], F_PROJ, "k_project"),
-                "riccati(k_riccati)": (kms[2], F_RIC, "k_riccati")}
+        kern = {"lq_approximation(k_lq)": (kms[0], f_rk4 + f_gn, "k_lq_cent" if cent else "k_lq<true>"), "projection(k_project)": (kms[1], f_proj, "k_project"),
+                "riccati(k_riccati)": (kms[2], f_ric, "k_riccati")}
         dom = max(kern, key=lambda n: kern[n][0])
         dom_ms, dom_flops, dom_key = kern[dom]
-        traffic = pmc_traffic(dom_key) if (B, N) == (256, 100) else None
+        traffic = pmc_traffic(dom_key) if (B, N) == (256, 100) and not cent else None
         ach_tf = nodes * dom_flops / (dom_ms * 1e-3) / 1e12
-        step_tf = nodes * F_NODE / (elapsed / args.steps) / 1e12
-        step_tbs = nodes * BYTES_NODE / (elapsed / args.steps) / 1e12
+        step_tf = nodes * f_node / (elapsed / args.steps) / 1e12
+        step_tbs = nodes * bytes_node / (elapsed / args.steps) / 1e12
         res = {
-            "metric": "SQP iters/sec (G1 WB-MPC, N=100)", "value": value, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps,
+            "metric": "SQP iters/sec (G1 centroidal MPC)" if cent else "SQP iters/sec (G1 WB-MPC, N=100)", "value": value, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {cfg}: G1 whole-body MPC, N={N}, dt={dt}, gait {args.gait}, {B} {'perturbed ' if not args.no_perturb else ''}instances per GPU, "
+            "config": {"workload": f"BASELINE config {cfg}: G1 {'centroidal' if cent else 'whole-body'} MPC, N={N}, dt={dt}, gait {args.gait}, {B} {'perturbed ' if not args.no_perturb else ''}instances per GPU, "
                                    "1 SQP iteration per step (LQ + projection + Riccati + full step + performance index), cold-start trajectory",
                        "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -230,9 +274,9 @@ def main():
                                "note": "hsqp_solve with host buffers (upload 36 MB + iterate incl. KKT check + download 39 MB at B=256, N=100); never `value`"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, N, BENCH_SEED)
+            res["cpu_baseline"] = cpu_baseline_centroidal(model, N, BENCH_SEED) if cent else cpu_baseline(model, N, BENCH_SEED)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
-            host = cpu_kernel_sources_on_host(model, N, BENCH_SEED)
+            host = None if cent else cpu_kernel_sources_on_host(model, N, BENCH_SEED)
             if host:
                 res["cpu_kernel_sources_on_host"] = host
                 res["speedup_vs_kernel_sources_on_host"] = value / host["value"]

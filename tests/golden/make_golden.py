@@ -35,6 +35,22 @@ def main():
             b=lq["b"], g=lq["g"], cost=lq["cost"], ne=lq["ne"], flow=lq["flow"], e=lq["CDe"][:, :, -1],
             AB_row29=lq["AB"][:, 29, :], H_diag=np.einsum("kii->ki", lq["H"]))
         print(name, "dx max", np.abs(r["dx"]).max(), "du max", np.abs(r["du"]).max())
+    # centroidal formulation (padded 58 / 35 layout; BASELINE configs 1-2 at a size the fixture stays small)
+    from test_oracle_centroidal_ocp import perturbed_centroidal_problem
+    cmodel = load_model(formulation="centroidal")
+    coracle = Oracle(cmodel)
+    for name, gait, n, seed in (("cent_walk_n8", "walk", 8, 31), ("cent_run_n14", "run", 14, 32), ("cent_stance_n4", "stance", 4, 33)):
+        x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, gait, seed=seed)
+        lq = coracle.cent_lq(dt, x, u, par)
+        r = coracle.cent_sqp_iteration(dt, x0, x, u, par)
+        pb, pa = r["perf_before"], r["perf_after"]
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), x_init=x0, x=x, u=u, par=par, dt=dt, dx=r["dx"], du=r["du"], kkt=r["kkt"],
+            perf_before=np.array([pb["cost"], pb["dynamics_sse"], pb["equality_sse"]]),
+            perf_after=np.array([pa["cost"], pa["dynamics_sse"], pa["equality_sse"]]),
+            b=lq["b"], g=lq["g"], cost=lq["cost"][:n], ne=lq["ne"], flow=lq["flow"], e=lq["CDe"][:, :, -1],
+            AB_row7=lq["AB"][:, 7, :], H_diag=np.einsum("kii->ki", lq["H"]))
+        print(name, "dx max", np.abs(r["dx"]).max(), "du max", np.abs(r["du"]).max())
 
 
 if __name__ == "__main__":

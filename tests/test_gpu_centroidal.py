@@ -1,0 +1,123 @@
+"""GPU parity tests of the centroidal formulation (BASELINE configs 1-2): the HIP path through the C ABI against
+the oracle and the committed golden fixtures.  Same tolerances as the whole-body tests (f64 end to end)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_centroidal_ocp import perturbed_centroidal_problem
+from wb_humanoid_mpc_amd import _abi
+from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NX, NU, NZ, CNX = _abi.NX, _abi.NU, _abi.NZ, _abi.CNX
+
+
+@pytest.fixture(scope="module")
+def cgpu(cmodel):
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    s = HipSqpSolver(cmodel, max_nodes=100, max_batch=8)
+    yield s
+    s.close()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("name", ["cent_stance_n4", "cent_walk_n8", "cent_run_n14"])
+def test_against_golden_fixtures(cgpu, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = cgpu.run(g["x_init"], g["x"], g["u"], g["par"], float(g["dt"]))
+    sc = max(1.0, np.abs(g["dx"]).max(), np.abs(g["du"]).max())
+    assert np.abs(out["dx"][0] - g["dx"]).max() <= 1e-8 * sc
+    assert np.abs(out["du"][0] - g["du"]).max() <= 1e-8 * sc
+    assert not out["dx"][0][:, CNX:].any() and not out["x"][0][:, CNX:].any()
+    for got, want in ((out["perf_before"][0], g["perf_before"]), (out["perf_after"][0], g["perf_after"])):
+        assert np.allclose([got["cost"], got["dynamics_sse"], got["equality_sse"]], want, rtol=1e-9, atol=1e-12)
+    assert out["kkt"][0, 0] <= 1e-9 * max(1.0, np.abs(g["g"]).max()) * sc and out["kkt"][0, 1] <= 1e-10 * sc
+    assert rel(cgpu.debug_read(_abi.BLK_BVEC)[0], g["b"]) <= 1e-12
+    assert rel(cgpu.debug_read(_abi.BLK_G)[0], g["g"]) <= 1e-11
+    assert rel(cgpu.debug_read(_abi.BLK_COST)[0][:-1], g["cost"]) <= 1e-11
+    assert rel(cgpu.debug_read(_abi.BLK_FLOW)[0], g["flow"]) <= 1e-12
+    assert np.array_equal(cgpu.debug_read(_abi.BLK_NE)[0], g["ne"])
+    assert rel(cgpu.debug_read(_abi.BLK_CDE)[0][:, :, -1], g["e"]) <= 1e-11
+    assert rel(cgpu.debug_read(_abi.BLK_AB)[0][:, 7, :], g["AB_row7"]) <= 1e-11
+    assert rel(np.einsum("kii->ki", cgpu.debug_read(_abi.BLK_H)[0]), g["H_diag"]) <= 1e-11
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 5), ("walk", 10), ("run", 14)])
+def test_lq_blocks_against_oracle(cgpu, cmodel, coracle, gait, n):
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, gait, seed=41)
+    if gait == "run":   # make sure a flight node is covered
+        par = par.copy()
+        par[3:5, _abi.P_CONTACT:_abi.P_CONTACT + 2] = 0.0
+    cgpu.run(x0, x, u, par, dt)
+    lq = coracle.cent_lq(dt, x, u, par, threads=4)
+    for blk, key in ((_abi.BLK_AB, "AB"), (_abi.BLK_BVEC, "b"), (_abi.BLK_H, "H"), (_abi.BLK_G, "g"), (_abi.BLK_CDE, "CDe"), (_abi.BLK_FLOW, "flow")):
+        assert rel(cgpu.debug_read(blk)[0], lq[key]) <= 1e-11, key
+    assert rel(cgpu.debug_read(_abi.BLK_COST)[0][:-1], lq["cost"][:-1]) <= 1e-11
+    assert np.array_equal(cgpu.debug_read(_abi.BLK_NE)[0], lq["ne"])
+
+
+def test_batch_of_perturbed_instances_against_oracle(cgpu, cmodel, coracle):
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=16, batch=6, perturb=True)
+    out = cgpu.run(x0, x, u, par, dt)
+    for b in range(6):
+        r = coracle.cent_sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=4)
+        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+        assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc, b
+        assert np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc, b
+        for key in ("cost", "dynamics_sse", "equality_sse"):
+            assert np.isclose(out["perf_before"][b][key], r["perf_before"][key], rtol=1e-9, atol=1e-12)
+            assert np.isclose(out["perf_after"][b][key], r["perf_after"][key], rtol=1e-8, atol=1e-10)
+    solo = cgpu.run(x0[3], x[3], u[3], par[3], dt)
+    assert np.array_equal(solo["dx"][0], out["dx"][3]) and np.array_equal(solo["du"][0], out["du"][3])
+
+
+def test_config2_size_properties(cgpu, cmodel):
+    """BASELINE config 2 (centroidal, N = 100, one instance): size-independent properties of the QP step."""
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=100, batch=1, gait="walk")
+    x0 = x0.copy()
+    x0[:, :CNX] += 1e-3
+    out = cgpu.run(x0, x, u, par, dt)
+    dx, du = out["dx"], out["du"]
+    AB, b = cgpu.debug_read(_abi.BLK_AB), cgpu.debug_read(_abi.BLK_BVEC)
+    CDe, ne = cgpu.debug_read(_abi.BLK_CDE), cgpu.debug_read(_abi.BLK_NE)
+    sc = max(1.0, np.abs(dx).max(), np.abs(du).max())
+    assert np.abs(dx[:, 0] - (x0 - x[:, 0])).max() <= 1e-12
+    z = np.concatenate([dx[:, :-1], du], axis=2)
+    assert np.abs(dx[:, 1:] - np.einsum("bkij,bkj->bki", AB, z) - b).max() <= 1e-9 * sc
+    assert np.abs(np.einsum("bkrj,bkj->bkr", CDe[..., :NZ], z) + CDe[..., NZ]).max() <= 1e-7 * sc
+    assert set(np.unique(ne)) <= {12, 13, 14} and 13 in ne
+    assert out["kkt"][:, 1].max() <= 1e-9 * sc
+    assert out["kkt"][:, 0].max() <= 1e-9 * max(1.0, np.abs(cgpu.debug_read(_abi.BLK_G)).max()) * sc
+    assert np.all(np.isfinite(out["x"])) and not out["x"][..., CNX:].any()
+
+
+def test_multi_iteration_with_linesearch_reduces_the_violation(cgpu, cmodel):
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=20, batch=2, gait="walk")
+    cgpu.upload(x0, x, u, par, dt)
+    cgpu.iterate(1, take_step=True, linesearch=True)
+    first = cgpu.download()
+    cgpu.iterate(4, take_step=True, linesearch=True)
+    last = cgpu.download()
+    v = lambda p: p["dynamics_sse"] + p["equality_sse"]  # noqa: E731
+    for b in range(2):
+        assert v(last["perf_after"][b]) < v(first["perf_before"][b])
+        assert 0.0 < last["alpha"][b] <= 1.0
+
+
+def test_entry_points_that_are_whole_body_only_fail_cleanly(cgpu, cmodel):
+    from wb_humanoid_mpc_amd.solver import HsqpError
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=4, batch=1, gait="stance")
+    cgpu.run(x0, x, u, par, dt)
+    with pytest.raises(HsqpError) as e:
+        cgpu.joint_torques(x[0, 0], u[0, 0])
+    assert e.value.code == _abi.ERR_BAD_ARG
+    bad = x.copy()
+    bad[0, 1, 40] = 1.0
+    with pytest.raises(HsqpError) as e:
+        cgpu.run(x0, bad, u, par, dt)
+    assert e.value.code == _abi.ERR_BAD_ARG

@@ -12,6 +12,7 @@
 #include "hsqp_riccati.h"
 #include "hsqp_params.h"
 #include "hsqp_policy.h"
+#include "hsqp_cent.h"
 
 using namespace hsqp;
 
@@ -60,12 +61,34 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
                  DERIV ? rec + (size_t)node * REC_SIZE + REC_MISC : misc + (size_t)node * 8);
 }
 
+// ---- centroidal LQ approximation (hsqp_cent.h): one 128-thread workgroup per (instance, node), lane = tangent direction;
+//      no LDS, the per-lane kinematic arrays live in private memory
+constexpr int CENT_THREADS = 128;
+__global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                          const double* __restrict__ par, double dt, int N, double* __restrict__ rec) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  cent_lq_node(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, rec + (size_t)node * REC_SIZE);
+}
+// ---- centroidal value-only pass: one lane per (instance, node)
+__global__ __launch_bounds__(64) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                      const double* __restrict__ par, double dt, int N, int nodes, double* __restrict__ misc,
+                                                      const LsState* __restrict__ ls) {
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= nodes) return;
+  const int b = node / N, k = node % N;
+  if (ls && !ls[b].active) return;
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, misc + (size_t)node * 8);
+}
+
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof) {
+__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof, int cent) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
-  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE);
+  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE, cent != 0);
 }
 
 // ---- Riccati backward sweep + closed-loop forward sweep (dx): one workgroup per instance
@@ -392,6 +415,13 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
     h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
     return HSQP_ERR_BAD_ARG;
   }
+  if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) {   // padding states of the centroidal layout must be zero (include/hsqp.h)
+    for (size_t r = 0; r < (size_t)p->batch * (p->n_nodes + 2); ++r) {
+      const double* row = r < (size_t)p->batch ? p->x_init + r * NX : p->x_traj + (r - p->batch) * NX;
+      for (int i = HSQP_CNX; i < NX; ++i)
+        if (row[i] != 0.0) { h->err = "centroidal formulation: entries 35..57 of every state row must be zero"; return HSQP_ERR_BAD_ARG; }
+    }
+  }
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes;
   HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, hipMemcpyHostToDevice, h->stream));
@@ -406,6 +436,7 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
 
 int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_reference* r) {
   if (!h) return HSQP_ERR_BAD_ARG;
+  if (h->hdm.formulation != HSQP_FORM_WB) { h->err = "device-side parameter generation is implemented for the whole-body formulation only"; return HSQP_ERR_BAD_ARG; }
   if (!p || !r || !p->x_init || !p->x_traj || !p->u_traj || !r->n_events || !r->event_times || !r->mode_sequence || !r->target_times || !r->target_states) {
     h->err = "null problem / reference pointer";
     return HSQP_ERR_BAD_ARG;
@@ -469,13 +500,17 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
   HCHECK(hipSetDevice(h->device));
   const int B = h->B, N = h->N;
   const int nodes = B * N;
+  const bool cent = h->hdm.formulation == HSQP_FORM_CENTROIDAL;
   for (int it = 0; it < n_iterations; ++it) {
     const bool last = it == n_iterations - 1;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
-    hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
-                       h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
+    if (cent)
+      hipLaunchKernelGGL(k_lq_cent, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N, h->d_rec);
+    else
+      hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
+                         h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128);
+    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     if (want_kkt && !h->d_vf) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
@@ -490,8 +525,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt);
     }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
-    hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
-                       N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);
+    if (cent)
+      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(64), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes, h->d_misc,
+                         (const LsState*)nullptr);
+    else
+      hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+                         N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
                        (const LsState*)nullptr);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
@@ -510,8 +549,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         if (counts[0] > 0)
           hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
         if (counts[1] == 0) break;
-        hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
-                           N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
+        if (cent)
+          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(64), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes,
+                             h->d_misc, (const LsState*)h->d_ls);
+        else
+          hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+                             N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
         hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
                            (const LsState*)h->d_ls);
       }
@@ -579,6 +622,7 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 }
 
 static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s_or_x, const double* u_in, double* x_out, double* u_out, double* tau) {
+  if (h->hdm.formulation != HSQP_FORM_WB) { h->err = "policy evaluation / joint torques are implemented for the whole-body formulation only"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
   const size_t nin = from_solution ? (size_t)n : (size_t)n * (NX + NU);
   const size_t o_in = 0, o_x = o_in + align256(nin * 8), o_u = o_x + align256((size_t)n * NX * 8), o_tau = o_u + align256((size_t)n * NU * 8),
@@ -658,7 +702,10 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
     case HSQP_BLK_AB: {
       if (!fetch_rec(rec)) return HSQP_ERR_HIP;
       out.resize(nodes * NX * NZ);
-      for (size_t n = 0; n < nodes; ++n) expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
+      for (size_t n = 0; n < nodes; ++n) {
+        if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) cent_expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
+        else expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
+      }
       break;
     }
     case HSQP_BLK_BVEC: case HSQP_BLK_FLOW: {
