@@ -118,7 +118,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   const DevModel& dm = *static_cast<DevModel*>(h);
   const bool cent = dm.formulation == HSQP_FORM_CENTROIDAL;
   Ctx ctx{0, 1, nullptr};
-  std::vector<double> rec((size_t)N * REC_SIZE), qp((size_t)N * QP_SIZE), ric((size_t)N * RIC_SIZE), ut((size_t)N * NUT);
+  std::vector<double> rec((size_t)N * REC_SIZE), qp((size_t)N * QP_SIZE), ric((size_t)N * RIC_SIZE, std::nan("")), ut((size_t)N * NUT);   // ric poisoned: parts nobody writes must not be read
   auto lw = std::make_unique<LqWST<true>>();
   auto lwv = std::make_unique<LqWST<false>>();
   auto pw = std::make_unique<ProjWS>();
@@ -134,9 +134,11 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto terminal = [&](const double* xx) { double c = 0; for (int i = 0; i < NX; ++i) { const double d = xx[N * NX + i] - par[N * NP + HSQP_P_XDES + i]; c += 0.5 * dm.Qf[i] * d * d; } return c; };
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
-  riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
+  if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
+  else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
-  riccati_forward(ctx, *rw, x_init, x, ric.data(), N, dx);
+  if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, ric.data(), N, dx);
+  else riccati_forward(ctx, *rw, x_init, x, ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();
   for (int k = 0; k < N; ++k)
     step_node(ctx, *sw, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const d
 }
 
 // ---- Riccati backward sweep + closed-loop forward sweep (dx): one workgroup per instance
+template <int NXE>
 __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
                                                          const double* __restrict__ x, const double* __restrict__ par,
                                                          const double* __restrict__ qp, double* __restrict__ ric, int N,
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   for (int k = threadIdx.x; k < N; k += blockDim.x)
     if (qpb[(size_t)k * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
   const int bad = __syncthreads_or(mybad);
-  riccati_backward(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
+  riccati_backward<NXE>(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
   PH_TICK(ctx, 0);
-  riccati_forward(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
+  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
   if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
 }
@@ -401,8 +402,9 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
-  hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
-  if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  hipError_t a5 = hipFuncSetAttribute((const void*)k_riccati<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess || a5 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   *out = h;
   g_create_error.clear();
   return HSQP_OK;
@@ -516,8 +518,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
     }
-    hipLaunchKernelGGL(k_riccati, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                       h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
+    if (cent)   // the recursion on the 35 centroidal states only (the padding states are decoupled)
+      hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                         h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
+    else
+      hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                         h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
     hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                        h->d_xnew, h->d_unew, h->d_stepinfo);
     if (want_kkt) {

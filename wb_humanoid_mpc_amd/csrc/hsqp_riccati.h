@@ -52,6 +52,11 @@ struct RicWS {
 // qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
 // vf (optional, [N+1][VF_SIZE]): the value function S_k, s_k of every node, for the KKT check (lam_k = S_k dx_k + s_k).
 constexpr int VF_SIZE = NX * NX + NX;
+// NXE: number of leading states that take part in the recursion.  NX for the whole-body problem; 35 for the centroidal problem
+// embedded in the 58-state layout, whose padding states are decoupled (A~ = I, B~ = 0, no cost there), so S, s, K, Acl - I, bcl
+// vanish on them identically: every product is restricted to the leading NXE x NXE blocks (leading dimensions stay NX) and the
+// padding parts of the outputs are written as zeros / left untouched where nothing reads them.
+template <int NXE = NX>
 HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const double* xN, const double* parN, const double* qp,
                               double* ric, int N, double* vf = nullptr) {
   WG_FOR(ctx, i, NX * NX + NX + 1) {
@@ -85,8 +90,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     PH_MARK(ctx);
     // ---- P2: SA = S A, SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
     {
-      const XtyJob jobs[2] = {xty_job(NX, NX, NX, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
-                              xty_job(NX, NUT, NX, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
+      const XtyJob jobs[2] = {xty_job(NXE, NXE, NXE, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
+                              xty_job(NXE, NUT, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
@@ -97,7 +102,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         WG_FOR(hc, it, RIC_HELPERS) {
           double t[7];
           if (k > 0) load_batch<7>(it, nh, qn + QP_A, t);
-          if (it < NX) w.sb[it] = w.sv[it] + dot_strided<NX>(&w.S[0][it], NX, w.bt);
+          if (it < NXE) w.sb[it] = w.sv[it] + dot_strided<NXE>(&w.S[0][it], NX, w.bt);
           if (k > 0) store_batch<7>(it, nh, t, [&](int i, double v) { An[i / NX][i % NX] = v; });
         }
       }
@@ -108,8 +113,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     PH_MARK(ctx);
     // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
     {
-      const XtyJob jobs[2] = {xty_job(NUT, NX, NX, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
-                              xty_job(NUT, NUT, NX, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
+      const XtyJob jobs[2] = {xty_job(NUT, NXE, NXE, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
+                              xty_job(NUT, NUT, NXE, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
       constexpr int nh = (NX * NX) / 2, na = nbatches(NX * NX - nh, 7);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
@@ -125,10 +130,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           for (int j = it; j < NUT * (LDF - NUT); j += RIC_HELPERS) { const int r = j / (LDF - NUT), c = NUT + j % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
           if (it < 4 * NUT) {   // g = r~ + B^T sb in four partial sums per row (columns 0..3 of Em, added where g is used)
             const int r = it >> 2, p = it & 3;
-            constexpr int LA = (NX + 3) / 4;
+            constexpr int LA = (NXE + 3) / 4;
             double sg = rv;
 #pragma unroll
-            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NX ? ll : NX - 1; const double a = w.B[lc][r], b = w.sb[lc]; sg += ll < NX ? a * b : 0.0; }
+            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = w.B[lc][r], b = w.sb[lc]; sg += ll < NXE ? a * b : 0.0; }
             w.Em[r][EM_GVP + p] = sg;
           }
           if (k > 0) store_batch<7>(it, NX * NX - nh, t, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
@@ -206,7 +211,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     WG_SYNC(ctx);
     // ---- P4c: Z = L^-1 G (matrix cores), z = L^-1 g
     {
-      const XtyJob job = xty_job(NUT, NX, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
+      const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
@@ -221,7 +226,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     WG_SYNC(ctx);
     // ---- P4d: K = -L^-T Z (matrix cores, over the G block), k = -L^-T z; both also to the record
     {
-      const XtyJob job = xty_job(NUT, NX, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0);
+      const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
@@ -240,10 +245,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A + B K, s <- q + A^T sb - Z^T z, bcl = b + B k ; K -> record;
     //          prefetch of the next stage's B~, b~ (B is dead since P3)
     {
-      XtyJob js = xty_job(NX, NX, NX, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
+      XtyJob js = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
       js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
       js.sym = 1;   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
-      const XtyJob jobs[2] = {js, xty_job(NX, NX, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX)};
+      const XtyJob jobs[2] = {js, xty_job(NXE, NXE, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX)};
       constexpr int nbb = nbatches(NX * LDB, 8);
       if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
@@ -251,22 +256,22 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         WG_FOR(hc, it, 5 * NX + NUT * NX) {
           if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in P6): short chains, 232 lanes
             const int r = it >> 2, p = it & 3;
-            constexpr int LA = (NX + 3) / 4, LZ = (NUT + 3) / 4;
+            constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
             double s = p == 0 ? q[QP_QV + r] : 0.0;
 #pragma unroll
-            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NX ? ll : NX - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NX ? a * b : 0.0; }
+            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
 #pragma unroll
             for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
-            w.part[it] = s;
+            w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
           } else if (it < 5 * NX) {
             const int r = it - 4 * NX;
             double s = w.bt[r];
 #pragma unroll
             for (int l = 0; l < NUT; ++l) s += w.Em[l][EM_BT + r] * w.kv[l];
-            rk[RIC_BCL + r] = s;
+            rk[RIC_BCL + r] = (NXE == NX || r < NXE) ? s : 0.0;
           } else {
             const int j = it - 5 * NX;
-            rk[RIC_K + j] = w.Em[j / NX][EM_G + j % NX];
+            rk[RIC_K + j] = (NXE == NX || j % NX < NXE) ? w.Em[j / NX][EM_G + j % NX] : 0.0;
           }
         }
         WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage (unless the elimination phase already did)
@@ -307,6 +312,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 }
 
 // Forward sweep dx+ = Acl dx + bcl (serial over stages); writes dx [N+1][58].
+template <int NXE = NX>
 HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* ric, int N, double* dx_out) {
   WG_FOR(ctx, i, NX) {
     const double d = x_init[i] - x[i];
@@ -316,10 +322,11 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
   WG_SYNC(ctx);
   for (int k = 0; k < N; ++k) {
     const double* rk = ric + (size_t)k * RIC_SIZE;
-    WG_FOR(ctx, it, NX * 4) w.part[it] = matvec_part<NX>(rk + RIC_ACL + (it >> 2) * NX, w.dx, it & 3);
+    WG_FOR(ctx, it, NXE * 4) w.part[it] = matvec_part<NXE>(rk + RIC_ACL + (it >> 2) * NX, w.dx, it & 3);
     WG_SYNC(ctx);
     WG_FOR(ctx, i, NX) {
-      const double s = rk[RIC_BCL + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
+      // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
+      const double s = (NXE == NX || i < NXE) ? rk[RIC_BCL + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3])) : w.dx[i];
       w.dx[i] = s;
       dx_out[(size_t)(k + 1) * NX + i] = s;
     }
