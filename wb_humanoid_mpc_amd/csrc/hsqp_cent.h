@@ -88,101 +88,167 @@ template <class T> HSQP_HD void t_inverse3(const T* a, T* c) {
   for (int i = 0; i < 9; ++i) c[i] = c[i] * inv;
 }
 
-// ---- per-lane kinematic state of one model pass
+// ---- per-lane state of one model pass.  The tree is walked chain by chain (DevModel::chain_*: maximal single-child paths): inside
+// a chain the parent is the previous body and stays in registers; only the records of the chain ENDS (where other chains attach)
+// are kept in a small table.  What the cost / constraint terms need later is collected in side tables while the walk passes the
+// bodies concerned (stage 1 only: TERMS = true).
+template <class T>
+struct BodyRec { T R[9], p[3], om[3], v[3]; };   // placement; angular / origin velocity RELATIVE to the base (joint rates only)
+constexpr int CENT_MAX_SLOTS = 8;                // base + chains of the kinematic tree (build_dev_model checks)
+
+template <class T>
+struct CentSide {
+  BodyRec<T> foot[2], torso;
+  T pts[10][3];                  // collision points (order of DevModel::coll_body)
+  T ea[2][6][4];                 // external-torque joints: tau = pos_foot . ea[0..2] + ea[3]  (ea = {f x w_j, w_j . m - p_j . (f x w_j)})
+};
 template <class T>
 struct CentKin {
-  T R[NB][9], p[NB][3];
-  T w[NB][3];                    // joint axes, world
-  T om[NB][3], v[NB][3];         // angular / origin velocity of the bodies RELATIVE to the base (joint rates only)
+  BodyRec<T> ends[CENT_MAX_SLOTS];   // slot 0 = base, slot 1 + c = last body of chain c
   T E[9];                        // E[3 r + e]: world axis of euler rate e (z, y, x)
-  T com[3];
+  T p0[3], com[3];
   T vb[6];                       // [pdot; euler rates]
   T wb[3];                       // angular velocity of the base = E euler rates
+  CentSide<T> side;
 };
+
+// momentum sums of the walk: total m c, momentum of the joint motion about the world origin, composite inertia about the origin
+template <class T>
+struct CentSums { T mc[3], lin[3], angO[3], IO[6]; };
+
+template <class T>
+HSQP_HD void cent_accumulate(const DevModel& dm, int i, const BodyRec<T>& b, CentSums<T>& a) {
+  const double m = dm.mass[i];
+  T rc[3], c[3], t[3], vc[3];
+  t_mulc(b.R, dm.com[i], rc);
+  for (int r = 0; r < 3; ++r) c[r] = b.p[r] + rc[r];
+  t_cross(b.om, rc, t);
+  for (int r = 0; r < 3; ++r) vc[r] = b.v[r] + t[r];
+  // Iw = R I R^T (symmetric): RI = R I first
+  T RI[9], Iw[6];
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc) RI[3 * r + cc] = b.R[3 * r] * dm.inertia[i][cc] + b.R[3 * r + 1] * dm.inertia[i][3 + cc] + b.R[3 * r + 2] * dm.inertia[i][6 + cc];
+  {
+    int n = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = r; cc < 3; ++cc) Iw[n++] = RI[3 * r] * b.R[3 * cc] + RI[3 * r + 1] * b.R[3 * cc + 1] + RI[3 * r + 2] * b.R[3 * cc + 2];
+  }
+  const T c2 = t_dot(c, c);
+  a.IO[0] = a.IO[0] + Iw[0] + (c2 - c[0] * c[0]) * m; a.IO[1] = a.IO[1] + Iw[1] - (c[0] * c[1]) * m; a.IO[2] = a.IO[2] + Iw[2] - (c[0] * c[2]) * m;
+  a.IO[3] = a.IO[3] + Iw[3] + (c2 - c[1] * c[1]) * m; a.IO[4] = a.IO[4] + Iw[4] - (c[1] * c[2]) * m; a.IO[5] = a.IO[5] + Iw[5] + (c2 - c[2] * c[2]) * m;
+  T mv[3], cxmv[3];
+  for (int r = 0; r < 3; ++r) { mv[r] = vc[r] * m; a.mc[r] = a.mc[r] + c[r] * m; a.lin[r] = a.lin[r] + mv[r]; }
+  t_cross(c, mv, cxmv);
+  const T* o = b.om;
+  a.angO[0] = a.angO[0] + Iw[0] * o[0] + Iw[1] * o[1] + Iw[2] * o[2] + cxmv[0];
+  a.angO[1] = a.angO[1] + Iw[1] * o[0] + Iw[3] * o[1] + Iw[4] * o[2] + cxmv[1];
+  a.angO[2] = a.angO[2] + Iw[2] * o[0] + Iw[4] * o[1] + Iw[5] * o[2] + cxmv[2];
+}
+
+// side tables for body i (world joint axis w; W = contact wrenches of the node)
+template <class T>
+HSQP_HD void cent_collect(const DevModel& dm, int i, const BodyRec<T>& b, const T* w, const T* W, CentSide<T>& sd) {
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+    if (i == dm.contact_body[f]) sd.foot[f] = b;
+  if (i == dm.torso_body) sd.torso = b;
+#pragma unroll
+  for (int p = 0; p < 10; ++p)
+    if (i == dm.coll_body[p]) {
+      T rp[3];
+      t_mulc(b.R, dm.coll_p[p], rp);
+      for (int r = 0; r < 3; ++r) sd.pts[p][r] = b.p[r] + rp[r];
+    }
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+      if (i == 1 + dm.ext_joint[f][a]) {
+        // tau_j = w_j . (m + (pos - p_j) x f) = pos . (f x w_j) + (w_j . m - p_j . (f x w_j)); zero unless joint j carries the foot
+        const int cb = dm.contact_body[f];
+        const bool carries = cb >= i && cb < i + dm.subtree_size[i];
+        T fxw[3];
+        t_cross(W + 6 * f, w, fxw);
+        const T rest = t_dot(w, W + 6 * f + 3) - t_dot(b.p, fxw);
+        for (int r = 0; r < 3; ++r) sd.ea[f][a][r] = carries ? fxw[r] : cst<T>(0.0);
+        sd.ea[f][a][3] = carries ? rest : cst<T>(0.0);
+      }
+}
 
 // One pass over the kinematic tree at q = [p_b, euler, q_j] with joint rates qd, then the base velocity from the normalized
 // momentum h and the normalized momentum rate for the contact wrenches W.  xdot[0..11] = [d(h/m)/dt ; pdot ; euler rates].
-template <class T>
+template <class T, bool TERMS>
 HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, const T* qd, CentKin<T>& k, T* xdot) {
-  T sz, cz, sy, cy, sx, cx;
-  dsincos(q[3], sz, cz); dsincos(q[4], sy, cy); dsincos(q[5], sx, cx);
-  // R_0 = Rz Ry Rx
-  k.R[0][0] = cz * cy; k.R[0][1] = cz * sy * sx - sz * cx; k.R[0][2] = cz * sy * cx + sz * sx;
-  k.R[0][3] = sz * cy; k.R[0][4] = sz * sy * sx + cz * cx; k.R[0][5] = sz * sy * cx - cz * sx;
-  k.R[0][6] = -sy;     k.R[0][7] = cy * sx;                k.R[0][8] = cy * cx;
   const T zero = cst<T>(0.0), one = cst<T>(1.0);
-  k.E[0] = zero; k.E[3] = zero; k.E[6] = one;            // z axis
-  k.E[1] = -sz;  k.E[4] = cz;   k.E[7] = zero;           // Rz e_y
-  k.E[2] = cz * cy; k.E[5] = sz * cy; k.E[8] = -sy;      // Rz Ry e_x
-  for (int r = 0; r < 3; ++r) { k.p[0][r] = q[r]; k.om[0][r] = zero; k.v[0][r] = zero; k.w[0][r] = zero; }
-  T mc[3] = {zero, zero, zero}, lin[3] = {zero, zero, zero}, angO[3] = {zero, zero, zero};
-  T IO[6] = {zero, zero, zero, zero, zero, zero};        // xx xy xz yy yz zz about the world origin
-  for (int i = 0; i < NB; ++i) {
-    if (i > 0) {
-      const int par = dm.parent[i];
+  CentSums<T> sums;
+  for (int r = 0; r < 3; ++r) { sums.mc[r] = zero; sums.lin[r] = zero; sums.angO[r] = zero; sums.IO[r] = zero; sums.IO[3 + r] = zero; }
+  T pc[2][3];   // contact points
+  {
+    T sz, cz, sy, cy, sx, cx;
+    dsincos(q[3], sz, cz); dsincos(q[4], sy, cy); dsincos(q[5], sx, cx);
+    BodyRec<T> b0;   // R_0 = Rz Ry Rx
+    b0.R[0] = cz * cy; b0.R[1] = cz * sy * sx - sz * cx; b0.R[2] = cz * sy * cx + sz * sx;
+    b0.R[3] = sz * cy; b0.R[4] = sz * sy * sx + cz * cx; b0.R[5] = sz * sy * cx - cz * sx;
+    b0.R[6] = -sy;     b0.R[7] = cy * sx;                b0.R[8] = cy * cx;
+    k.E[0] = zero; k.E[3] = zero; k.E[6] = one;            // z axis
+    k.E[1] = -sz;  k.E[4] = cz;   k.E[7] = zero;           // Rz e_y
+    k.E[2] = cz * cy; k.E[5] = sz * cy; k.E[8] = -sy;      // Rz Ry e_x
+    for (int r = 0; r < 3; ++r) { b0.p[r] = q[r]; k.p0[r] = q[r]; b0.om[r] = zero; b0.v[r] = zero; }
+    cent_accumulate(dm, 0, b0, sums);
+    if constexpr (TERMS) { const T w0[3] = {zero, zero, zero}; cent_collect(dm, 0, b0, w0, W, k.side); }
+    for (int f = 0; f < 2; ++f)
+      if (dm.contact_body[f] == 0) { T rp[3]; t_mulc(b0.R, dm.contact_p[f], rp); for (int r = 0; r < 3; ++r) pc[f][r] = b0.p[r] + rp[r]; }
+    k.ends[0] = b0;
+  }
+  for (int c = 0; c < dm.n_chains; ++c) {
+    BodyRec<T> cur = k.ends[dm.chain_par_slot[c]];
+    const int i0 = dm.chain_start[c], len = dm.chain_len[c];
+    for (int i = i0; i < i0 + len; ++i) {
+      BodyRec<T> nb;
       T Rj[9];
       for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-          Rj[3 * r + c] = k.R[par][3 * r] * dm.Rfix[i][c] + k.R[par][3 * r + 1] * dm.Rfix[i][3 + c] + k.R[par][3 * r + 2] * dm.Rfix[i][6 + c];
-      T s, c;
-      dsincos(q[5 + i], s, c);
+        for (int cc = 0; cc < 3; ++cc)
+          Rj[3 * r + cc] = cur.R[3 * r] * dm.Rfix[i][cc] + cur.R[3 * r + 1] * dm.Rfix[i][3 + cc] + cur.R[3 * r + 2] * dm.Rfix[i][6 + cc];
+      T sn, cs;
+      dsincos(q[5 + i], sn, cs);
       const double* a = dm.axis[i];
       // Rodrigues: Rot = I + s K + (1 - c) K^2,  K = [a]x (unit axis)
-      const T omc = one - c;
+      const T omc = one - cs;
       T Rot[9];
-      Rot[0] = one + omc * (a[0] * a[0] - 1.0);     Rot[1] = omc * (a[0] * a[1]) - s * a[2];      Rot[2] = omc * (a[0] * a[2]) + s * a[1];
-      Rot[3] = omc * (a[0] * a[1]) + s * a[2];      Rot[4] = one + omc * (a[1] * a[1] - 1.0);     Rot[5] = omc * (a[1] * a[2]) - s * a[0];
-      Rot[6] = omc * (a[0] * a[2]) - s * a[1];      Rot[7] = omc * (a[1] * a[2]) + s * a[0];      Rot[8] = one + omc * (a[2] * a[2] - 1.0);
+      Rot[0] = one + omc * (a[0] * a[0] - 1.0);     Rot[1] = omc * (a[0] * a[1]) - sn * a[2];     Rot[2] = omc * (a[0] * a[2]) + sn * a[1];
+      Rot[3] = omc * (a[0] * a[1]) + sn * a[2];     Rot[4] = one + omc * (a[1] * a[1] - 1.0);     Rot[5] = omc * (a[1] * a[2]) - sn * a[0];
+      Rot[6] = omc * (a[0] * a[2]) - sn * a[1];     Rot[7] = omc * (a[1] * a[2]) + sn * a[0];     Rot[8] = one + omc * (a[2] * a[2] - 1.0);
       for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) k.R[i][3 * r + cc] = Rj[3 * r] * Rot[cc] + Rj[3 * r + 1] * Rot[3 + cc] + Rj[3 * r + 2] * Rot[6 + cc];
-      T off[3], t[3];
-      t_mulc(k.R[par], dm.pfix[i], off);
-      t_mulc(Rj, dm.axis[i], k.w[i]);
-      t_cross(k.om[par], off, t);
+        for (int cc = 0; cc < 3; ++cc) nb.R[3 * r + cc] = Rj[3 * r] * Rot[cc] + Rj[3 * r + 1] * Rot[3 + cc] + Rj[3 * r + 2] * Rot[6 + cc];
+      T off[3], t[3], w[3];
+      t_mulc(cur.R, dm.pfix[i], off);
+      t_mulc(Rj, dm.axis[i], w);
+      t_cross(cur.om, off, t);
       for (int r = 0; r < 3; ++r) {
-        k.p[i][r] = k.p[par][r] + off[r];
-        k.om[i][r] = k.om[par][r] + k.w[i][r] * qd[i - 1];
-        k.v[i][r] = k.v[par][r] + t[r];
+        nb.p[r] = cur.p[r] + off[r];
+        nb.om[r] = cur.om[r] + w[r] * qd[i - 1];
+        nb.v[r] = cur.v[r] + t[r];
       }
+      cent_accumulate(dm, i, nb, sums);
+      if constexpr (TERMS) cent_collect(dm, i, nb, w, W, k.side);
+      for (int f = 0; f < 2; ++f)
+        if (dm.contact_body[f] == i) { T rp[3]; t_mulc(nb.R, dm.contact_p[f], rp); for (int r = 0; r < 3; ++r) pc[f][r] = nb.p[r] + rp[r]; }
+      cur = nb;
     }
-    // body i: centre of mass, world inertia, momentum of the joint motion about the world origin
-    const double m = dm.mass[i];
-    T rc[3], c[3], t[3], vc[3];
-    t_mulc(k.R[i], dm.com[i], rc);
-    for (int r = 0; r < 3; ++r) c[r] = k.p[i][r] + rc[r];
-    t_cross(k.om[i], rc, t);
-    for (int r = 0; r < 3; ++r) vc[r] = k.v[i][r] + t[r];
-    // Iw = R I R^T (symmetric): RI = R I first
-    T RI[9], Iw[6];
-    for (int r = 0; r < 3; ++r)
-      for (int cc = 0; cc < 3; ++cc) RI[3 * r + cc] = k.R[i][3 * r] * dm.inertia[i][cc] + k.R[i][3 * r + 1] * dm.inertia[i][3 + cc] + k.R[i][3 * r + 2] * dm.inertia[i][6 + cc];
-    {
-      int n = 0;
-      for (int r = 0; r < 3; ++r)
-        for (int cc = r; cc < 3; ++cc) Iw[n++] = RI[3 * r] * k.R[i][3 * cc] + RI[3 * r + 1] * k.R[i][3 * cc + 1] + RI[3 * r + 2] * k.R[i][3 * cc + 2];
-    }
-    const T c2 = t_dot(c, c);
-    IO[0] = IO[0] + Iw[0] + (c2 - c[0] * c[0]) * m; IO[1] = IO[1] + Iw[1] - (c[0] * c[1]) * m; IO[2] = IO[2] + Iw[2] - (c[0] * c[2]) * m;
-    IO[3] = IO[3] + Iw[3] + (c2 - c[1] * c[1]) * m; IO[4] = IO[4] + Iw[4] - (c[1] * c[2]) * m; IO[5] = IO[5] + Iw[5] + (c2 - c[2] * c[2]) * m;
-    T mv[3], cxmv[3];
-    for (int r = 0; r < 3; ++r) { mv[r] = vc[r] * m; mc[r] = mc[r] + c[r] * m; lin[r] = lin[r] + mv[r]; }
-    t_cross(c, mv, cxmv);
-    const T* o = k.om[i];
-    angO[0] = angO[0] + Iw[0] * o[0] + Iw[1] * o[1] + Iw[2] * o[2] + cxmv[0];
-    angO[1] = angO[1] + Iw[1] * o[0] + Iw[3] * o[1] + Iw[4] * o[2] + cxmv[1];
-    angO[2] = angO[2] + Iw[2] * o[0] + Iw[4] * o[1] + Iw[5] * o[2] + cxmv[2];
+    k.ends[1 + c] = cur;
   }
   const double M = dm.total_mass, iM = 1.0 / M;
-  for (int r = 0; r < 3; ++r) k.com[r] = mc[r] * iM;
+  for (int r = 0; r < 3; ++r) k.com[r] = sums.mc[r] * iM;
   const T* cm = k.com;
+  const T* IO = sums.IO;
   const T cm2 = t_dot(cm, cm);
   T Ic[9];
   Ic[0] = IO[0] - (cm2 - cm[0] * cm[0]) * M; Ic[1] = IO[1] + (cm[0] * cm[1]) * M; Ic[2] = IO[2] + (cm[0] * cm[2]) * M;
   Ic[4] = IO[3] - (cm2 - cm[1] * cm[1]) * M; Ic[5] = IO[4] + (cm[1] * cm[2]) * M; Ic[8] = IO[5] - (cm2 - cm[2] * cm[2]) * M;
   Ic[3] = Ic[1]; Ic[6] = Ic[2]; Ic[7] = Ic[5];
   T angJ[3], t[3];
-  t_cross(cm, lin, t);
-  for (int r = 0; r < 3; ++r) angJ[r] = angO[r] - t[r];
+  t_cross(cm, sums.lin, t);
+  for (int r = 0; r < 3; ++r) angJ[r] = sums.angO[r] - t[r];
   // euler rates = (Ic E)^-1 (M h_ang - angJ)
   T A22[9], A22i[9], rhs[3];
   for (int r = 0; r < 3; ++r)
@@ -192,16 +258,14 @@ HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, c
   t_mulv(A22i, rhs, k.vb + 3);
   t_mulv(k.E, k.vb + 3, k.wb);
   T d[3];
-  for (int r = 0; r < 3; ++r) d[r] = cm[r] - k.p[0][r];
+  for (int r = 0; r < 3; ++r) d[r] = cm[r] - k.p0[r];
   t_cross(k.wb, d, t);
-  for (int r = 0; r < 3; ++r) k.vb[r] = h[r] - lin[r] * iM - t[r];
+  for (int r = 0; r < 3; ++r) k.vb[r] = h[r] - sums.lin[r] * iM - t[r];
   // normalized momentum rate (getNormalizedCentroidalMomentumRate; gravity 9.81 hard-coded as upstream does)
   T fs[3] = {zero, zero, cst<T>(-9.81 * M)}, ns[3] = {zero, zero, zero};
   for (int f = 0; f < 2; ++f) {
-    const int b = dm.contact_body[f];
-    T rp[3], arm[3];
-    t_mulc(k.R[b], dm.contact_p[f], rp);
-    for (int r = 0; r < 3; ++r) arm[r] = k.p[b][r] + rp[r] - cm[r];
+    T arm[3];
+    for (int r = 0; r < 3; ++r) arm[r] = pc[f][r] - cm[r];
     t_cross(arm, W + 6 * f, t);
     for (int r = 0; r < 3; ++r) { fs[r] = fs[r] + W[6 * f + r]; ns[r] = ns[r] + t[r] + W[6 * f + 3 + r]; }
   }
@@ -209,15 +273,15 @@ HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, c
   for (int r = 0; r < 6; ++r) xdot[6 + r] = k.vb[r];
 }
 
-// world position and LOCAL_WORLD_ALIGNED velocity of a point fixed to body b (velocity-level model: base motion + joint motion)
+// world position and LOCAL_WORLD_ALIGNED velocity of a point fixed to a body (velocity-level model: base motion + joint motion)
 template <class T>
-HSQP_HD void cent_point(const CentKin<T>& k, int b, const double* pl, T* pos, T* vlin, T* vang) {
+HSQP_HD void cent_point(const CentKin<T>& k, const BodyRec<T>& b, const double* pl, T* pos, T* vlin, T* vang) {
   T rp[3], d[3], t1[3], t2[3];
-  t_mulc(k.R[b], pl, rp);
-  for (int r = 0; r < 3; ++r) { pos[r] = k.p[b][r] + rp[r]; d[r] = pos[r] - k.p[0][r]; vang[r] = k.wb[r] + k.om[b][r]; }
+  t_mulc(b.R, pl, rp);
+  for (int r = 0; r < 3; ++r) { pos[r] = b.p[r] + rp[r]; d[r] = pos[r] - k.p0[r]; vang[r] = k.wb[r] + b.om[r]; }
   t_cross(k.wb, d, t1);          // rigid base motion of the point
-  t_cross(k.om[b], rp, t2);      // joint motion relative to the base
-  for (int r = 0; r < 3; ++r) vlin[r] = k.vb[r] + t1[r] + k.v[b][r] + t2[r];
+  t_cross(b.om, rp, t2);         // joint motion relative to the base
+  for (int r = 0; r < 3; ++r) vlin[r] = k.vb[r] + t1[r] + b.v[r] + t2[r];
 }
 
 // quaternion (x, y, z, w) of a rotation matrix, branch chosen on the values (oracle ASSUMPTION A8)
@@ -270,12 +334,12 @@ HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, con
   };
   // ---- torso task-space cost: EndEffectorKinematicsQuadraticCost.cpp:110-138 (quaternionDistance, velocity differences)
   {
-    const int b = dm.torso_body;
+    const BodyRec<T>& tb = k.side.torso;
     T Rt[9], qc[4], pos[3], vl[3], va[3];
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) Rt[3 * r + c] = k.R[b][3 * r] * dm.torso_R[c] + k.R[b][3 * r + 1] * dm.torso_R[3 + c] + k.R[b][3 * r + 2] * dm.torso_R[6 + c];
+      for (int c = 0; c < 3; ++c) Rt[3 * r + c] = tb.R[3 * r] * dm.torso_R[c] + tb.R[3 * r + 1] * dm.torso_R[3 + c] + tb.R[3 * r + 2] * dm.torso_R[6 + c];
     cent_quat(Rt, qc);
-    cent_point(k, b, dm.torso_p, pos, vl, va);
+    cent_point(k, tb, dm.torso_p, pos, vl, va);
     const double* ref = par + HSQP_PC_TORSO;
     const T rv[3] = {cst<T>(ref[3]), cst<T>(ref[4]), cst<T>(ref[5])};
     T cr[3];
@@ -288,12 +352,7 @@ HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, con
   }
   // ---- foot collision (FootCollisionConstraint.cpp:92-144), inactive in double support
   if (!both) {
-    T pts[10][3];
-    for (int p = 0; p < 10; ++p) {
-      T rp[3];
-      t_mulc(k.R[dm.coll_body[p]], dm.coll_p[p], rp);
-      for (int r = 0; r < 3; ++r) pts[p][r] = k.p[dm.coll_body[p]][r] + rp[r];
-    }
+    const T (*pts)[3] = k.side.pts;
     for (int r = 0; r < 16; ++r) {
       int a, b;
       coll_pair(r, a, b);
@@ -306,12 +365,13 @@ HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, con
   // ---- per foot
   o.hfric_d1[0] = o.hfric_d1[1] = 0.0;
   for (int f = 0; f < 2; ++f) {
-    const int ct = o.contact[f], b = dm.contact_body[f];
+    const int ct = o.contact[f];
+    const BodyRec<T>& fb = k.side.foot[f];
     T pos[3], vl[3], va[3], ori[3];
-    cent_point(k, b, dm.contact_p[f], pos, vl, va);
+    cent_point(k, fb, dm.contact_p[f], pos, vl, va);
     {  // orientation error to the ground plane (oracle ASSUMPTION A2): (n x a) / sqrt(2 (1 + a.n)), a = R e_z, n = e_z
-      const T s = dsqrt((k.R[b][8] + 1.0) * 2.0);
-      ori[0] = -k.R[b][5] / s; ori[1] = k.R[b][2] / s; ori[2] = zero;
+      const T s = dsqrt((fb.R[8] + 1.0) * 2.0);
+      ori[0] = -fb.R[5] / s; ori[1] = fb.R[2] / s; ori[2] = zero;
     }
     const T* Wf = u + 6 * f;
     if (ct) {
@@ -327,22 +387,15 @@ HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, con
       o.row[CROW_FRIC + 4 * f + 3] = Wf[0] * val(Wf[1]) - Wf[1] * val(Wf[0]); o.sc[CROW_FRIC + 4 * f + 3] = sqrt(-p.d1 / T3);
       // contact moment XY (ContactMomentXYConstraintCppAd.cpp:77-104): wrench in the contact frame
       T lf[3], lm[3];
-      t_tmulv(k.R[b], Wf, lf);
-      t_tmulv(k.R[b], Wf + 3, lm);
+      t_tmulv(fb.R, Wf, lf);
+      t_tmulv(fb.R, Wf + 3, lm);
       const T hm[4] = {lm[0] - lf[2] * dm.rect_y_min, lf[2] * dm.rect_y_max - lm[0], -lm[1] - lf[2] * dm.rect_x_min, lm[1] + lf[2] * dm.rect_x_max};
       for (int r = 0; r < 4; ++r) pen(CROW_MXY + 4 * f + r, hm[r], relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, val(hm[r])));
       // external torque cost (ExternalTorqueQuadraticCostAD.cpp:110-135): (J_ee^T W)[6 + j] .* sqrtW * (1 - impactProximity of the other foot)
       const double mid = 1.0 - par[HSQP_P_IMPACT + (1 - f)];
       for (int a = 0; a < 6; ++a) {
-        const int bj = 1 + dm.ext_joint[f][a];
-        T tau = zero;
-        if (b >= bj && b < bj + dm.subtree_size[bj]) {
-          T arm[3], t[3];
-          for (int r = 0; r < 3; ++r) arm[r] = pos[r] - k.p[bj][r];
-          t_cross(arm, Wf, t);
-          for (int r = 0; r < 3; ++r) t[r] = t[r] + Wf[3 + r];
-          tau = t_dot(k.w[bj], t);
-        }
+        const T* ea = k.side.ea[f][a];
+        const T tau = pos[0] * ea[0] + pos[1] * ea[1] + pos[2] * ea[2] + ea[3];
         gn(crow_ext(f, both, a), tau, dm.ext_sqrt_w[f][a] * mid);
       }
     }
@@ -395,7 +448,7 @@ HSQP_HD void cent_program(const DevModel& dm, const double* x, const double* u, 
   else if (dir >= CNX && dir < CNZ) set_tan(us[dir - CNX]);
   T x0[CNX];
   for (int i = 0; i < CNX; ++i) x0[i] = xs[i];
-  cent_pass<T>(dm, xs, xs + 6, us, us + 12, k, k1);
+  cent_pass<T, true>(dm, xs, xs + 6, us, us + 12, k, k1);
   cent_terms<T>(dm, k, xs, us, par, o);
   for (int r = 0; r < 12; ++r) { flow[r] = k1[r]; acc[r] = k1[r]; }
   // stages 2..4: x_s = x + c k_{s-1}; the joint rows of every k are qd_j
@@ -405,7 +458,7 @@ HSQP_HD void cent_program(const DevModel& dm, const double* x, const double* u, 
     for (int r = 0; r < 12; ++r) xs[r] = x0[r] + kp[r] * c;
     for (int j = 0; j < NJ; ++j) xs[12 + j] = x0[12 + j] + us[12 + j] * c;
     T kn[12];
-    cent_pass<T>(dm, xs, xs + 6, us, us + 12, k, kn);
+    cent_pass<T, false>(dm, xs, xs + 6, us, us + 12, k, kn);
     const double wgt = s == 3 ? 1.0 : 2.0;
     for (int r = 0; r < 12; ++r) { ks[r] = kn[r]; acc[r] = acc[r] + kn[r] * wgt; }
   }

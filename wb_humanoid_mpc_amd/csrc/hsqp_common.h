@@ -147,6 +147,7 @@ struct DevModel {
   // centroidal formulation (hsqp_cent.h); unused by the whole-body kernels
   int formulation, torso_body;
   int ext_joint[2][6];
+  int chain_par_slot[NB];        // per chain: where its first body's parent record sits (0 = base, 1 + c = last body of chain c)
   double torso_p[3], torso_R[9], torso_sqrt_w[12], cent_foot_sqrt_w[12], ext_sqrt_w[2][6];
 };
 

@@ -70,6 +70,16 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
       for (int k = 0; k < NANC; ++k) dm.anc[i][k] = (unsigned char)(k < n ? path[n - 1 - k] : i);   // padded with the body itself (valid index)
     }
     dm.chain_start[dm.n_chains] = 0; dm.chain_len[dm.n_chains] = 1;   // the base
+    // the parent of a chain's first body is the base or the LAST body of an earlier chain (a body with several children ends its chain)
+    for (int c = 0; c < dm.n_chains; ++c) {
+      const int pb = dm.parent[dm.chain_start[c]];
+      int slot = pb == 0 ? 0 : -1;
+      for (int c2 = 0; c2 < c && slot < 0; ++c2)
+        if (dm.chain_start[c2] + dm.chain_len[c2] - 1 == pb) slot = 1 + c2;
+      if (slot < 0) return "internal: a chain does not attach to the end of an earlier chain";
+      dm.chain_par_slot[c] = slot;
+    }
+    if (md.formulation == HSQP_FORM_CENTROIDAL && dm.n_chains + 1 > 8) return "centroidal: kinematic trees with more than 7 chains are not supported";
     for (int i = 1; i < NB; ++i) {
       const hsqp_body& b = md.bodies[i];
       for (int r = 0; r < 3; ++r) dm.axis_p[i][r] = b.R[3 * r] * b.axis[0] + b.R[3 * r + 1] * b.axis[1] + b.R[3 * r + 2] * b.axis[2];
