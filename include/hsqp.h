@@ -163,7 +163,7 @@ typedef struct hsqp_reference {
   const int32_t* mode_sequence;         /* [B][max_events + 1]   0 FLY, 1 RF, 2 LF, 3 STANCE (MotionPhaseDefinition.h:47-56) */
   int32_t n_knots;                      /* knots of the TargetTrajectories (>= 1)                                  */
   const double* target_times;           /* [B][n_knots]                                                           */
-  const double* target_states;          /* [B][n_knots][58]                                                       */
+  const double* target_states;          /* [B][n_knots][58]  (centroidal: the first 35 entries of a row, rest zero)     */
   hsqp_swing_config swing;
   double terrain_height;
   int32_t arm_swing;                    /* 0 disables the arm-swing reference                                     */
@@ -226,7 +226,8 @@ int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solut
 int hsqp_upload(hsqp_handle* h, const hsqp_problem* problem);
 /* Like hsqp_upload, but hsqp_problem::node_params may be NULL: the per-node table is generated on the device from `ref`
  * (batch, n_nodes, dt must agree).  Fails with HSQP_ERR_BAD_ARG if a swing phase has no lift-off / touch-down inside
- * the schedule (the reference's SwingTrajectoryPlanner throws there). */
+ * the schedule (the reference's SwingTrajectoryPlanner throws there).  Centroidal formulation: the torso task-space reference
+ * of every node is computed on the device as well (kinematics of the torso link at the interpolated target state). */
 int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* problem, const hsqp_reference* ref);
 #define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
 #define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */

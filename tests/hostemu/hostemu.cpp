@@ -84,6 +84,18 @@ int emu_node_params(const hsqp_swing_config* cfg, double terrain, int arm_swing,
   return bad;
 }
 
+// the same for the centroidal formulation: the torso task-space reference is appended from the device code's tree pass
+int emu_cent_node_params(void* h, const hsqp_swing_config* cfg, double terrain, int arm_swing, int n_ev, const double* ev, const int* seq, int n_knots,
+                         const double* tt, const double* ts, double t0, double dt, int N, double* par) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  int bad = 0;
+  for (int k = 0; k <= N; ++k) {
+    if (!node_params_eval(*cfg, terrain, arm_swing, n_ev, ev, seq, n_knots, tt, ts, t0 + k * dt, par + (size_t)k * NP)) bad = 1;
+    cent_params_finish(dm, par + (size_t)k * NP);
+  }
+  return bad;
+}
+
 // joint torques of one (x, u) pair through the device code path (hsqp_policy.h)
 void emu_joint_torques(void* h, const double* x, const double* u, double* tau) {
   const DevModel& dm = *static_cast<DevModel*>(h);

@@ -77,3 +77,51 @@ def test_device_table_and_solve_equal_the_uploaded_table(model, gait, n, v_cmd):
         assert np.abs(out["x"] - ref["x"]).max() <= 1e-9 * sc and np.abs(out["u"] - ref["u"]).max() <= 1e-9 * sc
     finally:
         s.close()
+
+
+# ---------------------------------------------------------------------------------------------- centroidal formulation
+@pytest.mark.parametrize("gait,n,v_cmd", CASES)
+def test_centroidal_table_equals_the_host_generators(cmodel, emu, gait, n, v_cmd):
+    """The torso task-space reference is generated on the device too (tree pass of hsqp_cent.h at the interpolated target state)
+    and must equal the independent numpy kinematics of reference.torso_reference."""
+    from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+    B = 2
+    x0, x, u, par, dt, (schedules, targets, t0) = make_centroidal_problem(cmodel, n_nodes=n, batch=B, gait=gait, v_cmd=v_cmd, perturb=True, seed=21,
+                                                                           with_reference=True)
+    n_events, ev, seq, tt, ts = pack_reference(schedules, targets)
+    cfg = swing_config(cmodel)
+    emu.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(emu.emu_create(C.byref(cmodel.desc), err, 256))
+    assert h.value, err.value
+    for b in range(B):
+        out = np.zeros((n + 1, _abi.NODE_PARAMS))
+        evb, seqb, ttb, tsb = np.ascontiguousarray(ev[b]), np.ascontiguousarray(seq[b]), np.ascontiguousarray(tt[b]), np.ascontiguousarray(ts[b])
+        bad = emu.emu_cent_node_params(h, C.byref(cfg), C.c_double(0.0), 1, int(n_events[b]), evb.ctypes.data_as(_dp), seqb.ctypes.data_as(_ip),
+                                       tt.shape[1], ttb.ctypes.data_as(_dp), tsb.ctypes.data_as(_dp), C.c_double(t0), C.c_double(dt), n,
+                                       out.ctypes.data_as(_dp))
+        assert bad == 0
+        np.testing.assert_allclose(out, par[b], rtol=0, atol=1e-12)
+    assert np.abs(par[..., _abi.PC_TORSO + 7]).max() > 1e-3 or gait == "stance"   # the torso velocity reference is exercised
+
+
+@pytest.mark.gpu
+def test_centroidal_device_table_and_solve_equal_the_uploaded_table(cmodel):
+    from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    gait, n, v_cmd = CASES[0]
+    B = 3
+    x0, x, u, par, dt, (schedules, targets, t0) = make_centroidal_problem(cmodel, n_nodes=n, batch=B, gait=gait, v_cmd=v_cmd, perturb=True, seed=21,
+                                                                           with_reference=True)
+    n_events, ev, seq, tt, ts = pack_reference(schedules, targets)
+    s = HipSqpSolver(cmodel, max_nodes=n, max_batch=B)
+    try:
+        ref = s.run(x0, x, u, par, dt)
+        s.upload_reference(x0, x, u, dt, t0, n_events, ev, seq, tt, ts, swing_config(cmodel))
+        np.testing.assert_allclose(s.device_params(), par, rtol=0, atol=1e-12)
+        s.iterate(1, take_step=True, kkt=True)
+        out = s.download()
+        sc = max(1.0, np.abs(ref["dx"]).max(), np.abs(ref["du"]).max())
+        assert np.abs(out["x"] - ref["x"]).max() <= 1e-8 * sc and np.abs(out["u"] - ref["u"]).max() <= 1e-8 * sc
+    finally:
+        s.close()

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
-timeout 170 python -m pytest tests/test_gpu_centroidal.py -q 2>&1 | tail -40 > "$OUT/pytest_cent.log"
+timeout 170 python -m pytest tests/test_gpu_centroidal.py tests/test_device_params.py -m gpu -q 2>&1 | tail -40 > "$OUT/pytest_cent.log"
 tail -5 "$OUT/pytest_cent.log"
 timeout 60 python tools/cent_timing.py > "$OUT/cent_timing.log" 2>&1
 tail -4 "$OUT/cent_timing.log"

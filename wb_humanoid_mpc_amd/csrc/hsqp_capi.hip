@@ -209,8 +209,8 @@ __global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, 
 }
 
 // ---- per-node parameter table from the compact per-instance reference: one thread per (instance, node)
-__global__ __launch_bounds__(64) void k_params(hsqp_swing_config cfg, double terrain, int arm_swing, int max_events, const int* __restrict__ n_events,
-                                               const double* __restrict__ ev, const int* __restrict__ seq, int n_knots,
+__global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, hsqp_swing_config cfg, double terrain, int arm_swing, int max_events,
+                                               const int* __restrict__ n_events, const double* __restrict__ ev, const int* __restrict__ seq, int n_knots,
                                                const double* __restrict__ tt, const double* __restrict__ ts, double t0, double dt, int N, int B,
                                                double* __restrict__ par, int* __restrict__ bad) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void k_params(hsqp_swing_config cfg, double ter
   const int b = id / (N + 1), k = id % (N + 1);
   const bool ok = node_params_eval(cfg, terrain, arm_swing, n_events[b], ev + (size_t)b * max_events, seq + (size_t)b * (max_events + 1), n_knots,
                                    tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, t0 + k * dt, par + (size_t)id * NP);
+  if (dm->formulation == HSQP_FORM_CENTROIDAL) cent_params_finish(*dm, par + (size_t)id * NP);   // torso task-space reference
   if (!ok) atomicExch(bad, 1);
 }
 
@@ -410,6 +411,17 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   return HSQP_OK;
 }
 
+// centroidal formulation: the padding states of every state row must be zero (include/hsqp.h)
+static bool padding_is_zero(hsqp_handle* h, const hsqp_problem* p) {
+  if (h->hdm.formulation != HSQP_FORM_CENTROIDAL) return true;
+  for (size_t r = 0; r < (size_t)p->batch * (p->n_nodes + 2); ++r) {
+    const double* row = r < (size_t)p->batch ? p->x_init + r * NX : p->x_traj + (r - p->batch) * NX;
+    for (int i = HSQP_CNX; i < NX; ++i)
+      if (row[i] != 0.0) { h->err = "centroidal formulation: entries 35..57 of every state row must be zero"; return false; }
+  }
+  return true;
+}
+
 int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!p || !p->x_init || !p->x_traj || !p->u_traj || !p->node_params) { h->err = "null problem pointer"; return HSQP_ERR_BAD_ARG; }
@@ -417,13 +429,7 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
     h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
     return HSQP_ERR_BAD_ARG;
   }
-  if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) {   // padding states of the centroidal layout must be zero (include/hsqp.h)
-    for (size_t r = 0; r < (size_t)p->batch * (p->n_nodes + 2); ++r) {
-      const double* row = r < (size_t)p->batch ? p->x_init + r * NX : p->x_traj + (r - p->batch) * NX;
-      for (int i = HSQP_CNX; i < NX; ++i)
-        if (row[i] != 0.0) { h->err = "centroidal formulation: entries 35..57 of every state row must be zero"; return HSQP_ERR_BAD_ARG; }
-    }
-  }
+  if (!padding_is_zero(h, p)) return HSQP_ERR_BAD_ARG;
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes;
   HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, hipMemcpyHostToDevice, h->stream));
@@ -438,7 +444,6 @@ int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
 
 int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_reference* r) {
   if (!h) return HSQP_ERR_BAD_ARG;
-  if (h->hdm.formulation != HSQP_FORM_WB) { h->err = "device-side parameter generation is implemented for the whole-body formulation only"; return HSQP_ERR_BAD_ARG; }
   if (!p || !r || !p->x_init || !p->x_traj || !p->u_traj || !r->n_events || !r->event_times || !r->mode_sequence || !r->target_times || !r->target_states) {
     h->err = "null problem / reference pointer";
     return HSQP_ERR_BAD_ARG;
@@ -453,6 +458,7 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   }
   for (int b = 0; b < r->batch; ++b)
     if (r->n_events[b] < 1 || r->n_events[b] > r->max_events) { h->err = "n_events outside [1, max_events]"; return HSQP_ERR_BAD_ARG; }
+  if (!padding_is_zero(h, p)) return HSQP_ERR_BAD_ARG;
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes, E = r->max_events, K = r->n_knots;
   // staging area for the compact reference (a few KB per instance)
@@ -480,7 +486,7 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   step(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, hipMemcpyHostToDevice, h->stream), "upload u");
   if (rc == HSQP_OK) {
     const int total = (int)(B * (N + 1));
-    hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
+    hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->d_dm, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
                        (int)K, d_tt, d_ts, r->t0, r->dt, (int)N, (int)B, h->d_par, d_bad);
     step(hipGetLastError(), "k_params");
   }

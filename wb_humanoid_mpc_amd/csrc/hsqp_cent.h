@@ -542,6 +542,28 @@ HSQP_HD void cent_value_node(const DevModel& dm, const double* x, const double* 
   cent_write_values<double>(dm, o, xn, flow, x, u, xnext, par, dt, nullptr, misc);
 }
 
+// Device-side parameter generation, centroidal part (after node_params_eval has filled the desired state, contact flags, swing
+// references, impact proximity and arm-swing factor of the row): the torso task-space reference = kinematics of the torso link at
+// (xRef, uRef = 0) — EndEffectorKinematicsQuadraticCost::getParameters / getReferenceCostElement
+// (humanoid_common_mpc/src/cost/EndEffectorKinematicsQuadraticCost.cpp:80-104) — from the same tree pass the LQ kernel uses.
+HSQP_HD void cent_params_finish(const DevModel& dm, double* par) {
+  CentKin<double> k;
+  double xd[12], W[12], qd[NJ];
+  for (int i = 0; i < 12; ++i) W[i] = 0.0;
+  for (int i = 0; i < NJ; ++i) qd[i] = 0.0;
+  cent_pass<double, true>(dm, par + HSQP_P_XDES, par + HSQP_P_XDES + 6, W, qd, k, xd);
+  const BodyRec<double>& tb = k.side.torso;
+  double Rt[9], pos[3], vl[3], va[3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = tb.R[3 * r] * dm.torso_R[c] + tb.R[3 * r + 1] * dm.torso_R[3 + c] + tb.R[3 * r + 2] * dm.torso_R[6 + c];
+  cent_point(k, tb, dm.torso_p, pos, vl, va);
+  double* ref = par + HSQP_PC_TORSO;
+  cent_quat(Rt, ref + 3);
+  for (int r = 0; r < 3; ++r) { ref[r] = pos[r]; ref[7 + r] = vl[r]; ref[10 + r] = va[r]; }
+  for (int i = HSQP_PC_TORSO + 13; i < NX; ++i) par[HSQP_P_XDES + i] = 0.0;
+  par[HSQP_P_SWING + 2] = 0.0; par[HSQP_P_SWING + 5] = 0.0;   // the velocity-level constraints have no acceleration reference
+}
+
 // Expand the centroidal record into the dense padded [A|B] (58 x 93) — debug / parity path and tests.
 inline void cent_expand_AB(const double* rec, double dt, double* AB) {
   for (int i = 0; i < NX * NZ; ++i) AB[i] = 0.0;

@@ -476,8 +476,15 @@ def build_centroidal_node_params(model, schedule, targets, t0, dt, n_nodes, arm_
     return par
 
 
+def pad_targets(targets):
+    """TargetTrajectories with the 35-wide centroidal knots padded to the ABI's 58-double rows (for pack_reference)."""
+    st = np.zeros((len(targets.times), _abi.NX))
+    st[:, :_abi.CNX] = targets.states
+    return TargetTrajectories(targets.times, st)
+
+
 def make_centroidal_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3, 0.0, 0.7925, 0.0), dt=None, perturb=False,
-                            seed=BENCH_SEED, t0=0.0):
+                            seed=BENCH_SEED, t0=0.0, with_reference=False):
     """Synthetic inputs of BASELINE.md configs 1-2 in the ABI's padded layout: (x_init[B,58], x[B,N+1,58], u[B,N,35],
     params[B,N+1,72], dt); only the first 35 entries of a state row are used.  Cold start as CentroidalWeightCompInitializer
     (x_k = x0 with the momentum extended, u_k = weight compensation)."""
@@ -487,6 +494,7 @@ def make_centroidal_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3
     rng = np.random.Generator(np.random.PCG64(seed))
     nj = model.nj
     xs, us, ps, x0s = [], [], [], []
+    schedules, targets_all = [], []
     for _ in range(batch):
         x0 = model.initial_state.copy()
         offset = 0.0
@@ -502,4 +510,7 @@ def make_centroidal_problem(model, n_nodes=100, batch=1, gait="walk", v_cmd=(0.3
         x0p[:_abi.CNX] = x0
         x, u = cold_start(model, x0p, par)
         xs.append(x); us.append(u); ps.append(par); x0s.append(x0p)
+        schedules.append(schedule); targets_all.append(pad_targets(targets))
+    if with_reference:
+        return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt, (schedules, targets_all, t0)
     return np.stack(x0s), np.stack(xs), np.stack(us), np.stack(ps), dt
