@@ -76,6 +76,21 @@ def test_batch_of_perturbed_instances_against_oracle(cgpu, cmodel, coracle):
     assert np.array_equal(solo["dx"][0], out["dx"][3]) and np.array_equal(solo["du"][0], out["du"][3])
 
 
+@pytest.mark.parametrize("cfg,n,gait,v_cmd", [(1, 20, "stance", (0.0, 0.0, 0.7925, 0.0)), (2, 100, "walk", (0.3, 0.0, 0.7925, 0.0))])
+def test_baseline_configs_1_and_2_against_the_oracle(cgpu, cmodel, coracle, cfg, n, gait, v_cmd):
+    """BASELINE.md §4 configs 1 (N = 20, stance, v_cmd = 0) and 2 (N = 100, walk) exactly as specified: cold start from task.info's
+    initialState, one SQP iteration, full size against the oracle."""
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=n, batch=1, gait=gait, v_cmd=v_cmd)
+    out = cgpu.run(x0, x, u, par, dt)
+    r = coracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=4)
+    sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+    assert np.abs(out["dx"][0] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][0] - r["du"]).max() <= 1e-8 * sc
+    for key in ("cost", "dynamics_sse", "equality_sse"):
+        assert np.isclose(out["perf_before"][0][key], r["perf_before"][key], rtol=1e-9, atol=1e-12)
+        assert np.isclose(out["perf_after"][0][key], r["perf_after"][key], rtol=1e-8, atol=1e-10)
+    assert out["kkt"][0, 1] <= 1e-10 * sc and r["kkt"][1] <= 1e-10 * sc
+
+
 def test_config2_size_properties(cgpu, cmodel):
     """BASELINE config 2 (centroidal, N = 100, one instance): size-independent properties of the QP step."""
     x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=100, batch=1, gait="walk")
