@@ -11,14 +11,15 @@ os.environ["HSQP_LIB"] = os.path.join(ROOT, "wb_humanoid_mpc_amd", "libhsqp_hip_
 import numpy as np  # noqa: E402
 
 from wb_humanoid_mpc_amd import load_model  # noqa: E402
-from wb_humanoid_mpc_amd.reference import make_problem  # noqa: E402
+from wb_humanoid_mpc_amd.reference import make_centroidal_problem, make_problem  # noqa: E402
 from wb_humanoid_mpc_amd.solver import HipSqpSolver  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 iters = 3
-m = load_model()
-x0, x, u, par, dt = make_problem(m, n_nodes=N, batch=B, perturb=True)
+CENT = len(sys.argv) > 3 and sys.argv[3] == "centroidal"   # phase_profile.py B N centroidal: k_riccati<35> etc.
+m = load_model(formulation="centroidal" if CENT else "wb")
+x0, x, u, par, dt = make_centroidal_problem(m, n_nodes=N, batch=B, perturb=B > 1) if CENT else make_problem(m, n_nodes=N, batch=B, perturb=True)
 s = HipSqpSolver(m, max_nodes=N, max_batch=B)
 s.upload(x0, x, u, par, dt)
 for _ in range(iters):
