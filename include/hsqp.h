@@ -129,6 +129,12 @@ typedef struct hsqp_model_desc {
 } hsqp_model_desc;
 
 #define HSQP_FLAG_LINESEARCH 1   /* hsqp_solve runs the filter line search (as the reference's SqpSolver does) instead of alpha = 1 */
+/* Backward sweep of the stage QP.  Default: the serial Riccati recursion, one workgroup per instance; for the centroidal
+ * formulation with at most HSQP_SCAN_AUTO_BATCH instances the parallel-in-time sweep (associative scan over the stages,
+ * ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because a handful of serial chains leaves the device idle. */
+#define HSQP_FLAG_SERIAL_RICCATI 2     /* always the serial recursion                                              */
+#define HSQP_FLAG_PARALLEL_RICCATI 4   /* always the scan (centroidal formulation only; hsqp_create fails otherwise) */
+#define HSQP_SCAN_AUTO_BATCH 8
 typedef struct hsqp_settings {
   int32_t max_nodes;            /* N_max: shooting intervals per instance                                */
   int32_t max_batch;            /* independent MPC instances per call on this device                     */

@@ -10,10 +10,44 @@
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_host.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_scan.h"
 
 using namespace hsqp;
 
+static int g_scan = 0;   // centroidal formulation: backward sweep by the parallel scan (hsqp_scan.h) instead of the serial recursion
+
+// the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
+template <int n>
+static int scan_backward(const DevModel& dm, int N, const double* x, const double* par, const double* qp, double* ric, double* vf) {
+  Ctx ctx{0, 1, nullptr};
+  using E = ScanEl<n>;
+  std::vector<double> ea((size_t)(N + 1) * E::SIZE), eb((size_t)(N + 1) * E::SIZE);
+  auto iw = std::make_unique<ScanInitWS<n>>();
+  auto cw = std::make_unique<ScanCombWS<n>>();
+  auto rw = std::make_unique<RicWS>();
+  for (int k = 0; k <= N; ++k)
+    scan_init_node<n>(ctx, *iw, qp + (size_t)(k < N ? k : 0) * QP_SIZE, &ea[(size_t)k * E::SIZE], k == N, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP);
+  int ok = 1;
+  for (int d = 1; d < N + 1; d *= 2) {
+    for (int k = 0; k <= N; ++k) {
+      if (k + d <= N) scan_combine<n>(ctx, *cw, &ea[(size_t)k * E::SIZE], &ea[(size_t)(k + d) * E::SIZE], &eb[(size_t)k * E::SIZE], &ok);
+      else std::copy(&ea[(size_t)k * E::SIZE], &ea[(size_t)(k + 1) * E::SIZE], &eb[(size_t)k * E::SIZE]);
+    }
+    ea.swap(eb);
+  }
+  if (!ok) return 0;
+  for (int k = 0; k < N; ++k) {   // one stage of the Riccati code per node, started from the scanned value function of node k + 1 (S = J, s = -eta)
+    const double* en = &ea[(size_t)(k + 1) * E::SIZE];
+    riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
+                        vf + (size_t)k * VF_SIZE, en + E::J, en + E::ETA, k == N - 1, -1.0);
+    if (!rw->ok) return 0;
+  }
+  return 1;
+}
+
 extern "C" {
+
+void emu_set_scan(int on) { g_scan = on; }
 
 void* emu_create(const hsqp_model_desc* md, char* err, int errlen) {
   DevModel* dm = new DevModel;
@@ -146,7 +180,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto terminal = [&](const double* xx) { double c = 0; for (int i = 0; i < NX; ++i) { const double d = xx[N * NX + i] - par[N * NP + HSQP_P_XDES + i]; c += 0.5 * dm.Qf[i] * d * d; } return c; };
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
-  if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
+  if (cent && g_scan) { if (!scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data())) return HSQP_ERR_NUMERIC; rw->ok = 1; }
+  else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
   if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, ric.data(), N, dx);

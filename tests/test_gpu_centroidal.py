@@ -151,3 +151,34 @@ def test_entry_points_that_are_whole_body_only_fail_cleanly(cgpu, cmodel):
     with pytest.raises(HsqpError) as e:
         cgpu.run(x0, bad, u, par, dt)
     assert e.value.code == _abi.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("n,batch,gait", [(100, 1, "walk"), (20, 1, "stance"), (37, 3, "run"), (64, 12, "walk")])
+def test_parallel_in_time_backward_sweep_equals_the_serial_recursion(cmodel, coracle, n, batch, gait):
+    """hsqp_scan.h on the device (k_scan_init / k_scan_combine / k_scan_gains / k_scan_forward) against k_riccati<35> on the same
+    QP, and against the oracle; batch 12 forces the scan beyond its automatic range."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=n, batch=batch, gait=gait, perturb=batch > 1, seed=13)
+    outs = {}
+    for mode in ("serial", "parallel"):
+        s = HipSqpSolver(cmodel, max_nodes=n, max_batch=batch, riccati=mode)
+        try:
+            outs[mode] = s.run(x0, x, u, par, dt)
+        finally:
+            s.close()
+    a, b = outs["serial"], outs["parallel"]
+    sc = max(1.0, np.abs(a["dx"]).max(), np.abs(a["du"]).max())
+    assert np.abs(a["dx"] - b["dx"]).max() <= 1e-9 * sc and np.abs(a["du"] - b["du"]).max() <= 1e-9 * sc
+    assert b["kkt"][:, 0].max() <= 1e-8 * sc and b["kkt"][:, 1].max() <= 1e-10 * sc
+    for key in ("cost", "dynamics_sse", "equality_sse"):
+        for i in range(batch):
+            assert np.isclose(a["perf_after"][i][key], b["perf_after"][i][key], rtol=1e-8, atol=1e-10)
+    r = coracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=4)
+    assert np.abs(b["dx"][0] - r["dx"]).max() <= 1e-8 * sc and np.abs(b["du"][0] - r["du"]).max() <= 1e-8 * sc
+
+
+def test_parallel_riccati_flag_needs_the_centroidal_formulation(model):
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver, HsqpError
+    with pytest.raises(HsqpError) as e:
+        HipSqpSolver(model, max_nodes=4, max_batch=1, riccati="parallel")
+    assert e.value.code == _abi.ERR_BAD_ARG

@@ -114,3 +114,29 @@ def test_whole_body_model_is_rejected_where_it_does_not_apply(cmodel):
     d.torso_sqrt_w[0] = 1.0
     err = C.create_string_buffer(256)
     assert not lib.emu_create(C.byref(d), err, 256) and b"position weights" in err.value
+
+
+@pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14), ("flight", 8), ("walk", 37)])
+def test_parallel_scan_backward_sweep_equals_the_serial_recursion(cmodel, coracle, cemu, gait, n):
+    """hsqp_scan.h: the backward sweep as an associative scan (init, ceil(log2(N+1)) levels of combinations, single-stage gains)
+    against the serial recursion of the same kernel sources and against the oracle."""
+    lib, h = cemu
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, "run" if gait == "flight" else gait, seed=5)
+    if gait == "flight":
+        par = _force_flight(par, slice(3, 6))
+    res = []
+    for scan in (0, 1):
+        lib.emu_set_scan(scan)
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        qp = np.zeros((n, lib.emu_qp_size()))
+        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+        lib.emu_set_scan(0)
+        assert rc == 0
+        res.append((dx, du, kkt, pa))
+    (dx0_, du0_, kkt0, pa0), (dx1, du1, kkt1, pa1) = res
+    sc = max(1.0, np.abs(dx0_).max(), np.abs(du0_).max())
+    assert np.abs(dx1 - dx0_).max() <= 1e-9 * sc and np.abs(du1 - du0_).max() <= 1e-9 * sc
+    assert kkt1[0] <= 1e-8 * sc and kkt1[1] <= 1e-10 * sc       # KKT residual with the scanned value functions as costates
+    r = coracle.cent_sqp_iteration(dt, x0, x, u, par)
+    assert np.abs(dx1 - r["dx"]).max() <= 1e-8 * sc and np.abs(du1 - r["du"]).max() <= 1e-8 * sc

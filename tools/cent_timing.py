@@ -23,7 +23,7 @@ def main():
         cases = cases[:int(sys.argv[1])]
     for name, n, b in cases:
         x0, x, u, par, dt = make_centroidal_problem(model, n_nodes=n, batch=b, perturb=b > 1)
-        s = HipSqpSolver(model, max_nodes=n, max_batch=b)
+        s = HipSqpSolver(model, max_nodes=n, max_batch=b, riccati=os.environ.get("HSQP_RICCATI", "auto"))
         s.upload(x0, x, u, par, dt)
         for _ in range(2):
             s.iterate(1)

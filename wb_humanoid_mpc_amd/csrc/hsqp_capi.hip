@@ -13,6 +13,7 @@
 #include "hsqp_params.h"
 #include "hsqp_policy.h"
 #include "hsqp_cent.h"
+#include "hsqp_scan.h"
 
 using namespace hsqp;
 
@@ -115,6 +116,60 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
   if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
+}
+
+// ---- parallel-in-time backward sweep (hsqp_scan.h).  Elements: [B][N + 1][ScanEl<n>::SIZE], two buffers (ping-pong per level).
+constexpr int SCAN_INIT_THREADS = 256, SCAN_COMB_THREADS = 512;
+template <int n>
+__global__ __launch_bounds__(SCAN_INIT_THREADS) void k_scan_init(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+                                                                 const double* __restrict__ qp, int N, double* __restrict__ el) {
+  ScanInitWS<n>& w = *reinterpret_cast<ScanInitWS<n>*>(hsqp_smem);
+  const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  scan_init_node<n>(ctx, w, qp + ((size_t)b * N + (k < N ? k : 0)) * QP_SIZE, el + (size_t)id * ScanEl<n>::SIZE, k == N, dm->Qf,
+                    x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP);
+}
+template <int n>
+__global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double* __restrict__ ein, double* __restrict__ eout, int N, int d, int* __restrict__ status) {
+  ScanCombWS<n>& w = *reinterpret_cast<ScanCombWS<n>*>(hsqp_smem);
+  const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  constexpr int SZ = ScanEl<n>::SIZE;
+  if (k + d <= N) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    scan_combine<n>(ctx, w, ein + (size_t)id * SZ, ein + (size_t)(id + d) * SZ, eout + (size_t)id * SZ, &ok);
+    __syncthreads();
+    if (threadIdx.x == 0 && !ok) atomicOr(&status[b], 2);
+  } else {
+    for (int i = threadIdx.x; i < SZ; i += blockDim.x) eout[(size_t)id * SZ + i] = ein[(size_t)id * SZ + i];
+  }
+}
+// one stage of the Riccati code per node, started from the scanned value function of node k + 1
+template <int n>
+__global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+                                                            const double* __restrict__ qp, const double* __restrict__ el, double* __restrict__ ric, int N,
+                                                            int* __restrict__ status, double* __restrict__ vf) {
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const double* en = el + ((size_t)b * (N + 1) + k + 1) * ScanEl<n>::SIZE;
+  const double* q = qp + (size_t)node * QP_SIZE;
+  riccati_backward<n>(ctx, w, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, q, ric + (size_t)node * RIC_SIZE, 1,
+                      vf ? vf + ((size_t)b * (N + 1) + k) * VF_SIZE : nullptr, en + ScanEl<n>::J, en + ScanEl<n>::ETA, k == N - 1, -1.0);
+  if (threadIdx.x == 0) {
+    const int st = (q[QP_NUT] < 0.0 ? 1 : 0) | (w.ok ? 0 : 2);
+    if (st) atomicOr(&status[b], st);
+  }
+}
+template <int n>
+__global__ __launch_bounds__(256) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ ric, int N,
+                                                      double* __restrict__ dx) {
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  riccati_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, ric + (size_t)b * N * RIC_SIZE, N, dx + (size_t)b * (N + 1) * NX);
 }
 
 // ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
@@ -288,6 +343,8 @@ struct hsqp_handle {
   LsState* d_ls = nullptr;
   int* d_counts = nullptr;
   hsqp_linesearch_settings ls_settings;
+  double* d_el[2] = {nullptr, nullptr};   // scan elements (allocated when the parallel-in-time sweep is first used)
+  size_t el_capacity = 0;                 // in elements
   void* d_stage = nullptr;        // grow-only staging area for the small per-call inputs (reference, policy queries)
   size_t stage_bytes = 0;
   bool ls_ran = false;
@@ -338,7 +395,8 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage};
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
+                  h->d_el[0], h->d_el[1]};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -368,6 +426,10 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (!model || !settings || !out) { g_create_error = "null argument"; return HSQP_ERR_BAD_ARG; }
   *out = nullptr;
   if (settings->max_nodes < 1 || settings->max_batch < 1) { g_create_error = "max_nodes and max_batch must be >= 1"; return HSQP_ERR_BAD_ARG; }
+  if ((settings->flags & HSQP_FLAG_PARALLEL_RICCATI) && (model->formulation != HSQP_FORM_CENTROIDAL || (settings->flags & HSQP_FLAG_SERIAL_RICCATI))) {
+    g_create_error = "HSQP_FLAG_PARALLEL_RICCATI needs the centroidal formulation and excludes HSQP_FLAG_SERIAL_RICCATI";
+    return HSQP_ERR_BAD_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device visible (this library has no CPU path)"; return HSQP_ERR_NO_DEVICE; }
   if (settings->device < 0 || settings->device >= ndev) { g_create_error = "device ordinal out of range"; return HSQP_ERR_BAD_ARG; }
@@ -405,6 +467,10 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
   hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   hipError_t a5 = hipFuncSetAttribute((const void*)k_riccati<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_init<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanInitWS<CNX>));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_combine<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanCombWS<CNX>));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_gains<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_forward<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess || a5 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   *out = h;
   g_create_error.clear();
@@ -524,7 +590,29 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
     }
-    if (cent)   // the recursion on the 35 centroidal states only (the padding states are decoupled)
+    const bool scan = cent && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || B <= HSQP_SCAN_AUTO_BATCH);
+    if (scan) {
+      // parallel-in-time backward sweep (hsqp_scan.h): elements of all stages, ceil(log2(N+1)) scan levels, single-stage gains, roll-out
+      constexpr int SZ = ScanEl<CNX>::SIZE;
+      const size_t need = (size_t)B * (N + 1);
+      if (need > h->el_capacity) {
+        for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
+        h->el_capacity = 0;
+        for (auto& p : h->d_el)
+          if (hipMalloc(&p, need * SZ * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
+        h->el_capacity = need;
+      }
+      HCHECK(hipMemsetAsync(h->d_status, 0, (size_t)B * sizeof(int), h->stream));
+      hipLaunchKernelGGL(k_scan_init<CNX>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<CNX>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
+      int cur = 0;
+      for (int d = 1; d < N + 1; d *= 2) {
+        hipLaunchKernelGGL(k_scan_combine<CNX>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<CNX>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status);
+        cur = 1 - cur;
+      }
+      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur], h->d_ric, N,
+                         h->d_status, want_kkt ? h->d_vf : (double*)nullptr);
+      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(256), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_ric, N, h->d_dx);
+    } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
       hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                          h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
     else

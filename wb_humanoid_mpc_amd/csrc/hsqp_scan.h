@@ -1,0 +1,218 @@
+// Parallel-in-time backward sweep of the stage QP (BASELINE north star: "the serial Riccati recursion run as a cyclic-reduction /
+// parallel-scan over stages"): the value functions S_k, s_k of all nodes from an associative scan over conditional value functions
+// instead of N dependent Riccati stages.  Used for single-instance problems of the centroidal formulation, where the serial chain
+// of N = 100 stages leaves all but one CU idle (config 2: 1.6 of 2.2 ms).
+//
+// Formulation (Särkkä & García-Fernández, "Temporal parallelization of dynamic programming and linear quadratic control",
+// IEEE TAC 2023; algebra restated and checked in oracle/parallel_scan.py): an element (A, b, C, eta, J) of the interval i -> j stands
+// for   V_{i->j}(x_i, x_j) = const + 1/2 x_i' J x_i - eta' x_i + max_lam { -1/2 lam' C lam - lam' (x_j - A x_i - b) } ;
+// i -> j combined with j -> k:
+//     M = I + C1 J2,  [XA | XC | xb] = M^-1 [A1 | C1 | b1 + C1 eta2],  y = eta2 - J2 b1
+//     A = A2 XA,  b = A2 xb + b2,  C = A2 XC A2' + C2,  J = A1' J2 XA + J1,  eta = A1' (y - J2 XC y) + eta1 ;
+// the value function of node k is S_k = J, s_k = -eta of the suffix k -> N+1.  One stage x+ = A x + B u + b with cost
+// 1/2 x'Qx + u'Px + 1/2 u'Ru + q'x + r'u is the element (A - B R^-1 P, b - B R^-1 r, B R^-1 B', -(q - P' R^-1 r), Q - P' R^-1 P), the
+// terminal cost the element (0, 0, 0, -q_N, Q_N).
+//
+// Kernels (hsqp_capi.hip): k_scan_init (one workgroup per node: stage -> element), k_scan_combine (one per node and level:
+// Hillis-Steele suffix scan, ceil(log2(N+1)) levels, ping-pong element buffers), k_scan_gains (one per node: ONE stage of the
+// existing Riccati code started from S_{k+1}, s_{k+1} -> K, k, Acl, bcl and S_k for the KKT check), k_scan_forward (the mat-vec
+// roll-out dx+ = Acl dx + bcl).  The record the step / KKT kernels read is the one k_riccati writes.
+//
+// Numerics: M is solved by Gauss-Jordan elimination with row pivoting.  On the projected QPs of the centroidal problem
+// cond(M) <= 1e5 and the scan reproduces the serial recursion to 1e-11 of the step's scale; on the whole-body problem cond(M)
+// reaches 1e9 (5e-8 / 1.4e-6 agreement, tests/test_parallel_scan.py), so the whole-body path keeps the serial recursion.
+#pragma once
+#include "hsqp_riccati.h"
+
+namespace hsqp {
+
+// ---- element layout in global memory (doubles), dimension n = NXE, row-major with leading dimension n
+template <int n> struct ScanEl {
+  static constexpr int A = 0, C = A + n * n, J = C + n * n, B = J + n * n, ETA = B + n, SIZE = ((ETA + n + 7) / 8) * 8;
+};
+
+// Gauss-Jordan elimination of the n x ncol matrix G (LDS, leading dimension ld) whose first n columns hold M: afterwards row
+// piv[j] holds (unscaled) the solution row j, G[piv[j]][j] its pivot.  PIVOT = false: diagonal pivots (symmetric positive definite
+// M).  Two barrier-separated phases per column: pivot choice (one item), elimination of every other row (items = (row, column
+// chunk); column j itself is only read).
+struct GjWS { int piv[64], used[64], p; double pv; int ok; };
+template <bool PIVOT>
+HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int n, int ncol, GjWS& g) {
+  WG_FOR(ctx, i, 64 + 1) { if (i < 64) g.used[i] = 0; else g.ok = 1; }
+  WG_SYNC(ctx);
+  constexpr int CH = 8;                       // columns per item
+  for (int j = 0; j < n; ++j) {
+    WG_FOR(ctx, it, 1) {
+      int p = j;
+      if (PIVOT) {
+        double best = -1.0;
+        p = 0;
+        for (int i = 0; i < n; ++i) { const double a = fabs(G[i * ld + j]); if (!g.used[i] && a > best) { best = a; p = i; } }
+      }
+      g.p = p; g.piv[j] = p; g.used[p] = 1; g.pv = G[p * ld + j];
+      if (!(fabs(g.pv) > 1e-300)) { g.ok = 0; g.pv = 1.0; }
+    }
+    WG_SYNC(ctx);
+    const int nch = (ncol - (j + 1) + CH - 1) / CH;
+    WG_FOR(ctx, it, n * nch) {
+      const int i = it / nch, c0 = j + 1 + (it % nch) * CH;
+      const int p = g.p;
+      if (i != p) {
+        const double f = G[i * ld + j] * fast_rcp(g.pv);
+#pragma unroll
+        for (int c = c0; c < c0 + CH; ++c)
+          if (c < ncol) G[i * ld + c] -= f * G[p * ld + c];
+      }
+    }
+    WG_SYNC(ctx);
+  }
+}
+
+// ---- stage -> element
+template <int n>
+struct ScanInitWS {
+  double G[NUT][2 * NUT + 2];     // [R | I] -> R^-1 in the right half
+  double Ri[NUT][NUT + 1];
+  double BT[NUT][n + 1], Pm[NUT][n + 1];
+  double WB[NUT][n + 1], WP[NUT][n + 1];   // R^-1 B', R^-1 P
+  double wr[NUT], rv[NUT];
+  GjWS gj;
+};
+
+// q: QP record of the stage (hsqp_project.h), el: element out.  terminal: the element of the terminal cost 1/2 x'diag(Qf)x + qN'x.
+template <int n>
+HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, double* el, bool terminal, const double* Qf, const double* xN,
+                            const double* parN) {
+  using E = ScanEl<n>;
+  if (terminal) {
+    WG_FOR(ctx, i, E::SIZE) {
+      double v = 0.0;
+      if (i >= E::J && i < E::J + n * n) { const int r = (i - E::J) / n, c = (i - E::J) % n; v = r == c ? Qf[r] : 0.0; }
+      else if (i >= E::ETA && i < E::ETA + n) { const int r = i - E::ETA; v = -Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]); }
+      el[i] = v;
+    }
+    WG_SYNC(ctx);
+    return;
+  }
+  constexpr int LG = 2 * NUT + 2;
+  WG_FOR(ctx, i, NUT * LG + 2 * NUT * (n + 1) + NUT) {
+    if (i < NUT * LG) {
+      const int r = i / LG, c = i % LG;
+      w.G[r][c] = c < NUT ? q[QP_R + r * NUT + c] : (c - NUT == r ? 1.0 : 0.0);
+    } else if (i < NUT * LG + NUT * (n + 1)) {
+      const int j = i - NUT * LG, r = j / (n + 1), c = j % (n + 1);
+      w.BT[r][c] = c < n ? q[QP_B + c * NUT + r] : 0.0;
+    } else if (i < NUT * LG + 2 * NUT * (n + 1)) {
+      const int j = i - NUT * LG - NUT * (n + 1), r = j / (n + 1), c = j % (n + 1);
+      w.Pm[r][c] = c < n ? q[QP_P + r * NX + c] : 0.0;
+    } else {
+      w.rv[i - NUT * LG - 2 * NUT * (n + 1)] = q[QP_RV + i - NUT * LG - 2 * NUT * (n + 1)];
+    }
+  }
+  WG_SYNC(ctx);
+  gauss_jordan<false>(ctx, &w.G[0][0], LG, NUT, 2 * NUT, w.gj);
+  WG_FOR(ctx, i, NUT * NUT) { const int r = i / NUT, c = i % NUT; w.Ri[r][c] = w.G[r][NUT + c] / w.G[r][r]; }
+  WG_SYNC(ctx);
+  {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
+    const XtyJob jobs[2] = {xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1),
+                            xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1)};
+    wg_xty_jobs(ctx, jobs, 2);
+    WG_FOR(ctx, r, NUT) { double s = 0.0; for (int l = 0; l < NUT; ++l) s += w.Ri[r][l] * w.rv[l]; w.wr[r] = s; }
+  }
+  WG_SYNC(ctx);
+  {  // A - B WP, C = B WB, J = Q - P' WP  (X^T Y with X = BT resp. Pm; the additive terms come from the QP record)
+    const XtyJob jobs[3] = {xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WP[0][0], n + 1, el + E::A, n, q + QP_A, NX, -1.0),
+                            xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1, el + E::C, n),
+                            xty_job(n, n, NUT, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1, el + E::J, n, q + QP_Q, NX, -1.0)};
+    wg_xty_jobs(ctx, jobs, 3);
+    WG_FOR(ctx, i, 2 * n + (E::SIZE - E::ETA - n)) {
+      if (i < n) { double s = q[QP_BV + i]; for (int l = 0; l < NUT; ++l) s -= w.BT[l][i] * w.wr[l]; el[E::B + i] = s; }
+      else if (i < 2 * n) { const int r = i - n; double s = q[QP_QV + r]; for (int l = 0; l < NUT; ++l) s -= w.Pm[l][r] * w.wr[l]; el[E::ETA + r] = -s; }
+      else el[E::ETA + n + (i - 2 * n)] = 0.0;
+    }
+  }
+  WG_SYNC(ctx);
+}
+
+// ---- combination of two elements
+template <int n>
+struct ScanCombWS {
+  static constexpr int LD = n + 1, LG = 3 * n + 2;
+  union {
+    double G[n][LG];                  // [M | A1 | C1 | b1 + C1 eta2]
+    struct { double Co[n][LD], Jo[n][LD]; } out;   // results before symmetrisation (G is dead by then)
+  };
+  double A1[n][LD], C1[n][LD], A2T[n][LD], J2[n][LD];
+  double X[n][2 * n + 2];             // [XA | XC | xb] in natural row order
+  double T[n][LD], V[n][LD];          // A2 XC, J2 XA
+  double b1[n], eta1[n], b2[n], eta2[n], y[n], z[n], t[n];
+  GjWS gj;
+};
+
+// e1 (i -> j), e2 (j -> k) -> out (i -> k); returns through *ok whether every pivot was usable
+template <int n>
+HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, const double* e2, double* out, int* ok) {
+  using E = ScanEl<n>;
+  constexpr int LD = ScanCombWS<n>::LD, LG = ScanCombWS<n>::LG;
+  WG_FOR(ctx, i, 4 * n * n + 4 * n) {
+    if (i < n * n) { const int r = i / n, c = i % n; const double v = e1[E::A + i]; w.A1[r][c] = v; w.G[r][n + c] = v; }
+    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; const double v = e1[E::C + j]; w.C1[r][c] = v; w.G[r][2 * n + c] = v; }
+    else if (i < 3 * n * n) { const int j = i - 2 * n * n, r = j / n, c = j % n; w.A2T[c][r] = e2[E::A + j]; }
+    else if (i < 4 * n * n) { const int j = i - 3 * n * n, r = j / n, c = j % n; w.J2[r][c] = e2[E::J + j]; }
+    else {
+      const int j = i - 4 * n * n, r = j % n;
+      if (j < n) w.b1[r] = e1[E::B + r];
+      else if (j < 2 * n) w.eta1[r] = e1[E::ETA + r];
+      else if (j < 3 * n) w.b2[r] = e2[E::B + r];
+      else w.eta2[r] = e2[E::ETA + r];
+    }
+  }
+  WG_SYNC(ctx);
+  {  // M = I + C1 J2 (C1 symmetric: X = C1), right-hand side b1 + C1 eta2, y = eta2 - J2 b1
+    const XtyJob job = xty_job(n, n, n, &w.C1[0][0], LD, &w.J2[0][0], LD, &w.G[0][0], LG);
+    wg_xty_jobs(ctx, &job, 1);
+    WG_FOR(ctx, i, 2 * n) {
+      if (i < n) { double s = w.b1[i]; for (int l = 0; l < n; ++l) s += w.C1[i][l] * w.eta2[l]; w.G[i][3 * n] = s; w.G[i][3 * n + 1] = 0.0; }
+      else { const int r = i - n; double s = w.eta2[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.b1[l]; w.y[r] = s; }
+    }
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, n) w.G[i][i] += 1.0;
+  WG_SYNC(ctx);
+  gauss_jordan<true>(ctx, &w.G[0][0], LG, n, 3 * n + 1, w.gj);
+  WG_FOR(ctx, i, n * (2 * n + 2)) {
+    const int r = i / (2 * n + 2), c = i % (2 * n + 2);
+    const int p = w.gj.piv[r];
+    w.X[r][c] = c <= 2 * n ? w.G[p][n + c] / w.G[p][r] : 0.0;
+  }
+  WG_SYNC(ctx);   // G is dead from here on (out aliases it)
+  {  // A = A2 XA (to the output), T = A2 XC, V = J2 XA;  z = XC y, b = A2 xb + b2
+    const XtyJob jobs[3] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], 2 * n + 2, out + E::A, n),
+                            xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], 2 * n + 2, &w.T[0][0], LD),
+                            xty_job(n, n, n, &w.J2[0][0], LD, &w.X[0][0], 2 * n + 2, &w.V[0][0], LD)};
+    wg_xty_jobs(ctx, jobs, 3);
+    WG_FOR(ctx, i, 2 * n) {
+      if (i < n) { double s = 0.0; for (int l = 0; l < n; ++l) s += w.X[i][n + l] * w.y[l]; w.z[i] = s; }
+      else { const int r = i - n; double s = w.b2[r]; for (int l = 0; l < n; ++l) s += w.A2T[l][r] * w.X[l][2 * n]; out[E::B + r] = s; }
+    }
+  }
+  WG_SYNC(ctx);
+  {  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]), J = A1' V + J1;  t = y - J2 z
+    XtyJob jc = xty_job(n, n, n, &w.T[0][0], 1, &w.A2T[0][0], LD, &w.out.Co[0][0], LD, e2 + E::C, n);
+    jc.sx1 = LD;
+    const XtyJob jobs[2] = {jc, xty_job(n, n, n, &w.A1[0][0], LD, &w.V[0][0], LD, &w.out.Jo[0][0], LD, e1 + E::J, n)};
+    wg_xty_jobs(ctx, jobs, 2);
+    WG_FOR(ctx, r, n) { double s = w.y[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.z[l]; w.t[r] = s; }
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, 2 * n * n + n + (E::SIZE - E::ETA - n) + 1) {
+    if (i < n * n) { const int r = i / n, c = i % n; out[E::C + i] = 0.5 * (w.out.Co[r][c] + w.out.Co[c][r]); }
+    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; out[E::J + j] = 0.5 * (w.out.Jo[r][c] + w.out.Jo[c][r]); }
+    else if (i < 2 * n * n + n) { const int r = i - 2 * n * n; double s = w.eta1[r]; for (int l = 0; l < n; ++l) s += w.A1[l][r] * w.t[l]; out[E::ETA + r] = s; }
+    else if (i < 2 * n * n + n + (E::SIZE - E::ETA - n)) out[E::ETA + n + (i - 2 * n * n - n)] = 0.0;
+    else if (!w.gj.ok) *ok = 0;
+  }
+  WG_SYNC(ctx);
+}
+
+}  // namespace hsqp

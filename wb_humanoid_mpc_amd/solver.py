@@ -65,11 +65,13 @@ def _c(a):
 
 
 class HipSqpSolver:
-    def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False):
-        """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step."""
+    def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False, riccati="auto"):
+        """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step.
+        riccati: "auto" (serial recursion; parallel-in-time scan for a centroidal problem with <= 8 instances), "serial", "parallel"."""
         self.lib = load_library()
         self.model = model
-        st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=_abi.FLAG_LINESEARCH if linesearch else 0)
+        flags = (_abi.FLAG_LINESEARCH if linesearch else 0) | {"auto": 0, "serial": _abi.FLAG_SERIAL_RICCATI, "parallel": _abi.FLAG_PARALLEL_RICCATI}[riccati]
+        st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=flags)
         h = C.c_void_p()
         rc = self.lib.hsqp_create(C.byref(model.desc), C.byref(st), C.byref(h))
         if rc != 0:
