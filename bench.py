@@ -246,7 +246,7 @@ def main():
         f_node, bytes_node = f_rk4 + f_gn + f_proj + f_ric, CENT_BYTES_NODE if cent else BYTES_NODE
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
         kern = {"lq_approximation(k_lq)": (kms[0], f_rk4 + f_gn, "k_lq_cent" if cent else "k_lq<true>"), "projection(k_project)": (kms[1], f_proj, "k_project"),
-                "riccati(k_riccati)": (kms[2], f_ric, "k_riccati")}
+                ("backward_sweep(k_scan_*: parallel-in-time scan)" if cent and B <= 2 and N >= 48 else "riccati(k_riccati)"): (kms[2], f_ric, "k_riccati")}
         dom = max(kern, key=lambda n: kern[n][0])
         dom_ms, dom_flops, dom_key = kern[dom]
         traffic = pmc_traffic(dom_key) if (B, N) == (256, 100) and not cent else None

@@ -87,19 +87,24 @@ def test_full_iteration_matches_oracle(cmodel, coracle, cemu, gait, n):
         assert np.allclose(got, [want["cost"], want["dynamics_sse"], want["equality_sse"]], rtol=1e-9, atol=1e-12)
 
 
-def test_lanes_are_independent(cmodel, cemu):
+@pytest.mark.parametrize("scan", [0, 1])
+def test_lanes_are_independent(cmodel, cemu, scan):
     """Race check as for the whole-body kernels: the build that runs the work items (= lanes) of every phase in reverse order must
-    reproduce the forward build bit for bit."""
+    reproduce the forward build bit for bit (scan = 1: with the parallel-in-time backward sweep, whose elimination steps let every
+    item find the pivot itself)."""
     lib, h = cemu
     rev, hr = _load("libhsqp_hostemu_rev.so", cmodel)
     n = 6
     x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, n, "walk", seed=5)
     res = []
     for L, hh in ((lib, h), (rev, hr)):
+        L.emu_set_scan(scan)
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
         qp = np.zeros((n, L.emu_qp_size()))
-        assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp)) == 0
+        rc = L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+        L.emu_set_scan(0)
+        assert rc == 0
         res.append((dx, du, qp, pb, pa))
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)

@@ -130,10 +130,11 @@ __global__ __launch_bounds__(SCAN_INIT_THREADS) void k_scan_init(const DevModel*
                     x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP);
 }
 template <int n>
-__global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double* __restrict__ ein, double* __restrict__ eout, int N, int d, int* __restrict__ status) {
+__global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double* __restrict__ ein, double* __restrict__ eout, int N, int d, int* __restrict__ status,
+                                                                    long long* prof) {
   ScanCombWS<n>& w = *reinterpret_cast<ScanCombWS<n>*>(hsqp_smem);
   const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   constexpr int SZ = ScanEl<n>::SIZE;
   if (k + d <= N) {
     __shared__ int ok;
@@ -590,7 +591,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
     }
-    const bool scan = cent && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || B <= HSQP_SCAN_AUTO_BATCH);
+    const bool scan = cent && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
     if (scan) {
       // parallel-in-time backward sweep (hsqp_scan.h): elements of all stages, ceil(log2(N+1)) scan levels, single-stage gains, roll-out
       constexpr int SZ = ScanEl<CNX>::SIZE;
@@ -606,7 +607,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       hipLaunchKernelGGL(k_scan_init<CNX>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<CNX>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
       int cur = 0;
       for (int d = 1; d < N + 1; d *= 2) {
-        hipLaunchKernelGGL(k_scan_combine<CNX>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<CNX>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status);
+        hipLaunchKernelGGL(k_scan_combine<CNX>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<CNX>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status, h->d_prof + 256);
         cur = 1 - cur;
       }
       hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur], h->d_ric, N,

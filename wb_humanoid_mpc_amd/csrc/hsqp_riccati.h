@@ -329,6 +329,42 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
     dx_out[i] = d;
   }
   WG_SYNC(ctx);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads >= NXE * 4) {
+    // device path: the closed-loop rows come from global memory (written by the backward sweep); the row slice and bcl of stage
+    // k + 1 are fetched into registers while stage k is being combined, so the chain only waits on LDS and the two barriers
+    constexpr int NC = (NXE + 3) / 4;
+    const int it = ctx.tid, row = it >> 2, p = it & 3;
+    const bool mine = it < NXE * 4;
+    double a[NC], an[NC], bc = 0.0, bcn = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; an[c] = (mine && cc < NXE) ? ric[RIC_ACL + row * NX + cc] : 0.0; }
+    if (it < NX) bcn = (NXE == NX || it < NXE) ? ric[RIC_BCL + it] : 0.0;
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c] = an[c];
+      bc = bcn;
+      if (k + 1 < N) {
+        const double* rn = ric + (size_t)(k + 1) * RIC_SIZE;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; an[c] = (mine && cc < NXE) ? rn[RIC_ACL + row * NX + cc] : 0.0; }
+        if (it < NX) bcn = (NXE == NX || it < NXE) ? rn[RIC_BCL + it] : 0.0;
+      }
+      if (mine) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[c] * w.dx[cc]; }
+        w.part[it] = s;
+      }
+      WG_SYNC(ctx);
+      double s = 0.0;
+      if (it < NX) s = (NXE == NX || it < NXE) ? bc + ((w.part[4 * it] + w.part[4 * it + 1]) + (w.part[4 * it + 2] + w.part[4 * it + 3])) : w.dx[it];
+      if (it < NX) { w.dx[it] = s; dx_out[(size_t)(k + 1) * NX + it] = s; }   // every partial sum read dx before the barrier above
+      WG_SYNC(ctx);
+    }
+    return;
+  }
+#endif
   for (int k = 0; k < N; ++k) {
     const double* rk = ric + (size_t)k * RIC_SIZE;
     WG_FOR(ctx, it, NXE * 4) w.part[it] = matvec_part<NXE>(rk + RIC_ACL + (it >> 2) * NX, w.dx, it & 3);

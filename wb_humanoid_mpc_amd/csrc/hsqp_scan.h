@@ -33,35 +33,83 @@ template <int n> struct ScanEl {
 
 // Gauss-Jordan elimination of the n x ncol matrix G (LDS, leading dimension ld) whose first n columns hold M: afterwards row
 // piv[j] holds (unscaled) the solution row j, G[piv[j]][j] its pivot.  PIVOT = false: diagonal pivots (symmetric positive definite
-// M).  Two barrier-separated phases per column: pivot choice (one item), elimination of every other row (items = (row, column
-// chunk); column j itself is only read).
-struct GjWS { int piv[64], used[64], p; double pv; int ok; };
-template <bool PIVOT>
-HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int n, int ncol, GjWS& g) {
-  WG_FOR(ctx, i, 64 + 1) { if (i < 64) g.used[i] = 0; else g.ok = 1; }
+// M), one barrier-separated phase per column.  PIVOT = true: row pivoting scaled by the rows' initial magnitudes (implicit
+// equilibration), two phases per column: the pivot choice (the first row of largest scaled magnitude among the unused ones) and the
+// elimination of every other row (items = (row, column chunk); column j itself is only read, the pivot row is not written).  On the
+// device the choice is made by wave 0 with a butterfly of cross-lane exchanges (lane = row; ~200 cycles instead of a serial scan —
+// measured: with the scan done by one item, or redundantly by every item, the 35 steps were 77 % of the combination kernel).
+struct GjWS { int piv[64], used[64]; double rscale[64]; int p; double pv; int ok; };
+template <int n, bool PIVOT>
+HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int ncol, GjWS& g) {
+  static_assert(n <= 64, "one lane per row in the pivot search");
+  WG_FOR(ctx, i, 64 + 1) {
+    if (i < 64) {
+      double m = 0.0;
+      if (PIVOT && i < n) for (int c = 0; c < n; ++c) m = fmax(m, fabs(G[i * ld + c]));
+      g.rscale[i] = m > 0.0 ? 1.0 / m : 1.0;
+      g.piv[i] = 0; g.used[i] = 0;
+    } else g.ok = 1;
+  }
   WG_SYNC(ctx);
   constexpr int CH = 8;                       // columns per item
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool wave_search = PIVOT && ctx.nthreads >= 64;
+  const double myscale = (wave_search && ctx.tid < n) ? g.rscale[ctx.tid] : 0.0;
+  bool myused = false;
+#endif
   for (int j = 0; j < n; ++j) {
-    WG_FOR(ctx, it, 1) {
-      int p = j;
-      if (PIVOT) {
+    if (PIVOT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (wave_search) {
+        if (ctx.tid < 64) {
+          const int i = ctx.tid;
+          double a = (i < n && !myused) ? fabs(G[i * ld + j]) * myscale : -1.0;
+          int idx = i;
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const double oa = __shfl_xor(a, off);
+            const int oi = __shfl_xor(idx, off);
+            if (oa > a || (oa == a && oi < idx)) { a = oa; idx = oi; }
+          }
+          if (i == idx) myused = true;
+          if (i == 0) {
+            double pv = G[idx * ld + j];
+            if (!(fabs(pv) > 1e-300)) { g.ok = 0; pv = 1.0; }
+            g.p = idx; g.piv[j] = idx; g.pv = pv;
+          }
+        }
+      } else
+#endif
+      WG_FOR(ctx, it, 1) {
         double best = -1.0;
-        p = 0;
-        for (int i = 0; i < n; ++i) { const double a = fabs(G[i * ld + j]); if (!g.used[i] && a > best) { best = a; p = i; } }
+        int p = 0;
+        for (int i = 0; i < n; ++i) { const double a = fabs(G[i * ld + j]) * g.rscale[i]; if (!g.used[i] && a > best) { best = a; p = i; } }
+        double pv = G[p * ld + j];
+        if (!(fabs(pv) > 1e-300)) { g.ok = 0; pv = 1.0; }
+        g.p = p; g.piv[j] = p; g.used[p] = 1; g.pv = pv;
       }
-      g.p = p; g.piv[j] = p; g.used[p] = 1; g.pv = G[p * ld + j];
-      if (!(fabs(g.pv) > 1e-300)) { g.ok = 0; g.pv = 1.0; }
+      WG_SYNC(ctx);
     }
-    WG_SYNC(ctx);
     const int nch = (ncol - (j + 1) + CH - 1) / CH;
     WG_FOR(ctx, it, n * nch) {
+      int p = j;
+      double pv;
+      if (PIVOT) { p = g.p; pv = g.pv; }
+      else {
+        pv = G[j * ld + j];
+        const bool bad = !(fabs(pv) > 1e-300);
+        if (bad) pv = 1.0;
+        if (it == 0) { g.piv[j] = j; if (bad) g.ok = 0; }
+      }
       const int i = it / nch, c0 = j + 1 + (it % nch) * CH;
-      const int p = g.p;
       if (i != p) {
-        const double f = G[i * ld + j] * fast_rcp(g.pv);
+        const double f = G[i * ld + j] * fast_rcp(pv);
+        double a[CH], b[CH];
 #pragma unroll
-        for (int c = c0; c < c0 + CH; ++c)
-          if (c < ncol) G[i * ld + c] -= f * G[p * ld + c];
+        for (int c = 0; c < CH; ++c) { const int cc = c0 + c < ncol ? c0 + c : ncol - 1; a[c] = G[i * ld + cc]; b[c] = G[p * ld + cc]; }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          if (c0 + c < ncol) G[i * ld + c0 + c] = a[c] - f * b[c];
       }
     }
     WG_SYNC(ctx);
@@ -110,7 +158,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     }
   }
   WG_SYNC(ctx);
-  gauss_jordan<false>(ctx, &w.G[0][0], LG, NUT, 2 * NUT, w.gj);
+  gauss_jordan<NUT, false>(ctx, &w.G[0][0], LG, 2 * NUT, w.gj);
   WG_FOR(ctx, i, NUT * NUT) { const int r = i / NUT, c = i % NUT; w.Ri[r][c] = w.G[r][NUT + c] / w.G[r][r]; }
   WG_SYNC(ctx);
   {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
@@ -154,6 +202,7 @@ template <int n>
 HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, const double* e2, double* out, int* ok) {
   using E = ScanEl<n>;
   constexpr int LD = ScanCombWS<n>::LD, LG = ScanCombWS<n>::LG;
+  PH_TICK(ctx, 126);
   WG_FOR(ctx, i, 4 * n * n + 4 * n) {
     if (i < n * n) { const int r = i / n, c = i % n; const double v = e1[E::A + i]; w.A1[r][c] = v; w.G[r][n + c] = v; }
     else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; const double v = e1[E::C + j]; w.C1[r][c] = v; w.G[r][2 * n + c] = v; }
@@ -168,6 +217,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 20);
   {  // M = I + C1 J2 (C1 symmetric: X = C1), right-hand side b1 + C1 eta2, y = eta2 - J2 b1
     const XtyJob job = xty_job(n, n, n, &w.C1[0][0], LD, &w.J2[0][0], LD, &w.G[0][0], LG);
     wg_xty_jobs(ctx, &job, 1);
@@ -179,13 +229,16 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   WG_SYNC(ctx);
   WG_FOR(ctx, i, n) w.G[i][i] += 1.0;
   WG_SYNC(ctx);
-  gauss_jordan<true>(ctx, &w.G[0][0], LG, n, 3 * n + 1, w.gj);
+  PH_TICK(ctx, 21);
+  gauss_jordan<n, true>(ctx, &w.G[0][0], LG, 3 * n + 1, w.gj);
+  PH_TICK(ctx, 22);
   WG_FOR(ctx, i, n * (2 * n + 2)) {
     const int r = i / (2 * n + 2), c = i % (2 * n + 2);
     const int p = w.gj.piv[r];
     w.X[r][c] = c <= 2 * n ? w.G[p][n + c] / w.G[p][r] : 0.0;
   }
   WG_SYNC(ctx);   // G is dead from here on (out aliases it)
+  PH_TICK(ctx, 23);
   {  // A = A2 XA (to the output), T = A2 XC, V = J2 XA;  z = XC y, b = A2 xb + b2
     const XtyJob jobs[3] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], 2 * n + 2, out + E::A, n),
                             xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], 2 * n + 2, &w.T[0][0], LD),
@@ -197,6 +250,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 24);
   {  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]), J = A1' V + J1;  t = y - J2 z
     XtyJob jc = xty_job(n, n, n, &w.T[0][0], 1, &w.A2T[0][0], LD, &w.out.Co[0][0], LD, e2 + E::C, n);
     jc.sx1 = LD;
@@ -205,6 +259,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     WG_FOR(ctx, r, n) { double s = w.y[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.z[l]; w.t[r] = s; }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 25);
   WG_FOR(ctx, i, 2 * n * n + n + (E::SIZE - E::ETA - n) + 1) {
     if (i < n * n) { const int r = i / n, c = i % n; out[E::C + i] = 0.5 * (w.out.Co[r][c] + w.out.Co[c][r]); }
     else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; out[E::J + j] = 0.5 * (w.out.Jo[r][c] + w.out.Jo[c][r]); }
@@ -213,6 +268,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     else if (!w.gj.ok) *ok = 0;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 26);
 }
 
 }  // namespace hsqp

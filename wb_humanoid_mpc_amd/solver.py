@@ -67,7 +67,8 @@ def _c(a):
 class HipSqpSolver:
     def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False, riccati="auto"):
         """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step.
-        riccati: "auto" (serial recursion; parallel-in-time scan for a centroidal problem with <= 8 instances), "serial", "parallel"."""
+        riccati: "auto" (serial recursion; parallel-in-time scan for a centroidal problem with <= 2 instances and >= 48 nodes),
+        "serial", "parallel"."""
         self.lib = load_library()
         self.model = model
         flags = (_abi.FLAG_LINESEARCH if linesearch else 0) | {"auto": 0, "serial": _abi.FLAG_SERIAL_RICCATI, "parallel": _abi.FLAG_PARALLEL_RICCATI}[riccati]
