@@ -49,6 +49,19 @@ extern "C" {
 
 void emu_set_scan(int on) { g_scan = on; }
 
+// Gauss-Jordan of hsqp_scan.h on a 35 x ncol system [M | RHS] (row-major, leading dimension ncol): X = M^-1 RHS; returns ok
+int emu_gauss_jordan35(const double* Gin, int ncol, int pivot, double* X) {
+  constexpr int n = 35;
+  std::vector<double> G(Gin, Gin + (size_t)n * ncol);
+  GjWS g;
+  Ctx ctx{0, 1, nullptr};
+  if (pivot) gauss_jordan<n, true>(ctx, G.data(), ncol, ncol, g);
+  else gauss_jordan<n, false>(ctx, G.data(), ncol, ncol, g);
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < ncol - n; ++c) X[r * (ncol - n) + c] = G[(size_t)g.piv[r] * ncol + n + c] / G[(size_t)g.piv[r] * ncol + r];
+  return g.ok;
+}
+
 void* emu_create(const hsqp_model_desc* md, char* err, int errlen) {
   DevModel* dm = new DevModel;
   std::string e = build_dev_model(*md, *dm);

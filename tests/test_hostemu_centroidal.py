@@ -145,3 +145,30 @@ def test_parallel_scan_backward_sweep_equals_the_serial_recursion(cmodel, coracl
     assert kkt1[0] <= 1e-8 * sc and kkt1[1] <= 1e-10 * sc       # KKT residual with the scanned value functions as costates
     r = coracle.cent_sqp_iteration(dt, x0, x, u, par)
     assert np.abs(dx1 - r["dx"]).max() <= 1e-8 * sc and np.abs(du1 - r["du"]).max() <= 1e-8 * sc
+
+
+def test_gauss_jordan_with_scaled_row_pivoting(cemu):
+    """The elimination of the scan's combination step on systems that NEED row exchanges (zero / tiny diagonal entries, badly
+    scaled rows), against numpy; without pivoting the same code handles a symmetric positive definite system."""
+    lib, _ = cemu
+    rng = np.random.default_rng(3)
+    n, m = 35, 71
+    for trial in range(4):
+        M = rng.standard_normal((n, n))
+        M[np.arange(0, n, 3), np.arange(0, n, 3)] = 0.0                 # zero pivots on the diagonal
+        M *= 10.0 ** rng.uniform(-4, 4, size=(n, 1))                    # rows of very different magnitude
+        R = rng.standard_normal((n, m))
+        G = np.ascontiguousarray(np.concatenate([M, R], axis=1))
+        X = np.zeros((n, m))
+        assert lib.emu_gauss_jordan35(P(G), n + m, 1, P(X)) == 1
+        want = np.linalg.solve(M, R)
+        assert np.abs(X - want).max() <= 1e-9 * np.abs(want).max() * max(1.0, np.linalg.cond(M / np.abs(M).max(axis=1, keepdims=True)) * 1e-3)
+    A = rng.standard_normal((n, n))
+    S = A @ A.T + n * np.eye(n)
+    R = rng.standard_normal((n, m))
+    G = np.ascontiguousarray(np.concatenate([S, R], axis=1))
+    X = np.zeros((n, m))
+    assert lib.emu_gauss_jordan35(P(G), n + m, 0, P(X)) == 1
+    assert np.abs(X - np.linalg.solve(S, R)).max() <= 1e-12
+    G[:, :n] = 0.0                                                         # singular: reported, no NaN factory
+    assert lib.emu_gauss_jordan35(P(G), n + m, 1, P(X)) == 0

@@ -33,84 +33,70 @@ template <int n> struct ScanEl {
 
 // Gauss-Jordan elimination of the n x ncol matrix G (LDS, leading dimension ld) whose first n columns hold M: afterwards row
 // piv[j] holds (unscaled) the solution row j, G[piv[j]][j] its pivot.  PIVOT = false: diagonal pivots (symmetric positive definite
-// M), one barrier-separated phase per column.  PIVOT = true: row pivoting scaled by the rows' initial magnitudes (implicit
-// equilibration), two phases per column: the pivot choice (the first row of largest scaled magnitude among the unused ones) and the
-// elimination of every other row (items = (row, column chunk); column j itself is only read, the pivot row is not written).  On the
-// device the choice is made by wave 0 with a butterfly of cross-lane exchanges (lane = row; ~200 cycles instead of a serial scan —
-// measured: with the scan done by one item, or redundantly by every item, the 35 steps were 77 % of the combination kernel).
-struct GjWS { int piv[64], used[64]; double rscale[64]; int p; double pv; int ok; };
+// M).  PIVOT = true: row pivoting scaled by the rows' initial magnitudes (implicit equilibration): the first unused row of largest
+// scaled magnitude in column j.  ONE barrier per column in both cases: the items that update column j + 1 also publish the rows'
+// pivot candidates for the next step (double-buffered; -1 for used rows), and after the barrier every thread takes the maximum of
+// the n candidates itself (the same addresses in every lane: LDS broadcasts) instead of waiting for a dedicated search phase.
+// Measured on the combination kernel (35 steps on 35 x 106, 512 threads, tools/phase_profile.py): search by one item or redundantly
+// on the raw column 8 k cycles per step; search by wave 0 with cross-lane exchanges behind a second barrier 4.2 k; this form 3.8 k
+// (1.6 k candidate scan, 2.2 k update, 0.3 k barrier) — still the largest part (60 %) of the combination.
+struct GjWS { int piv[64]; double rscale[64]; float cand[2][64]; int ok; };
 template <int n, bool PIVOT>
 HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int ncol, GjWS& g) {
-  static_assert(n <= 64, "one lane per row in the pivot search");
+  static_assert(n <= 64, "row bookkeeping is a 64-bit mask");
   WG_FOR(ctx, i, 64 + 1) {
     if (i < 64) {
       double m = 0.0;
       if (PIVOT && i < n) for (int c = 0; c < n; ++c) m = fmax(m, fabs(G[i * ld + c]));
-      g.rscale[i] = m > 0.0 ? 1.0 / m : 1.0;
-      g.piv[i] = 0; g.used[i] = 0;
+      const double sc = m > 0.0 ? 1.0 / m : 1.0;
+      g.rscale[i] = sc;
+      g.cand[0][i] = (PIVOT && i < n) ? (float)(fabs(G[i * ld]) * sc) : -1.0f;
+      g.piv[i] = 0;
     } else g.ok = 1;
   }
   WG_SYNC(ctx);
-  constexpr int CH = 8;                       // columns per item
-#if defined(__HIP_DEVICE_COMPILE__)
-  const bool wave_search = PIVOT && ctx.nthreads >= 64;
-  const double myscale = (wave_search && ctx.tid < n) ? g.rscale[ctx.tid] : 0.0;
-  bool myused = false;
-#endif
+  // fixed item grid over ALL columns: item (row i, residue ch) owns the columns ch + c NCH, c < CH, of its row for the whole
+  // elimination (consecutive lanes = consecutive words of a row; no index arithmetic that depends on the step); columns <= j are
+  // simply skipped.  The candidates are compared in single precision: the pivot only has to be large, not the largest.
+  constexpr int CH = 8;
+  const int NCH = (ncol + CH - 1) / CH;
+  unsigned long long used = 0ull;             // rows used as pivots so far: the same value in every thread
   for (int j = 0; j < n; ++j) {
+    const float* cd = g.cand[j & 1];
+    float* cn = g.cand[(j + 1) & 1];
+    int p = j;
     if (PIVOT) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (wave_search) {
-        if (ctx.tid < 64) {
-          const int i = ctx.tid;
-          double a = (i < n && !myused) ? fabs(G[i * ld + j]) * myscale : -1.0;
-          int idx = i;
+      float c[n];
 #pragma unroll
-          for (int off = 32; off >= 1; off >>= 1) {
-            const double oa = __shfl_xor(a, off);
-            const int oi = __shfl_xor(idx, off);
-            if (oa > a || (oa == a && oi < idx)) { a = oa; idx = oi; }
-          }
-          if (i == idx) myused = true;
-          if (i == 0) {
-            double pv = G[idx * ld + j];
-            if (!(fabs(pv) > 1e-300)) { g.ok = 0; pv = 1.0; }
-            g.p = idx; g.piv[j] = idx; g.pv = pv;
-          }
-        }
-      } else
-#endif
-      WG_FOR(ctx, it, 1) {
-        double best = -1.0;
-        int p = 0;
-        for (int i = 0; i < n; ++i) { const double a = fabs(G[i * ld + j]) * g.rscale[i]; if (!g.used[i] && a > best) { best = a; p = i; } }
-        double pv = G[p * ld + j];
-        if (!(fabs(pv) > 1e-300)) { g.ok = 0; pv = 1.0; }
-        g.p = p; g.piv[j] = p; g.used[p] = 1; g.pv = pv;
-      }
-      WG_SYNC(ctx);
+      for (int i = 0; i < n; ++i) c[i] = cd[i];
+      float best = -1.0f;
+      p = 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) if (c[i] > best) { best = c[i]; p = i; }
     }
-    const int nch = (ncol - (j + 1) + CH - 1) / CH;
-    WG_FOR(ctx, it, n * nch) {
-      int p = j;
-      double pv;
-      if (PIVOT) { p = g.p; pv = g.pv; }
-      else {
-        pv = G[j * ld + j];
-        const bool bad = !(fabs(pv) > 1e-300);
-        if (bad) pv = 1.0;
-        if (it == 0) { g.piv[j] = j; if (bad) g.ok = 0; }
-      }
-      const int i = it / nch, c0 = j + 1 + (it % nch) * CH;
+    double pv = G[p * ld + j];
+    const bool bad = !(fabs(pv) > 1e-300);
+    if (bad) pv = 1.0;
+    used |= 1ull << p;
+    const double rpv = fast_rcp(pv);
+    WG_FOR(ctx, it, n * NCH) {
+      if (it == 0) { g.piv[j] = p; if (bad) g.ok = 0; }
+      const int i = it / NCH, ch = it - i * NCH;
       if (i != p) {
-        const double f = G[i * ld + j] * fast_rcp(pv);
+        const double f = G[i * ld + j] * rpv;
         double a[CH], b[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { const int cc = c0 + c < ncol ? c0 + c : ncol - 1; a[c] = G[i * ld + cc]; b[c] = G[p * ld + cc]; }
+        for (int c = 0; c < CH; ++c) { const int cc = ch + c * NCH < ncol ? ch + c * NCH : ncol - 1; a[c] = G[i * ld + cc]; b[c] = G[p * ld + cc]; }
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-          if (c0 + c < ncol) G[i * ld + c0 + c] = a[c] - f * b[c];
-      }
+        for (int c = 0; c < CH; ++c) {
+          const int cc = ch + c * NCH;
+          if (cc > j && cc < ncol) {
+            const double v = a[c] - f * b[c];
+            G[i * ld + cc] = v;
+            if (PIVOT && cc == j + 1 && cc < n) cn[i] = ((used >> i) & 1ull) ? -1.0f : (float)(fabs(v) * g.rscale[i]);
+          }
+        }
+      } else if (PIVOT && j + 1 < n && ch == (j + 1) % NCH) cn[i] = -1.0f;
     }
     WG_SYNC(ctx);
   }
