@@ -49,14 +49,15 @@ extern "C" {
 
 void emu_set_scan(int on) { g_scan = on; }
 
-// Gauss-Jordan of hsqp_scan.h on a 35 x ncol system [M | RHS] (row-major, leading dimension ncol): X = M^-1 RHS; returns ok
-int emu_gauss_jordan35(const double* Gin, int ncol, int pivot, double* X) {
-  constexpr int n = 35;
+// Gauss-Jordan of hsqp_scan.h on a 35 x 106 system [M | RHS] (row-major, leading dimension 106; the shape of the combination step):
+// X = M^-1 RHS (35 x 71); returns ok
+int emu_gauss_jordan35(const double* Gin, int pivot, double* X) {
+  constexpr int n = 35, ncol = 3 * n + 1;
   std::vector<double> G(Gin, Gin + (size_t)n * ncol);
   GjWS g;
   Ctx ctx{0, 1, nullptr};
-  if (pivot) gauss_jordan<n, true>(ctx, G.data(), ncol, ncol, g);
-  else gauss_jordan<n, false>(ctx, G.data(), ncol, ncol, g);
+  if (pivot) gauss_jordan<n, ncol, ncol, true>(ctx, G.data(), g);
+  else gauss_jordan<n, ncol, ncol, false>(ctx, G.data(), g);
   for (int r = 0; r < n; ++r)
     for (int c = 0; c < ncol - n; ++c) X[r * (ncol - n) + c] = G[(size_t)g.piv[r] * ncol + n + c] / G[(size_t)g.piv[r] * ncol + r];
   return g.ok;
@@ -167,7 +168,7 @@ void emu_cent_lq_node(void* h, const double* x, const double* u, const double* x
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
   if (deriv) cent_lq_node(ctx, dm, x, u, xnext, par, dt, rec);
-  else cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC);
+  else { cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 0); cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 1); }
 }
 void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_AB(rec, dt, AB); }
 // one full SQP iteration of one instance through the kernel sources; returns 0 or HSQP_ERR_NUMERIC
@@ -217,7 +218,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {
-    if (cent) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, r2.data() + REC_MISC);
+    if (cent) { for (int part = 0; part < 2; ++part) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, r2.data() + REC_MISC, part); }
     else lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
     pa[0] += r2[REC_MISC + 1]; pa[1] += r2[REC_MISC + 3]; pa[2] += r2[REC_MISC + 2];
   }

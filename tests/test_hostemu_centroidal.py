@@ -160,7 +160,7 @@ def test_gauss_jordan_with_scaled_row_pivoting(cemu):
         R = rng.standard_normal((n, m))
         G = np.ascontiguousarray(np.concatenate([M, R], axis=1))
         X = np.zeros((n, m))
-        assert lib.emu_gauss_jordan35(P(G), n + m, 1, P(X)) == 1
+        assert lib.emu_gauss_jordan35(P(G), 1, P(X)) == 1
         want = np.linalg.solve(M, R)
         assert np.abs(X - want).max() <= 1e-9 * np.abs(want).max() * max(1.0, np.linalg.cond(M / np.abs(M).max(axis=1, keepdims=True)) * 1e-3)
     A = rng.standard_normal((n, n))
@@ -168,7 +168,7 @@ def test_gauss_jordan_with_scaled_row_pivoting(cemu):
     R = rng.standard_normal((n, m))
     G = np.ascontiguousarray(np.concatenate([S, R], axis=1))
     X = np.zeros((n, m))
-    assert lib.emu_gauss_jordan35(P(G), n + m, 0, P(X)) == 1
+    assert lib.emu_gauss_jordan35(P(G), 0, P(X)) == 1
     assert np.abs(X - np.linalg.solve(S, R)).max() <= 1e-12
     G[:, :n] = 0.0                                                         # singular: reported, no NaN factory
-    assert lib.emu_gauss_jordan35(P(G), n + m, 1, P(X)) == 0
+    assert lib.emu_gauss_jordan35(P(G), 1, P(X)) == 0

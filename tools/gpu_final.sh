@@ -10,4 +10,4 @@ R=$PWD
 (cd /tmp && timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cent -o cent -- python $R/tools/cent_timing.py > $R/gpurun_out/cent_timing.log 2>&1)
 sed -E 's/"perf_before.*//' "$OUT/cent_timing.log" | grep -E "^config|^N100" 
 timeout 100 python bench.py --formulation centroidal --nodes 100 > "$OUT/bench_cent_cfg2.log" 2> "$OUT/bench_cent_cfg2.err"; tail -c 300 "$OUT/bench_cent_cfg2.log"; echo
-timeout 200 python bench.py > "$OUT/bench_wb.log" 2> "$OUT/bench_wb.err"; tail -c 300 "$OUT/bench_wb.log"; echo
+if [ "${WB_BENCH:-1}" = 1 ]; then timeout 200 python bench.py > "$OUT/bench_wb.log" 2> "$OUT/bench_wb.err"; tail -c 300 "$OUT/bench_wb.log"; echo; fi

@@ -62,9 +62,8 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
                  DERIV ? rec + (size_t)node * REC_SIZE + REC_MISC : misc + (size_t)node * 8);
 }
 
-// ---- centroidal LQ approximation (hsqp_cent.h): one 128-thread workgroup per (instance, node), lane = tangent direction;
-//      no LDS, the per-lane kinematic arrays live in private memory
-constexpr int CENT_THREADS = 128;
+// ---- centroidal LQ approximation (hsqp_cent.h): one 256-thread workgroup per (instance, node), lane = tangent direction, waves
+//      0-1 the RK4 half, waves 2-3 the terms half; no LDS
 __global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
                                                           const double* __restrict__ par, double dt, int N, double* __restrict__ rec) {
   const int node = blockIdx.x, b = node / N, k = node % N;
@@ -72,16 +71,16 @@ __global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __rest
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   cent_lq_node(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, rec + (size_t)node * REC_SIZE);
 }
-// ---- centroidal value-only pass: one lane per (instance, node)
-__global__ __launch_bounds__(64) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+// ---- centroidal value-only pass: two lanes per (instance, node) in different waves (wave 0: RK4 defect, wave 1: terms)
+__global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
                                                       const double* __restrict__ par, double dt, int N, int nodes, double* __restrict__ misc,
                                                       const LsState* __restrict__ ls) {
-  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  const int node = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   if (node >= nodes) return;
   const int b = node / N, k = node % N;
   if (ls && !ls[b].active) return;
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, misc + (size_t)node * 8);
+  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, misc + (size_t)node * 8, part);
 }
 
 // ---- projection: one workgroup per (instance, node)
@@ -627,7 +626,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     if (cent)
-      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(64), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes, h->d_misc,
+      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes, h->d_misc,
                          (const LsState*)nullptr);
     else
       hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
@@ -651,7 +650,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
         if (counts[1] == 0) break;
         if (cent)
-          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(64), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes,
+          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes,
                              h->d_misc, (const LsState*)h->d_ls);
         else
           hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,

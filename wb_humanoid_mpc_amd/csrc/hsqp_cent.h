@@ -436,20 +436,23 @@ HSQP_HD void cent_nominal(const DevModel& dm, const double* x, const double* par
   }
 }
 
-// The whole scalar program of one node on the number type T with tangent direction `dir` (0..69, or -1 for none): RK4 of the
-// flow map (u held constant; joint rows q_j+ = q_j + dt qd_j exactly), the terms at (x, u).  Returns x_next (35), flow (12 rows).
+// The scalar program of one node on the number type T with tangent direction `dir` (0..69, or -1 for none) comes in two halves that
+// do not depend on each other and run on different lanes: the RK4 step of the flow map (u held constant; joint rows
+// q_j+ = q_j + dt qd_j exactly) and the cost / constraint terms at (x, u).
 template <class T>
-HSQP_HD void cent_program(const DevModel& dm, const double* x, const double* u, const double* par, double dt, int dir, CentKin<T>& k, CentOut<T>& o,
-                          T* xn /*[CNX]*/, T* flow /*[12]*/) {
-  T xs[CNX], us[NU], k1[12], ks[12], acc[12];
+HSQP_HD void cent_seed(const double* x, const double* u, int dir, T* xs, T* us) {
   for (int i = 0; i < CNX; ++i) xs[i] = cst<T>(x[i]);
   for (int i = 0; i < NU; ++i) us[i] = cst<T>(u[i]);
   if (dir >= 0 && dir < CNX) set_tan(xs[dir]);
   else if (dir >= CNX && dir < CNZ) set_tan(us[dir - CNX]);
-  T x0[CNX];
+}
+// RK4: x_next (35) and the flow (12 dense rows) at (x, u)
+template <class T>
+HSQP_HD void cent_rk4(const DevModel& dm, const double* x, const double* u, double dt, int dir, CentKin<T>& k, T* xn /*[CNX]*/, T* flow /*[12]*/) {
+  T xs[CNX], us[NU], x0[CNX], k1[12], ks[12], acc[12];
+  cent_seed<T>(x, u, dir, xs, us);
   for (int i = 0; i < CNX; ++i) x0[i] = xs[i];
-  cent_pass<T, true>(dm, xs, xs + 6, us, us + 12, k, k1);
-  cent_terms<T>(dm, k, xs, us, par, o);
+  cent_pass<T, false>(dm, xs, xs + 6, us, us + 12, k, k1);
   for (int r = 0; r < 12; ++r) { flow[r] = k1[r]; acc[r] = k1[r]; }
   // stages 2..4: x_s = x + c k_{s-1}; the joint rows of every k are qd_j
   for (int s = 1; s < 4; ++s) {
@@ -465,11 +468,29 @@ HSQP_HD void cent_program(const DevModel& dm, const double* x, const double* u, 
   for (int r = 0; r < 12; ++r) xn[r] = x0[r] + acc[r] * (dt / 6.0);
   for (int j = 0; j < NJ; ++j) xn[12 + j] = x0[12 + j] + us[12 + j] * dt;
 }
-
-// value lane: cost, defect, misc; returns nothing, writes misc[0..7] and (if rec) the value pieces of the record
+// terms: one tree pass with the side tables, then every cost / constraint term
 template <class T>
-HSQP_HD void cent_write_values(const DevModel& dm, const CentOut<T>& o, const T* xn, const T* flow, const double* x, const double* u, const double* xnext,
-                               const double* par, double dt, double* rec, double* misc) {
+HSQP_HD void cent_terms_program(const DevModel& dm, const double* x, const double* u, const double* par, int dir, CentKin<T>& k, CentOut<T>& o) {
+  T xs[CNX], us[NU], k1[12];
+  cent_seed<T>(x, u, dir, xs, us);
+  cent_pass<T, true>(dm, xs, xs + 6, us, us + 12, k, k1);
+  cent_terms<T>(dm, k, xs, us, par, o);
+}
+
+// value lane of the RK4 half: defect, flow; misc[3] = dt |b|^2
+template <class T>
+HSQP_HD void cent_write_dynamics(const T* xn, const T* flow, const double* u, const double* xnext, double dt, double* rec, double* misc) {
+  double dyn = 0.0;
+  for (int i = 0; i < CNX; ++i) { const double b = val(xn[i]) - xnext[i]; dyn += b * b; if (rec) rec[REC_B + i] = b; }
+  misc[3] = dt * dyn;
+  if (!rec) return;
+  for (int i = CNX; i < 64; ++i) rec[REC_B + i] = 0.0;
+  for (int i = 0; i < 64; ++i) rec[REC_FLOW + i] = i < 12 ? val(flow[i]) : (i < CNX ? u[i] : 0.0);   // joint rows: qd_j = u[12 + (i - 12)]
+}
+// value lane of the terms half: cost, equality values, row data; misc[0..2, 4..7]
+template <class T>
+HSQP_HD void cent_write_terms(const DevModel& dm, const CentOut<T>& o, const double* x, const double* u, const double* par, double dt, double* rec,
+                              double* misc) {
   double xnom[CNX], unom[NU];
   cent_nominal(dm, x, par, xnom, unom);
   const double sdt = sqrt(dt);
@@ -479,14 +500,11 @@ HSQP_HD void cent_write_values(const DevModel& dm, const CentOut<T>& o, const T*
   for (int s = 0; s < NRS; ++s) cost += o.pen[s];
   for (int j = 0; j < NJ; ++j)   // JointLimitsSoftConstraint.cpp:64-100
     cost += pwp_barrier(dm.jl_bmu, dm.jl_bdelta, x[12 + j] - dm.q_lo[j]).p + pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - x[12 + j]).p;
-  double dyn = 0.0, eq = 0.0;
-  for (int i = 0; i < CNX; ++i) { const double b = val(xn[i]) - xnext[i]; dyn += b * b; if (rec) rec[REC_B + i] = b; }
+  double eq = 0.0;
   for (int r = 0; r < o.ne; ++r) eq += val(o.eq[r]) * val(o.eq[r]);
-  misc[0] = (double)o.ne; misc[1] = dt * cost; misc[2] = dt * eq; misc[3] = dt * dyn;
+  misc[0] = (double)o.ne; misc[1] = dt * cost; misc[2] = dt * eq;
   misc[4] = (double)o.contact[0]; misc[5] = (double)o.contact[1]; misc[6] = (double)o.eq_off[0]; misc[7] = (double)o.eq_off[1];
   if (!rec) return;
-  for (int i = CNX; i < 64; ++i) rec[REC_B + i] = 0.0;
-  for (int i = 0; i < 64; ++i) rec[REC_FLOW + i] = i < 12 ? val(flow[i]) : (i < CNX ? u[12 + i - 12] : 0.0);
   for (int s = 0; s < NRS; ++s) rec[REC_RHO + s] = sdt * o.rho[s];
   const double shift = -(o.hfric_d1[0] + o.hfric_d1[1]) * dm.friction_hess_shift;   // hessianDiagonalShift on every state and input
   for (int i = 0; i < LDJ; ++i) {
@@ -504,42 +522,57 @@ HSQP_HD void cent_write_values(const DevModel& dm, const CentOut<T>& o, const T*
   for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + NZ] = r < o.ne ? val(o.eq[r]) : 0.0;
 }
 
-// ---- the LQ kernel body: lane = tangent direction.  Workspace: none (private memory only).
+// ---- the LQ kernel body: lane = tangent direction, two lane groups of 128 (group 0: RK4 -> [A|B], defect, flow; group 1: terms
+//      -> residual rows, equality rows, diagonals).  Workspace: none (private memory only).
+constexpr int CENT_GROUP = 128, CENT_THREADS = 2 * CENT_GROUP;
 HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt,
                           double* rec) {
-  WG_FOR(ctx, lane, CENT_LANES) {
-    if (lane > CNZ) {   // zero-fill lanes: padding columns 35..57 and 93..95 of every row of the record
+  WG_FOR(ctx, it, CENT_THREADS) {
+    const int grp = it / CENT_GROUP, lane = it % CENT_GROUP;
+    if (lane >= CENT_LANES) continue;
+    if (lane > CNZ) {   // zero-fill lanes: padding columns 35..57 and 93..95 of the rows of this group
       const int col = lane - CNZ - 1 < NX - CNX ? CNX + (lane - CNZ - 1) : NZ + (lane - CNZ - 1 - (NX - CNX));
-      for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = 0.0;
-      for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = 0.0;
-      if (col != NZ) for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = 0.0;
+      if (grp == 0) {
+        for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = 0.0;
+      } else {
+        for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = 0.0;
+        if (col != NZ) for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = 0.0;
+      }
       continue;
     }
-    CentKin<Dual1> k;
-    CentOut<Dual1> o;
-    Dual1 xn[CNX], flow[12];
-    cent_program<Dual1>(dm, x, u, par, dt, lane < CNZ ? lane : -1, k, o, xn, flow);
-    if (lane == CNZ) {
-      cent_write_values<Dual1>(dm, o, xn, flow, x, u, xnext, par, dt, rec, rec + REC_MISC);
-      continue;
-    }
+    const int dir = lane < CNZ ? lane : -1;
     const int col = lane < CNX ? lane : NX + (lane - CNX);
-    const double sdt = sqrt(dt);
-    // [A|B] - [I|0] on the 12 dense rows (the joint rows are q_j+ = q_j + dt qd_j: structure known to the projection)
-    for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = xn[r].d - (r == lane ? 1.0 : 0.0);
-    for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = sdt * o.sc[s] * o.row[s].d;
-    for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = r < o.ne ? o.eq[r].d : 0.0;
+    CentKin<Dual1> k;
+    if (grp == 0) {
+      Dual1 xn[CNX], flow[12];
+      cent_rk4<Dual1>(dm, x, u, dt, dir, k, xn, flow);
+      if (lane == CNZ) { cent_write_dynamics<Dual1>(xn, flow, u + 12 - 12, xnext, dt, rec, rec + REC_MISC); continue; }
+      // [A|B] - [I|0] on the 12 dense rows (the joint rows are q_j+ = q_j + dt qd_j: structure known to the projection)
+      for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = xn[r].d - (r == lane ? 1.0 : 0.0);
+    } else {
+      CentOut<Dual1> o;
+      cent_terms_program<Dual1>(dm, x, u, par, dir, k, o);
+      if (lane == CNZ) { cent_write_terms<Dual1>(dm, o, x, u, par, dt, rec, rec + REC_MISC); continue; }
+      const double sdt = sqrt(dt);
+      for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = sdt * o.sc[s] * o.row[s].d;
+      for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = r < o.ne ? o.eq[r].d : 0.0;
+    }
   }
   WG_SYNC(ctx);
 }
 
-// value-only evaluation of one node (performance index / line search): misc[0..7] as the LQ kernel's
-HSQP_HD void cent_value_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc) {
+// value-only evaluation of one node (performance index / line search), in the same two halves: part 0 writes misc[3], part 1 the rest
+HSQP_HD void cent_value_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc, int part) {
   CentKin<double> k;
-  CentOut<double> o;
-  double xn[CNX], flow[12];
-  cent_program<double>(dm, x, u, par, dt, -1, k, o, xn, flow);
-  cent_write_values<double>(dm, o, xn, flow, x, u, xnext, par, dt, nullptr, misc);
+  if (part == 0) {
+    double xn[CNX], flow[12];
+    cent_rk4<double>(dm, x, u, dt, -1, k, xn, flow);
+    cent_write_dynamics<double>(xn, flow, u, xnext, dt, nullptr, misc);
+  } else {
+    CentOut<double> o;
+    cent_terms_program<double>(dm, x, u, par, -1, k, o);
+    cent_write_terms<double>(dm, o, x, u, par, dt, nullptr, misc);
+  }
 }
 
 // Device-side parameter generation, centroidal part (after node_params_eval has filled the desired state, contact flags, swing

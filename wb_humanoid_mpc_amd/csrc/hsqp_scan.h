@@ -41,8 +41,9 @@ template <int n> struct ScanEl {
 // on the raw column 8 k cycles per step; search by wave 0 with cross-lane exchanges behind a second barrier 4.2 k; this form 3.8 k
 // (1.6 k candidate scan, 2.2 k update, 0.3 k barrier) — still the largest part (60 %) of the combination.
 struct GjWS { int piv[64]; double rscale[64]; float cand[2][64]; int ok; };
-template <int n, bool PIVOT>
-HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int ncol, GjWS& g) {
+// ld, ncol are compile-time constants: the item -> (row, residue) map and every address offset fold into immediates
+template <int n, int ld, int ncol, bool PIVOT>
+HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
   static_assert(n <= 64, "row bookkeeping is a 64-bit mask");
   WG_FOR(ctx, i, 64 + 1) {
     if (i < 64) {
@@ -59,7 +60,7 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, int ld, int ncol, GjWS& g) 
   // elimination (consecutive lanes = consecutive words of a row; no index arithmetic that depends on the step); columns <= j are
   // simply skipped.  The candidates are compared in single precision: the pivot only has to be large, not the largest.
   constexpr int CH = 8;
-  const int NCH = (ncol + CH - 1) / CH;
+  constexpr int NCH = (ncol + CH - 1) / CH;
   unsigned long long used = 0ull;             // rows used as pivots so far: the same value in every thread
   for (int j = 0; j < n; ++j) {
     const float* cd = g.cand[j & 1];
@@ -144,7 +145,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     }
   }
   WG_SYNC(ctx);
-  gauss_jordan<NUT, false>(ctx, &w.G[0][0], LG, 2 * NUT, w.gj);
+  gauss_jordan<NUT, LG, 2 * NUT, false>(ctx, &w.G[0][0], w.gj);
   WG_FOR(ctx, i, NUT * NUT) { const int r = i / NUT, c = i % NUT; w.Ri[r][c] = w.G[r][NUT + c] / w.G[r][r]; }
   WG_SYNC(ctx);
   {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
@@ -216,7 +217,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   WG_FOR(ctx, i, n) w.G[i][i] += 1.0;
   WG_SYNC(ctx);
   PH_TICK(ctx, 21);
-  gauss_jordan<n, true>(ctx, &w.G[0][0], LG, 3 * n + 1, w.gj);
+  gauss_jordan<n, LG, 3 * n + 1, true>(ctx, &w.G[0][0], w.gj);
   PH_TICK(ctx, 22);
   WG_FOR(ctx, i, n * (2 * n + 2)) {
     const int r = i / (2 * n + 2), c = i % (2 * n + 2);
