@@ -8,12 +8,13 @@
 // step, KKT and performance kernels run unchanged on the record this file writes; only the structured [A|B] differs
 // (project_node(..., cent = true)).
 //
-// First version of the device path: forward-mode derivatives with ONE tangent direction per lane.  Lane c of the workgroup
-// evaluates the whole scalar program of the node (4 RK4 stages of the flow map + every cost / constraint term) on dual numbers
-// whose tangent is d/dz_c, z = [x(35); u(35)]; lane 70 carries no tangent and writes the values; lanes 71..96 zero-fill the
-// padding columns of the record.  Lanes never exchange data: there are no barriers and no LDS traffic, the per-lane kinematic
-// arrays live in private memory.  The value-only pass (performance index, line search) runs the same program on plain doubles,
-// one lane per node.
+// Device path: forward-mode derivatives with ONE tangent direction per lane.  Lane c of a lane group evaluates a scalar program of
+// the node on dual numbers whose tangent is d/dz_c, z = [x(35); u(35)]; lane 70 carries no tangent and writes the values; lanes
+// 71..96 zero-fill the padding columns of the record.  The program has two independent halves that run on different waves of the
+// workgroup: the four RK4 stages of the flow map (group 0) and one tree pass plus every cost / constraint term (group 1).  Lanes
+// never exchange data: there are no barriers and no LDS traffic; the tree pass keeps the parent's record in registers (chain
+// walk) and what does not fit lives in private memory.  The value-only pass (performance index, line search) runs the same two
+// halves on plain doubles, two lanes per node.
 //
 // The flow map is NOT evaluated as the reference / the oracle write it (centroidal momentum matrix column by column,
 // ocs2_centroidal_model — oracle ASSUMPTION A7) but from the momentum balance directly:
@@ -546,7 +547,7 @@ HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, c
     if (grp == 0) {
       Dual1 xn[CNX], flow[12];
       cent_rk4<Dual1>(dm, x, u, dt, dir, k, xn, flow);
-      if (lane == CNZ) { cent_write_dynamics<Dual1>(xn, flow, u + 12 - 12, xnext, dt, rec, rec + REC_MISC); continue; }
+      if (lane == CNZ) { cent_write_dynamics<Dual1>(xn, flow, u, xnext, dt, rec, rec + REC_MISC); continue; }
       // [A|B] - [I|0] on the 12 dense rows (the joint rows are q_j+ = q_j + dt qd_j: structure known to the projection)
       for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = xn[r].d - (r == lane ? 1.0 : 0.0);
     } else {
