@@ -36,10 +36,19 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
     ea.swap(eb);
   }
   if (!ok) return 0;
-  for (int k = 0; k < N; ++k) {   // one stage of the Riccati code per node, started from the scanned value function of node k + 1 (S = J, s = -eta)
+  // one stage of the Riccati code per node, started from the scanned value function of node k + 1 (S = J, s = -eta) ...
+  std::vector<double> vf1((size_t)(N + 1) * VF_SIZE);
+  for (int k = 0; k < N; ++k) {
     const double* en = &ea[(size_t)(k + 1) * E::SIZE];
     riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
-                        vf + (size_t)k * VF_SIZE, en + E::J, en + E::ETA, k == N - 1, -1.0);
+                        vf1.data() + (size_t)k * VF_SIZE, en + E::J, en + E::ETA, k == N - 1, -1.0);
+    if (!rw->ok) return 0;
+  }
+  // ... and once more from the value functions of that pass (refinement: the exact Riccati map contracts the scan's rounding error)
+  for (int k = 0; k < N; ++k) {
+    const double* vn = vf1.data() + (size_t)(k + 1) * VF_SIZE;
+    riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
+                        vf + (size_t)k * VF_SIZE, vn, vn + NX * NX, k == N - 1, 1.0, NX);
     if (!rw->ok) return 0;
   }
   return 1;

@@ -146,18 +146,22 @@ __global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double
     for (int i = threadIdx.x; i < SZ; i += blockDim.x) eout[(size_t)id * SZ + i] = ein[(size_t)id * SZ + i];
   }
 }
-// one stage of the Riccati code per node, started from the scanned value function of node k + 1
+// one stage of the Riccati code per node, started from the value function of node k + 1: the scanned one (element el; vf_in = null)
+// or, in the refinement pass, the one the first pass computed (vf_in: [N + 1][VF_SIZE] per instance).  Applying the exact Riccati map
+// once more contracts the scan's rounding error (oracle-level experiment: 5e-8 -> 5e-9 on the worst whole-body case).
 template <int n>
 __global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
-                                                            const double* __restrict__ qp, const double* __restrict__ el, double* __restrict__ ric, int N,
-                                                            int* __restrict__ status, double* __restrict__ vf) {
+                                                            const double* __restrict__ qp, const double* __restrict__ el, const double* __restrict__ vf_in,
+                                                            double* __restrict__ ric, int N, int* __restrict__ status, double* __restrict__ vf) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* en = el + ((size_t)b * (N + 1) + k + 1) * ScanEl<n>::SIZE;
+  const double* vn = vf_in ? vf_in + ((size_t)b * (N + 1) + k + 1) * VF_SIZE : nullptr;
   const double* q = qp + (size_t)node * QP_SIZE;
   riccati_backward<n>(ctx, w, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, q, ric + (size_t)node * RIC_SIZE, 1,
-                      vf ? vf + ((size_t)b * (N + 1) + k) * VF_SIZE : nullptr, en + ScanEl<n>::J, en + ScanEl<n>::ETA, k == N - 1, -1.0);
+                      vf ? vf + ((size_t)b * (N + 1) + k) * VF_SIZE : nullptr, vn ? vn : en + ScanEl<n>::J, vn ? vn + NX * NX : en + ScanEl<n>::ETA, k == N - 1,
+                      vn ? 1.0 : -1.0, vn ? NX : n);
   if (threadIdx.x == 0) {
     const int st = (q[QP_NUT] < 0.0 ? 1 : 0) | (w.ok ? 0 : 2);
     if (st) atomicOr(&status[b], st);
@@ -337,6 +341,7 @@ struct hsqp_handle {
   double *d_dx = nullptr, *d_du = nullptr, *d_ut = nullptr, *d_xnew = nullptr, *d_unew = nullptr;
   double *d_misc = nullptr, *d_kkt = nullptr;
   double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
+  double* d_vf2 = nullptr;        // scan path: value functions of the refinement pass (the KKT check then reads these)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   double* d_stepinfo = nullptr;   // [B][N][4] per-node {armijo, |dx|^2, |du|^2}
@@ -396,7 +401,7 @@ void hsqp_destroy(hsqp_handle* h) {
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
                   h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
-                  h->d_el[0], h->d_el[1]};
+                  h->d_el[0], h->d_el[1], h->d_vf2};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -609,8 +614,16 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         hipLaunchKernelGGL(k_scan_combine<CNX>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<CNX>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status, h->d_prof + 256);
         cur = 1 - cur;
       }
-      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur], h->d_ric, N,
-                         h->d_status, want_kkt ? h->d_vf : (double*)nullptr);
+      // gains in two passes: from the scanned value functions (which also yields S_k of every node), then once more from those
+      for (double** pv : {&h->d_vf, &h->d_vf2})
+        if (!*pv) {
+          const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
+          if (hipMalloc(pv, bytes) != hipSuccess) { *pv = nullptr; h->err = "hipMalloc failed (value functions of the scan, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+        }
+      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
+                         (const double*)nullptr, h->d_ric, N, h->d_status, h->d_vf);
+      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
+                         (const double*)h->d_vf, h->d_ric, N, h->d_status, want_kkt ? h->d_vf2 : (double*)nullptr);
       hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(256), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_ric, N, h->d_dx);
     } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
       hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
@@ -622,7 +635,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                        h->d_xnew, h->d_unew, h->d_stepinfo);
     if (want_kkt) {
       HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
-      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt);
+      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt);
     }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     if (cent)

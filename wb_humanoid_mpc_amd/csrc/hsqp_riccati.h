@@ -56,17 +56,17 @@ constexpr int VF_SIZE = NX * NX + NX;
 // embedded in the 58-state layout, whose padding states are decoupled (A~ = I, B~ = 0, no cost there), so S, s, K, Acl - I, bcl
 // vanish on them identically: every product is restricted to the leading NXE x NXE blocks (leading dimensions stay NX) and the
 // padding parts of the outputs are written as zeros / left untouched where nothing reads them.
-// termS / terms (optional): start the recursion from the value function 1/2 x' termS x + terms' x (NXE x NXE row-major, NXE) instead
+// termS / terms (optional): start the recursion from the value function 1/2 x' termS x + terms' x (NXE x NXE, leading dimension term_ld; NXE) instead
 // of the terminal cost — the parallel-in-time path (hsqp_scan.h) runs single stages from the scanned value functions (terms_sign = -1:
 // the scan carries eta = -s); then vf_terminal = false leaves vf[N] to the workgroup that owns it.
 template <int NXE = NX>
 HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const double* xN, const double* parN, const double* qp,
                               double* ric, int N, double* vf = nullptr, const double* termS = nullptr, const double* terms = nullptr,
-                              bool vf_terminal = true, double terms_sign = 1.0) {
+                              bool vf_terminal = true, double terms_sign = 1.0, int term_ld = NXE) {
   WG_FOR(ctx, i, NX * NX + NX + 1) {
     if (i < NX * NX) {
       const int r = i / NX, c = i % NX;
-      w.S[r][c] = termS ? ((r < NXE && c < NXE) ? termS[r * NXE + c] : 0.0) : (r == c ? Qf[r] : 0.0);
+      w.S[r][c] = termS ? ((r < NXE && c < NXE) ? termS[r * term_ld + c] : 0.0) : (r == c ? Qf[r] : 0.0);
     } else if (i < NX * NX + NX) {
       const int r = i - NX * NX;
       w.sv[r] = termS ? (r < NXE ? terms_sign * terms[r] : 0.0) : Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]);
