@@ -2,7 +2,7 @@
 """Experiment (CPU, numpy; run from the repo root): parallel single-stage Riccati sweeps after the scan on the WHOLE-BODY stage QPs.
 One sweep takes the disagreement with the serial recursion from 5e-8 to 5e-9; further sweeps plateau at ~3e-9."""
 import sys, ctypes as C
-sys.path[:0]=['/root/repo','/root/repo/oracle','/root/repo/tests','/root/repo/tools']
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [_R, os.path.join(_R, 'oracle'), os.path.join(_R, 'tests'), os.path.join(_R, 'tests', 'experiments')]
 import numpy as np
 import parallel_scan as ps
 import scan_scaling_experiment as E   # reuses run() (prints its own table first)

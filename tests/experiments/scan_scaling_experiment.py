@@ -3,14 +3,14 @@
 of the parallel-scan backward sweep on the WHOLE-BODY stage QPs?  Result recorded in DESIGN.md: cond(I + C1 J2) drops from ~1e9 to
 1e6-1e7, the disagreement with the serial recursion does not (5e-8 -> 3e-8): the loss is not the conditioning of the solve alone."""
 import sys, ctypes as C, os, math
-sys.path[:0]=['/root/repo','/root/repo/oracle','/root/repo/tests']
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [_R, os.path.join(_R, 'oracle'), os.path.join(_R, 'tests')]
 import numpy as np
 import parallel_scan as ps
 import test_parallel_scan as T
 from test_oracle_lq import perturbed_problem
 from wb_humanoid_mpc_amd import load_model, _abi
 m=load_model()
-lib=C.CDLL('/root/repo/tests/hostemu/libhsqp_hostemu.so'); lib.emu_create.restype=C.c_void_p
+lib=C.CDLL(os.path.join(_R, 'tests', 'hostemu', 'libhsqp_hostemu.so')); lib.emu_create.restype=C.c_void_p
 err=C.create_string_buffer(256); h=C.c_void_p(lib.emu_create(C.byref(m.desc),err,256))
 P=T.P
 def run(gait,n,seed=5):
