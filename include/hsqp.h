@@ -1,13 +1,14 @@
 /*
  * hsqp.h — C ABI of the MI355X-native multiple-shooting SQP iteration for the
- * ocs2-based humanoid NMPC of manumerous/wb_humanoid_mpc (Unitree G1, whole-body
- * acceleration-level formulation).
+ * ocs2-based humanoid NMPC of manumerous/wb_humanoid_mpc (Unitree G1): the whole-body
+ * acceleration-level formulation and the centroidal formulation (hsqp_model_desc::formulation).
  *
  * This is the drop-in boundary.  It replaces what the reference
  * reaches through `ocs2::SqpMpc` / `ocs2::SolverBase`:
  *   - humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:64      (SqpMpc construction)
  *   - humanoid_nmpc/humanoid_wb_mpc_ros2/src/WBMpcSqpNode.cpp:85-89   (solver ptr handed to MPC_ROS_Interface)
  *   - humanoid_nmpc/humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:200-213 (advanceMpc -> SolverBase::run)
+ *   - humanoid_nmpc/humanoid_centroidal_mpc_ros2/src/CentroidalMpcSqpNode.cpp:63  (the same seam of the centroidal MPC)
  * The per-node callbacks the reference's solver makes into the problem
  * definition (SystemDynamicsBase / StateInputCost / StateInputConstraint /
  * PreComputation virtuals) do not cross this boundary: their bodies are device
