@@ -123,7 +123,7 @@ def cpu_baseline(model, n_nodes, seed):
             "value_4_threads": done4 / wall4, "sample_4_threads": f"{done4} iterations in {wall4:.1f} s on 4 threads (the reference's nThreads)"}
 
 
-def cpu_kernel_sources_on_host(model, n_nodes, seed):
+def cpu_kernel_sources_on_host(model, n_nodes, seed, cent=False):
     """Second, stronger CPU figure (reported beside `cpu_baseline`, never instead of it): the SAME kernel sources
     (wb_humanoid_mpc_amd/csrc/*.h: analytic derivatives, structured RK4 chain, projection, Riccati) compiled for the host
     with a one-thread context (tests/hostemu, g++ -O2), one instance per host thread, all cores."""
@@ -141,7 +141,11 @@ def cpu_kernel_sources_on_host(model, n_nodes, seed):
         return None
     cores = os.cpu_count() or 1
     n_inst = 8
-    x0, x, u, par, dt = make_problem(model, n_nodes=n_nodes, batch=n_inst, perturb=True, seed=seed)
+    if cent:   # centroidal: every lane of the LQ kernel is emulated one after the other (70 tangent lanes per node), serial Riccati sweep
+        from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+        x0, x, u, par, dt = make_centroidal_problem(model, n_nodes=n_nodes, batch=n_inst, perturb=True, seed=seed)
+    else:
+        x0, x, u, par, dt = make_problem(model, n_nodes=n_nodes, batch=n_inst, perturb=True, seed=seed)
     dp = C.POINTER(C.c_double)
     t0 = time.perf_counter()
 
@@ -276,7 +280,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_centroidal(model, N, BENCH_SEED) if cent else cpu_baseline(model, N, BENCH_SEED)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
-            host = None if cent else cpu_kernel_sources_on_host(model, N, BENCH_SEED)
+            host = cpu_kernel_sources_on_host(model, N, BENCH_SEED, cent=cent)
             if host:
                 res["cpu_kernel_sources_on_host"] = host
                 res["speedup_vs_kernel_sources_on_host"] = value / host["value"]
