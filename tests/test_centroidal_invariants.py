@@ -1,0 +1,91 @@
+"""Physical invariants of the centroidal flow map, checked on the oracle AND on the kernel sources compiled for the host: they pin
+the frame conventions of both restatements (oracle ASSUMPTION A7 and the momentum-balance form of hsqp_cent.h) independently of
+each other — world translation invariance, equivariance under a rotation of the world about the vertical, and the momentum
+identity A(q) v = m h for the velocity the mapping returns."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_oracle_centroidal_ocp import perturbed_centroidal_problem
+from wb_humanoid_mpc_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+CNX, NX, NU = _abi.CNX, _abi.NX, _abi.NU
+
+
+@pytest.fixture(scope="module")
+def emu_flow(cmodel):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu"), "all"])
+    lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
+    lib.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(cmodel.desc), err, 256))
+    assert h.value, err.value
+    RS, mo = lib.emu_rec_size(), lib.emu_rec_misc_offset()
+    flow_off = mo + 8          # REC_FLOW follows the 8 misc doubles (hsqp_lq.h)
+
+    def flow(x35, u, par, dt=0.02):
+        x = np.zeros(NX)
+        x[:CNX] = x35
+        rec = np.zeros(RS)
+        lib.emu_cent_lq_node(h, P(x), P(np.ascontiguousarray(u)), P(x), P(np.ascontiguousarray(par)), C.c_double(dt), 1, P(rec))
+        return rec[flow_off:flow_off + CNX].copy()
+    return flow
+
+
+def rotz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def rotate_world(x, u, a):
+    """The same physical situation seen from a world frame rotated by -a about z (all world vectors rotate by +a)."""
+    R = rotz(a)
+    x2, u2 = x.copy(), u.copy()
+    x2[0:3], x2[3:6], x2[6:9] = R @ x[0:3], R @ x[3:6], R @ x[6:9]
+    x2[9] = x[9] + a                       # euler Z
+    for f in range(2):
+        u2[6 * f:6 * f + 3], u2[6 * f + 3:6 * f + 6] = R @ u[6 * f:6 * f + 3], R @ u[6 * f + 3:6 * f + 6]
+    return x2, u2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_flow_map_invariants(cmodel, coracle, emu_flow, seed):
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, 2, "walk", seed=seed)
+    xs, us = x[0, :CNX].copy(), u[0].copy()
+    for name, f in (("oracle", lambda a, b: coracle.cent_flow_map(a, b)), ("kernel sources", lambda a, b: emu_flow(a, b, par[0]))):
+        f0 = f(xs, us)
+        # (i) translating the world origin changes nothing
+        xt = xs.copy()
+        xt[6:9] += np.array([3.0, -2.0, 0.7])
+        assert np.abs(f(xt, us) - f0).max() <= 1e-11 * max(1.0, np.abs(f0).max()), name
+        # (ii) rotating the world about the vertical rotates the vector rows and leaves euler rates / joint rows alone
+        a = 0.83
+        xr, ur = rotate_world(xs, us, a)
+        fr = f(xr, ur)
+        R = rotz(a)
+        want = f0.copy()
+        want[0:3], want[3:6], want[6:9] = R @ f0[0:3], R @ f0[3:6], R @ f0[6:9]
+        assert np.abs(fr - want).max() <= 1e-10 * max(1.0, np.abs(f0).max()), name
+    # (iii) the generalized velocity of the mapping reproduces the normalized momentum through the momentum matrix: A(q) v = m h
+    A, com = coracle.cent_momentum_matrix(xs[6:CNX])
+    f0 = coracle.cent_flow_map(xs, us)
+    v = np.concatenate([f0[6:12], us[12:]])
+    assert np.abs(A @ v - cmodel.total_mass * xs[:6]).max() <= 1e-10 * max(1.0, np.abs(A @ v).max())
+    f1 = emu_flow(xs, us, par[0])
+    v1 = np.concatenate([f1[6:12], us[12:]])
+    assert np.abs(A @ v1 - cmodel.total_mass * xs[:6]).max() <= 1e-10 * max(1.0, np.abs(A @ v1).max())
+
+
+def test_free_fall_keeps_the_angular_momentum(cmodel, coracle, emu_flow):
+    """No contact wrenches: the normalized momentum rate is gravity alone, whatever the configuration and joint rates."""
+    x0, x, u, par, dt = perturbed_centroidal_problem(cmodel, 2, "run", seed=4)
+    us = u[0].copy()
+    us[:12] = 0.0
+    for f in (coracle.cent_flow_map(x[0, :CNX], us), emu_flow(x[0, :CNX], us, par[0])):
+        assert np.allclose(f[:6], [0.0, 0.0, -9.81, 0.0, 0.0, 0.0], atol=1e-12)
