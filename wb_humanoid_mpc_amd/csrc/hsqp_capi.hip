@@ -2,6 +2,7 @@
 // Product path: there is NO CPU fallback — without a usable HIP device every entry point fails with
 // HSQP_ERR_NO_DEVICE / HSQP_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   PH_TICK(ctx, 0);
   riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
-  if (threadIdx.x == 0) status[b] = (bad ? 1 : 0) | (w.ok ? 0 : 2);
+  // OR-accumulated over the iterations of one hsqp_iterate_device call (the host clears it once per call): a numeric failure
+  // in an early iteration must not be masked by a later clean one
+  if (threadIdx.x == 0) { const int st = (bad ? 1 : 0) | (w.ok ? 0 : 2); if (st) atomicOr(&status[b], st); }
 }
 
 // ---- parallel-in-time backward sweep (hsqp_scan.h).  Elements: [B][N + 1][ScanEl<n>::SIZE], two buffers (ping-pong per level).
@@ -417,10 +420,18 @@ void hsqp_linesearch_defaults(hsqp_linesearch_settings* s) {
   s->delta_tol = 1e-4;                   // task.info deltaTol
 }
 
+// trials after which every instance has either accepted a step or fallen below alpha_min (zero step)
+static int ls_max_trials(const hsqp_linesearch_settings& s) { return (int)ceil(log(s.alpha_min) / log(s.alpha_decay)) + 2; }
+#define HSQP_LS_MAX_TRIALS 4096
+
 int hsqp_set_linesearch(hsqp_handle* h, const hsqp_linesearch_settings* s) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!s || !(s->alpha_decay > 0.0 && s->alpha_decay < 1.0) || !(s->alpha_min > 0.0) || !(s->g_max >= s->g_min)) {
     h->err = "line-search settings: need 0 < alpha_decay < 1, alpha_min > 0, g_max >= g_min";
+    return HSQP_ERR_BAD_ARG;
+  }
+  if (s->alpha_min < 1.0 && ls_max_trials(*s) > HSQP_LS_MAX_TRIALS) {
+    h->err = "line-search settings: more than 4096 back-tracking trials (alpha_decay too close to 1 for this alpha_min)";
     return HSQP_ERR_BAD_ARG;
   }
   h->ls_settings = *s;
@@ -580,6 +591,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
   const int B = h->B, N = h->N;
   const int nodes = B * N;
   const bool cent = h->hdm.formulation == HSQP_FORM_CENTROIDAL;
+  HCHECK(hipMemsetAsync(h->d_status, 0, (size_t)B * sizeof(int), h->stream));   // once per call: the kernels OR into it
   for (int it = 0; it < n_iterations; ++it) {
     const bool last = it == n_iterations - 1;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
@@ -607,7 +619,6 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           if (hipMalloc(&p, need * SZ * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
         h->el_capacity = need;
       }
-      HCHECK(hipMemsetAsync(h->d_status, 0, (size_t)B * sizeof(int), h->stream));
       hipLaunchKernelGGL(k_scan_init<CNX>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<CNX>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
       int cur = 0;
       for (int d = 1; d < N + 1; d *= 2) {
@@ -653,7 +664,11 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       // back-tracking: decide the pending trials on the device, shorten the rejected steps, re-evaluate only those instances
       LsSettings lst{h->ls_settings.g_max, h->ls_settings.g_min, h->ls_settings.gamma_c, h->ls_settings.armijo_factor, h->ls_settings.alpha_decay,
                      h->ls_settings.alpha_min, h->ls_settings.delta_tol};
-      for (int trial = 0; trial < 64; ++trial) {
+      // alpha_decay^n < alpha_min ends every instance's back-tracking with a zero step (ls_decide), so this bound is never the
+      // reason the loop ends; hsqp_set_linesearch keeps it <= HSQP_LS_MAX_TRIALS
+      const int max_trials = ls_max_trials(h->ls_settings);
+      int still_active = 0;
+      for (int trial = 0; trial < max_trials; ++trial) {
         HCHECK(hipMemsetAsync(h->d_counts, 0, 2 * sizeof(int), h->stream));
         hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
         int counts[2];
@@ -661,6 +676,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         HCHECK(hipStreamSynchronize(h->stream));
         if (counts[0] > 0)
           hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
+        still_active = counts[1];
         if (counts[1] == 0) break;
         if (cent)
           hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes,
@@ -671,6 +687,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
                            (const LsState*)h->d_ls);
       }
+      if (still_active) { h->err = "line search: trials exhausted with instances still undecided (internal error)"; return HSQP_ERR_NUMERIC; }
     }
     h->ls_ran = linesearch != 0;
     if (last) HCHECK(hipEventRecord(h->ev[4], h->stream));

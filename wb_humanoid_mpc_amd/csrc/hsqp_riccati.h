@@ -500,15 +500,16 @@ HSQP_HD void kkt_node(const Ctx& ctx, KktWS& w, const double* q, const double* v
       a = w.dxn[r] - q[QP_BV + r];
       for (int j = 0; j < NX; ++j) a -= q[QP_A + r * NX + j] * w.dx[j];
       for (int j = 0; j < NUT; ++j) a -= q[QP_B + r * NUT + j] * w.ut[j];
-      if (dx0) a = fmax(fabs(a), fabs(w.dx[r] - dx0[r]));
+      if (dx0) { const double a0 = fabs(w.dx[r] - dx0[r]); a = (a0 != a0 || a0 > fabs(a)) ? a0 : fabs(a); }
     }
     w.res[i] = fabs(a);
   }
   WG_SYNC(ctx);
   WG_FOR(ctx, it, 2) {
     double m = 0.0;
-    if (it == 0) { for (int i = 0; i < NX + NUT; ++i) m = fmax(m, w.res[i]); }
-    else { for (int i = NX + NUT; i < 2 * NX + NUT; ++i) m = fmax(m, w.res[i]); }
+    // fmax() drops NaN: a non-finite residual must surface (as +inf, which also wins the atomic max on the bit patterns)
+    const int lo = it == 0 ? 0 : NX + NUT, hi = it == 0 ? NX + NUT : 2 * NX + NUT;
+    for (int i = lo; i < hi; ++i) { const double r = w.res[i]; m = (r != r) ? HUGE_VAL : fmax(m, r); }
     out2[it] = m;
   }
   WG_SYNC(ctx);
