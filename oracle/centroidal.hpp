@@ -557,7 +557,7 @@ void orc_cent_lq(void* h, int N, double dt, const double* x, const double* u, co
 
 // One SQP iteration of the centroidal problem (same outputs as orc_sqp_iteration); 0 ok, -4 numeric failure
 int orc_cent_sqp_iteration(void* h, int N, double dt, const double* x_init, const double* x, const double* u, const double* par, int threads,
-                           double* dx, double* du, double* x_new, double* u_new, hsqp_perf* before, hsqp_perf* after, double* kkt) {
+                           double* dx, double* du, double* x_new, double* u_new, hsqp_perf* before, hsqp_perf* after, double* kkt, double* armijo_out) {
   const Oracle& o = *static_cast<Oracle*>(h);
   std::vector<Projected> st(N);
   int fail = 0;
@@ -587,9 +587,27 @@ int orc_cent_sqp_iteration(void* h, int N, double dt, const double* x_init, cons
     }
   }
   if (kkt) kkt_residual(st, HN, gN, dx0, N, r, &kkt[0], &kkt[1]);
+  if (armijo_out) {  // ASSUMPTION A5 (as orc_sqp_iteration)
+    double am = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const Projected& p = st[k];
+      for (int i = 0; i < NX; ++i) am += p.qt[i] * r.dx[k * NX + i];
+      for (int j = 0; j < p.nut; ++j) am += p.rt[j] * r.ut[k * NU + j];
+    }
+    for (int i = 0; i < NX; ++i) am += gN[i] * r.dx[N * NX + i];
+    *armijo_out = am;
+  }
   if (before) cent_performance(o, N, dt, x, u, par, threads, before);
   if (after) cent_performance(o, N, dt, x_new, u_new, par, threads, after);
   return 0;
+}
+// filter line search of the centroidal problem (ASSUMPTION A6, the code of orc_linesearch on the centroidal performance index)
+void orc_cent_linesearch(void* h, int N, double dt, const double* x, const double* u, const double* dx, const double* du, const double* par,
+                         int threads, const double* settings, double armijo, double* alpha_out, int* type_out, int* trials_out,
+                         double* x_new, double* u_new, hsqp_perf* perf_new) {
+  const Oracle& o = *static_cast<Oracle*>(h);
+  filter_linesearch([&](const double* xx, const double* uu, hsqp_perf* out) { cent_performance(o, N, dt, xx, uu, par, threads, out); }, N, x, u, dx, du,
+                    settings, armijo, alpha_out, type_out, trials_out, x_new, u_new, perf_new);
 }
 void orc_cent_performance(void* h, int N, double dt, const double* x, const double* u, const double* par, int threads, hsqp_perf* out) {
   cent_performance(*static_cast<Oracle*>(h), N, dt, x, u, par, threads, out);

@@ -145,7 +145,11 @@ class Oracle:
 
     LS_DEFAULTS = dict(g_max=1e-2, g_min=1e-6, gamma_c=1e-6, armijo_factor=1e-4, alpha_decay=0.5, alpha_min=1e-4, delta_tol=1e-4)
 
-    def linesearch(self, dt, x, u, dx, du, par, armijo, threads=1, **settings):
+    def cent_linesearch(self, dt, x, u, dx, du, par, armijo, threads=1, **settings):
+        """Filter line search of the centroidal problem (same code as linesearch on the centroidal performance index)."""
+        return self.linesearch(dt, x, u, dx, du, par, armijo, threads, _fn="orc_cent_linesearch", **settings)
+
+    def linesearch(self, dt, x, u, dx, du, par, armijo, threads=1, _fn="orc_linesearch", **settings):
         """Filter line search (oracle ASSUMPTION A6); settings override LS_DEFAULTS."""
         x, u, dx, du, par = _c(x), _c(u), _c(dx), _c(du), _c(par)
         st = dict(self.LS_DEFAULTS)
@@ -154,7 +158,7 @@ class Oracle:
         alpha, typ, trials = C.c_double(), C.c_int(), C.c_int()
         xn, un = np.zeros_like(x), np.zeros_like(u)
         p = _abi.Perf()
-        self.lib.orc_linesearch(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(dx), _p(du), _p(par), threads, _p(sv),
+        getattr(self.lib, _fn)(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(dx), _p(du), _p(par), threads, _p(sv),
                                 C.c_double(armijo), C.byref(alpha), C.byref(typ), C.byref(trials), _p(xn), _p(un), C.byref(p))
         return dict(alpha=alpha.value, step_type=typ.value, trials=trials.value, x=xn, u=un,
                     perf=dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse))
@@ -254,11 +258,12 @@ class Oracle:
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         pb, pa = _abi.Perf(), _abi.Perf()
         kkt = np.zeros(2)
+        armijo = C.c_double(0.0)
         rc = self.lib.orc_cent_sqp_iteration(self.h, N, C.c_double(dt), _p(x_init), _p(x), _p(u), _p(par), threads, _p(dx), _p(du),
-                                             _p(xn), _p(un), C.byref(pb), C.byref(pa), _p(kkt))
+                                             _p(xn), _p(un), C.byref(pb), C.byref(pa), _p(kkt), C.byref(armijo))
         if rc != 0:
             raise RuntimeError(f"oracle cent_sqp_iteration failed: {rc}")
-        return dict(x=xn, u=un, dx=dx, du=du, kkt=kkt,
+        return dict(x=xn, u=un, dx=dx, du=du, kkt=kkt, armijo=armijo.value,
                     perf_before=dict(merit=pb.merit, cost=pb.cost, dynamics_sse=pb.dynamics_sse, equality_sse=pb.equality_sse),
                     perf_after=dict(merit=pa.merit, cost=pa.cost, dynamics_sse=pa.dynamics_sse, equality_sse=pa.equality_sse))
 

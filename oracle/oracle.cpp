@@ -1110,14 +1110,15 @@ int orc_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
 
 // Filter line search on the step (dx, du) from (x, u): ASSUMPTION A6.  settings = {g_max, g_min, gamma_c, armijoFactor,
 // alpha_decay, alpha_min, deltaTol}.  step type: 0 COST, 1 DUAL, 2 CONSTRAINT, 3 ZERO.
-void orc_linesearch(void* h, int N, double dt, const double* x, const double* u, const double* dx, const double* du, const double* par,
-                    int threads, const double* settings, double armijo, double* alpha_out, int* type_out, int* trials_out,
-                    double* x_new, double* u_new, hsqp_perf* perf_new) {
-  const Oracle& o = *static_cast<Oracle*>(h);
+}  // extern "C"
+template <class Perf>
+static void filter_linesearch(const Perf& performance_of, int N, const double* x, const double* u, const double* dx, const double* du,
+                              const double* settings, double armijo, double* alpha_out, int* type_out, int* trials_out,
+                              double* x_new, double* u_new, hsqp_perf* perf_new) {
   const double g_max = settings[0], g_min = settings[1], gamma_c = settings[2], armijo_factor = settings[3], decay = settings[4],
                alpha_min = settings[5], delta_tol = settings[6];
   hsqp_perf base;
-  performance(o, N, dt, x, u, par, threads, &base);
+  performance_of(x, u, &base);
   double nx2 = 0.0, nu2 = 0.0;
   for (int i = 0; i < (N + 1) * NX; ++i) nx2 += dx[i] * dx[i];
   for (int i = 0; i < N * NU; ++i) nu2 += du[i] * du[i];
@@ -1130,7 +1131,7 @@ void orc_linesearch(void* h, int N, double dt, const double* x, const double* u,
     for (int i = 0; i < (N + 1) * NX; ++i) xn[i] = x[i] + alpha * dx[i];
     for (int i = 0; i < N * NU; ++i) un[i] = u[i] + alpha * du[i];
     hsqp_perf pn;
-    performance(o, N, dt, xn.data(), un.data(), par, threads, &pn);
+    performance_of(xn.data(), un.data(), &pn);
     ++trials;
     const double gn = std::sqrt(pn.dynamics_sse + pn.equality_sse);
     const double am = alpha * armijo;
@@ -1153,6 +1154,14 @@ void orc_linesearch(void* h, int N, double dt, const double* x, const double* u,
   std::memcpy(x_new, x, sizeof(double) * (N + 1) * NX);
   std::memcpy(u_new, u, sizeof(double) * N * NU);
   *perf_new = base;
+}
+extern "C" {
+void orc_linesearch(void* h, int N, double dt, const double* x, const double* u, const double* dx, const double* du, const double* par,
+                    int threads, const double* settings, double armijo, double* alpha_out, int* type_out, int* trials_out,
+                    double* x_new, double* u_new, hsqp_perf* perf_new) {
+  const Oracle& o = *static_cast<Oracle*>(h);
+  filter_linesearch([&](const double* xx, const double* uu, hsqp_perf* out) { performance(o, N, dt, xx, uu, par, threads, out); }, N, x, u, dx, du,
+                    settings, armijo, alpha_out, type_out, trials_out, x_new, u_new, perf_new);
 }
 
 void orc_performance(void* h, int N, double dt, const double* x, const double* u, const double* par, int threads, hsqp_perf* out) {

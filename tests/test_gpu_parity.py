@@ -1,12 +1,13 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the committed
-golden fixtures.  Tolerances (BASELINE.md §6, f64 end to end): trajectories/steps max-abs <= 1e-8 * scale,
-QP KKT residuals <= 1e-9 * max(1, |g|_inf), performance-index terms rel <= 1e-9."""
+golden fixtures.  Tolerances = BASELINE.md §6 without relaxation (tests/tolerances.py): trajectories / steps max-abs <= 1e-8
+absolute, QP KKT residuals <= 1e-9 * max(1, |g|_inf), performance-index terms rel <= 1e-10."""
 import os
 
 import numpy as np
 import pytest
 
 from test_oracle_lq import perturbed_problem
+from tolerances import KKT_REL, TRAJ_ABS, assert_kkt, assert_perf, assert_perf_arrays, assert_step, assert_linear_residual
 from wb_humanoid_mpc_amd import _abi
 from wb_humanoid_mpc_amd.reference import make_problem
 
@@ -31,14 +32,11 @@ def rel(a, b):
 def test_against_golden_fixtures(gpu_solver, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     out = gpu_solver.run(g["x_init"], g["x"], g["u"], g["par"], float(g["dt"]))
-    sc = max(1.0, np.abs(g["dx"]).max(), np.abs(g["du"]).max())
-    assert np.abs(out["dx"][0] - g["dx"]).max() <= 1e-8 * sc
-    assert np.abs(out["du"][0] - g["du"]).max() <= 1e-8 * sc
-    assert np.allclose(out["x"][0], g["x"] + g["dx"], atol=1e-8 * sc) and np.allclose(out["u"][0], g["u"] + g["du"], atol=1e-8 * sc)
+    assert_step(out, dict(dx=g["dx"], du=g["du"], x=g["x"] + g["dx"], u=g["u"] + g["du"]), 0, name)
     pb, pa = out["perf_before"][0], out["perf_after"][0]
     for got, want in ((pb, g["perf_before"]), (pa, g["perf_after"])):
-        assert np.allclose([got["cost"], got["dynamics_sse"], got["equality_sse"]], want, rtol=1e-9, atol=1e-12)
-    assert out["kkt"][0, 0] <= 1e-9 * max(1.0, np.abs(g["g"]).max()) * sc and out["kkt"][0, 1] <= 1e-10 * sc
+        assert_perf_arrays([got["cost"], got["dynamics_sse"], got["equality_sse"]], want, name)
+    assert_kkt(out["kkt"][0], np.abs(g["g"]).max(), name)
     # intermediate blocks
     assert rel(gpu_solver.debug_read(_abi.BLK_BVEC)[0], g["b"]) <= 1e-12
     assert rel(gpu_solver.debug_read(_abi.BLK_G)[0], g["g"]) <= 1e-11
@@ -67,12 +65,9 @@ def test_batch_of_perturbed_instances_against_oracle(gpu_solver, model, oracle):
     out = gpu_solver.run(x0, x, u, par, dt)
     for b in range(6):
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=4)
-        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
-        assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc, b
-        assert np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc, b
-        for key in ("cost", "dynamics_sse", "equality_sse"):
-            assert np.isclose(out["perf_before"][b][key], r["perf_before"][key], rtol=1e-9, atol=1e-12)
-            assert np.isclose(out["perf_after"][b][key], r["perf_after"][key], rtol=1e-8, atol=1e-10)
+        assert_step(out, r, b)
+        assert_perf(out["perf_before"][b], r["perf_before"], f"instance {b} before")
+        assert_perf(out["perf_after"][b], r["perf_after"], f"instance {b} after")
     # instances are independent: solving one alone gives the same bits as inside the batch
     solo = gpu_solver.run(x0[3], x[3], u[3], par[3], dt)
     assert np.array_equal(solo["dx"][0], out["dx"][3]) and np.array_equal(solo["du"][0], out["du"][3])
@@ -88,20 +83,19 @@ def test_full_size_properties(gpu_solver, model):
     b = gpu_solver.debug_read(_abi.BLK_BVEC)
     CDe = gpu_solver.debug_read(_abi.BLK_CDE)
     ne = gpu_solver.debug_read(_abi.BLK_NE)
-    sc = max(1.0, np.abs(dx).max(), np.abs(du).max())
     assert np.abs(dx[:, 0] - (x0 - x[:, 0])).max() <= 1e-12
     z = np.concatenate([dx[:, :-1], du], axis=2)
     defect = dx[:, 1:] - np.einsum("bkij,bkj->bki", AB, z) - b
-    assert np.abs(defect).max() <= 1e-9 * sc                      # linearised dynamics hold
+    assert_linear_residual(AB, z, np.abs(b) + np.abs(dx[:, 1:]), defect, 1e-10, "linearised dynamics")
     eq = np.einsum("bkrj,bkj->bkr", CDe[..., :NZ], z) + CDe[..., NZ]
-    assert np.abs(eq).max() <= 1e-7 * sc                          # linearised equality constraints hold
+    assert_linear_residual(CDe[..., :NZ], z, CDe[..., NZ], eq, 1e-10, "linearised equality constraints")
     assert set(np.unique(ne)) <= {12, 13, 14} and 13 in ne
-    assert out["kkt"][:, 1].max() <= 1e-9 * sc
     g = gpu_solver.debug_read(_abi.BLK_G)
-    assert out["kkt"][:, 0].max() <= 1e-9 * max(1.0, np.abs(g).max()) * sc
+    for bb in range(4):
+        assert_kkt(out["kkt"][bb], np.abs(g[bb]).max(), f"instance {bb}")
     assert np.all(np.isfinite(out["x"])) and np.all(np.isfinite(out["u"]))
     # the full step is x + dx
-    assert np.allclose(out["x"], x + dx, atol=1e-12 * sc) and np.allclose(out["u"], u + du, atol=1e-12 * sc)
+    assert np.abs(out["x"] - (x + dx)).max() <= 1e-12 and np.abs(out["u"] - (u + du)).max() <= 1e-11
 
 
 def test_device_resident_iterations_equal_repeated_solves(gpu_solver, model):
@@ -157,13 +151,10 @@ def test_filter_linesearch_against_oracle(gpu_solver, model, oracle, override):
     for b in range(B):
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=4)
         ls = oracle.linesearch(dt, x[b], u[b], r["dx"], r["du"], par[b], r["armijo"], threads=4, **override)
-        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
-        assert out["armijo"][b] == pytest.approx(r["armijo"], rel=1e-8, abs=1e-8 * sc)
+        assert out["armijo"][b] == pytest.approx(r["armijo"], rel=1e-9, abs=1e-9)
         assert out["alpha"][b] == ls["alpha"] and out["step_type"][b] == ls["step_type"], (b, out["alpha"][b], ls)
-        assert np.abs(out["x"][b] - ls["x"]).max() <= 1e-8 * sc and np.abs(out["u"][b] - ls["u"]).max() <= 1e-8 * sc
-        got = out["perf_after"][b]
-        assert np.allclose([got["cost"], got["dynamics_sse"], got["equality_sse"]],
-                           [ls["perf"]["cost"], ls["perf"]["dynamics_sse"], ls["perf"]["equality_sse"]], rtol=1e-8, atol=1e-10)
+        assert np.abs(out["x"][b] - ls["x"]).max() <= TRAJ_ABS and np.abs(out["u"][b] - ls["u"]).max() <= TRAJ_ABS
+        assert_perf(out["perf_after"][b], ls["perf"], f"instance {b} accepted trial")
         alphas.append(ls["alpha"])
     if override.get("g_max") == 1e-9:
         assert all(a == 0.0 for a in alphas)            # nothing can be accepted: zero step, trajectory kept
@@ -234,8 +225,48 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
         s.close()
     for b in (37, 255):
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4, want_perf=False)
-        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
-        assert np.abs(out["dx"][b] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][b] - r["du"]).max() <= 1e-8 * sc
+        assert_step(out, r, b, "config 4")
+
+
+def test_config3_exactly_against_the_oracle(model, oracle):
+    """BASELINE config 3 as specified: whole-body, N = 100, ONE unperturbed instance, walk, cold start — against the CPU oracle at
+    the BASELINE.md §6 tolerances, with the QP's KKT residuals judged against the gradient scale."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=100, batch=1, gait="walk")
+    s = HipSqpSolver(model, max_nodes=100, max_batch=1)
+    try:
+        out = s.run(x0, x, u, par, dt)
+        g = s.debug_read(_abi.BLK_G)
+    finally:
+        s.close()
+    r = oracle.sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=os.cpu_count() or 4)
+    assert_step(out, r, 0, "config 3")
+    assert_perf(out["perf_before"][0], r["perf_before"], "config 3 before")
+    assert_perf(out["perf_after"][0], r["perf_after"], "config 3 after")
+    assert_kkt(out["kkt"][0], np.abs(g[0]).max(), "config 3")
+    assert out["alpha"][0] == 1.0 and out["step_type"][0] == _abi.STEP_FULL
+
+
+def test_config5_slice_against_the_oracle(model, oracle):
+    """BASELINE config 5 (N = 200 long horizon, slow_walk, 6-DoF contact constraints as scheduled, perturbed instances): the first
+    8 of its 1024 instances against the CPU oracle at full horizon length."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 8, 200
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait="slow_walk", perturb=True)
+    s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+    try:
+        out = s.run(x0, x, u, par, dt)
+        g = s.debug_read(_abi.BLK_G)
+        ne = s.debug_read(_abi.BLK_NE)
+    finally:
+        s.close()
+    assert set(np.unique(ne)) <= {12, 13} and 12 in ne and 13 in ne      # double and single support both occur
+    for b in range(B):
+        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4)
+        assert_step(out, r, b, "config 5")
+        assert_perf(out["perf_before"][b], r["perf_before"], f"config 5 instance {b} before")
+        assert_perf(out["perf_after"][b], r["perf_after"], f"config 5 instance {b} after")
+        assert_kkt(out["kkt"][b], np.abs(g[b]).max(), f"config 5 instance {b}")
 
 
 def test_edge_sizes_and_settings_errors(model, oracle):
@@ -248,8 +279,7 @@ def test_edge_sizes_and_settings_errors(model, oracle):
         x0, x, u, par, dt = make_problem(model, n_nodes=1, batch=1, perturb=True, seed=4)
         out = s.run(x0, x, u, par, dt)
         r = oracle.sqp_iteration(dt, x0[0], x[0], u[0], par[0])
-        sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
-        assert np.abs(out["dx"][0] - r["dx"]).max() <= 1e-8 * sc and np.abs(out["du"][0] - r["du"]).max() <= 1e-8 * sc
+        assert_step(out, r, 0, "N = 1")
         with pytest.raises(HsqpError) as e:                                # batch larger than the handle
             s.run(*make_problem(model, n_nodes=2, batch=3))
         assert e.value.code == _abi.ERR_BAD_ARG
