@@ -149,11 +149,17 @@ typedef struct hsqp_settings {
 typedef struct hsqp_problem {
   int32_t batch;                /* B independent instances                                               */
   int32_t n_nodes;              /* N shooting intervals -> N+1 nodes                                     */
-  double dt;                    /* uniform node spacing (no event nodes)                                 */
+  double dt;                    /* node spacing of a uniform grid (used when dt_nodes is NULL)             */
   const double* x_init;         /* [B][58]        measured state                                          */
   const double* x_traj;         /* [B][N+1][58]   linearisation trajectory (warm start)                   */
   const double* u_traj;         /* [B][N][35]                                                            */
   const double* node_params;    /* [B][N+1][HSQP_NODE_PARAMS]                                            */
+  /* Optional non-uniform grid with event nodes (ocs2 multiple-shooting transcription, SURVEY.md A.5: the grid is split at the
+   * mode-switch times, the last interval is shortened to the final time, and at an event time a pre- and a post-event node share
+   * the time stamp, joined by the identity jump map).  dt_nodes[b][k] >= 0 is the length of interval k of instance b;
+   * dt_nodes[b][k] == 0 marks interval k as an EVENT: x_{k+1} = x_k (A = I, B = 0, defect x_k - x_{k+1} counted unscaled in the
+   * dynamics SSE), no cost, no constraints, du_k = 0.  NULL: every interval has length dt. */
+  const double* dt_nodes;       /* optional [B][N]                                                       */
 } hsqp_problem;
 
 /* ---- device-side parameter generation ------------------------------------
@@ -178,6 +184,8 @@ typedef struct hsqp_reference {
   double terrain_height;
   int32_t arm_swing;                    /* 0 disables the arm-swing reference                                     */
   int32_t reserved;
+  const double* node_times;             /* optional [B][N+1]: time stamp of every node (non-uniform grids / event nodes: a post-event
+                                           node carries t_event + epsilon, as ocs2's getIntervalStart does); NULL: t0 + k dt  */
 } hsqp_reference;
 
 typedef struct hsqp_perf {      /* ocs2::PerformanceIndex subset, per instance                           */
@@ -216,6 +224,8 @@ typedef struct hsqp_solution {
   double* alpha;                /* optional [B]  accepted step length (1 without line search)            */
   int32_t* step_type;           /* optional [B]  HSQP_STEP_*                                              */
   double* armijo;               /* optional [B]  descent metric  sum_k q~.dx + r~.ut  of the projected QP */
+  double* grad_inf;             /* optional [B]  |g|_inf of the projected QP (q~_k, r~_k of every node): the scale the KKT residuals are
+                                   judged against (r <= 1e-9 max(1, |g|_inf)); filled when kkt is                   */
   hsqp_timings timings;
 } hsqp_solution;
 
@@ -248,6 +258,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags);
 void hsqp_linesearch_defaults(hsqp_linesearch_settings* s);
 int hsqp_set_linesearch(hsqp_handle* h, const hsqp_linesearch_settings* s);
 int hsqp_download(hsqp_handle* h, hsqp_solution* solution);
+/* The same two with every array pointer of hsqp_problem / hsqp_solution being DEVICE memory of the handle's GPU (multi-GPU data
+ * path, SURVEY.md §8e: the shards RCCL scatters arrive in HBM and the solutions are gathered from HBM — no host staging).
+ * hsqp_upload_device: centroidal padding is the caller's responsibility.  hsqp_download_device: alpha / step_type / armijo must be
+ * NULL; the numeric status is still checked on the host and reported through the return code. */
+int hsqp_upload_device(hsqp_handle* h, const hsqp_problem* problem);
+int hsqp_download_device(hsqp_handle* h, hsqp_solution* solution);
 
 /* Debug/parity access to intermediate device blocks of the LAST iteration.
  * `what` is one of the HSQP_BLK_* ids; copies min(bytes, block size) and

@@ -435,6 +435,7 @@ void cent_rk4_value(const Oracle& o, const double* x, const double* u, double dt
 
 // x, xnext: padded 58-double rows (first 35 used); u: 35
 void cent_node_lq(const Oracle& o, const double* x, const double* u, const double* xnext, const double* par, double dt, NodeLQ& lq) {
+  if (dt == 0.0) { jump_node_lq(x, xnext, lq); return; }   // event interval (the padding states are zero on both sides)
   double phi[CNX];
   std::fill(lq.flow, lq.flow + NX, 0.0);
   cent_rk4_sensitivity(o, x, u, dt, lq.AB, phi, lq.flow);
@@ -451,10 +452,15 @@ void cent_performance(const Oracle& o, int N, double dt, const double* x, const 
   for (int k = 0; k < N; ++k) {
     double phi[CNX], eq[NE_MAX];
     int ne = 0;
-    cent_rk4_value(o, x + k * NX, u + k * NU, dt, phi);
-    for (int i = 0; i < CNX; ++i) { const double d = phi[i] - x[(k + 1) * NX + i]; dyn += dt * d * d; }
-    cost += dt * cent_stage_terms(o, x + k * NX, u + k * NU, par + k * NP, nullptr, eq, &ne);
-    for (int i = 0; i < ne; ++i) eqs += dt * eq[i] * eq[i];
+    const double dtk = dt_at(o, k, dt);
+    if (dtk == 0.0) {
+      for (int i = 0; i < CNX; ++i) { const double d = x[k * NX + i] - x[(k + 1) * NX + i]; dyn += d * d; }
+      continue;
+    }
+    cent_rk4_value(o, x + k * NX, u + k * NU, dtk, phi);
+    for (int i = 0; i < CNX; ++i) { const double d = phi[i] - x[(k + 1) * NX + i]; dyn += dtk * d * d; }
+    cost += dtk * cent_stage_terms(o, x + k * NX, u + k * NU, par + k * NP, nullptr, eq, &ne);
+    for (int i = 0; i < ne; ++i) eqs += dtk * eq[i] * eq[i];
   }
   cost += terminal_cost(o, x + N * NX, par + N * NP, nullptr, nullptr);   // Qf is zero on the padding states
   out->cost = cost; out->dynamics_sse = dyn; out->equality_sse = eqs; out->merit = cost;
@@ -543,7 +549,7 @@ void orc_cent_lq(void* h, int N, double dt, const double* x, const double* u, co
 #pragma omp parallel for num_threads(threads) schedule(dynamic)
   for (int k = 0; k < N; ++k) {
     std::unique_ptr<NodeLQ> lq(new NodeLQ);
-    cent_node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, *lq);
+    cent_node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt_at(o, k, dt), *lq);
     if (AB) std::copy(lq->AB, lq->AB + NX * NZ, AB + (size_t)k * NX * NZ);
     if (b) std::copy(lq->b, lq->b + NX, b + (size_t)k * NX);
     if (H) std::copy(lq->H, lq->H + NZ * NZ, H + (size_t)k * NZ * NZ);
@@ -564,7 +570,7 @@ int orc_cent_sqp_iteration(void* h, int N, double dt, const double* x_init, cons
 #pragma omp parallel for num_threads(threads) schedule(dynamic)
   for (int k = 0; k < N; ++k) {
     std::unique_ptr<NodeLQ> lq(new NodeLQ);
-    cent_node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, *lq);
+    cent_node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt_at(o, k, dt), *lq);
     if (!project_node(*lq, st[k])) {
 #pragma omp atomic write
       fail = 1;

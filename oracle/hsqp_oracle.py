@@ -49,6 +49,15 @@ class Oracle:
         except Exception:
             pass
 
+    def set_grid(self, dts=None):
+        """Non-uniform grid / event intervals (hsqp_problem::dt_nodes of one instance) for the following lq / sqp_iteration /
+        linesearch / performance calls; None restores the uniform dt argument."""
+        if dts is None:
+            self.lib.orc_set_grid(self.h, 0, None)
+        else:
+            d = _c(dts)
+            self.lib.orc_set_grid(self.h, len(d), _p(d))
+
     def total_mass(self):
         return self.lib.orc_total_mass(self.h)
 

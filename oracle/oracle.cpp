@@ -138,7 +138,11 @@ struct Oracle {
   hsqp_model_desc md;
   bool anc[NB][NB];  // anc[j][i]: body j is i or an ancestor of i
   double total_mass;
+  // optional non-uniform time grid with event intervals (hsqp_problem::dt_nodes of ONE instance; set by orc_set_grid): empty = uniform
+  std::vector<double> grid;
 };
+// length of interval k: the grid's, or the uniform dt
+inline double dt_at(const Oracle& o, int k, double dt) { return o.grid.empty() ? dt : o.grid[(size_t)k]; }
 
 void init_oracle(Oracle& o, const hsqp_model_desc* md) {
   o.md = *md;
@@ -658,7 +662,22 @@ double stage_terms(const Oracle& o, const double* x, const double* u, const doub
 }
 
 // Intermediate node: multiple_shooting::setupIntermediateNode semantics: cost and soft constraints scaled by dt.
+// Event interval (dt = 0): the identity jump map x+ = x between the pre- and the post-event node, no cost, no
+// constraints.  The inputs of the pre-event node do not enter anything; a unit Hessian pins their step to zero.
+void jump_node_lq(const double* x, const double* xnext, NodeLQ& lq) {
+  std::fill(lq.AB, lq.AB + NX * NZ, 0.0);
+  std::fill(lq.H, lq.H + NZ * NZ, 0.0);
+  std::fill(lq.g, lq.g + NZ, 0.0);
+  std::fill(lq.CDe, lq.CDe + NE_MAX * (NZ + 1), 0.0);
+  std::fill(lq.flow, lq.flow + NX, 0.0);
+  for (int i = 0; i < NX; ++i) { lq.AB[i * NZ + i] = 1.0; lq.b[i] = x[i] - xnext[i]; }
+  for (int i = NX; i < NZ; ++i) lq.H[i * NZ + i] = 1.0;
+  lq.cost = 0.0;
+  lq.ne = 0;
+}
+
 void node_lq(const Oracle& o, const double* x, const double* u, const double* xnext, const double* par, double dt, NodeLQ& lq) {
+  if (dt == 0.0) { jump_node_lq(x, xnext, lq); return; }
   double phi[NX];
   rk4_sensitivity(o, x, u, dt, lq.AB, phi, lq.flow);
   for (int i = 0; i < NX; ++i) lq.b[i] = phi[i] - xnext[i];
@@ -917,10 +936,15 @@ void performance(const Oracle& o, int N, double dt, const double* x, const doubl
   for (int k = 0; k < N; ++k) {
     double phi[NX], eq[NE_MAX];
     int ne = 0;
-    rk4_value(o, x + k * NX, u + k * NU, dt, phi);
-    for (int i = 0; i < NX; ++i) { const double d = phi[i] - x[(k + 1) * NX + i]; dyn += dt * d * d; }
-    cost += dt * stage_terms(o, x + k * NX, u + k * NU, par + k * NP, nullptr, eq, &ne);
-    for (int i = 0; i < ne; ++i) eqs += dt * eq[i] * eq[i];
+    const double dtk = dt_at(o, k, dt);
+    if (dtk == 0.0) {   // event interval: jump defect, unscaled (upstream computeEventPerformance)
+      for (int i = 0; i < NX; ++i) { const double d = x[k * NX + i] - x[(k + 1) * NX + i]; dyn += d * d; }
+      continue;
+    }
+    rk4_value(o, x + k * NX, u + k * NU, dtk, phi);
+    for (int i = 0; i < NX; ++i) { const double d = phi[i] - x[(k + 1) * NX + i]; dyn += dtk * d * d; }
+    cost += dtk * stage_terms(o, x + k * NX, u + k * NU, par + k * NP, nullptr, eq, &ne);
+    for (int i = 0; i < ne; ++i) eqs += dtk * eq[i] * eq[i];
   }
   cost += terminal_cost(o, x + N * NX, par + N * NP, nullptr, nullptr);
   out->cost = cost; out->dynamics_sse = dyn; out->equality_sse = eqs; out->merit = cost;
@@ -937,6 +961,11 @@ void* orc_create(const hsqp_model_desc* md) {
   return o;
 }
 void orc_destroy(void* h) { delete static_cast<Oracle*>(h); }
+// non-uniform grid / event intervals of the next calls (N interval lengths, 0 = event); dts == null: back to the uniform dt argument
+void orc_set_grid(void* h, int N, const double* dts) {
+  Oracle& o = *static_cast<Oracle*>(h);
+  if (dts) o.grid.assign(dts, dts + N); else o.grid.clear();
+}
 double orc_total_mass(void* h) { return static_cast<Oracle*>(h)->total_mass; }
 
 void orc_flow_map(void* h, const double* x, const double* u, double* xdot) { flow_map<double>(*static_cast<Oracle*>(h), x, u, xdot); }
@@ -1024,7 +1053,7 @@ void orc_lq(void* h, int N, double dt, const double* x, const double* u, const d
 #pragma omp parallel for num_threads(threads) schedule(dynamic)
   for (int k = 0; k < N; ++k) {
     NodeLQ* lq = new NodeLQ;
-    node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, *lq);
+    node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt_at(o, k, dt), *lq);
     if (AB) std::memcpy(AB + (size_t)k * NX * NZ, lq->AB, sizeof(lq->AB));
     if (bvec) std::memcpy(bvec + k * NX, lq->b, sizeof(lq->b));
     if (H) std::memcpy(H + (size_t)k * NZ * NZ, lq->H, sizeof(lq->H));
@@ -1049,7 +1078,7 @@ int orc_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
 #pragma omp parallel for num_threads(threads) schedule(dynamic)
   for (int k = 0; k < N; ++k) {
     NodeLQ* lq = new NodeLQ;
-    node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, *lq);
+    node_lq(o, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt_at(o, k, dt), *lq);
     if (!project_node(*lq, st[k])) {
 #pragma omp atomic write
       bad = 1;

@@ -160,6 +160,10 @@ void emu_joint_torques(void* h, const double* x, const double* u, double* tau) {
   auto ws = std::make_unique<StageWST<false>>();
   policy_node(ctx, dm, *ws, x, u, tau);
 }
+void emu_policy_interpolate_grid(const double* xt, const double* ut, int N, const double* dts, double s, double* x, double* u) {
+  Ctx ctx{0, 1, nullptr};
+  policy_interpolate_grid(ctx, xt, ut, N, dts, s, x, u);
+}
 void emu_policy_interpolate(const double* xt, const double* ut, int N, double dt, double s, double* x, double* u) {
   Ctx ctx{0, 1, nullptr};
   policy_interpolate(ctx, xt, ut, N, dt, s, x, u);
@@ -183,7 +187,7 @@ void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_
 // one full SQP iteration of one instance through the kernel sources; returns 0 or HSQP_ERR_NUMERIC
 int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const double* x, const double* u, const double* par,
                       double* x_new, double* u_new, double* dx, double* du, double* kkt, double* perf_before /*3: cost,dyn,eq*/,
-                      double* perf_after, double* qp_out) {
+                      double* perf_after, double* qp_out, const double* dts /*null: uniform dt; else [N] interval lengths, 0 = event*/) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   const bool cent = dm.formulation == HSQP_FORM_CENTROIDAL;
   Ctx ctx{0, 1, nullptr};
@@ -193,10 +197,13 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto pw = std::make_unique<ProjWS>();
   auto rw = std::make_unique<RicWS>();
   double pb[3] = {0, 0, 0};
+  const double dt_uniform = dt;
   for (int k = 0; k < N; ++k) {
+    const double dt = dts ? dts[k] : dt_uniform;
     if (cent) cent_lq_node(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);
     else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
+    if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) return HSQP_ERR_NUMERIC;
     pb[0] += rec[(size_t)k * REC_SIZE + REC_MISC + 1]; pb[1] += rec[(size_t)k * REC_SIZE + REC_MISC + 3]; pb[2] += rec[(size_t)k * REC_SIZE + REC_MISC + 2];
   }
@@ -227,6 +234,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   double pa[3] = {0, 0, 0};
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {
+    const double dt = dts ? dts[k] : dt_uniform;
     if (cent) { for (int part = 0; part < 2; ++part) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, r2.data() + REC_MISC, part); }
     else lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
     pa[0] += r2[REC_MISC + 1]; pa[1] += r2[REC_MISC + 3]; pa[2] += r2[REC_MISC + 2];

@@ -49,7 +49,7 @@ def test_kernel_sources_on_the_host_reproduce_the_fixture(model, cmodel, name):
     xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
     kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
     rc = lib.emu_sqp_iteration(h, n, C.c_double(float(g["dt"])), P(g["x_init"]), P(x), P(u), P(g["par"]), P(xn), P(un), P(dx), P(du), P(kkt), P(pb),
-                               P(pa), None)
+                               P(pa), None, None)
     assert rc == 0
     sc = max(1.0, np.abs(g["dx"]).max(), np.abs(g["du"]).max())
     assert np.abs(dx - g["dx"]).max() <= 1e-8 * sc and np.abs(du - g["du"]).max() <= 1e-8 * sc

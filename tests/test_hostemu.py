@@ -65,7 +65,7 @@ def test_full_iteration_matches_oracle(model, oracle, emu, gait, n):
     xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
     kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
     qp = np.zeros((n, lib.emu_qp_size()))
-    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
     assert rc == 0
     sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
     assert np.abs(dx - r["dx"]).max() <= 1e-9 * sc and np.abs(du - r["du"]).max() <= 1e-9 * sc
@@ -90,7 +90,7 @@ def test_phases_are_free_of_intra_phase_dependencies(model, emu, gait, n):
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
         qp = np.zeros((n, L.emu_qp_size()))
-        assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp)) == 0
+        assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None) == 0
         res.append((dx, du, qp, pb, pa))
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)

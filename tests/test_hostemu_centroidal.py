@@ -77,7 +77,7 @@ def test_full_iteration_matches_oracle(cmodel, coracle, cemu, gait, n):
     xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
     kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
     qp = np.zeros((n, lib.emu_qp_size()))
-    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+    rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
     assert rc == 0
     sc = max(1.0, np.abs(r["dx"]).max(), np.abs(r["du"]).max())
     assert np.abs(dx - r["dx"]).max() <= 1e-9 * sc and np.abs(du - r["du"]).max() <= 1e-9 * sc
@@ -102,7 +102,7 @@ def test_lanes_are_independent(cmodel, cemu, scan):
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
         qp = np.zeros((n, L.emu_qp_size()))
-        rc = L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+        rc = L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
         L.emu_set_scan(0)
         assert rc == 0
         res.append((dx, du, qp, pb, pa))
@@ -135,7 +135,7 @@ def test_parallel_scan_backward_sweep_equals_the_serial_recursion(cmodel, coracl
         xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
         kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
         qp = np.zeros((n, lib.emu_qp_size()))
-        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp))
+        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
         lib.emu_set_scan(0)
         assert rc == 0
         res.append((dx, du, kkt, pa))

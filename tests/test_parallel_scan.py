@@ -62,7 +62,7 @@ def test_scan_reproduces_the_serial_riccati_solution(model, cmodel, form, gait, 
     xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
     kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
     qp = np.zeros((n, lib.emu_qp_size()))
-    assert lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp)) == 0
+    assert lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None) == 0
     nxe = _abi.CNX if cent else NX
     Qf = np.array(m.raw["Qf"])
     qN = Qf * (x[n, :nxe] - par[n, :nxe])

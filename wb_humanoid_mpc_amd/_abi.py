@@ -59,7 +59,7 @@ class Settings(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("batch", C.c_int32), ("n_nodes", C.c_int32), ("dt", C.c_double),
                 ("x_init", C.POINTER(C.c_double)), ("x_traj", C.POINTER(C.c_double)),
-                ("u_traj", C.POINTER(C.c_double)), ("node_params", C.POINTER(C.c_double))]
+                ("u_traj", C.POINTER(C.c_double)), ("node_params", C.POINTER(C.c_double)), ("dt_nodes", C.POINTER(C.c_double))]
 
 
 class Perf(C.Structure):
@@ -76,7 +76,7 @@ class Solution(C.Structure):
     _fields_ = [("x", C.POINTER(C.c_double)), ("u", C.POINTER(C.c_double)), ("dx", C.POINTER(C.c_double)),
                 ("du", C.POINTER(C.c_double)), ("perf_before", C.POINTER(Perf)), ("perf_after", C.POINTER(Perf)),
                 ("kkt", C.POINTER(C.c_double)), ("alpha", C.POINTER(C.c_double)), ("step_type", C.POINTER(C.c_int32)),
-                ("armijo", C.POINTER(C.c_double)), ("timings", Timings)]
+                ("armijo", C.POINTER(C.c_double)), ("grad_inf", C.POINTER(C.c_double)), ("timings", Timings)]
 
 
 class SwingConfig(C.Structure):
@@ -89,7 +89,8 @@ class Reference(C.Structure):
     _fields_ = [("batch", C.c_int32), ("n_nodes", C.c_int32), ("t0", C.c_double), ("dt", C.c_double), ("max_events", C.c_int32),
                 ("n_events", C.POINTER(C.c_int32)), ("event_times", C.POINTER(C.c_double)), ("mode_sequence", C.POINTER(C.c_int32)),
                 ("n_knots", C.c_int32), ("target_times", C.POINTER(C.c_double)), ("target_states", C.POINTER(C.c_double)),
-                ("swing", SwingConfig), ("terrain_height", C.c_double), ("arm_swing", C.c_int32), ("reserved", C.c_int32)]
+                ("swing", SwingConfig), ("terrain_height", C.c_double), ("arm_swing", C.c_int32), ("reserved", C.c_int32),
+                ("node_times", C.POINTER(C.c_double))]
 
 
 class LinesearchSettings(C.Structure):

@@ -49,7 +49,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 // ---- LQ approximation: one workgroup per (instance, node)
 template <bool DERIV>
 __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_WPE : HSQP_LQV_WPE) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
-                                                   const double* __restrict__ u, const double* __restrict__ par, double dt, int N,
+                                                   const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts, int N,
                                                    double* __restrict__ rec, double* __restrict__ misc, long long* prof,
                                                    const LsState* __restrict__ ls) {
   const int node = blockIdx.x, b = node / N, k = node % N;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  lq_node<DERIV>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt,
+  lq_node<DERIV>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node],
                  DERIV ? rec + (size_t)node * REC_SIZE : nullptr,
                  DERIV ? rec + (size_t)node * REC_SIZE + REC_MISC : misc + (size_t)node * 8);
 }
@@ -66,30 +66,38 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
 // ---- centroidal LQ approximation (hsqp_cent.h): one 256-thread workgroup per (instance, node), lane = tangent direction, waves
 //      0-1 the RK4 half, waves 2-3 the terms half; no LDS
 __global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                          const double* __restrict__ par, double dt, int N, double* __restrict__ rec) {
+                                                          const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_lq_node(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, rec + (size_t)node * REC_SIZE);
+  cent_lq_node(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
 }
 // ---- centroidal value-only pass: two lanes per (instance, node) in different waves (wave 0: RK4 defect, wave 1: terms)
 __global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                      const double* __restrict__ par, double dt, int N, int nodes, double* __restrict__ misc,
+                                                      const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes, double* __restrict__ misc,
                                                       const LsState* __restrict__ ls) {
   const int node = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   if (node >= nodes) return;
   const int b = node / N, k = node % N;
   if (ls && !ls[b].active) return;
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dt, misc + (size_t)node * 8, part);
+  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], misc + (size_t)node * 8, part);
 }
 
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, double dt, double* __restrict__ qp, long long* prof, int cent) {
+__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
-  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dt, qp + (size_t)blockIdx.x * QP_SIZE, cent != 0);
+  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0);
+}
+
+// ---- event intervals (jump_node_qp, hsqp_project.h): one workgroup per node; only launched when the grid has such intervals
+__global__ __launch_bounds__(256) void k_jump(const double* __restrict__ dts, const double* __restrict__ rec, double* __restrict__ qp) {
+  const int node = blockIdx.x;
+  if (dts[node] != 0.0) return;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  jump_node_qp(ctx, rec + (size_t)node * REC_SIZE, qp + (size_t)node * QP_SIZE);
 }
 
 // ---- Riccati backward sweep + closed-loop forward sweep (dx): one workgroup per instance
@@ -254,9 +262,9 @@ __global__ __launch_bounds__(64) void k_ls_retake(const double* __restrict__ x, 
 //      per-instance maxima by atomic max on the bit patterns of the (non-negative) residuals
 __global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
                                              const double* __restrict__ vf, const double* __restrict__ dx, const double* __restrict__ ut, int N,
-                                             double* __restrict__ kkt) {
+                                             double* __restrict__ kkt, double* __restrict__ ginf) {
   __shared__ KktWS w;
-  __shared__ double dx0[NX], r2[2];
+  __shared__ double dx0[NX], r2[2], gred[128];
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   if (k == 0) {
@@ -268,18 +276,30 @@ __global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, 
   kkt_node(ctx, w, qp + (size_t)node * QP_SIZE, vfb + (size_t)k * VF_SIZE, vfb + (size_t)(k + 1) * VF_SIZE, dxb + (size_t)k * NX,
            dxb + (size_t)(k + 1) * NX, ut + (size_t)node * NUT, k == 0 ? dx0 : nullptr, r2);
   if (threadIdx.x < 2) atomicMax(reinterpret_cast<unsigned long long*>(kkt + 2 * b + threadIdx.x), (unsigned long long)__double_as_longlong(r2[threadIdx.x]));
+  // |g|_inf of the projected QP: q~ (58) and r~ (23) of this node
+  {
+    const double* q = qp + (size_t)node * QP_SIZE;
+    const int i = threadIdx.x;
+    gred[i] = i < NX ? fabs(q[QP_QV + i]) : (i < NX + NUT ? fabs(q[QP_RV + i - NX]) : 0.0);
+    __syncthreads();
+    if (i == 0) {
+      double m = 0.0;
+      for (int l = 0; l < 128; ++l) m = (gred[l] != gred[l]) ? HUGE_VAL : fmax(m, gred[l]);
+      atomicMax(reinterpret_cast<unsigned long long*>(ginf + b), (unsigned long long)__double_as_longlong(m));
+    }
+  }
 }
 
 // ---- per-node parameter table from the compact per-instance reference: one thread per (instance, node)
 __global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, hsqp_swing_config cfg, double terrain, int arm_swing, int max_events,
                                                const int* __restrict__ n_events, const double* __restrict__ ev, const int* __restrict__ seq, int n_knots,
-                                               const double* __restrict__ tt, const double* __restrict__ ts, double t0, double dt, int N, int B,
-                                               double* __restrict__ par, int* __restrict__ bad) {
+                                               const double* __restrict__ tt, const double* __restrict__ ts, double t0, double dt, const double* __restrict__ times,
+                                               int N, int B, double* __restrict__ par, int* __restrict__ bad) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= B * (N + 1)) return;
   const int b = id / (N + 1), k = id % (N + 1);
   const bool ok = node_params_eval(cfg, terrain, arm_swing, n_events[b], ev + (size_t)b * max_events, seq + (size_t)b * (max_events + 1), n_knots,
-                                   tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, t0 + k * dt, par + (size_t)id * NP);
+                                   tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, times ? times[id] : t0 + k * dt, par + (size_t)id * NP);
   if (dm->formulation == HSQP_FORM_CENTROIDAL) cent_params_finish(*dm, par + (size_t)id * NP);   // torso task-space reference
   if (!ok) atomicExch(bad, 1);
 }
@@ -288,14 +308,15 @@ __global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, 
 //      instance blockIdx.x at s[blockIdx.x] first; otherwise take the pair from xin / uin.
 struct PolicyWS { StageWST<false> st; double x[NX], u[NU]; };
 __global__ __launch_bounds__(128) void k_policy(const DevModel* __restrict__ dm, const double* __restrict__ xt, const double* __restrict__ ut, int N,
-                                                double dt, const double* __restrict__ s, const double* __restrict__ xin,
+                                                double dt, const double* __restrict__ dts, const double* __restrict__ s, const double* __restrict__ xin,
                                                 const double* __restrict__ uin, double* __restrict__ xout, double* __restrict__ uout,
                                                 double* __restrict__ tau) {
   PolicyWS& w = *reinterpret_cast<PolicyWS*>(hsqp_smem);
   const int b = blockIdx.x;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   if (xt) {
-    policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], w.x, w.u);
+    if (dts) policy_interpolate_grid(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dts + (size_t)b * N, s[b], w.x, w.u);
+    else policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], w.x, w.u);
   } else {
     for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) w.x[i] = xin[(size_t)b * NX + i]; else w.u[i - NX] = uin[(size_t)b * NU + i - NX]; }
     __syncthreads();
@@ -342,7 +363,10 @@ struct hsqp_handle {
   double *d_xinit = nullptr, *d_x = nullptr, *d_u = nullptr, *d_par = nullptr;
   double *d_rec = nullptr, *d_qp = nullptr, *d_ric = nullptr;
   double *d_dx = nullptr, *d_du = nullptr, *d_ut = nullptr, *d_xnew = nullptr, *d_unew = nullptr;
-  double *d_misc = nullptr, *d_kkt = nullptr;
+  double *d_misc = nullptr, *d_kkt = nullptr, *d_ginf = nullptr;
+  double* d_dt = nullptr;         // [B][N] length of every interval (uniform grids: filled with dt)
+  std::vector<double> h_dt;       // host copy (debug reads), empty for device-resident uploads
+  bool uniform_grid = true, has_events = false;
   double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
   double* d_vf2 = nullptr;        // scan path: value functions of the refinement pass (the KKT check then reads these)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
@@ -403,7 +427,7 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_ginf, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
                   h->d_el[0], h->d_el[1], h->d_vf2};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
@@ -470,7 +494,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_qp, B * N * (size_t)QP_SIZE * 8}, {(void**)&h->d_ric, B * N * (size_t)RIC_SIZE * 8},
       {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
-      {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
+      {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_ginf, B * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
       {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
       {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
   for (const Alloc& a : allocs)
@@ -504,25 +528,66 @@ static bool padding_is_zero(hsqp_handle* h, const hsqp_problem* p) {
   return true;
 }
 
-int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) {
+// interval lengths of the problem: hsqp_problem::dt_nodes, or the uniform dt.  Host arrays are validated (finite, >= 0, no event
+// as the last interval); device-resident ones are the caller's responsibility and are scanned for events on the device side later.
+static int set_grid(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
+  const size_t B = p->batch, N = p->n_nodes;
+  h->has_events = false;
+  if (!p->dt_nodes) {
+    h->h_dt.assign(B * N, p->dt);
+    h->uniform_grid = true;
+    HCHECK(hipMemcpyAsync(h->d_dt, h->h_dt.data(), B * N * 8, hipMemcpyHostToDevice, h->stream));
+    return HSQP_OK;
+  }
+  h->uniform_grid = false;
+  if (device_src) {
+    h->h_dt.resize(B * N);
+    HCHECK(hipMemcpyAsync(h->d_dt, p->dt_nodes, B * N * 8, hipMemcpyDeviceToDevice, h->stream));
+    HCHECK(hipMemcpyAsync(h->h_dt.data(), h->d_dt, B * N * 8, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(hipStreamSynchronize(h->stream));
+  } else {
+    h->h_dt.assign(p->dt_nodes, p->dt_nodes + B * N);
+  }
+  for (size_t b = 0; b < B; ++b)
+    for (size_t k = 0; k < N; ++k) {
+      const double d = h->h_dt[b * N + k];
+      if (!(d >= 0.0) || d > 1e6) { h->err = "dt_nodes: interval lengths must be finite and >= 0"; return HSQP_ERR_BAD_ARG; }
+      if (d == 0.0) {
+        if (k == N - 1 || k == 0) { h->err = "dt_nodes: the first and the last interval cannot be events (dt = 0)"; return HSQP_ERR_BAD_ARG; }
+        h->has_events = true;
+      }
+    }
+  if (h->has_events && h->hdm.formulation == HSQP_FORM_CENTROIDAL && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (p->batch <= HSQP_SCAN_AUTO_BATCH && p->n_nodes >= HSQP_SCAN_AUTO_MIN_NODES && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI)))) {
+    // the scan's stage elements invert R~ of every stage; an event stage has R~ = I, so it is fine — nothing to reject
+  }
+  if (!device_src) HCHECK(hipMemcpyAsync(h->d_dt, h->h_dt.data(), B * N * 8, hipMemcpyHostToDevice, h->stream));
+  return HSQP_OK;
+}
+
+static int upload_impl(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!p || !p->x_init || !p->x_traj || !p->u_traj || !p->node_params) { h->err = "null problem pointer"; return HSQP_ERR_BAD_ARG; }
-  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || !(p->dt > 0.0)) {
+  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || (!p->dt_nodes && !(p->dt > 0.0))) {
     h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
     return HSQP_ERR_BAD_ARG;
   }
-  if (!padding_is_zero(h, p)) return HSQP_ERR_BAD_ARG;
+  if (!device_src && !padding_is_zero(h, p)) return HSQP_ERR_BAD_ARG;   // device-resident inputs: the caller guarantees the zero padding
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes;
-  HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, hipMemcpyHostToDevice, h->stream));
-  HCHECK(hipMemcpyAsync(h->d_x, p->x_traj, B * (N + 1) * NX * 8, hipMemcpyHostToDevice, h->stream));
-  HCHECK(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, hipMemcpyHostToDevice, h->stream));
-  HCHECK(hipMemcpyAsync(h->d_par, p->node_params, B * (N + 1) * NP * 8, hipMemcpyHostToDevice, h->stream));
+  const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, kind, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_x, p->x_traj, B * (N + 1) * NX * 8, kind, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, kind, h->stream));
+  HCHECK(hipMemcpyAsync(h->d_par, p->node_params, B * (N + 1) * NP * 8, kind, h->stream));
+  { const int rc = set_grid(h, p, device_src); if (rc != HSQP_OK) return rc; }
   HCHECK(hipStreamSynchronize(h->stream));
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
   return HSQP_OK;
 }
+
+int hsqp_upload(hsqp_handle* h, const hsqp_problem* p) { return upload_impl(h, p, false); }
+int hsqp_upload_device(hsqp_handle* h, const hsqp_problem* p) { return upload_impl(h, p, true); }
 
 int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_reference* r) {
   if (!h) return HSQP_ERR_BAD_ARG;
@@ -530,12 +595,16 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
     h->err = "null problem / reference pointer";
     return HSQP_ERR_BAD_ARG;
   }
-  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || !(p->dt > 0.0)) {
+  if (p->batch < 1 || p->batch > h->st.max_batch || p->n_nodes < 1 || p->n_nodes > h->st.max_nodes || (!p->dt_nodes && !(p->dt > 0.0))) {
     h->err = "batch / n_nodes outside the handle's capacity, or dt <= 0";
     return HSQP_ERR_BAD_ARG;
   }
-  if (r->batch != p->batch || r->n_nodes != p->n_nodes || r->dt != p->dt || r->max_events < 1 || r->n_knots < 1) {
+  if (r->batch != p->batch || r->n_nodes != p->n_nodes || (!r->node_times && r->dt != p->dt) || r->max_events < 1 || r->n_knots < 1) {
     h->err = "reference does not match the problem (batch, n_nodes, dt) or is empty";
+    return HSQP_ERR_BAD_ARG;
+  }
+  if ((p->dt_nodes != nullptr) != (r->node_times != nullptr)) {
+    h->err = "a non-uniform grid needs both hsqp_problem::dt_nodes and hsqp_reference::node_times";
     return HSQP_ERR_BAD_ARG;
   }
   for (int b = 0; b < r->batch; ++b)
@@ -545,7 +614,8 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   const size_t B = p->batch, N = p->n_nodes, E = r->max_events, K = r->n_knots;
   // staging area for the compact reference (a few KB per instance)
   const size_t o_ne = 0, o_seq = o_ne + align256(B * 4), o_bad = o_seq + align256(B * (E + 1) * 4), o_ev = o_bad + 256,
-               o_tt = o_ev + align256(B * E * 8), o_ts = o_tt + align256(B * K * 8), total = o_ts + align256(B * K * NX * 8);
+               o_tt = o_ev + align256(B * E * 8), o_ts = o_tt + align256(B * K * 8), o_nt = o_ts + align256(B * K * NX * 8),
+               total = o_nt + align256(r->node_times ? B * (N + 1) * 8 : 0);
   char* base = static_cast<char*>(stage_area(h, total));
   if (!base) { h->err = "hipMalloc failed (reference staging)"; return HSQP_ERR_OOM; }
   int* d_ne = reinterpret_cast<int*>(base + o_ne);
@@ -554,9 +624,12 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   double* d_ev = reinterpret_cast<double*>(base + o_ev);
   double* d_tt = reinterpret_cast<double*>(base + o_tt);
   double* d_ts = reinterpret_cast<double*>(base + o_ts);
+  double* d_nt = r->node_times ? reinterpret_cast<double*>(base + o_nt) : nullptr;
   auto release = []() {};
-  int rc = HSQP_OK;
+  int rc = set_grid(h, p, false);
+  if (rc != HSQP_OK) return rc;
   auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
+  if (d_nt) step(hipMemcpyAsync(d_nt, r->node_times, B * (N + 1) * 8, hipMemcpyHostToDevice, h->stream), "upload node_times");
   step(hipMemcpyAsync(d_ne, r->n_events, B * 4, hipMemcpyHostToDevice, h->stream), "upload n_events");
   step(hipMemcpyAsync(d_seq, r->mode_sequence, B * (E + 1) * 4, hipMemcpyHostToDevice, h->stream), "upload mode_sequence");
   step(hipMemcpyAsync(d_ev, r->event_times, B * E * 8, hipMemcpyHostToDevice, h->stream), "upload event_times");
@@ -569,7 +642,7 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   if (rc == HSQP_OK) {
     const int total = (int)(B * (N + 1));
     hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->d_dm, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
-                       (int)K, d_tt, d_ts, r->t0, r->dt, (int)N, (int)B, h->d_par, d_bad);
+                       (int)K, d_tt, d_ts, r->t0, r->dt, (const double*)d_nt, (int)N, (int)B, h->d_par, d_bad);
     step(hipGetLastError(), "k_params");
   }
   int bad = 0;
@@ -596,12 +669,13 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool last = it == n_iterations - 1;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     if (cent)
-      hipLaunchKernelGGL(k_lq_cent, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N, h->d_rec);
+      hipLaunchKernelGGL(k_lq_cent, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
     else
-      hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->dt, N,
+      hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0);
+    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0);
+    if (h->has_events) hipLaunchKernelGGL(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     if (want_kkt && !h->d_vf) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
@@ -646,14 +720,15 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                        h->d_xnew, h->d_unew, h->d_stepinfo);
     if (want_kkt) {
       HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
-      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt);
+      HCHECK(hipMemsetAsync(h->d_ginf, 0, (size_t)B * 8, h->stream));
+      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
     }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     if (cent)
-      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes, h->d_misc,
+      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
                          (const LsState*)nullptr);
     else
-      hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+      hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                          N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
                        (const LsState*)nullptr);
@@ -679,10 +754,10 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         still_active = counts[1];
         if (counts[1] == 0) break;
         if (cent)
-          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt, N, nodes,
+          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
                              h->d_misc, (const LsState*)h->d_ls);
         else
-          hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->dt,
+          hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                              N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
         hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
                            (const LsState*)h->d_ls);
@@ -706,18 +781,21 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
   return HSQP_OK;
 }
 
-int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
+static int download_impl(hsqp_handle* h, hsqp_solution* s, bool device_dst) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (!s || !h->have_solution) { h->err = "no solution on the device"; return HSQP_ERR_BAD_ARG; }
+  if (device_dst && (s->alpha || s->step_type || s->armijo)) { h->err = "hsqp_download_device: alpha / step_type / armijo must be NULL (host-side fields)"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
   const size_t B = h->B, N = h->N;
-  if (s->x) HCHECK(hipMemcpy(s->x, h->d_xnew, B * (N + 1) * NX * 8, hipMemcpyDeviceToHost));
-  if (s->u) HCHECK(hipMemcpy(s->u, h->d_unew, B * N * NU * 8, hipMemcpyDeviceToHost));
-  if (s->dx) HCHECK(hipMemcpy(s->dx, h->d_dx, B * (N + 1) * NX * 8, hipMemcpyDeviceToHost));
-  if (s->du) HCHECK(hipMemcpy(s->du, h->d_du, B * N * NU * 8, hipMemcpyDeviceToHost));
-  if (s->perf_before) HCHECK(hipMemcpy(s->perf_before, h->d_perf_before, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
-  if (s->perf_after) HCHECK(hipMemcpy(s->perf_after, h->d_perf_after, B * sizeof(hsqp_perf), hipMemcpyDeviceToHost));
-  if (s->kkt) HCHECK(hipMemcpy(s->kkt, h->d_kkt, B * 2 * 8, hipMemcpyDeviceToHost));
+  const hipMemcpyKind kind = device_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (s->x) HCHECK(hipMemcpy(s->x, h->d_xnew, B * (N + 1) * NX * 8, kind));
+  if (s->u) HCHECK(hipMemcpy(s->u, h->d_unew, B * N * NU * 8, kind));
+  if (s->dx) HCHECK(hipMemcpy(s->dx, h->d_dx, B * (N + 1) * NX * 8, kind));
+  if (s->du) HCHECK(hipMemcpy(s->du, h->d_du, B * N * NU * 8, kind));
+  if (s->perf_before) HCHECK(hipMemcpy(s->perf_before, h->d_perf_before, B * sizeof(hsqp_perf), kind));
+  if (s->perf_after) HCHECK(hipMemcpy(s->perf_after, h->d_perf_after, B * sizeof(hsqp_perf), kind));
+  if (s->kkt) HCHECK(hipMemcpy(s->kkt, h->d_kkt, B * 2 * 8, kind));
+  if (s->grad_inf) HCHECK(hipMemcpy(s->grad_inf, h->d_ginf, B * 8, kind));
   if (s->alpha || s->step_type || s->armijo) {
     std::vector<LsState> ls(B);
     HCHECK(hipMemcpy(ls.data(), h->d_ls, B * sizeof(LsState), hipMemcpyDeviceToHost));
@@ -742,6 +820,9 @@ int hsqp_download(hsqp_handle* h, hsqp_solution* s) {
     }
   return HSQP_OK;
 }
+
+int hsqp_download(hsqp_handle* h, hsqp_solution* s) { return download_impl(h, s, false); }
+int hsqp_download_device(hsqp_handle* h, hsqp_solution* s) { return download_impl(h, s, true); }
 
 int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
   int rc = hsqp_upload(h, problem);
@@ -775,11 +856,11 @@ static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s
   if (rc == HSQP_OK) {
     step(hipFuncSetAttribute((const void*)k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicyWS)), "hipFuncSetAttribute");
     if (from_solution)
-      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->N, h->dt, d_in, (const double*)nullptr,
-                         (const double*)nullptr, d_x, d_u, d_tau);
+      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->N, h->dt, h->uniform_grid ? (const double*)nullptr : (const double*)h->d_dt,
+                         d_in, (const double*)nullptr, (const double*)nullptr, d_x, d_u, d_tau);
     else
       hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)nullptr, (const double*)nullptr, 0, 0.0,
-                         (const double*)nullptr, d_in, d_in + (size_t)n * NX, d_x, d_u, d_tau);
+                         (const double*)nullptr, (const double*)nullptr, d_in, d_in + (size_t)n * NX, d_x, d_u, d_tau);
     step(hipGetLastError(), "k_policy");
   }
   if (x_out) step(hipMemcpyAsync(x_out, d_x, (size_t)n * NX * 8, hipMemcpyDeviceToHost, h->stream), "download x");
@@ -833,8 +914,8 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
       if (!fetch_rec(rec)) return HSQP_ERR_HIP;
       out.resize(nodes * NX * NZ);
       for (size_t n = 0; n < nodes; ++n) {
-        if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) cent_expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
-        else expand_AB(&rec[n * REC_SIZE], h->dt, &out[n * NX * NZ]);
+        if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) cent_expand_AB(&rec[n * REC_SIZE], h->h_dt[n], &out[n * NX * NZ]);
+        else expand_AB(&rec[n * REC_SIZE], h->h_dt[n], &out[n * NX * NZ]);
       }
       break;
     }

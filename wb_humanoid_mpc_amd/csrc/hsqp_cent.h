@@ -483,7 +483,7 @@ template <class T>
 HSQP_HD void cent_write_dynamics(const T* xn, const T* flow, const double* u, const double* xnext, double dt, double* rec, double* misc) {
   double dyn = 0.0;
   for (int i = 0; i < CNX; ++i) { const double b = val(xn[i]) - xnext[i]; dyn += b * b; if (rec) rec[REC_B + i] = b; }
-  misc[3] = dt * dyn;
+  misc[3] = (dt > 0.0 ? dt : 1.0) * dyn;   // event interval (dt = 0): unscaled, as hsqp_lq.h
   if (!rec) return;
   for (int i = CNX; i < 64; ++i) rec[REC_B + i] = 0.0;
   for (int i = 0; i < 64; ++i) rec[REC_FLOW + i] = i < 12 ? val(flow[i]) : (i < CNX ? u[i] : 0.0);   // joint rows: qd_j = u[12 + (i - 12)]

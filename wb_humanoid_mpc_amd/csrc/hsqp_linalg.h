@@ -9,6 +9,9 @@
 #pragma once
 #include "hsqp_common.h"
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <vector>
+#endif
 namespace hsqp {
 
 // Generic tile loop:  C = X1^T Y1 + sign2 * X2^T Y2  (second product optional: L2 = 0; sign2 = +1 or -1).
@@ -313,19 +316,38 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
     for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane, prof);
   }
 #else
+  // host build (tests/hostemu, oracle/cpu_baseline.cpp): rank-1 updates over contiguous rows of Y so that the inner loop
+  // vectorises; every element still accumulates its products in the order l = 0 .. L1-1, then L2 (the order of the naive
+  // dot product), so the result does not depend on this loop structure
+  static thread_local std::vector<double> accbuf;
   for (int jn = 0; jn < njobs; ++jn) {
     const XtyJob& j = jobs[jn];
-    WG_FOR(ctx, e, j.M * j.N) {
-      const int r = e / j.N, c = e % j.N;
-      if (j.sym && (c >> 4) < (r >> 4)) continue;   // mirrored from the tile above the diagonal
-      double acc = 0.0;
-      for (int l = 0; l < j.L1; ++l) acc += j.X1[l * j.ldx1 + r * j.sx1] * j.Y1[l * j.ldy1 + c];
-      for (int l = 0; l < j.L2; ++l) acc += j.sign2 * j.X2[l * j.ldx2 + r * j.sx2] * j.Y2[l * j.ldy2 + c];
-      double v = j.scale * acc;
-      if (j.Add) v += j.Add[r * j.ldadd + c];
-      j.C[r * j.ldc + c] = v;
-      if (j.sym && (c >> 4) != (r >> 4)) j.C[c * j.ldc + r] = v;
+    const int M = j.M, N = j.N;
+    if (accbuf.size() < (size_t)M * N) accbuf.resize((size_t)M * N);
+    double* acc = accbuf.data();
+    for (int e = 0; e < M * N; ++e) acc[e] = 0.0;
+    for (int part = 0; part < 2; ++part) {
+      const int L = part ? j.L2 : j.L1, ldx = part ? j.ldx2 : j.ldx1, ldy = part ? j.ldy2 : j.ldy1, sx = part ? j.sx2 : j.sx1;
+      const double* X = part ? j.X2 : j.X1;
+      const double* Y = part ? j.Y2 : j.Y1;
+      const double sg = part ? j.sign2 : 1.0;
+      for (int l = 0; l < L; ++l) {
+        const double* xr = X + (size_t)l * ldx;
+        const double* yr = Y + (size_t)l * ldy;
+        for (int r = 0; r < M; ++r) {
+          const double a = sg * xr[r * sx];
+          double* ar = acc + (size_t)r * N;
+          for (int c = j.sym ? (r >> 4) << 4 : 0; c < N; ++c) ar[c] += a * yr[c];
+        }
+      }
     }
+    for (int r = 0; r < M; ++r)
+      for (int c = j.sym ? (r >> 4) << 4 : 0; c < N; ++c) {
+        double v = j.scale * acc[(size_t)r * N + c];
+        if (j.Add) v += j.Add[r * j.ldadd + c];
+        j.C[r * j.ldc + c] = v;
+        if (j.sym && (c >> 4) != (r >> 4)) j.C[c * j.ldc + r] = v;
+      }
   }
 #endif
 }

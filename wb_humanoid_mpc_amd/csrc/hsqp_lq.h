@@ -169,7 +169,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     misc[0] = (double)w.nw.ne;
     misc[1] = dt * w.nw.cost;
     misc[2] = dt * eq;
-    misc[3] = dt * dyn;
+    misc[3] = (dt > 0.0 ? dt : 1.0) * dyn;   // an event interval (dt = 0, identity jump map) counts its defect unscaled
     // structure of the equality rows for the projection: a swing foot's zero-wrench rows are unit rows of D (and have C = 0)
     misc[4] = (double)w.nw.contact[0]; misc[5] = (double)w.nw.contact[1];
     misc[6] = (double)w.nw.eq_off[0]; misc[7] = (double)w.nw.eq_off[1];

@@ -79,4 +79,27 @@ HSQP_HD void policy_interpolate(const Ctx& ctx, const double* xt, const double* 
   WG_SYNC(ctx);
 }
 
+// The same on a non-uniform grid (hsqp_problem::dt_nodes; zero-length event intervals): node k of the state trajectory sits at
+// t_k = sum_{i<k} dts[i], the inputs at t_0 .. t_{N-1}.  At an event time the post-event node is taken (the last node with t_k <= s).
+HSQP_HD void policy_interpolate_grid(const Ctx& ctx, const double* xt, const double* ut, int N, const double* dts, double s, double* x, double* u) {
+  if (s < 0.0) s = 0.0;
+  double tk = 0.0;       // start of interval kx
+  int kx = 0;
+  while (kx < N - 1 && tk + dts[kx] <= s) { tk += dts[kx]; ++kx; }
+  while (kx < N - 1 && dts[kx] == 0.0) ++kx;              // never interpolate across a jump
+  const double h = dts[kx];
+  double ax = h > 0.0 ? (s - tk) / h : 1.0;
+  if (ax > 1.0) ax = 1.0;
+  // inputs: stamps t_0 .. t_{N-1}; beyond the last stamp the last input is held
+  int ku = kx;
+  double au = ax;
+  if (ku > N - 2) { ku = N - 2 > 0 ? N - 2 : 0; au = N >= 2 ? 1.0 : 0.0; }
+  if (N >= 2 && dts[ku] == 0.0) au = 1.0;
+  WG_FOR(ctx, i, NX + NU) {
+    if (i < NX) x[i] = (1.0 - ax) * xt[(size_t)kx * NX + i] + ax * xt[(size_t)(kx + 1) * NX + i];
+    else { const int c = i - NX; u[c] = N >= 2 ? (1.0 - au) * ut[(size_t)ku * NU + c] + au * ut[(size_t)(ku + 1) * NU + c] : ut[c]; }
+  }
+  WG_SYNC(ctx);
+}
+
 }  // namespace hsqp

@@ -65,6 +65,21 @@ struct ProjWS {
   double gacc[LDTM];             // gradient partial sums of pass A
 };
 
+// Event interval (hsqp_problem::dt_nodes[b][k] == 0): the stage of the QP is the identity jump map
+// dx+ = dx + (x_k - x_{k+1}) with no cost and the inputs pinned (R~ = I, everything else zero -> ut = 0, du = 0).  b~ is the defect
+// the LQ kernel computed with dt = 0.  Overwrites what project_node wrote for this node.
+HSQP_HD void jump_node_qp(const Ctx& ctx, const double* rec, double* qp) {
+  WG_FOR(ctx, i, QP_SIZE) {
+    double v = 0.0;
+    if (i < QP_B) { const int a = i / NX, c = i % NX; v = a == c ? 1.0 : 0.0; }
+    else if (i >= QP_BV && i < QP_Q) v = rec[REC_B + i - QP_BV];
+    else if (i >= QP_R && i < QP_QV) { const int a = (i - QP_R) / NUT, c = (i - QP_R) % NUT; v = a == c ? 1.0 : 0.0; }
+    else if (i == QP_NUT) v = (double)NUT;
+    qp[i] = v;
+  }
+  WG_SYNC(ctx);
+}
+
 // cent = true: the record comes from the centroidal LQ kernel (hsqp_cent.h): the dense rows of [A|B] - [I|0] are rows 0..11
 // (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false) {

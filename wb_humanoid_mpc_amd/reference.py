@@ -291,6 +291,57 @@ def cold_start(model, x0, par):
     return x, u
 
 
+# ------------------------------------------------------------------------------------ time grid with event nodes
+EVENT_EPS = 1e-9   # a post-event node is sampled at t_event + EVENT_EPS (ocs2 getIntervalStart adds an epsilon of its own)
+
+
+def time_discretization_with_events(t0, tf, dt, event_times, dt_min=1e-4):
+    """ocs2 multiple-shooting time grid (upstream ocs2_oc timeDiscretizationWithEvents, restated from the published source; the fork's
+    copy is absent): nodes every dt from t0, an event time inside (t0, tf) becomes a PRE-event node and a POST-event node with the same
+    time stamp, the node before it is dropped if it would be closer than dt_min, the last interval is shortened to hit tf.
+    Returns (times[n+1], is_post_event[n+1])."""
+    times, post = [float(t0)], [False]
+    ev = [e for e in event_times if t0 < e < tf]
+    ie = 0
+    while times[-1] < tf:
+        t_next, is_event = times[-1] + dt, False
+        if ie < len(ev) and t_next >= ev[ie]:
+            t_next, is_event = ev[ie], True
+            ie += 1
+        if t_next >= tf:
+            t_next, is_event = float(tf), False
+        if t_next > times[-1] + dt_min or post[-1]:
+            times.append(t_next); post.append(False)
+        else:
+            times[-1] = t_next
+        if is_event:
+            times.append(t_next); post.append(True)
+    return np.array(times), np.array(post)
+
+
+def event_grid(t0, tf, dt, event_times):
+    """(dt_nodes[N], node_times[N+1]) for hsqp_problem::dt_nodes / hsqp_reference::node_times: interval lengths with 0 on the
+    pre -> post event intervals, and the sampling time of every node (post-event nodes at t + EVENT_EPS, so that look-ups by
+    lower_bound see the new mode)."""
+    times, post = time_discretization_with_events(t0, tf, dt, event_times)
+    return np.diff(times), times + EVENT_EPS * post
+
+
+def build_node_params_at(model, schedule, targets, node_times, arm_swing=True):
+    """build_node_params on explicit node times (non-uniform grid / event nodes)."""
+    planner = SwingTrajectoryPlanner(model.swing, schedule)
+    par = np.zeros((len(node_times), _abi.NODE_PARAMS))
+    for k, t in enumerate(node_times):
+        flags = mode_to_contact_flags(schedule.mode_at(t))
+        par[k, _abi.P_XDES:_abi.P_XDES + model.nx] = targets.desired_state(t)
+        par[k, _abi.P_ARMSWING] = math.sin(2.0 * math.pi * (phase_variable(schedule, t) - 0.15)) if arm_swing else 0.0
+        par[k, _abi.P_CONTACT:_abi.P_CONTACT + 2] = flags
+        for leg in range(2):
+            par[k, _abi.P_SWING + 3 * leg:_abi.P_SWING + 3 * leg + 3] = planner.z_refs(leg, t)
+            par[k, _abi.P_IMPACT + leg] = planner.impact_proximity(leg, t)
+    return par
+
+
 # ------------------------------------------------------------------------------------ benchmark configs (BASELINE.md §4)
 BENCH_SEED = 20250808
 

@@ -45,6 +45,8 @@ def load_library():
     lib.hsqp_upload_reference.argtypes = [C.c_void_p, C.POINTER(_abi.Problem), C.POINTER(_abi.Reference)]
     lib.hsqp_iterate_device.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.hsqp_download.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
+    lib.hsqp_upload_device.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
+    lib.hsqp_download_device.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
     lib.hsqp_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
     lib.hsqp_debug_read.restype = C.c_longlong
     lib.hsqp_last_kernel_ms.argtypes = [C.c_void_p, _dp]
@@ -110,20 +112,31 @@ class HipSqpSolver:
         if x_traj.shape != (B, N + 1, _abi.NX) or u_traj.shape != (B, N, _abi.NU) or \
                 params.shape != (B, N + 1, _abi.NODE_PARAMS) or x_init.shape != (B, _abi.NX):
             raise ValueError("inconsistent problem array shapes")
-        keep = (x_init, x_traj, u_traj, params)
+        dt, grid = self._grid(dt, B, N)
+        keep = (x_init, x_traj, u_traj, params, grid)
         p = _abi.Problem(batch=B, n_nodes=N, dt=dt, x_init=x_init.ctypes.data_as(_dp), x_traj=x_traj.ctypes.data_as(_dp),
-                         u_traj=u_traj.ctypes.data_as(_dp), node_params=params.ctypes.data_as(_dp))
+                         u_traj=u_traj.ctypes.data_as(_dp), node_params=params.ctypes.data_as(_dp),
+                         dt_nodes=None if grid is None else grid.ctypes.data_as(_dp))
         return p, keep, (B, N)
+
+    @staticmethod
+    def _grid(dt, B, N):
+        """dt: the uniform node spacing, or the interval lengths of a non-uniform grid ([N] shared by all instances or [B][N];
+        a zero marks an event interval, hsqp_problem::dt_nodes)."""
+        if np.ndim(dt) == 0:
+            return float(dt), None
+        grid = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, dtype=np.float64), (B, N)))
+        return 0.0, grid
 
     def _alloc_solution(self, B, N):
         out = dict(x=np.zeros((B, N + 1, _abi.NX)), u=np.zeros((B, N, _abi.NU)), dx=np.zeros((B, N + 1, _abi.NX)),
                    du=np.zeros((B, N, _abi.NU)), kkt=np.zeros((B, 2)), alpha=np.zeros(B), step_type=np.zeros(B, dtype=np.int32),
-                   armijo=np.zeros(B))
+                   armijo=np.zeros(B), grad_inf=np.zeros(B))
         pb, pa = (_abi.Perf * B)(), (_abi.Perf * B)()
         s = _abi.Solution(x=out["x"].ctypes.data_as(_dp), u=out["u"].ctypes.data_as(_dp), dx=out["dx"].ctypes.data_as(_dp),
                           du=out["du"].ctypes.data_as(_dp), perf_before=pb, perf_after=pa, kkt=out["kkt"].ctypes.data_as(_dp),
                           alpha=out["alpha"].ctypes.data_as(_dp), step_type=out["step_type"].ctypes.data_as(C.POINTER(C.c_int32)),
-                          armijo=out["armijo"].ctypes.data_as(_dp))
+                          armijo=out["armijo"].ctypes.data_as(_dp), grad_inf=out["grad_inf"].ctypes.data_as(_dp))
         return s, out, pb, pa
 
     @staticmethod
@@ -152,9 +165,10 @@ class HipSqpSolver:
         self._check(self.lib.hsqp_upload(self.h, C.byref(p)))
 
     def upload_reference(self, x_init, x_traj, u_traj, dt, t0, n_events, event_times, mode_sequence, target_times, target_states,
-                         swing, terrain_height=0.0, arm_swing=True):
+                         swing, terrain_height=0.0, arm_swing=True, node_times=None):
         """hsqp_upload_reference: the per-node parameter table is generated on the device from the compact reference
-        (mode schedule + target knots per instance; see reference.pack_reference)."""
+        (mode schedule + target knots per instance; see reference.pack_reference).  Non-uniform grid: dt = interval lengths
+        ([N] or [B][N]) together with node_times ([N+1] or [B][N+1])."""
         x_traj, u_traj, x_init = _c(x_traj), _c(u_traj), _c(x_init)
         if x_traj.ndim == 2:
             x_traj, u_traj, x_init = x_traj[None], u_traj[None], x_init[None]
@@ -165,9 +179,11 @@ class HipSqpSolver:
         if event_times.shape[0] != B or mode_sequence.shape != (B, event_times.shape[1] + 1) or target_states.shape != (B, target_times.shape[1], _abi.NX):
             raise ValueError("inconsistent reference array shapes")
         ip = C.POINTER(C.c_int32)
+        dt, grid = self._grid(dt, B, N)
+        nt = None if node_times is None else np.ascontiguousarray(np.broadcast_to(np.asarray(node_times, dtype=np.float64), (B, N + 1)))
         p = _abi.Problem(batch=B, n_nodes=N, dt=dt, x_init=x_init.ctypes.data_as(_dp), x_traj=x_traj.ctypes.data_as(_dp),
-                         u_traj=u_traj.ctypes.data_as(_dp), node_params=None)
-        r = _abi.Reference(batch=B, n_nodes=N, t0=t0, dt=dt, max_events=event_times.shape[1], n_events=n_events.ctypes.data_as(ip),
+                         u_traj=u_traj.ctypes.data_as(_dp), node_params=None, dt_nodes=None if grid is None else grid.ctypes.data_as(_dp))
+        r = _abi.Reference(batch=B, n_nodes=N, t0=t0, dt=dt, node_times=None if nt is None else nt.ctypes.data_as(_dp), max_events=event_times.shape[1], n_events=n_events.ctypes.data_as(ip),
                            event_times=event_times.ctypes.data_as(_dp), mode_sequence=mode_sequence.ctypes.data_as(ip),
                            n_knots=target_times.shape[1], target_times=target_times.ctypes.data_as(_dp),
                            target_states=target_states.ctypes.data_as(_dp), swing=swing, terrain_height=terrain_height,
@@ -201,6 +217,21 @@ class HipSqpSolver:
             setattr(s, k, float(v))
         self._check(self.lib.hsqp_set_linesearch(self.h, C.byref(s)))
         return s
+
+    # ---- multi-GPU data path: problem shards / solutions that are already in this GPU's HBM (e.g. the tensors RCCL
+    #      scattered / will gather); pointers are raw device addresses (torch: tensor.data_ptr())
+    def upload_device(self, batch, n_nodes, dt, x_init_ptr, x_ptr, u_ptr, params_ptr, dt_nodes_ptr=0):
+        cast = lambda a: C.cast(C.c_void_p(int(a)), _dp) if a else None  # noqa: E731
+        p = _abi.Problem(batch=batch, n_nodes=n_nodes, dt=float(dt), x_init=cast(x_init_ptr), x_traj=cast(x_ptr), u_traj=cast(u_ptr),
+                         node_params=cast(params_ptr), dt_nodes=cast(dt_nodes_ptr))
+        self._check(self.lib.hsqp_upload_device(self.h, C.byref(p)))
+        self._shape = (batch, n_nodes)
+
+    def download_device(self, x_ptr=0, u_ptr=0, dx_ptr=0, du_ptr=0, perf_before_ptr=0, perf_after_ptr=0, kkt_ptr=0, grad_inf_ptr=0):
+        cast = lambda a, t=_dp: C.cast(C.c_void_p(int(a)), t) if a else None  # noqa: E731
+        s = _abi.Solution(x=cast(x_ptr), u=cast(u_ptr), dx=cast(dx_ptr), du=cast(du_ptr), perf_before=cast(perf_before_ptr, C.POINTER(_abi.Perf)),
+                          perf_after=cast(perf_after_ptr, C.POINTER(_abi.Perf)), kkt=cast(kkt_ptr), grad_inf=cast(grad_inf_ptr))
+        self._check(self.lib.hsqp_download_device(self.h, C.byref(s)))
 
     def download(self):
         B, N = self._shape
