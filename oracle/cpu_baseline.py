@@ -33,6 +33,27 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Hardware threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container with
+    `cpu.max = 1600000 100000` gets 16 CPUs' worth of time however many threads os.cpu_count() reports)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, int(quota + 0.5))) if quota else n, n, quota
+
+
 class CpuBaseline:
     def __init__(self, model):
         self.lib = C.CDLL(build())
