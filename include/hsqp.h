@@ -289,6 +289,11 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]);
  * Joint torques as the reference's computeJointTorques (humanoid_common_mpc/src/pinocchio_model/DynamicsHelperFunctions.cpp:
  * 233-270): tau_j = M_j [a_b; qdd_j] + nle_j - (sum J^T W)_j with a_b from the flow map's base solve, for n (x, u) pairs. */
 int hsqp_joint_torques(hsqp_handle* h, int n, const double* x /*[n][58]*/, const double* u /*[n][35]*/, double* tau /*[n][23]*/);
+/* Centroidal handle (CentroidalMpcMrtJointController::computeJointControlAction, humanoid_centroidal_mpc/src/mrt/
+ * CentroidalMpcMrtJointController.cpp:155-175): the same computeJointTorques with q = the state's generalized coordinates, the
+ * generalized velocities from the centroidal momentum (v_b = A_b^-1 (m h - A_j qd_j)), the input's contact wrenches, and the DESIRED
+ * joint accelerations the controller forms from its PD law, passed in entries 35..57 of the state row (zeros: pure feed-forward);
+ * hsqp_evaluate_policy on a centroidal handle uses zeros there. */
 /* Feed-forward policy of the solution resident on the device (MPC_MRT_Interface::evaluatePolicy as used in
  * humanoid_wb_mpc/src/mrt/WBMpcMrtJointController.cpp:136-147): clamped linear interpolation of the optimal state / input
  * trajectories at s[b] seconds after the first node, and the joint torques there.  Any output may be NULL. */

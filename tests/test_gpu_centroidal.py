@@ -137,18 +137,58 @@ def test_multi_iteration_with_linesearch(cmodel):
         s.close()
 
 
-def test_entry_points_that_are_whole_body_only_fail_cleanly(cgpu, cmodel):
+def test_invalid_centroidal_inputs_fail_cleanly(cgpu, cmodel):
     from wb_humanoid_mpc_amd.solver import HsqpError
     x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=4, batch=1, gait="stance")
     cgpu.run(x0, x, u, par, dt)
-    with pytest.raises(HsqpError) as e:
-        cgpu.joint_torques(x[0, 0], u[0, 0])
-    assert e.value.code == _abi.ERR_BAD_ARG
     bad = x.copy()
     bad[0, 1, 40] = 1.0
     with pytest.raises(HsqpError) as e:
         cgpu.run(x0, bad, u, par, dt)
     assert e.value.code == _abi.ERR_BAD_ARG
+
+
+def test_centroidal_policy_and_joint_torques(cgpu, cmodel, model, oracle):
+    """hsqp_evaluate_policy / hsqp_joint_torques on a centroidal handle (CentroidalMpcMrtJointController.cpp:155-175): the policy is
+    the interpolated trajectory; the torques are the reference's computeJointTorques at q = the state's generalized coordinates,
+    qd = the generalized velocities of the centroidal momentum (independent numpy restatement: reference.centroidal_base_velocity),
+    the policy's wrenches and the desired joint accelerations handed over in entries 35..57 — checked against the whole-body
+    oracle's full inverse dynamics."""
+    from test_policy import oracle_torques
+    from wb_humanoid_mpc_amd.reference import centroidal_base_velocity
+    B, N = 3, 8
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=N, batch=B, perturb=True, seed=3)
+    out = cgpu.run(x0, x, u, par, dt)
+    tq = np.array([0.004, 1.7 * dt, N * dt])
+    xp, up, tau = cgpu.evaluate_policy(tq)
+    t = np.arange(N + 1) * dt
+    nj = cmodel.nj
+    rng = np.random.default_rng(1)
+    for b in range(B):
+        xw = np.array([np.interp(tq[b], t, out["x"][b][:, i]) for i in range(NX)])
+        ue = np.vstack([out["u"][b], out["u"][b][-1:]])
+        uw = np.array([np.interp(tq[b], t, ue[:, i]) for i in range(NU)])
+        np.testing.assert_allclose(xp[b], xw, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(up[b], uw, rtol=0, atol=1e-9)
+        assert not xp[b][CNX:].any()
+
+        def want_torques(xc, uc, qdd):
+            q = xc[6:CNX]
+            vb = centroidal_base_velocity(cmodel, q, xc[:6], uc[12:])
+            x_wb = np.concatenate([q, vb, uc[12:]])
+            u_wb = np.concatenate([uc[:12], qdd])
+            return oracle_torques(oracle, x_wb, u_wb)
+
+        want = want_torques(xp[b], up[b], np.zeros(nj))
+        assert np.abs(tau[b] - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+        # with a PD-shaped desired joint acceleration in the padding entries of the state row
+        qdd = rng.standard_normal(nj)
+        xr = xp[b].copy()
+        xr[CNX:] = qdd
+        got = cgpu.joint_torques(xr, up[b])[0]
+        want = want_torques(xp[b], up[b], qdd)
+        assert np.abs(got - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+    assert np.abs(tau).max() > 1.0
 
 
 @pytest.mark.parametrize("n,batch,gait", [(100, 1, "walk"), (20, 1, "stance"), (37, 3, "run"), (64, 12, "walk")])

@@ -304,24 +304,59 @@ __global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, 
   if (!ok) atomicExch(bad, 1);
 }
 
-// ---- policy evaluation / joint torques: one workgroup per (x, u) pair.  xt != null: interpolate the trajectories of
-//      instance blockIdx.x at s[blockIdx.x] first; otherwise take the pair from xin / uin.
-struct PolicyWS { StageWST<false> st; double x[NX], u[NU]; };
-__global__ __launch_bounds__(128) void k_policy(const DevModel* __restrict__ dm, const double* __restrict__ xt, const double* __restrict__ ut, int N,
-                                                double dt, const double* __restrict__ dts, const double* __restrict__ s, const double* __restrict__ xin,
-                                                const double* __restrict__ uin, double* __restrict__ xout, double* __restrict__ uout,
-                                                double* __restrict__ tau) {
-  PolicyWS& w = *reinterpret_cast<PolicyWS*>(hsqp_smem);
+// ---- policy evaluation / joint torques in three small kernels.
+//  k_policy_inputs: one workgroup per pair — xt != null: interpolate the trajectories of instance blockIdx.x at s[blockIdx.x]
+//                   (uniform grid, or dts != null: the instance's interval lengths); otherwise take the pair from xin / uin.
+//  k_cent_policy_map (centroidal handles): one thread per pair — the whole-body (x, u) computeJointTorques needs
+//                   (CentroidalMpcMrtJointController::computeJointControlAction, humanoid_centroidal_mpc/src/mrt/
+//                   CentroidalMpcMrtJointController.cpp:155-175): q = getGeneralizedCoordinates(x), qd = getGeneralizedVelocities(x, u)
+//                   with the base velocity from the centroidal momentum, v_b = A_b^-1 (m h - A_j qd_j) = rows 6..11 of the flow map,
+//                   the contact wrenches, and the desired joint accelerations carried in entries 35..57 of the INPUT state row.
+//  k_policy_torques: one workgroup per pair — model evaluation + torques (hsqp_policy.h).
+__global__ __launch_bounds__(64) void k_policy_inputs(const double* __restrict__ xt, const double* __restrict__ ut, int N, double dt, const double* __restrict__ dts,
+                                                      const double* __restrict__ s, const double* __restrict__ xin, const double* __restrict__ uin,
+                                                      double* __restrict__ xout, double* __restrict__ uout) {
   const int b = blockIdx.x;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   if (xt) {
-    if (dts) policy_interpolate_grid(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dts + (size_t)b * N, s[b], w.x, w.u);
-    else policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], w.x, w.u);
+    if (dts) policy_interpolate_grid(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dts + (size_t)b * N, s[b], xout + (size_t)b * NX, uout + (size_t)b * NU);
+    else policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], xout + (size_t)b * NX, uout + (size_t)b * NU);
   } else {
-    for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) w.x[i] = xin[(size_t)b * NX + i]; else w.u[i - NX] = uin[(size_t)b * NU + i - NX]; }
-    __syncthreads();
+    for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) xout[(size_t)b * NX + i] = xin[(size_t)b * NX + i]; else uout[(size_t)b * NU + i - NX] = uin[(size_t)b * NU + i - NX]; }
   }
-  for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) xout[(size_t)b * NX + i] = w.x[i]; else uout[(size_t)b * NU + i - NX] = w.u[i - NX]; }
+}
+// (kept out of line: inlined into the kernel below, this pass crashes the gfx950 backend of ROCm 7.2's clang)
+__device__ __attribute__((noinline)) void cent_base_velocity(const DevModel& dm, const double* hq, const double* W, const double* qd, double* xdot) {
+  CentKin<double> kin;
+  cent_pass<double, true>(dm, hq, hq + 6, W, qd, kin, xdot);
+}
+__global__ __launch_bounds__(64) void k_cent_policy_map(const DevModel* __restrict__ dm, int n, const double* __restrict__ xc, const double* __restrict__ uc,
+                                                        double* __restrict__ xwb, double* __restrict__ uwb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const double* x = xc + (size_t)b * NX;
+  const double* u = uc + (size_t)b * NU;
+  double xdot[12];
+  double hq[HSQP_CNX], W[12], qd[NJ];   // local copies, as cent_params_finish does (the <double, false> instantiation on global pointers crashes this compiler)
+  for (int i = 0; i < HSQP_CNX; ++i) hq[i] = x[i];
+  for (int i = 0; i < 12; ++i) W[i] = u[i];
+  for (int i = 0; i < NJ; ++i) qd[i] = u[12 + i];
+  cent_base_velocity(*dm, hq, W, qd, xdot);
+  double* xo = xwb + (size_t)b * NX;
+  double* uo = uwb + (size_t)b * NU;
+  for (int i = 0; i < NV; ++i) xo[i] = x[6 + i];
+  for (int i = 0; i < 6; ++i) xo[NV + i] = xdot[6 + i];
+  for (int j = 0; j < NJ; ++j) { xo[NV + 6 + j] = u[12 + j]; uo[12 + j] = x[HSQP_CNX + j]; }
+  for (int i = 0; i < 12; ++i) uo[i] = u[i];
+}
+struct PolicyWS { StageWST<false> st; double x[NX], u[NU]; };
+__global__ __launch_bounds__(128) void k_policy_torques(const DevModel* __restrict__ dm, const double* __restrict__ xwb, const double* __restrict__ uwb,
+                                                        double* __restrict__ tau) {
+  PolicyWS& w = *reinterpret_cast<PolicyWS*>(hsqp_smem);
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) w.x[i] = xwb[(size_t)b * NX + i]; else w.u[i - NX] = uwb[(size_t)b * NU + i - NX]; }
+  __syncthreads();
   policy_node(ctx, *dm, w.st, w.x, w.u, tau + (size_t)b * NJ);
 }
 
@@ -827,24 +862,27 @@ int hsqp_download_device(hsqp_handle* h, hsqp_solution* s) { return download_imp
 int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
   int rc = hsqp_upload(h, problem);
   if (rc != HSQP_OK) return rc;
-  rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | ((h->st.flags & HSQP_FLAG_LINESEARCH) ? HSQP_ITER_LINESEARCH : 0));
+  // the KKT residual is a report, not part of the step: it is only computed when the caller asks for it (solution->kkt / grad_inf)
+  const int want_kkt = (solution && (solution->kkt || solution->grad_inf)) ? HSQP_ITER_KKT : 0;
+  rc = hsqp_iterate_device(h, 1, HSQP_ITER_TAKE_STEP | want_kkt | ((h->st.flags & HSQP_FLAG_LINESEARCH) ? HSQP_ITER_LINESEARCH : 0));
   if (rc != HSQP_OK) return rc;
   return hsqp_download(h, solution);
 }
 
 static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s_or_x, const double* u_in, double* x_out, double* u_out, double* tau) {
-  if (h->hdm.formulation != HSQP_FORM_WB) { h->err = "policy evaluation / joint torques are implemented for the whole-body formulation only"; return HSQP_ERR_BAD_ARG; }
   HCHECK(hipSetDevice(h->device));
+  const bool cent = h->hdm.formulation == HSQP_FORM_CENTROIDAL;
   const size_t nin = from_solution ? (size_t)n : (size_t)n * (NX + NU);
   const size_t o_in = 0, o_x = o_in + align256(nin * 8), o_u = o_x + align256((size_t)n * NX * 8), o_tau = o_u + align256((size_t)n * NU * 8),
-               total = o_tau + align256((size_t)n * NJ * 8);
+               o_xw = o_tau + align256((size_t)n * NJ * 8), o_uw = o_xw + align256((size_t)n * NX * 8), total = o_uw + align256((size_t)n * NU * 8);
   char* base = static_cast<char*>(stage_area(h, total));
   if (!base) { h->err = "hipMalloc failed (policy evaluation staging)"; return HSQP_ERR_OOM; }
   double* d_in = reinterpret_cast<double*>(base + o_in);
   double* d_x = reinterpret_cast<double*>(base + o_x);
   double* d_u = reinterpret_cast<double*>(base + o_u);
   double* d_tau = reinterpret_cast<double*>(base + o_tau);
-  auto release = []() {};
+  double* d_xw = reinterpret_cast<double*>(base + o_xw);
+  double* d_uw = reinterpret_cast<double*>(base + o_uw);
   int rc = HSQP_OK;
   auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };
   if (from_solution) {
@@ -854,20 +892,25 @@ static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s
     step(hipMemcpyAsync(d_in + (size_t)n * NX, u_in, (size_t)n * NU * 8, hipMemcpyHostToDevice, h->stream), "upload u");
   }
   if (rc == HSQP_OK) {
-    step(hipFuncSetAttribute((const void*)k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicyWS)), "hipFuncSetAttribute");
+    step(hipFuncSetAttribute((const void*)k_policy_torques, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicyWS)), "hipFuncSetAttribute");
     if (from_solution)
-      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->N, h->dt, h->uniform_grid ? (const double*)nullptr : (const double*)h->d_dt,
-                         d_in, (const double*)nullptr, (const double*)nullptr, d_x, d_u, d_tau);
+      hipLaunchKernelGGL(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)h->d_xnew, (const double*)h->d_unew, h->N, h->dt,
+                         h->uniform_grid ? (const double*)nullptr : (const double*)h->d_dt, (const double*)d_in, (const double*)nullptr, (const double*)nullptr, d_x, d_u);
     else
-      hipLaunchKernelGGL(k_policy, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)nullptr, (const double*)nullptr, 0, 0.0,
-                         (const double*)nullptr, (const double*)nullptr, d_in, d_in + (size_t)n * NX, d_x, d_u, d_tau);
+      hipLaunchKernelGGL(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)nullptr, (const double*)nullptr, 0, 0.0, (const double*)nullptr,
+                         (const double*)nullptr, (const double*)d_in, (const double*)(d_in + (size_t)n * NX), d_x, d_u);
+    if (cent) {
+      hipLaunchKernelGGL(k_cent_policy_map, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_dm, n, (const double*)d_x, (const double*)d_u, d_xw, d_uw);
+      hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_xw, (const double*)d_uw, d_tau);
+    } else {
+      hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_x, (const double*)d_u, d_tau);
+    }
     step(hipGetLastError(), "k_policy");
   }
   if (x_out) step(hipMemcpyAsync(x_out, d_x, (size_t)n * NX * 8, hipMemcpyDeviceToHost, h->stream), "download x");
   if (u_out) step(hipMemcpyAsync(u_out, d_u, (size_t)n * NU * 8, hipMemcpyDeviceToHost, h->stream), "download u");
   if (tau) step(hipMemcpyAsync(tau, d_tau, (size_t)n * NJ * 8, hipMemcpyDeviceToHost, h->stream), "download tau");
   step(hipStreamSynchronize(h->stream), "sync");
-  release();
   return rc;
 }
 

@@ -29,7 +29,7 @@ constexpr int QP_NUT = QP_PE + NU;             // [1]  nu - ne, or -1 if D was r
 constexpr int QP_SIZE = ((QP_NUT + 1 + 7) / 8) * 8;
 
 constexpr int NTW = NX + NUT;                  // 81: projected stage variable [dx; ut]
-constexpr int LDTM = 84;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
+constexpr int LDTM = 88;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
 // The projected residual rows (64 slots + 35 input-weight rows sqrt(d_u) [Px|Pu|Pe]) are processed in two passes so that
 // the workspace stays under 80 KB (two workgroups per CU): pass A = slots 0..47, pass B = slots 48..63 + weight rows.
 constexpr int NRA = 48;                        // residual row slots of pass A
