@@ -74,9 +74,10 @@ class HipSqpSolver {
    * manager and the swing planner for every node (hsqp_upload_reference).
    */
   void runWithReference(int nodes, double dt, const double* xInit, const double* xTraj, const double* uTraj, const hsqp_reference& ref,
-                        bool takeStepWithLinesearch = false) {
+                        bool takeStepWithLinesearch = false, const double* dtNodes = nullptr /* non-uniform grid with event nodes: [batch][nodes] interval
+                        lengths (0 = event), together with ref.node_times */) {
     const int batch = ref.batch;
-    hsqp_problem p{batch, nodes, dt, xInit, xTraj, uTraj, nullptr};
+    hsqp_problem p{batch, nodes, dt, xInit, xTraj, uTraj, nullptr, dtNodes};
     int rc = hsqp_upload_reference(h_, &p, &ref);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_upload_reference failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
     rc = hsqp_iterate_device(h_, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0));
