@@ -54,11 +54,12 @@ PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 meas
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of one kernel from the committed rocprofv3 --pmc passes of this same command
-    (tools/gpu_pmc.sh -> profiles/r01_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    (tools/gpu_profiles_r02.sh -> profiles/r02_pmc_summary.json; FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as fh:
-            k = json.load(fh)["kernels"][kernel_key]
+            kernels = json.load(fh)["kernels"]
+            k = kernels.get(kernel_key) or kernels[kernel_key + "<58>"]
         return k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]
     except Exception:
         return None
@@ -316,7 +317,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE) from the committed rocprofv3 --pmc "
-                                         "passes of this command (profiles/r01_pmc_summary.json); null for other shapes",
+                                         "passes of this command (profiles/r02_pmc_summary.json); null for other shapes",
                          "note": "achieved = ALGORITHMIC (dense-count) flops of the dominant kernel / its HIP-event duration; the kernels exploit "
                                  "the flow map's structure and execute fewer flops than the dense count (DESIGN.md)",
                          "whole_step_algorithmic_TFLOPs": step_tf, "whole_step_frac_fp64": step_tf / PEAK_FP64_TFLOPS,
