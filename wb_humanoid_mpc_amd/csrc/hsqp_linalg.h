@@ -243,17 +243,21 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long
     if (c < j.N) {
       const int rb = r0[t] + kk;
       const bool mirror = j.sym && r0[t] != c0[t];
+      // a diagonal tile of a symmetric job: only the elements on / above the diagonal are stored, each also at its mirrored place, so
+      // the result is symmetric to the bit (the two triangles of the accumulator differ by rounding)
+      const bool diag = j.sym && r0[t] == c0[t];
       const int o1 = rb * j.ldc + c, o2 = c * j.ldc + rb;
       double v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = j.Add ? j.scale * acc[t][r] + addv[t][r] : j.scale * acc[t][r];
       auto put = [&](int r) {
+        if (diag && rb + 4 * r > c) return;
         if (SPACES & XTY_C_GLOBAL) {
           ((hsqp_gptr)j.C)[o1 + 4 * r * j.ldc] = v[r];
-          if (mirror) ((hsqp_gptr)j.C)[o2 + 4 * r] = v[r];
+          if (mirror || diag) ((hsqp_gptr)j.C)[o2 + 4 * r] = v[r];
         } else {
           j.C[o1 + 4 * r * j.ldc] = v[r];
-          if (mirror) j.C[o2 + 4 * r] = v[r];
+          if (mirror || diag) j.C[o2 + 4 * r] = v[r];
         }
       };
       if (r0[t] + 16 <= j.M) {
@@ -337,16 +341,16 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
         for (int r = 0; r < M; ++r) {
           const double a = sg * xr[r * sx];
           double* ar = acc + (size_t)r * N;
-          for (int c = j.sym ? (r >> 4) << 4 : 0; c < N; ++c) ar[c] += a * yr[c];
+          for (int c = j.sym ? r : 0; c < N; ++c) ar[c] += a * yr[c];
         }
       }
     }
     for (int r = 0; r < M; ++r)
-      for (int c = j.sym ? (r >> 4) << 4 : 0; c < N; ++c) {
+      for (int c = j.sym ? r : 0; c < N; ++c) {   // symmetric jobs: elements on / above the diagonal, mirrored
         double v = j.scale * acc[(size_t)r * N + c];
         if (j.Add) v += j.Add[r * j.ldadd + c];
         j.C[r * j.ldc + c] = v;
-        if (j.sym && (c >> 4) != (r >> 4)) j.C[c * j.ldc + r] = v;
+        if (j.sym && c != r) j.C[c * j.ldc + r] = v;
       }
   }
 #endif

@@ -27,6 +27,17 @@ constexpr int LDB = 24;                        // leading dimension of the 23-wi
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
 constexpr int EM_GVP = 0, EM_G = NUT, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns; 0..3: partial sums of g
 
+#ifndef HSQP_RIC_WAVE_ELIM
+#define HSQP_RIC_WAVE_ELIM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
+__device__ inline double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#endif
 constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
   union {
@@ -44,7 +55,7 @@ struct RicWS {
   };
   double Em[NUT][LDE];                         // [g partials (4) . | G -> K | . | B^T]
   double dsq[LDB];
-  double sv[NX], sb[NX], bt[NX], btn[NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];
+  double sv[NX], sb[NX], bt2[2][NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
   double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of Acl dx (forward sweep)
   int ok;
 };
@@ -69,7 +80,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       w.S[r][c] = termS ? ((r < NXE && c < NXE) ? termS[r * term_ld + c] : 0.0) : (r == c ? Qf[r] : 0.0);
     } else if (i < NX * NX + NX) {
       const int r = i - NX * NX;
-      w.sv[r] = termS ? (r < NXE ? terms_sign * terms[r] : 0.0) : Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]);
+      const double sr = termS ? (r < NXE ? terms_sign * terms[r] : 0.0) : Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]);
+      w.sv[r] = sr;
+      w.part[4 * r] = sr; w.part[4 * r + 1] = 0.0; w.part[4 * r + 2] = 0.0; w.part[4 * r + 3] = 0.0;   // s travels as four partial sums (P5 -> P2)
     }
     else w.ok = 1;
   }
@@ -85,7 +98,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     WG_FOR(ctx, it, na + NX * LDB + NX) {
       if (it < na) copy_batch<8>(it, NX * NX, q + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
       else if (it < na + NX * LDB) { const int i = it - na, r = i / LDB, c = i % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : 0.0; }
-      else w.bt[it - na - NX * LDB] = q[QP_BV + it - na - NX * LDB];
+      else w.bt2[(N - 1) & 1][it - na - NX * LDB] = q[QP_BV + it - na - NX * LDB];
     }
   }
   WG_SYNC(ctx);
@@ -95,6 +108,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     double* rk = ric + (size_t)k * RIC_SIZE;
     double(*A)[NX] = w.A2[k & 1];
     double(*An)[NX] = w.A2[(k + 1) & 1];
+    const double* btc = w.bt2[k & 1];     // b~ of this stage
+    double* btn = w.bt2[(k + 1) & 1];      // ... of the next one to be processed (k - 1)
     PH_TICK(ctx, 1);
     PH_MARK(ctx);
     // ---- P2: SA = S A, SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
@@ -111,7 +126,12 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         WG_FOR(hc, it, RIC_HELPERS) {
           double t[7];
           if (k > 0) load_batch<7>(it, nh, qn + QP_A, t);
-          if (it < NXE) w.sb[it] = w.sv[it] + dot_strided<NXE>(&w.S[0][it], NX, w.bt);
+          if (it < NX) {   // s of this stage = the four partial sums the previous stage's P5 left (no roll-up phase in between)
+            const double* sp = &w.part[4 * it];
+            const double svi = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+            w.sv[it] = svi;
+            if (it < NXE) w.sb[it] = svi + dot_strided<NXE>(&w.S[0][it], NX, btc);
+          }
           if (k > 0) store_batch<7>(it, nh, t, [&](int i, double v) { An[i / NX][i % NX] = v; });
         }
       }
@@ -158,14 +178,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     //      step is one LDS round trip + the reciprocal chain.  The multiplier is read from the (symmetric) upper part.
 #if defined(__HIP_DEVICE_COMPILE__)
     if (ctx.nthreads >= NUT * 16) {
-      // device path: every lane keeps its three elements of [Lam | I] in registers for the whole sweep; only the pivot
-      // row goes through LDS (row j+1 is published by its owners at the end of step j, when it is final)
-      const int i = ctx.tid >> 4, c0 = ctx.tid & 15;
-      const bool mine = ctx.tid < NUT * 16;
-      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-      if (mine) { e0 = w.fac.Ef[i][c0]; e1 = w.fac.Ef[i][c0 + 16]; e2 = w.fac.Ef[i][c0 + 32]; }
       // the two waves without elimination work fetch the next stage's B~, b~ meanwhile (B is dead since P3): the loads are
-      // issued here, travel while the barriers of the elimination go by, and land in LDS after the sweep
+      // issued here, travel while the elimination goes by, and land in LDS after the sweep
       constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
       const int pt = ctx.tid - 384;
       double pb[NPB];
@@ -173,6 +187,37 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 #pragma unroll
         for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
       }
+#if HSQP_RIC_WAVE_ELIM
+      // device path: the whole sweep inside ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of [Lam | 0 | I]
+      // (23 registers); the pivot of step j and the multipliers Ef[j][i] (row j, read from the symmetric upper part: lane i) come
+      // through v_readlane with compile-time lane numbers; the arithmetic per element is that of the phase-per-column form below.
+      if (ctx.tid < 64) {
+        const int c = ctx.tid < LDF ? ctx.tid : LDF - 1;
+        double e[NUT];
+#pragma unroll
+        for (int i = 0; i < NUT; ++i) e[i] = w.fac.Ef[i][c];
+#pragma unroll
+        for (int j = 0; j < NUT - 1; ++j) {
+          const double rp = fast_rcp(readlane_f64(e[j], j));
+#pragma unroll
+          for (int i = j + 1; i < NUT; ++i) {
+            const double f = readlane_f64(e[j], i) * rp;
+            e[i] -= f * e[j];
+          }
+        }
+        if (ctx.tid < LDF) {
+#pragma unroll
+          for (int i = 1; i < NUT; ++i) w.fac.Ef[i][c] = e[i];
+        }
+      }
+      WG_SYNC(ctx);
+#else
+      // device path: every lane keeps its three elements of [Lam | I] in registers for the whole sweep; only the pivot
+      // row goes through LDS (row j+1 is published by its owners at the end of step j, when it is final)
+      const int i = ctx.tid >> 4, c0 = ctx.tid & 15;
+      const bool mine = ctx.tid < NUT * 16;
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+      if (mine) { e0 = w.fac.Ef[i][c0]; e1 = w.fac.Ef[i][c0 + 16]; e2 = w.fac.Ef[i][c0 + 32]; }
       for (int j = 0; j < NUT - 1; ++j) {
         if (mine && i > j) {
           const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
@@ -183,12 +228,13 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         }
         WG_SYNC(ctx);
       }
+#endif
       if (pt >= 0 && k > 0) {
 #pragma unroll
         for (int t = 0; t < NPB; ++t) {
           const int idx = pt + 128 * t;
           if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
-          else if (idx < NX * NUT + NX) w.btn[idx - NX * NUT] = pb[t];
+          else if (idx < NX * NUT + NX) btn[idx - NX * NUT] = pb[t];
         }
       }
       prefetched_b = true;
@@ -274,7 +320,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
             w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
           } else if (it < 5 * NX) {
             const int r = it - 4 * NX;
-            double s = w.bt[r];
+            double s = btc[r];
 #pragma unroll
             for (int l = 0; l < NUT; ++l) s += w.Em[l][EM_BT + r] * w.kv[l];
             rk[RIC_BCL + r] = (NXE == NX || r < NXE) ? s : 0.0;
@@ -292,7 +338,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 #pragma unroll
               for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb; if (i < NX * LDB) w.B[i / LDB][i % LDB] = t[j]; }
             } else {
-              w.btn[bb - nbb] = qn[QP_BV + bb - nbb];
+              btn[bb - nbb] = qn[QP_BV + bb - nbb];
             }
           }
         }
@@ -301,20 +347,13 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     PH_ARRIVE(ctx, 2);
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
-    // ---- P6: symmetrise S inside the diagonal tiles (the off-diagonal tiles were mirrored), roll s and b~
-    WG_FOR(ctx, i, 4 * 256 + NX) {
-      if (i < 4 * 256) {
-        const int r = 16 * (i >> 8) + ((i >> 4) & 15), c = 16 * (i >> 8) + (i & 15);
-        if (c > r && c < NX) { const double a = 0.5 * (w.S[r][c] + w.S[c][r]); w.S[r][c] = a; w.S[c][r] = a; }
-      } else {
-        const double* sp = &w.part[4 * (i - 4 * 256)];
-        w.sv[i - 4 * 256] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-        if (k > 0) w.bt[i - 4 * 256] = w.btn[i - 4 * 256];
-      }
-    }
-    WG_SYNC(ctx);
+    // (no P6: the symmetric tile job writes the diagonal tiles of S symmetric itself — upper triangle computed, mirrored —, s stays
+    //  in its four partial sums until the next stage's P2 adds them, b~ is double-buffered)
     if (vf) {
-      WG_FOR(ctx, i, VF_SIZE) vf[(size_t)k * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : w.sv[i - NX * NX];
+      WG_FOR(ctx, i, VF_SIZE) {
+        const double* sp = &w.part[4 * (i >= NX * NX ? i - NX * NX : 0)];
+        vf[(size_t)k * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      }
     }
     PH_TICK(ctx, 6);
   }
