@@ -113,7 +113,7 @@ def test_first_linesearch_iterations_at_full_size_equal_the_oracle(model, cmodel
             # and 2.2e-8 (config 3) = 5e-10 / 6e-11 of the step, allowed: 1e-8 + 1e-9 |step|_inf
             lim = TRAJ_ABS + (0.0 if it == 0 else 1e-9 * max(np.abs(r["dx"]).max(), np.abs(r["du"]).max()))
             assert np.abs(out["x"][0] - ls["x"]).max() <= lim and np.abs(out["u"][0] - ls["u"]).max() <= lim, it
-            assert_perf(out["perf_after"][0], ls["perf"], f"{name} iteration {it}")
+            assert_perf(out["perf_after"][0], ls["perf"], f"{name} iteration {it}", rel=1e-10 if it == 0 else 1e-9)   # same relaxation (measured 2.4e-10)
             xs, us = out["x"], out["u"]
             xo, uo = out["x"][0], out["u"][0]      # the oracle follows the device's trajectory: errors are per iteration, not compounded
     finally:
