@@ -122,6 +122,27 @@ def test_kernel_sources_on_the_event_grid_equal_the_oracle(model, oracle, emu, s
     emu.emu_destroy(h)
 
 
+def test_event_grid_phases_are_race_free(model):
+    """The reverse-order host build (every phase executes its items backwards) reproduces the forward build bit for bit on the
+    event grid too (jump_node_qp and the dt = 0 paths of the LQ / value phases)."""
+    x0, x, u, par, dts, _, _, _ = walk_problem_with_events(model, perturb_seed=5)
+    n = len(dts)
+    outs = []
+    for lib_name in ("libhsqp_hostemu.so", "libhsqp_hostemu_rev.so"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu")])
+        lib = C.CDLL(os.path.join(HERE, "hostemu", lib_name))
+        lib.emu_create.restype = C.c_void_p
+        err = C.create_string_buffer(256)
+        h = C.c_void_p(lib.emu_create(C.byref(model.desc), err, 256))
+        P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        d = np.ascontiguousarray(dts)
+        assert lib.emu_sqp_iteration(h, n, C.c_double(0.0), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), None, P(d)) == 0
+        outs.append((dx.copy(), du.copy(), pa.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_policy_interpolation_on_a_grid_with_events(emu, rng):
     N = 7
     dts = np.array([0.03, 0.02, 0.0, 0.035, 0.035, 0.0, 0.01])
@@ -225,3 +246,10 @@ def test_device_centroidal_event_grid_equals_the_oracle(cmodel, coracle):
     assert_step(out, r, 0, "centroidal event grid")
     assert_perf(out["perf_after"][0], r["perf_after"], "after")
     assert not out["du"][0, np.flatnonzero(dts == 0.0)].any()
+    # the parallel-in-time sweep on the same grid (an event stage is the scan element (I, defect, 0, 0, 0))
+    s2 = HipSqpSolver(cmodel, max_nodes=N, max_batch=1, riccati="parallel")
+    try:
+        out2 = s2.run(x0p, x, u, par, dts)
+    finally:
+        s2.close()
+    assert_step(out2, r, 0, "centroidal event grid, scan")
