@@ -202,6 +202,39 @@ __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, cons
     for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
 }
 
+// ---- input recovery + full-step trial + its value pass in ONE kernel (the first evaluation of every iteration): k_step alone is
+//      HBM-bound (35 KB of gains / projection per node, 3.8 TB/s) while the value pass is issue-bound, so the reads of the one hide
+//      under the arithmetic of the other.  One wave per node; the step's scratch aliases the stage workspace (dead until the value
+//      pass starts), the stepped (x, u, x_next) go straight into the value pass's input slots — results are bit-identical to
+//      k_step followed by k_lq<false>.
+__global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const DevModel* __restrict__ dm, const double* __restrict__ qp, const double* __restrict__ ric,
+                                                                          const double* __restrict__ dx, const double* __restrict__ x, const double* __restrict__ u,
+                                                                          const double* __restrict__ par, const double* __restrict__ dts, int N, double alpha,
+                                                                          double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
+                                                                          double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  LqWST<false>& w = *reinterpret_cast<LqWST<false>*>(hsqp_smem);
+  static_assert(sizeof(StepWS) <= sizeof(w.st), "the step scratch aliases the stage workspace");
+  StepWS& sw = *reinterpret_cast<StepWS*>(&w.st);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
+  step_node(ctx, sw, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4);
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, NX + NU + NX) {
+    if (i < NX) w.nw.x[i] = x[xo + i] + alpha * sw.dx[i];
+    else if (i < NX + NU) w.nw.u[i - NX] = u[uo + i - NX] + alpha * sw.du[i - NX];
+    else {
+      const int j = i - NX - NU;
+      const double v = x[xo + NX + j] + alpha * dx[xo + NX + j];
+      w.xnext[j] = v;
+      if (k == N - 1) x_new[xo + NX + j] = v;   // the last node of an instance also steps x_N
+    }
+  }
+  WG_SYNC(ctx);
+  lq_node<false, true>(ctx, *dm, w, nullptr, nullptr, nullptr, par + ((size_t)b * (N + 1) + k) * NP, dts[node], nullptr, misc + (size_t)node * 8);
+}
+
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
 __global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
                                                 const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
@@ -539,6 +572,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
+  if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_step_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
   hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   hipError_t a5 = hipFuncSetAttribute((const void*)k_riccati<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
@@ -751,20 +785,21 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     else
       hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                          h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
-    hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                       h->d_xnew, h->d_unew, h->d_stepinfo);
+    if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
+    if (cent)
+      hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+                         h->d_xnew, h->d_unew, h->d_stepinfo);
+    else   // whole-body: the step and its value pass are one kernel (k_step_value)
+      hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
+                         h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
     if (want_kkt) {
       HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
       HCHECK(hipMemsetAsync(h->d_ginf, 0, (size_t)B * 8, h->stream));
       hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
     }
-    if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
     if (cent)
       hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
                          (const LsState*)nullptr);
-    else
-      hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
-                         N, (double*)nullptr, h->d_misc, h->d_prof + 384, (const LsState*)nullptr);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
                        (const LsState*)nullptr);
     hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,

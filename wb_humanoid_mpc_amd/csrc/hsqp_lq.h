@@ -90,7 +90,9 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
 
 // Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory); misc[0..3] = {ne, dt*cost, dt*|eq|^2, dt*|b|^2}.
 // DERIV = false: values only (performance index); rec is not touched and may be null.
-template <bool DERIV>
+// PRELOADED: w.nw.x, w.nw.u and w.xnext already hold the node's (x, u, x_next) — the fused step + value kernel writes the stepped
+// values there — and x / u / xnext are not read.
+template <bool DERIV, bool PRELOADED = false>
 HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w, const double* x, const double* u, const double* xnext,
                      const double* par, double dt, double* rec, double* misc) {
 #if HSQP_DM_LDS
@@ -107,10 +109,10 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
 #endif
   stage_topology(ctx, dm, w.st);
   WG_FOR(ctx, i, NX + NU + NP + NX) {
-    if (i < NX) w.nw.x[i] = x[i];
-    else if (i < NX + NU) w.nw.u[i - NX] = u[i - NX];
+    if (i < NX) { if (!PRELOADED) w.nw.x[i] = x[i]; }
+    else if (i < NX + NU) { if (!PRELOADED) w.nw.u[i - NX] = u[i - NX]; }
     else if (i < NX + NU + NP) w.nw.par[i - NX - NU] = par[i - NX - NU];
-    else w.xnext[i - NX - NU - NP] = xnext[i - NX - NU - NP];
+    else if (!PRELOADED) w.xnext[i - NX - NU - NP] = xnext[i - NX - NU - NP];
   }
   WG_SYNC(ctx);
   for (int s = 0; s < 4; ++s) {
