@@ -481,7 +481,7 @@ static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 extern "C" {
 
-const char* hsqp_version(void) { return "hsqp-hip 0.1 (gfx950, f64)"; }
+const char* hsqp_version(void) { return "hsqp-hip 0.2 (gfx950, f64)"; }
 
 int hsqp_device_count(void) {
   int n = 0;
