@@ -65,8 +65,8 @@ int iterate_instance(const DevModel& dm, int N, double dt, const double* x_init,
   else riccati_backward(ctx, rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, nullptr);
   if (!rw.ok) return HSQP_ERR_NUMERIC;
   double t2 = omp_get_wtime();
-  if (cent) riccati_forward<CNX>(ctx, rw, x_init, x, ric.data(), N, dx);
-  else riccati_forward(ctx, rw, x_init, x, ric.data(), N, dx);
+  if (cent) riccati_forward<CNX>(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx);
+  else riccati_forward(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx);
   double pa0 = 0, pa1 = 0, pa2 = 0;
 #pragma omp parallel for num_threads(inner) schedule(static) if (inner > 1)
   for (int k = 0; k < N; ++k) {

@@ -214,8 +214,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
-  if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, ric.data(), N, dx);
-  else riccati_forward(ctx, *rw, x_init, x, ric.data(), N, dx);
+  if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
+  else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();
   for (int k = 0; k < N; ++k)
     step_node(ctx, *sw, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],

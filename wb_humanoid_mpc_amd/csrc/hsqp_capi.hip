@@ -121,7 +121,7 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
   const int bad = __syncthreads_or(mybad);
   riccati_backward<NXE>(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
   PH_TICK(ctx, 0);
-  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, ricb, N, dx + (size_t)b * (N + 1) * NX);
+  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, qpb, ricb, N, dx + (size_t)b * (N + 1) * NX);
   PH_TICK(ctx, 10);
   // OR-accumulated over the iterations of one hsqp_iterate_device call (the host clears it once per call): a numeric failure
   // in an early iteration must not be masked by a later clean one
@@ -179,12 +179,12 @@ __global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __re
   }
 }
 template <int n>
-__global__ __launch_bounds__(256) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ ric, int N,
-                                                      double* __restrict__ dx) {
+__global__ __launch_bounds__(RIC_THREADS) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+                                                              const double* __restrict__ ric, int N, double* __restrict__ dx) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
-  riccati_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, ric + (size_t)b * N * RIC_SIZE, N, dx + (size_t)b * (N + 1) * NX);
+  riccati_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, qp + (size_t)b * N * QP_SIZE, ric + (size_t)b * N * RIC_SIZE, N, dx + (size_t)b * (N + 1) * NX);
 }
 
 // ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
@@ -778,7 +778,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                          (const double*)nullptr, h->d_ric, N, h->d_status, h->d_vf);
       hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
                          (const double*)h->d_vf, h->d_ric, N, h->d_status, want_kkt ? h->d_vf2 : (double*)nullptr);
-      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(256), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_ric, N, h->d_dx);
+      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_ric, N, h->d_dx);
     } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
       hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                          h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);

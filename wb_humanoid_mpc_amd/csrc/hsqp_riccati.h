@@ -6,9 +6,11 @@
 //   [Lam | G | g | B~^T] = [R~ + B~^T SB | P~ + B~^T SA | r~ + B~^T sb | B~^T]            (23 x 140, augmented)
 //   right-looking Cholesky of Lam applied to the whole augmented matrix:  U = L^T, Z = L^-1 G, z = L^-1 g, Y = L^-1 B~^T
 //   S = Q~ + A~^T SA - Z^T Z,  s = q~ + A~^T sb - Z^T z          (= Q + A^T S A - G^T Lam^-1 G)
-//   Acl = A~ - Y^T Z,  bcl = b~ - Y^T z                           (closed loop: dx+ = Acl dx + bcl)
-// so no triangular back-substitution sits on the serial critical path.  The forward sweep is the
-// 58x58 mat-vec chain dx+ = Acl dx + bcl; the feed-forward/feedback inputs
+//   K = -Lam^-1 G,  k = -Lam^-1 g
+// so no triangular back-substitution sits on the serial critical path.  The forward sweep is the mat-vec chain
+//   dx+ = A~ dx + B~ (K dx + k) + b~   (A~ dx and K dx in one phase, then the 23-term B~ ut rows);
+// the closed-loop matrix A~ + B~ K is never formed: it is not needed by the backward recursion, and forming it there put
+// 96 matrix instructions and four tile calls per stage on the serial path.  The feed-forward/feedback inputs
 //   ut = -U^-1 (Z dx + z),  du = Px dx + Pu ut + Pe
 // are then recovered for all nodes in parallel (step_node).  Every product is a register-tiled
 // X^T Y contraction (hsqp_linalg.h).
@@ -18,14 +20,12 @@
 
 namespace hsqp {
 
-constexpr int RIC_ACL = 0;                     // [58][58] closed-loop transition
-constexpr int RIC_BCL = RIC_ACL + NX * NX;     // [58]
-constexpr int RIC_K = RIC_BCL + NX;            // [23][58] feedback gain  K = -Lam^-1 G
+constexpr int RIC_K = 0;                       // [23][58] feedback gain  K = -Lam^-1 G
 constexpr int RIC_KV = RIC_K + NUT * NX;       // [23]     feed-forward   k = -Lam^-1 g
 constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
 constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
-constexpr int EM_GVP = 0, EM_G = NUT, EM_BT = NUT + NX + 1, LDE = NUT + NX + 1 + NX;   // 140 columns; 0..3: partial sums of g
+constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
 
 #ifndef HSQP_RIC_WAVE_ELIM
 #define HSQP_RIC_WAVE_ELIM 1
@@ -53,7 +53,7 @@ struct RicWS {
     double SB[NX][LDB];
     double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam is formed)
   };
-  double Em[NUT][LDE];                         // [g partials (4) . | G -> K | . | B^T]
+  double Em[NUT][LDE];                         // [g partials (4) . | G -> K | .]
   double dsq[LDB];
   double sv[NX], sb[NX], bt2[2][NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
   double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of Acl dx (forward sweep)
@@ -155,7 +155,6 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           double t[7];
           if (k > 0) load_batch<7>(it, NX * NX - nh, qn + QP_A + nh, t);
           const double rv = (it < 4 * NUT && (it & 3) == 0) ? q[QP_RV + (it >> 2)] : 0.0;
-          for (int j = it; j < NUT * NX; j += RIC_HELPERS) { const int r = j / NX, c = j % NX; w.Em[r][EM_BT + c] = w.B[c][r]; }
           for (int j = it; j < NUT * (LDF - NUT); j += RIC_HELPERS) { const int r = j / (LDF - NUT), c = NUT + j % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
           if (it < 4 * NUT) {   // g = r~ + B^T sb in four partial sums per row (columns 0..3 of Em, added where g is used)
             const int r = it >> 2, p = it & 3;
@@ -303,12 +302,11 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       XtyJob js = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
       js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
       js.sym = 1;   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
-      const XtyJob jobs[2] = {js, xty_job(NXE, NXE, NUT, &w.Em[0][EM_BT], LDE, &w.Em[0][EM_G], LDE, rk + RIC_ACL, NX, &A[0][0], NX)};
       constexpr int nbb = nbatches(NX * LDB, 8);
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
+      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &js, 1);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, 5 * NX + NUT * NX) {
+        WG_FOR(hc, it, 4 * NX + NUT * NX) {
           if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in P6): short chains, 232 lanes
             const int r = it >> 2, p = it & 3;
             constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
@@ -318,14 +316,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 #pragma unroll
             for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
             w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
-          } else if (it < 5 * NX) {
-            const int r = it - 4 * NX;
-            double s = btc[r];
-#pragma unroll
-            for (int l = 0; l < NUT; ++l) s += w.Em[l][EM_BT + r] * w.kv[l];
-            rk[RIC_BCL + r] = (NXE == NX || r < NXE) ? s : 0.0;
           } else {
-            const int j = it - 5 * NX;
+            const int j = it - 4 * NX;
             rk[RIC_K + j] = (NXE == NX || j % NX < NXE) ? w.Em[j / NX][EM_G + j % NX] : 0.0;
           }
         }
@@ -359,58 +351,105 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
   }
 }
 
-// Forward sweep dx+ = Acl dx + bcl (serial over stages); writes dx [N+1][58].
+// Forward sweep dx+ = A~ dx + B~ (K dx + k) + b~ (serial over stages); writes dx [N+1][58].  qp: the stage QP records, ric: the gains.
+// Three phases per stage: (1) the partial sums of A~ dx (58 rows) and K dx (23 rows), four per row; (2) the partial sums of B~ ut with
+// ut = k + K dx taken from the partial sums of (1) by every item itself (no separate phase for 23 numbers); (3) dx+.
 template <int NXE = NX>
-HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* ric, int N, double* dx_out) {
+HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* qp, const double* ric, int N, double* dx_out) {
   WG_FOR(ctx, i, NX) {
     const double d = x_init[i] - x[i];
     w.dx[i] = d;
     dx_out[i] = d;
   }
   WG_SYNC(ctx);
+  constexpr int NC = (NXE + 3) / 4, NCB = (NUT + 3) / 4;
+  constexpr int NR1 = 4 * (NX + NUT);            // items of phase 1: rows of A~ (NX), then rows of K (NUT), four partial sums each
+  double* part1 = w.SA[0];                       // the sweep's scratch: the backward sweep's SA is dead
+  double* part2 = w.SA[0] + NR1;
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (ctx.nthreads >= NXE * 4) {
-    // device path: the closed-loop rows come from global memory (written by the backward sweep); the row slice and bcl of stage
-    // k + 1 are fetched into registers while stage k is being combined, so the chain only waits on LDS and the two barriers
-    constexpr int NC = (NXE + 3) / 4;
+  if (ctx.nthreads >= NR1 + NUT) {
+    // device path: the row slices of stage k + 1 are fetched into registers while stage k is being combined, so the chain only waits
+    // on LDS and the three barriers.  Item it < NR1 owns row it >> 2 of [A~; K] (columns p + 4c) and, if it < 4 NX, row it >> 2 of
+    // B~ as well; items NR1 .. NR1 + NUT - 1 carry k.
     const int it = ctx.tid, row = it >> 2, p = it & 3;
-    const bool mine = it < NXE * 4;
-    double a[NC], an[NC], bc = 0.0, bcn = 0.0;
+    const bool rowA = it < 4 * NX, rowK = it >= 4 * NX && it < NR1, isk = it >= NR1 && it < NR1 + NUT;
+    const bool liveA = rowA && (NXE == NX || row < NXE);
+    double a[NC], an[NC], bq[NCB], bqn[NCB], sc = 0.0, scn = 0.0;   // sc: b~ of the row (p == 0 items of A~ rows) or k (isk items)
+    auto fetch = [&](int k, double* av, double* bv, double& s1) {
+      const double* q = qp + (size_t)k * QP_SIZE;
+      const double* rk = ric + (size_t)k * RIC_SIZE;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; an[c] = (mine && cc < NXE) ? ric[RIC_ACL + row * NX + cc] : 0.0; }
-    if (it < NX) bcn = (NXE == NX || it < NXE) ? ric[RIC_BCL + it] : 0.0;
+      for (int c = 0; c < NC; ++c) {
+        const int cc = p + 4 * c;
+        av[c] = (cc < NXE) ? (liveA ? q[QP_A + row * NX + cc] : (rowK ? rk[RIC_K + (row - NX) * NX + cc] : 0.0)) : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) { const int cc = p + 4 * c; bv[c] = (liveA && cc < NUT) ? q[QP_B + row * NUT + cc] : 0.0; }
+      s1 = (liveA && p == 0) ? q[QP_BV + row] : (isk ? rk[RIC_KV + it - NR1] : 0.0);
+    };
+    fetch(0, an, bqn, scn);
     for (int k = 0; k < N; ++k) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) a[c] = an[c];
-      bc = bcn;
-      if (k + 1 < N) {
-        const double* rn = ric + (size_t)(k + 1) * RIC_SIZE;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; an[c] = (mine && cc < NXE) ? rn[RIC_ACL + row * NX + cc] : 0.0; }
-        if (it < NX) bcn = (NXE == NX || it < NXE) ? rn[RIC_BCL + it] : 0.0;
-      }
-      if (mine) {
+      for (int c = 0; c < NCB; ++c) bq[c] = bqn[c];
+      sc = scn;
+      if (k + 1 < N) fetch(k + 1, an, bqn, scn);
+      if (it < NR1) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[c] * w.dx[cc]; }
-        w.part[it] = s;
+        part1[it] = s;
+      } else if (isk) w.kv[it - NR1] = sc;
+      WG_SYNC(ctx);
+      if (rowA) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          const int j = p + 4 * c, jc = j < NUT ? j : NUT - 1;
+          const double* pj = &part1[4 * (NX + jc)];
+          const double utj = w.kv[jc] + ((pj[0] + pj[1]) + (pj[2] + pj[3]));
+          s += (j < NUT) ? bq[c] * utj : 0.0;
+        }
+        part2[it] = (p == 0 ? sc : 0.0) + s;      // b~ rides on the first partial sum
       }
       WG_SYNC(ctx);
-      double s = 0.0;
-      if (it < NX) s = (NXE == NX || it < NXE) ? bc + ((w.part[4 * it] + w.part[4 * it + 1]) + (w.part[4 * it + 2] + w.part[4 * it + 3])) : w.dx[it];
-      if (it < NX) { w.dx[it] = s; dx_out[(size_t)(k + 1) * NX + it] = s; }   // every partial sum read dx before the barrier above
+      if (it < NX) {
+        const double* p1 = &part1[4 * it];
+        const double* p2 = &part2[4 * it];
+        // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
+        const double s = (NXE == NX || it < NXE) ? ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p2[0] + p2[1]) + (p2[2] + p2[3])) : w.dx[it];
+        w.dx[it] = s;
+        dx_out[(size_t)(k + 1) * NX + it] = s;
+      }
       WG_SYNC(ctx);
     }
     return;
   }
 #endif
   for (int k = 0; k < N; ++k) {
+    const double* q = qp + (size_t)k * QP_SIZE;
     const double* rk = ric + (size_t)k * RIC_SIZE;
-    WG_FOR(ctx, it, NXE * 4) w.part[it] = matvec_part<NXE>(rk + RIC_ACL + (it >> 2) * NX, w.dx, it & 3);
+    WG_FOR(ctx, it, NR1 + NUT) {
+      if (it < 4 * NX) part1[it] = ((it >> 2) < NXE) ? matvec_part<NXE>(q + QP_A + (it >> 2) * NX, w.dx, it & 3) : 0.0;
+      else if (it < NR1) part1[it] = matvec_part<NXE>(rk + RIC_K + ((it >> 2) - NX) * NX, w.dx, it & 3);
+      else w.kv[it - NR1] = rk[RIC_KV + it - NR1];
+    }
+    WG_SYNC(ctx);
+    WG_FOR(ctx, it, 4 * NX) {
+      const int row = it >> 2, p = it & 3;
+      double s = 0.0;
+      for (int c = 0; c < NCB; ++c) {
+        const int j = p + 4 * c;
+        if (j < NUT && row < NXE) { const double* pj = &part1[4 * (NX + j)]; s += q[QP_B + row * NUT + j] * (w.kv[j] + ((pj[0] + pj[1]) + (pj[2] + pj[3]))); }
+      }
+      part2[it] = ((p == 0 && row < NXE) ? q[QP_BV + row] : 0.0) + s;
+    }
     WG_SYNC(ctx);
     WG_FOR(ctx, i, NX) {
-      // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
-      const double s = (NXE == NX || i < NXE) ? rk[RIC_BCL + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3])) : w.dx[i];
+      const double* p1 = &part1[4 * i];
+      const double* p2 = &part2[4 * i];
+      const double s = (NXE == NX || i < NXE) ? ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p2[0] + p2[1]) + (p2[2] + p2[3])) : w.dx[i];
       w.dx[i] = s;
       dx_out[(size_t)(k + 1) * NX + i] = s;
     }
