@@ -300,6 +300,28 @@ HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The tiles of `njobs` jobs dealt round-robin over W waves of ANY count (rank = this wave's position among them, < 0: the wave does not
+// take part); a wave takes its tiles of a job two at a time.  Lets a phase spread its matrix work over all the waves that have
+// nothing else on its critical path (k_riccati: the helper waves take tiles after their copies, seven waves form S A~ while the
+// eighth eliminates).
+template <int SPACES = 0>
+HSQP_D void xty_deal(const XtyJob* jobs, int njobs, int rank, int W, int lane) {
+  if (rank < 0) return;
+  int g0 = 0;
+  for (int jn = 0; jn < njobs; ++jn) {
+    const XtyJob& j = jobs[jn];
+    const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
+    const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
+    int t = rank - g0 % W;
+    if (t < 0) t += W;
+    for (; t + W < nt; t += 2 * W) { const int pair[2] = {xty_tile_id(j.sym, tn, t), xty_tile_id(j.sym, tn, t + W)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane); }
+    if (t < nt) { const int one = xty_tile_id(j.sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane); }
+    g0 += nt;
+  }
+}
+#endif
+
 // Executes `njobs` independent products; must be called by every thread of the workgroup (no barrier inside).
 // UNROLL: the loop over the jobs is unrolled so that each job gets code specialised for its (constant) shape and the
 // descriptors stay in registers — pays off for long contractions in throughput kernels, not inside the Riccati stage loop.

@@ -2,8 +2,9 @@
 // the same QP with HPIPM through ocs2's HpipmInterface — the minimiser is unique, A.1).
 //
 // Backward sweep, one workgroup per MPC instance, stage matrices in LDS:
-//   SA = S+ A~, SB = S+ B~, sb = s+ + S+ b~
-//   [Lam | G | g | B~^T] = [R~ + B~^T SB | P~ + B~^T SA | r~ + B~^T sb | B~^T]            (23 x 140, augmented)
+//   SB = S+ B~, sb = s+ + S+ b~
+//   [Lam | G | g] = [R~ + B~^T SB | P~ + SB^T A~ | r~ + B~^T sb]                                (G from SB: S+ is symmetric)
+//   SA = S+ A~ is only needed by the update of S, so it is formed by the otherwise idle waves WHILE one wave eliminates [Lam | I]
 //   right-looking Cholesky of Lam applied to the whole augmented matrix:  U = L^T, Z = L^-1 G, z = L^-1 g, Y = L^-1 B~^T
 //   S = Q~ + A~^T SA - Z^T Z,  s = q~ + A~^T sb - Z^T z          (= Q + A^T S A - G^T Lam^-1 G)
 //   K = -Lam^-1 G,  k = -Lam^-1 g
@@ -27,9 +28,6 @@ constexpr int LDB = 24;                        // leading dimension of the 23-wi
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
 constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
 
-#ifndef HSQP_RIC_WAVE_ELIM
-#define HSQP_RIC_WAVE_ELIM 1
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
 __device__ inline double readlane_f64(double v, int lane) {
@@ -40,13 +38,11 @@ __device__ inline double readlane_f64(double v, int lane) {
 #endif
 constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
-  union {
-    double S[NX][NX];
-    struct {                                   // scratch of the factorisation (S is dead between P2 and P5)
-      double Ef[LDB][LDF];                     // [Lam | 0 | I] -> [U-ish | . | unit-lower inverse] -> columns 24.. scaled to L^-1
-      double LinvT[LDB][LDB];                  // (L^-1)^T
-    } fac;
-  };
+  double S[NX][NX];                            // alive through the whole stage: S A~ is formed during the factorisation
+  struct {                                     // scratch of the factorisation
+    double Ef[LDB][LDF];                       // [Lam | 0 | I] -> [U-ish | . | unit-lower inverse] -> columns 24.. scaled to L^-1
+    double LinvT[LDB][LDB];                    // (L^-1)^T
+  } fac;
   double A2[2][NX][NX], SA[NX][NX];            // A2: double-buffered A~ (stage k uses A2[k & 1])
   double B[NX][LDB];
   union {
@@ -54,11 +50,25 @@ struct RicWS {
     double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam is formed)
   };
   double Em[NUT][LDE];                         // [g partials (4) . | G -> K | .]
-  double dsq[LDB];
-  double sv[NX], sb[NX], bt2[2][NX], dx[NX], dxn[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
+  double sv[NX], sb[NX], bt2[2][NX], dx[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
   double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of Acl dx (forward sweep)
   int ok;
 };
+
+// The matrix products of one phase of the sweep.  In the 512-thread kernels every wave from `first_wave` on takes tiles (dealt
+// round-robin; a wave with copies / vector work in the same phase calls this AFTER that work); any other context (host build,
+// smaller workgroups) runs them on its matrix half as before.
+// waves [first_wave, first_wave + n_waves) take the tiles; n_waves = 0: the matrix half as before
+HSQP_HD void ric_products(const Ctx& ctx, const XtyJob* jobs, int njobs, int first_wave = 0, int n_waves = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads == 512 && n_waves > 0) {
+    const int r = (ctx.tid >> 6) - first_wave;
+    xty_deal(jobs, njobs, r < n_waves ? r : -1, n_waves, ctx.tid & 63);
+    return;
+  }
+#endif
+  if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, njobs);
+}
 
 // qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
 // vf (optional, [N+1][VF_SIZE]): the value function S_k, s_k of every node, for the KKT check (lam_k = S_k dx_k + s_k).
@@ -112,11 +122,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     double* btn = w.bt2[(k + 1) & 1];      // ... of the next one to be processed (k - 1)
     PH_TICK(ctx, 1);
     PH_MARK(ctx);
-    // ---- P2: SA = S A, SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
+    // ---- P2: SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
+    const XtyJob job_sa = xty_job(NXE, NXE, NXE, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX);   // runs under the elimination (P4a)
     {
-      const XtyJob jobs[2] = {xty_job(NXE, NXE, NXE, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX),
-                              xty_job(NXE, NUT, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB)};
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
+      const XtyJob job_sb = xty_job(NXE, NUT, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         // first half of the next stage's A~ into the other buffer (second half in P3).  One item = one batch of global loads,
@@ -135,6 +144,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (k > 0) store_batch<7>(it, nh, t, [&](int i, double v) { An[i / NX][i % NX] = v; });
         }
       }
+      ric_products(ctx, &job_sb, 1);
     }
     PH_ARRIVE(ctx, 0);
     WG_SYNC(ctx);
@@ -142,10 +152,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     PH_MARK(ctx);
     // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
     {
-      const XtyJob jobs[2] = {xty_job(NUT, NXE, NXE, &w.B[0][0], LDB, &w.SA[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
+      const XtyJob jobs[2] = {xty_job(NUT, NXE, NXE, &w.SB[0][0], LDB, &A[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
                               xty_job(NUT, NUT, NXE, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
       constexpr int nh = (NX * NX) / 2, na = nbatches(NX * NX - nh, 7);
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, 2);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         // same structure as in P2: global loads (second half of the next A~, r~) first, then the LDS-only work of the item
@@ -167,6 +176,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (k > 0) store_batch<7>(it, NX * NX - nh, t, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
         }
       }
+      ric_products(ctx, jobs, 2);   // (dealing these tiles to the helper waves as well was measured: 1.87 -> 2.3 ms)
     }
     PH_ARRIVE(ctx, 1);
     WG_SYNC(ctx);
@@ -186,8 +196,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 #pragma unroll
         for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
       }
-#if HSQP_RIC_WAVE_ELIM
-      // device path: the whole sweep inside ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of [Lam | 0 | I]
+      // The whole sweep inside ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of [Lam | 0 | I]
       // (23 registers); the pivot of step j and the multipliers Ef[j][i] (row j, read from the symmetric upper part: lane i) come
       // through v_readlane with compile-time lane numbers; the arithmetic per element is that of the phase-per-column form below.
       if (ctx.tid < 64) {
@@ -209,25 +218,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           for (int i = 1; i < NUT; ++i) w.fac.Ef[i][c] = e[i];
         }
       }
+      // meanwhile the other seven waves form SA = S A~ on the matrix cores (16 tiles): it is not needed before P5
+      ric_products(ctx, &job_sa, 1, 1, 7);
       WG_SYNC(ctx);
-#else
-      // device path: every lane keeps its three elements of [Lam | I] in registers for the whole sweep; only the pivot
-      // row goes through LDS (row j+1 is published by its owners at the end of step j, when it is final)
-      const int i = ctx.tid >> 4, c0 = ctx.tid & 15;
-      const bool mine = ctx.tid < NUT * 16;
-      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-      if (mine) { e0 = w.fac.Ef[i][c0]; e1 = w.fac.Ef[i][c0 + 16]; e2 = w.fac.Ef[i][c0 + 32]; }
-      for (int j = 0; j < NUT - 1; ++j) {
-        if (mine && i > j) {
-          const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
-          const double ej0 = w.fac.Ef[j][c0], ej1 = w.fac.Ef[j][c0 + 16], ej2 = w.fac.Ef[j][c0 + 32];
-          const double f = fji * fast_rcp(pj);
-          e0 -= f * ej0; e1 -= f * ej1; e2 -= f * ej2;
-          if (i == j + 1) { w.fac.Ef[i][c0] = e0; w.fac.Ef[i][c0 + 16] = e1; w.fac.Ef[i][c0 + 32] = e2; }
-        }
-        WG_SYNC(ctx);
-      }
-#endif
       if (pt >= 0 && k > 0) {
 #pragma unroll
         for (int t = 0; t < NPB; ++t) {
@@ -239,6 +232,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       prefetched_b = true;
     } else
 #endif
+    {
+    wg_xty_jobs(ctx, &job_sa, 1);
     for (int j = 0; j < NUT - 1; ++j) {
       WG_FOR(ctx, it, NUT * 16) {
         const int i = it >> 4, c0 = it & 15;
@@ -252,6 +247,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         w.fac.Ef[i][c0 + 32] = ei2 - f * ej2;
       }
       WG_SYNC(ctx);
+    }
     }
     // ---- P4b: Cholesky scaling: L^-1 = D^-1/2 Mi (in place) and its transpose
     WG_FOR(ctx, it, NUT * LDB) {
@@ -303,7 +299,6 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
       js.sym = 1;   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
       constexpr int nbb = nbatches(NX * LDB, 8);
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &js, 1);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         WG_FOR(hc, it, 4 * NX + NUT * NX) {
@@ -335,6 +330,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           }
         }
       }
+      ric_products(ctx, &js, 1);    // (same: 1.87 -> 2.1 ms with waves 4-5 taking the two spare tiles)
     }
     PH_ARRIVE(ctx, 2);
     WG_SYNC(ctx);
