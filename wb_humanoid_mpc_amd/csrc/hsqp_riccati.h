@@ -206,12 +206,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         for (int i = 0; i < NUT; ++i) e[i] = w.fac.Ef[i][c];
 #pragma unroll
         for (int j = 0; j < NUT - 1; ++j) {
-          const double rp = fast_rcp(readlane_f64(e[j], j));
+          const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));   // lane i: the multiplier of row i (one multiply per step, not per row)
 #pragma unroll
-          for (int i = j + 1; i < NUT; ++i) {
-            const double f = readlane_f64(e[j], i) * rp;
-            e[i] -= f * e[j];
-          }
+          for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
         }
         if (ctx.tid < LDF) {
 #pragma unroll
