@@ -5,7 +5,7 @@
 //   SB = S+ B~, sb = s+ + S+ b~
 //   [Lam | G | g] = [R~ + B~^T SB | P~ + SB^T A~ | r~ + B~^T sb]                                (G from SB: S+ is symmetric)
 //   SA = S+ A~ is only needed by the update of S, so it is formed by the otherwise idle waves WHILE one wave eliminates [Lam | I]
-//   right-looking Cholesky of Lam applied to the whole augmented matrix:  U = L^T, Z = L^-1 G, z = L^-1 g, Y = L^-1 B~^T
+//   Gauss-Jordan elimination of [Lam | I] on unscaled rows (one wave, in registers) -> L^-1, L^-T by row scaling;  Z = L^-1 G, z = L^-1 g
 //   S = Q~ + A~^T SA - Z^T Z,  s = q~ + A~^T sb - Z^T z          (= Q + A^T S A - G^T Lam^-1 G)
 //   K = -Lam^-1 G,  k = -Lam^-1 g
 // so no triangular back-substitution sits on the serial critical path.  The forward sweep is the mat-vec chain
@@ -51,7 +51,7 @@ struct RicWS {
   };
   double Em[NUT][LDE];                         // [g partials (4) . | G -> K | .]
   double sv[NX], sb[NX], bt2[2][NX], dx[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
-  double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of Acl dx (forward sweep)
+  double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of A~ dx (forward sweep)
   int ok;
 };
 
@@ -74,7 +74,7 @@ HSQP_HD void ric_products(const Ctx& ctx, const XtyJob* jobs, int njobs, int fir
 // vf (optional, [N+1][VF_SIZE]): the value function S_k, s_k of every node, for the KKT check (lam_k = S_k dx_k + s_k).
 constexpr int VF_SIZE = NX * NX + NX;
 // NXE: number of leading states that take part in the recursion.  NX for the whole-body problem; 35 for the centroidal problem
-// embedded in the 58-state layout, whose padding states are decoupled (A~ = I, B~ = 0, no cost there), so S, s, K, Acl - I, bcl
+// embedded in the 58-state layout, whose padding states are decoupled (A~ = I, B~ = 0, no cost there), so S, s, K
 // vanish on them identically: every product is restricted to the leading NXE x NXE blocks (leading dimensions stay NX) and the
 // padding parts of the outputs are written as zeros / left untouched where nothing reads them.
 // termS / terms (optional): start the recursion from the value function 1/2 x' termS x + terms' x (NXE x NXE, leading dimension term_ld; NXE) instead
@@ -289,7 +289,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     WG_SYNC(ctx);
     PH_TICK(ctx, 4);
     PH_MARK(ctx);
-    // ---- P5: S <- Q + A^T SA - Z^T Z, Acl = A + B K, s <- q + A^T sb - Z^T z, bcl = b + B k ; K -> record;
+    // ---- P5: S <- Q + A^T SA - Z^T Z, s <- q + A^T sb - Z^T z (left as four partial sums) ; K -> record;
     //          prefetch of the next stage's B~, b~ (B is dead since P3)
     {
       XtyJob js = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);

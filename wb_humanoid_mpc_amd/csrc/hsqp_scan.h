@@ -15,8 +15,8 @@
 //
 // Kernels (hsqp_capi.hip): k_scan_init (one workgroup per node: stage -> element), k_scan_combine (one per node and level:
 // Hillis-Steele suffix scan, ceil(log2(N+1)) levels, ping-pong element buffers), k_scan_gains (one per node: ONE stage of the
-// existing Riccati code started from S_{k+1}, s_{k+1} -> K, k, Acl, bcl and S_k for the KKT check), k_scan_forward (the mat-vec
-// roll-out dx+ = Acl dx + bcl).  The record the step / KKT kernels read is the one k_riccati writes.
+// existing Riccati code started from S_{k+1}, s_{k+1} -> K, k and S_k for the KKT check), k_scan_forward (the mat-vec
+// roll-out dx+ = A~ dx + B~ (K dx + k) + b~, riccati_forward).  The record the step / KKT kernels read is the one k_riccati writes.
 //
 // Numerics: M is solved by Gauss-Jordan elimination with row pivoting.  On the projected QPs of the centroidal problem
 // cond(M) <= 1e5 and the scan reproduces the serial recursion to 1e-11 of the step's scale; on the whole-body problem cond(M)
