@@ -38,9 +38,10 @@ constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 #define HSQP_PROJ_THREADS 256
 #endif
 #ifndef HSQP_PROJ_WPE
-#define HSQP_PROJ_WPE 2
+#define HSQP_PROJ_WPE 3
 #endif
-constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 77 KB workspace: two workgroups per CU
+constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 51 KB workspace: three workgroups of four waves per CU
+static_assert(PROJ_THREADS >= 256 && PROJ_THREADS % 64 == 0, "project_node hoists its staging loads assuming >= 256 threads; the Gram tiles are dealt to waves 0..3");
 constexpr int RIC_THREADS = 512;
 constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (22 KB workspace)
 

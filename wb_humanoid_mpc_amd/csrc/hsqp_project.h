@@ -8,6 +8,8 @@
 // The projected input dimension is padded to NUT = 23 with identity (R~ = 1, everything else 0) when
 // more than 12 equality rows are active, so the Riccati kernel sees a fixed stage size.
 #pragma once
+#include <cstddef>
+#include <vector>
 #include "hsqp_linalg.h"
 #include "hsqp_lq.h"
 
@@ -30,28 +32,37 @@ constexpr int QP_SIZE = ((QP_NUT + 1 + 7) / 8) * 8;
 
 constexpr int NTW = NX + NUT;                  // 81: projected stage variable [dx; ut]
 constexpr int LDTM = 88;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
-// The projected residual rows (64 slots + 35 input-weight rows sqrt(d_u) [Px|Pu|Pe]) are processed in two passes so that
-// the workspace stays under 80 KB (two workgroups per CU): pass A = slots 0..47, pass B = slots 48..63 + weight rows.
-constexpr int NRA = 48;                        // residual row slots of pass A
-constexpr int NRB = (NRS - NRA) + NU + 1;      // 16 slots + 35 input-weight rows + 1 zero row = 52
-static_assert(NRA % 4 == 0 && NRB % 4 == 0 && NRB >= NRA, "pass sizes");
+// The 64 residual row slots are projected in passes of NRP rows (24 + 24 + 16) through one small LDS block; the projected
+// Gauss-Newton Hessian J~^T J~ is accumulated ACROSS the passes in registers (the matrix-core accumulators of the 15 tiles on /
+// above the diagonal of its leading 80 x 80 block, dealt to the four waves; the last projected input and the gradient column
+// as per-thread sums), and the 35 input-weight rows sqrt(d_u) [Px | Pu | Pe] are accumulated straight from Tm.  Nothing of the
+// Hessian makes a round trip through memory between the passes, and the workspace is 51 KB: three workgroups per CU.
+constexpr int NRP = 24;
+static_assert(NRP % 4 == 0 && NRS == 2 * NRP + 16, "pass sizes");
+constexpr int NGT = 5;                         // 16-column tiles of the Gram matrix on the matrix cores: columns 0..79
+static_assert(16 * NGT == NTW - 1, "the matrix cores take the leading 80 columns");
 
 constexpr int LDR = 16;
 struct ProjWS {
   union {
     struct {
-      double CDe[NE_MAX][LDJ];
       double Rm[NU + 1][LDR];    // D^T (zero padded to 36 x 16), overwritten by R1
-      double QT[NU][NU];         // Q^T of the Householder QR (rows 0..ne-1 = Q1^T, the rest Q2^T)
-      double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
       double V[NE_MAX][NU + 1];  // Householder vectors
       double beta[NE_MAX], Rdiag[NE_MAX], rinv[LDR], ep[LDR];   // ep: e of the dense rows after the eliminated inputs are substituted
       double part[LDR][4], yk[LDR];   // per-step scratch: partial dots, row k of R
+      double Q1T[NE_MAX][NU];    // rows 0..ned-1 of Q^T (Q1^T); the rows of Q2^T go straight into Tm
+      double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
     } qr;                        // live until Tm is formed
-    double PV[2][6][LDJ];        // then the non-trivial rows of [A|B] (loaded when the QR data is dead) ...
-    double Jt[NRB][LDTM];        // ... then the projected residual rows of the current pass (column 81 = rho')
+    double PV[2][6][LDJ];        // the non-trivial rows of [A|B]: stored while Tm is being formed, over Rm / V / the scalars (dead by then)
+    struct {
+      double Jt[NRP][LDTM];      // the projected residual rows of the current pass (column 81 = rho')
+      double JuT[NU][NRP];       // transposed input block of the residual rows of the current (next) pass; overlaps Wm
+    } ps;
   };
-  double JuT[NU][NRA];           // transposed input block of the residual rows of the current pass
+  union {
+    double Tm[NU][LDTM];         // [Px (58) | Pu (23) | Pe | 0 ...]
+    double CDe[NE_MAX][LDJ];     // the equality rows, until W = R1^-T [C|e] is formed (Tm is written after that)
+  };
   int ne, nut, ok;
   // deflation of the unit rows of D (a swing foot's zero-wrench constraints W_f = 0 fix six inputs outright): the Householder
   // QR only sees the dense rows (ned of them) restricted to the free inputs (nub of them)
@@ -59,11 +70,12 @@ struct ProjWS {
   int ub[NU];                    // free input indices, then the eliminated ones (positions nub..NU-1)
   int urow[NU];                  // for an eliminated input: its unit constraint row; -1 for a free input
   int rd[NE_MAX];                // dense constraint rows
-  double Tm[NU][LDTM];           // [Px (58) | Pu (23) | Pe | 0 0]
+  double eu[NU];                 // -e of the unit row of an eliminated input (0 for a free input)
   double bvec[64];
   double rho[NRS], d[LDJ], gd[LDJ];   // mirror one contiguous piece of the LQ record
-  double gacc[LDTM];             // gradient partial sums of pass A
 };
+static_assert(sizeof(double) * 2 * 6 * LDJ <= offsetof(ProjWS, qr.Q1T), "PV may only overlap what is dead while Tm is formed");
+static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
 
 // Event interval (hsqp_problem::dt_nodes[b][k] == 0): the stage of the QP is the identity jump map
 // dx+ = dx + (x_k - x_{k+1}) with no cost and the inputs pinned (R~ = I, everything else zero -> ut = 0, du = 0).  b~ is the defect
@@ -80,6 +92,133 @@ HSQP_HD void jump_node_qp(const Ctx& ctx, const double* rec, double* qp) {
   WG_SYNC(ctx);
 }
 
+// ---- Gram accumulation across the passes: H (+)= X^T diag(s) X over the rows of X (columns 0..81 of Jt or Tm; column 81 carries
+// rho', so the same sums also give the gradient J~^T rho').  Device: each wave owns the accumulators of up to four 16 x 16 tiles on /
+// above the diagonal of the leading 80 x 80 block; threads 0..161 own one element each of column 80 (the last projected input) and
+// of the gradient column.  Host build: a plain upper-triangular array.
+struct GramAcc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  hsqp_d4 acc[4];
+  int xr[4], yc[4], nt;
+  double vs;
+#else
+  std::vector<double> h;         // [NTW][NTW + 1]: h[a][c] for a <= c <= 80, h[a][81] = gradient
+#endif
+};
+
+HSQP_HD void gram_init(const Ctx& ctx, GramAcc& g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int wave = ctx.tid >> 6, i = ctx.tid & 15;
+  g.nt = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int id = wave + 4 * t;                       // 15 tiles dealt round-robin to four waves
+    int tr = 0, tc = id < NGT * (NGT + 1) / 2 ? id : 0;
+    while (tc >= NGT - tr) { tc -= NGT - tr; ++tr; }
+    tc += tr;
+    g.xr[t] = 16 * tr + i;
+    g.yc[t] = 16 * tc + i;
+    g.acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
+    if (id < NGT * (NGT + 1) / 2) g.nt = t + 1;
+  }
+  g.vs = 0.0;
+#else
+  (void)ctx;
+  g.h.assign((size_t)NTW * (NTW + 1), 0.0);
+#endif
+}
+
+// WEIGHT = false: the rows are taken as they are.  WEIGHT = true (the input-weight rows, X = Tm): row k counts with weight du[k], and
+// the gradient column gets gdu[k] on top: sum_k X[k][a] (du[k] X[k][81] + gdu[k]) = (T_u^T (D_u Pe + g_u))[a].
+template <bool WEIGHT, int NR>
+HSQP_HD void gram_rows(const Ctx& ctx, GramAcc& g, const double* X, int ldx, const double* du, const double* gdu) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int kk = (ctx.tid & 63) >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < NR; k0 += 4) {
+    const int k = k0 + kk;
+    const bool ok = (NR % 4 == 0) || k < NR;
+    const double* row = X + (ok ? k : 0) * ldx;
+    const double sc = WEIGHT ? (ok ? du[ok ? k : 0] : 0.0) : 1.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < 3 || g.nt == 4) {
+        const double a = row[g.xr[t]];
+        double b = row[g.yc[t]];
+        if (WEIGHT || NR % 4 != 0) b *= (WEIGHT ? sc : (ok ? 1.0 : 0.0));
+        g.acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, g.acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (ctx.tid < 2 * NTW) {
+    const int a = ctx.tid < NTW ? ctx.tid : ctx.tid - NTW, cb = ctx.tid < NTW ? NTW - 1 : NTW;
+    double s = g.vs;
+#pragma unroll 4
+    for (int r = 0; r < NR; ++r) {
+      double xb = X[r * ldx + cb];
+      if (WEIGHT) xb = du[r] * xb + (cb == NTW ? gdu[r] : 0.0);
+      s += X[r * ldx + a] * xb;
+    }
+    g.vs = s;
+  }
+#else
+  (void)ctx;
+  for (int r = 0; r < NR; ++r)
+    for (int a = 0; a < NTW; ++a) {
+      const double xa = X[r * ldx + a];
+      double* ha = &g.h[(size_t)a * (NTW + 1)];
+      for (int c = a; c <= NTW; ++c) {
+        double xb = X[r * ldx + c];
+        if (WEIGHT) xb = du[r] * xb + (c == NTW ? gdu[r] : 0.0);
+        ha[c] += xa * xb;
+      }
+    }
+#endif
+}
+
+// The accumulated blocks to the QP record: Q~ (+ diag d_x), P~, R~ (identity on the unused projected inputs), q~ (+ g_x), r~.
+HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int nut, double* qp) {
+  auto put = [&](int r, int c, double v) {             // r <= c <= 80
+    if (c < NX) {
+      if (r == c) v += w.d[r];
+      qp[QP_Q + r * NX + c] = v;
+      if (r != c) qp[QP_Q + c * NX + r] = v;
+    } else if (r < NX) {
+      qp[QP_P + (c - NX) * NX + r] = v;
+    } else {
+      const int a = r - NX, b = c - NX;
+      if (a >= nut || b >= nut) v = (a == b) ? 1.0 : 0.0;
+      qp[QP_R + a * NUT + b] = v;
+      if (a != b) qp[QP_R + b * NUT + a] = v;
+    }
+  };
+  auto put_grad = [&](int a, double v) {
+    if (a < NX) qp[QP_QV + a] = v + w.gd[a]; else qp[QP_RV + a - NX] = v;
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int i = ctx.tid & 15, kk = (ctx.tid & 63) >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < 3 || g.nt == 4) {
+      const int r0 = g.xr[t] - i, c = g.yc[t];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = r0 + kk + 4 * reg;
+        if (r <= c) put(r, c, g.acc[t][reg]);
+      }
+    }
+  }
+  if (ctx.tid < NTW) put(ctx.tid, NTW - 1, g.vs);
+  else if (ctx.tid < 2 * NTW) put_grad(ctx.tid - NTW, g.vs);
+#else
+  (void)ctx;
+  for (int a = 0; a < NTW; ++a) {
+    for (int c = a; c < NTW; ++c) put(a, c, g.h[(size_t)a * (NTW + 1) + c]);
+    put_grad(a, g.h[(size_t)a * (NTW + 1) + NTW]);
+  }
+#endif
+}
+
 // cent = true: the record comes from the centroidal LQ kernel (hsqp_cent.h): the dense rows of [A|B] - [I|0] are rows 0..11
 // (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false) {
@@ -90,7 +229,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     constexpr int n1 = 64, n2 = NRS + 2 * LDJ, n3 = NE_MAX * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
     double* dst1 = &w.bvec[0];
     double* dst2 = &w.rho[0];
-    double* dst3 = &w.qr.CDe[0][0];
+    double* dst3 = &w.CDe[0][0];
     WG_FOR(ctx, b, nb) {
       double t[8];
 #pragma unroll
@@ -134,21 +273,22 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut, ned = w.ned, nub = w.nub;
+  (void)ne;
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
   // left untouched: its final diagonal goes to Rdiag, the vector to V).
-  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ned && r < nub) ? w.qr.CDe[w.rd[c]][NX + w.ub[r]] : 0.0; if (r == 0) {
+  WG_FOR(ctx, i, (NU + 1) * LDR) { const int r = i / LDR, c = i % LDR; w.qr.Rm[r][c] = (c < ned && r < nub) ? w.CDe[w.rd[c]][NX + w.ub[r]] : 0.0; if (r == 0) {
       w.qr.rinv[c] = 0.0;
       // e' = e - D_a e_U: the eliminated inputs are fixed at -e_U (the unit rows have C = 0)
       double ep = 0.0;
       if (c < ned) {
         const int ri = w.rd[c];
-        ep = w.qr.CDe[ri][NZ];
-        for (int t = nub; t < NU; ++t) { const int ue = w.ub[t]; ep -= w.qr.CDe[ri][NX + ue] * w.qr.CDe[w.urow[ue]][NZ]; }
+        ep = w.CDe[ri][NZ];
+        for (int t = nub; t < NU; ++t) { const int ue = w.ub[t]; ep -= w.CDe[ri][NX + ue] * w.CDe[w.urow[ue]][NZ]; }
       }
       w.qr.ep[c] = ep;
     }
-    if (i < NU) w.d[NX + i] = sqrt(w.d[NX + i]); }   // d_u -> sqrt(d_u) (only used for the weight rows)
+    if (i < NU) w.eu[i] = w.urow[i] >= 0 ? -w.CDe[w.urow[i]][NZ] : 0.0; }   // an eliminated input is fixed at -e of its unit row
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
   // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
@@ -194,8 +334,25 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     WG_SYNC(ctx);
   }
   PH_TICK(ctx, 9);
+  // ---- W = R1^-T [C | e'] over the dense rows: forward substitution per column, the column kept in registers (rows >= ned:
+  //      rinv = 0 -> 0).  Last use of the equality rows: Tm may be written from the next phase on.
+  WG_FOR(ctx, c, NX + 1) {
+    double wc[NE_MAX];
+#pragma unroll
+    for (int i = 0; i < NE_MAX; ++i) {
+      const int ri = w.rd[i];
+      double s = c < NX ? w.CDe[ri][c] : w.qr.ep[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * wc[j];
+      wc[i] = s * w.qr.rinv[i];
+      w.qr.Wm[i][c] = wc[i];
+    }
+  }
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 3);
   // Q^T = H_{ned-1} ... H_0 of the free inputs: one column per item, the column lives in registers while the reflectors are
-  // applied; it is stored at the ORIGINAL input index (column ub[c]); the columns of the eliminated inputs are zero
+  // applied; it belongs to the ORIGINAL input index ub[c].  Rows 0..ned-1 are Q1^T (-> Q1T), rows ned.. are Q2^T = Pu^T, written
+  // straight into Tm; the columns of the eliminated inputs are zero
   WG_FOR(ctx, c, NU) {
     double col[NU];
 #pragma unroll
@@ -210,64 +367,75 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
     const int uc = w.ub[c];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) w.qr.QT[i][uc] = col[i];
+    for (int i = 0; i < NU; ++i) {
+      if (i < NE_MAX && i < ned) w.qr.Q1T[i][uc] = col[i];
+      const int cc = i - ned;
+      if (cc >= 0 && cc < nut) w.Tm[uc][NX + cc] = col[i];
+    }
+#pragma unroll
+    for (int cc = 0; cc < NUT; ++cc) if (cc >= nut) w.Tm[uc][NX + cc] = 0.0;
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 2);
-  // ---- W = R1^-T [C | e'] over the dense rows: forward substitution per column, the column kept in registers (rows >= ned:
-  //      rinv = 0 -> 0)
-  WG_FOR(ctx, c, NX + 1) {
-    double wc[NE_MAX];
+  // ---- staging of the record's [A|B] rows and of the (transposed) input block of the residual rows r0 .. r0+nr.  Device: the
+  //      loads are issued a phase ahead of the stores (registers), so their HBM round trip runs under the phase's other work.
+  constexpr int NPV = 2 * 6 * LDJ;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TPV = (NPV + 255) / 256, TJU = (NRP * NU + 255) / 256;   // k_project runs with >= 256 threads (hsqp_capi.hip)
+  double tpv[TPV], tju[TJU];
+#endif
+  auto load_pv = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int i = 0; i < NE_MAX; ++i) {
-      const int ri = w.rd[i];
-      double s = c < NX ? w.qr.CDe[ri][c] : w.qr.ep[i];
-#pragma unroll
-      for (int j = 0; j < i; ++j) s -= w.qr.Rm[j][i] * wc[j];
-      wc[i] = s * w.qr.rinv[i];
-      w.qr.Wm[i][c] = wc[i];
-    }
-  }
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 3);
-  // ---- Tm = [Px | Pu | Pe | 0 0]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T),  Pu = Q2
-  {
-    const XtyJob job = xty_job(NU, NX, ned, &w.qr.QT[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
-    wg_xty_jobs<true>(ctx, &job, 1);
-    WG_FOR(ctx, i, NU * (NUT + 3)) {
-      const int r = i / (NUT + 3), cc = i % (NUT + 3);
-      if (cc < NUT) w.Tm[r][NX + cc] = cc < nut ? w.qr.QT[ned + cc][r] : 0.0;
-      else if (cc == NUT) {
-        double sdot = 0.0;
-        for (int j = 0; j < ned; ++j) sdot += w.qr.QT[j][r] * w.qr.Wm[j][NX];
-        w.Tm[r][NTW] = (w.urow[r] >= 0 ? -w.qr.CDe[w.urow[r]][NZ] : 0.0) - sdot;   // an eliminated input is fixed at -e of its unit row
-      }
-      else w.Tm[r][NTW + (cc - NUT)] = 0.0;
-    }
-  }
-  WG_SYNC(ctx);  // QR data dead from here: PV, then Jt alias it
-  PH_TICK(ctx, 4);
-  // ---- stage the (transposed) input block of the residual rows r0 .. r0+nr and, in pass A, the [A|B] rows
-  auto stage_inputs = [&](int r0, int nr, bool with_pv) {
-    const int nj = nr * NU, ntot = nj + (with_pv ? 2 * 6 * LDJ : 0), nb = (ntot + 7) / 8;
-    double* pv = &w.PV[0][0][0];
-    WG_FOR(ctx, b, nb) {
-      double t[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = b + j * nb;
-        t[j] = e < nj ? rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU] : (e < ntot ? rec[REC_PV + (e - nj)] : 0.0);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = b + j * nb;
-        if (e < nj) w.JuT[e % NU][e / NU] = t[j];
-        else if (e < ntot) pv[e - nj] = t[j];
-      }
-    }
+    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; tpv[j] = rec[REC_PV + (e < NPV ? e : 0)]; }
+#endif
   };
-  stage_inputs(0, NRA, true);
-  WG_SYNC(ctx);
+  auto store_pv = [&]() {
+    double* pv = &w.PV[0][0][0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[e] = tpv[j]; }
+#else
+    WG_FOR(ctx, e, NPV) pv[e] = rec[REC_PV + e];
+#endif
+  };
+  auto load_ju = [&](int r0, int nr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads, ec = e < nr * NU ? e : 0; tju[j] = rec[REC_J + (r0 + ec / NU) * LDJ + NX + ec % NU]; }
+#else
+    (void)r0; (void)nr;
+#endif
+  };
+  auto store_ju = [&](int r0, int nr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)r0;
+#pragma unroll
+    for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < nr * NU) w.ps.JuT[e % NU][e / NU] = tju[j]; }
+#else
+    WG_FOR(ctx, e, nr * NU) w.ps.JuT[e % NU][e / NU] = rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU];
+#endif
+  };
+  // ---- Tm = [Px | Pu | Pe | 0 ...]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T);  Pu is in place
+  load_pv();
+  load_ju(0, NRP);
+  {
+    const XtyJob job = xty_job(NU, NX, ned, &w.qr.Q1T[0][0], NU, &w.qr.Wm[0][0], NX + 2, &w.Tm[0][0], LDTM, nullptr, 0, -1.0);
+    wg_xty_jobs<true>(ctx, &job, 1);
+    WG_FOR(ctx, i, NU * (LDTM - NTW)) {
+      const int r = i / (LDTM - NTW), cc = i % (LDTM - NTW);
+      if (cc == 0) {
+        double sdot = 0.0;
+        for (int j = 0; j < ned; ++j) sdot += w.qr.Q1T[j][r] * w.qr.Wm[j][NX];
+        w.Tm[r][NTW] = w.eu[r] - sdot;
+      }
+      else w.Tm[r][NTW + cc] = 0.0;
+    }
+  }
+  store_pv();   // over Rm / V / the QR scalars: nothing reads them any more
+  WG_SYNC(ctx);  // QR data dead from here
+  PH_TICK(ctx, 4);
+  store_ju(0, NRP);
   // ---- write the projection
   WG_FOR(ctx, i, NU * (NX + NUT + 1) + 1) {
     int j = i;
@@ -307,68 +475,45 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   }
   WG_SYNC(ctx);  // PV dead: Jt aliases it
   PH_TICK(ctx, 5);
-  // ---- two passes over the residual rows: J~ = J T (+ rho' in column 81), then H~ (+)= J~^T J~ on the matrix cores (blocks
-  //      Q~, P~, R~ straight to the QP record; pass B adds to what the same lanes wrote in pass A) and the gradient
-  //      g~ = T^T gd + J~^T rho'
+  // ---- passes over the residual row slots: J~ = J T (+ rho' in column 81) on the matrix cores, then its Gram matrix onto the
+  //      accumulators while the input block of the next pass is fetched
+  GramAcc g;
+  gram_init(ctx, g);
+  auto project_rows = [&](int r0, int nr) {
+    const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
+                            xty_job(nr, NUT, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
+    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
+    WG_FOR(ctx, i, nr) {
+      double sdot = w.rho[r0 + i];
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int r0 = pass == 0 ? 0 : NRA, nr = pass == 0 ? NRA : NRS - NRA, nrows = pass == 0 ? NRA : NRB;
-    if (pass == 1) { stage_inputs(NRA, NRS - NRA, false); WG_SYNC(ctx); PH_TICK(ctx, 13); }
-    {
-      const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.JuT[0][0], NRA, &w.Tm[0][0], LDTM, &w.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
-                              xty_job(nr, NUT, NU, &w.JuT[0][0], NRA, &w.Tm[0][NX], LDTM, &w.Jt[0][NX], LDTM)};
-      wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
-      WG_FOR(ctx, i, nr + (pass == 1 ? (NU + 1) * LDTM : 0)) {
-        if (i < nr) {
-          double sdot = w.rho[r0 + i];
-#pragma unroll
-          for (int k = 0; k < NU; ++k) sdot += w.JuT[k][i] * w.Tm[k][NTW];
-          w.Jt[i][NTW] = sdot;
-        } else {   // pass B: the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the zero row
-          const int k = (i - nr) / LDTM, a = (i - nr) % LDTM;
-          w.Jt[nr + k][a] = (k < NU && a <= NTW) ? w.d[NX + k] * w.Tm[k][a] : 0.0;
-        }
-      }
+      for (int k = 0; k < NU; ++k) sdot += w.ps.JuT[k][i] * w.Tm[k][NTW];
+      w.ps.Jt[i][NTW] = sdot;
     }
-    WG_SYNC(ctx);
-    PH_TICK(ctx, pass == 0 ? 6 : 11);
-    {
-      const double* addq = pass == 0 ? nullptr : qp + QP_Q;
-      const double* addp = pass == 0 ? nullptr : qp + QP_P;
-      const double* addr = pass == 0 ? nullptr : qp + QP_R;
-      // Q~ and R~ are symmetric: only the tiles on/above the diagonal are computed (10 of 16, 3 of 4) and mirrored
-      XtyJob jq = xty_job(NX, NX, nrows, &w.Jt[0][0], LDTM, &w.Jt[0][0], LDTM, qp + QP_Q, NX, addq, NX);
-      XtyJob jr = xty_job(NUT, NUT, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][NX], LDTM, qp + QP_R, NUT, addr, NUT);
-      jq.sym = 1; jr.sym = 1;
-      const XtyJob jobs[3] = {jq, xty_job(NUT, NX, nrows, &w.Jt[0][NX], LDTM, &w.Jt[0][0], LDTM, qp + QP_P, NX, addp, NX), jr};
-      wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_C_GLOBAL>(ctx, jobs, 3);
-      PH_TICK(ctx, pass == 0 ? 14 : 15);
-      WG_FOR(ctx, a, NTW) {
-        double s = 0.0;
-#pragma unroll 4
-        for (int r = 0; r < nrows; ++r) s += w.Jt[r][a] * w.Jt[r][NTW];
-        if (pass == 0) {
-          if (a < NX) s += w.gd[a];
-#pragma unroll
-          for (int k = 0; k < NU; ++k) s += w.Tm[k][a] * w.gd[NX + k];
-          w.gacc[a] = s;
-        } else {
-          s += w.gacc[a];
-          if (a < NX) qp[QP_QV + a] = s; else qp[QP_RV + a - NX] = s;
-        }
-      }
-    }
-    WG_SYNC(ctx);
-    PH_TICK(ctx, pass == 0 ? 7 : 12);
-  }
-  // diagonal of Q~ and the identity padding of the unused projected inputs (read-modify-write of this node's own record)
-  WG_FOR(ctx, i, NX + NUT * NUT) {
-    if (i < NX) qp[QP_Q + i * NX + i] += w.d[i];
-    else {
-      const int a = (i - NX) / NUT, b = (i - NX) % NUT;
-      if (a >= nut || b >= nut) qp[QP_R + a * NUT + b] = (a == b) ? 1.0 : 0.0;
-    }
-  }
+  };
+  project_rows(0, NRP);
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 6);
+  load_ju(NRP, NRP);
+  gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  store_ju(NRP, NRP);
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 14);
+  project_rows(NRP, NRP);
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 11);
+  load_ju(2 * NRP, NRS - 2 * NRP);
+  gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  store_ju(2 * NRP, NRS - 2 * NRP);
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 15);
+  project_rows(2 * NRP, NRS - 2 * NRP);
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 7);
+  gram_rows<false, NRS - 2 * NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  // the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the diagonal part of the gradient, straight from Tm
+  gram_rows<true, NU>(ctx, g, &w.Tm[0][0], LDTM, &w.d[NX], &w.gd[NX]);
+  PH_TICK(ctx, 12);
+  gram_store(ctx, g, w, nut, qp);
   WG_SYNC(ctx);
   PH_TICK(ctx, 10);
 }
