@@ -55,19 +55,24 @@ struct RicWS {
   int ok;
 };
 
+static_assert(sizeof(RicWS) <= 163400, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) accepts 163 400 bytes on gfx950 and rejects 163 592");
+
 // The matrix products of one phase of the sweep.  In the 512-thread kernels every wave from `first_wave` on takes tiles (dealt
 // round-robin; a wave with copies / vector work in the same phase calls this AFTER that work); any other context (host build,
 // smaller workgroups) runs them on its matrix half as before.
 // waves [first_wave, first_wave + n_waves) take the tiles; n_waves = 0: the matrix half as before
+// SPACES = XTY_ADD_GLOBAL: the additive terms of the jobs are in global memory (the QP record) -> global instead of flat loads, which
+// would also count on lgkmcnt and hold up the LDS operand waits of the matrix loop
+template <int SPACES = 0>
 HSQP_HD void ric_products(const Ctx& ctx, const XtyJob* jobs, int njobs, int first_wave = 0, int n_waves = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads == 512 && n_waves > 0) {
     const int r = (ctx.tid >> 6) - first_wave;
-    xty_deal(jobs, njobs, r < n_waves ? r : -1, n_waves, ctx.tid & 63);
+    xty_deal<SPACES>(jobs, njobs, r < n_waves ? r : -1, n_waves, ctx.tid & 63);
     return;
   }
 #endif
-  if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), jobs, njobs);
+  if (is_mfma_half(ctx)) wg_xty_jobs<false, SPACES>(mfma_ctx(ctx), jobs, njobs);
 }
 
 // qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
@@ -176,7 +181,9 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (k > 0) store_batch<7>(it, NX * NX - nh, t, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
         }
       }
-      ric_products(ctx, jobs, 2);   // (dealing these tiles to the helper waves as well was measured: 1.87 -> 2.3 ms)
+      // (dealing these tiles to the helper waves as well was measured: 1.87 -> 2.3 ms.  The additive terms stay generic pointers here:
+      //  as a two-job call with address-space-qualified terms the gfx950 backend of ROCm 7.2's clang crashes, as two calls it spills)
+      ric_products(ctx, jobs, 2);
     }
     PH_ARRIVE(ctx, 1);
     WG_SYNC(ctx);
@@ -327,7 +334,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           }
         }
       }
-      ric_products(ctx, &js, 1);    // (same: 1.87 -> 2.1 ms with waves 4-5 taking the two spare tiles)
+      ric_products<XTY_ADD_GLOBAL>(ctx, &js, 1);    // (same: 1.87 -> 2.1 ms with waves 4-5 taking the two spare tiles)
     }
     PH_ARRIVE(ctx, 2);
     WG_SYNC(ctx);
