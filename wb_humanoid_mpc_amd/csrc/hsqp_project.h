@@ -390,13 +390,20 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; tpv[j] = rec[REC_PV + (e < NPV ? e : 0)]; }
 #endif
   };
+  // the constant part of the dense rows of A (identity; dt on the q-v coupling of the whole-body base rows) is folded in here, so
+  // that A~ of those rows is PV_x + B Px exactly as the matrix cores form it
+  auto pv_const = [&](int e) {
+    const int p = e / (6 * LDJ), r = (e / LDJ) % 6, c = e % LDJ;
+    const int row = cent ? 6 * p + r : (p == 0 ? r : NV + r);
+    return (c == row ? 1.0 : 0.0) + ((!cent && p == 0 && c == NV + r) ? dt : 0.0);
+  };
   auto store_pv = [&]() {
     double* pv = &w.PV[0][0][0];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[e] = tpv[j]; }
+    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[e] = tpv[j] + pv_const(e); }
 #else
-    WG_FOR(ctx, e, NPV) pv[e] = rec[REC_PV + e];
+    WG_FOR(ctx, e, NPV) pv[e] = rec[REC_PV + e] + pv_const(e);
 #endif
   };
   auto load_ju = [&](int r0, int nr) {
@@ -436,41 +443,54 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);  // QR data dead from here
   PH_TICK(ctx, 4);
   store_ju(0, NRP);
-  // ---- write the projection
-  WG_FOR(ctx, i, NU * (NX + NUT + 1) + 1) {
-    int j = i;
-    if (j < NU * NX) { qp[QP_PX + j] = w.Tm[j / NX][j % NX]; continue; }
-    j -= NU * NX;
-    if (j < NU * NUT) { qp[QP_PU + j] = w.Tm[j / NUT][NX + j % NUT]; continue; }
-    j -= NU * NUT;
-    if (j < NU) { qp[QP_PE + j] = w.Tm[j][NTW]; continue; }
-    qp[QP_NUT] = w.ok ? (double)nut : -1.0;
+  // ---- the projection and the dynamics A~ = A + B Px, B~ = B Pu, b~ = b + B Pe with the structured [A|B] (hsqp_lq.h) to the record.
+  // The twelve dense rows go through the matrix cores, straight to the record (PV_x + B_row [Px | Pu]); every other row is one
+  // scaled row of Tm: item = (column c of [Px | Pu | Pe], row group), which walks down its column with constant strides
+  {
+    const int r1 = cent ? 6 : NV;   // first row of the second dense block
+    XtyJob ja0 = xty_job(6, NX, NU, &w.PV[0][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A, NX, &w.PV[0][0][0], LDJ);
+    XtyJob ja1 = xty_job(6, NX, NU, &w.PV[1][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A + r1 * NX, NX, &w.PV[1][0][0], LDJ);
+    XtyJob jb0 = xty_job(6, NUT, NU, &w.PV[0][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B, NUT);
+    XtyJob jb1 = xty_job(6, NUT, NU, &w.PV[1][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B + r1 * NUT, NUT);
+    ja0.sx1 = LDJ; ja1.sx1 = LDJ; jb0.sx1 = LDJ; jb1.sx1 = LDJ;
+    const XtyJob jobs[4] = {ja0, ja1, jb0, jb1};
+    wg_xty_jobs<true, XTY_C_GLOBAL>(ctx, jobs, 4);
   }
-  // ---- dynamics: A~ = A + B Px, B~ = B Pu, b~ = b + B Pe  with the structured [A|B] (hsqp_lq.h)
-  WG_FOR(ctx, i, NX * (NTW + 1)) {
-    const int r = i / (NTW + 1), c = i % (NTW + 1);
-    double s = 0.0;
-    const bool base = cent ? r < 12 : ((r < 6) || (r >= NV && r < NV + 6));
-    const int pw = cent ? r / 6 : (r < 6 ? 0 : 1), pr = cent ? r % 6 : (r < 6 ? r : r - NV);   // block / row of PV (only used if base)
-    if (base) {  // B row r applied to column c of [Px | Pu | Pe]
+  constexpr int NCG = 3;   // row groups per column
+  WG_FOR(ctx, it, NCG * (NTW + 1) + 12) {
+    if (it >= NCG * (NTW + 1)) {   // b~ of the dense rows
+      const int i = it - NCG * (NTW + 1), pw = i / 6, pr = i % 6, r = cent ? i : (pw == 0 ? pr : NV + pr);
       const double* Brow = &w.PV[pw][pr][NX];
+      double s = w.bvec[r];
 #pragma unroll 5
-      for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][c];
-    } else if (cent) {
-      s = r < HSQP_CNX ? dt * w.Tm[r][c] : 0.0;            // input 12 + (r - 12) = r
-    } else {
-      const int j = r < NV ? r - 6 : r - NV - 6;
-      s = (r < NV ? 0.5 * dt * dt : dt) * w.Tm[12 + j][c];
+      for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][NTW];
+      qp[QP_BV + r] = s;
+      continue;
     }
-    if (c < NX) {
-      double a = (r == c) ? 1.0 : 0.0;
-      if (!cent && r < NV && c == NV + r) a += dt;
-      if (base) a += w.PV[pw][pr][c];
-      qp[QP_A + r * NX + c] = a + s;
-    } else if (c < NTW) {
-      qp[QP_B + r * NUT + (c - NX)] = s;
-    } else {
-      qp[QP_BV + r] = w.bvec[r] + s;
+    const int c = it % (NTW + 1), g = it / (NTW + 1);
+    if (it == 0) qp[QP_NUT] = w.ok ? (double)nut : -1.0;
+    {
+      double* dst = c < NX ? qp + QP_PX + c : (c < NTW ? qp + QP_PU + (c - NX) : qp + QP_PE);
+      const int st = c < NX ? NX : (c < NTW ? NUT : 1);
+      for (int k = g; k < NU; k += NCG) dst[k * st] = w.Tm[k][c];
+    }
+    double* dst = c < NX ? qp + QP_A + c : (c < NTW ? qp + QP_B + (c - NX) : qp + QP_BV);
+    const int st = c < NX ? NX : (c < NTW ? NUT : 1);
+    for (int r = g; r < NX; r += NCG) {
+      const bool base = cent ? r < 12 : ((r < 6) || (r >= NV && r < NV + 6));
+      if (base) continue;
+      double s;
+      if (cent) s = r < HSQP_CNX ? dt * w.Tm[r][c] : 0.0;            // input 12 + (r - 12) = r
+      else {
+        const int j = r < NV ? r - 6 : r - NV - 6;
+        s = (r < NV ? 0.5 * dt * dt : dt) * w.Tm[12 + j][c];
+      }
+      if (c < NX) {
+        double a = (r == c) ? 1.0 : 0.0;
+        if (!cent && r < NV && c == NV + r) a += dt;
+        s += a;
+      } else if (c == NTW) s += w.bvec[r];
+      dst[r * st] = s;
     }
   }
   WG_SYNC(ctx);  // PV dead: Jt aliases it
