@@ -18,7 +18,7 @@ static int g_scan = 0;   // centroidal formulation: backward sweep by the parall
 
 // the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
 template <int n>
-static int scan_backward(const DevModel& dm, int N, const double* x, const double* par, const double* qp, double* ric, double* vf) {
+static int scan_backward(const DevModel& dm, int N, const double* x, const double* par, const double* qp, double* ric, double* vf, double* acl) {
   Ctx ctx{0, 1, nullptr};
   using E = ScanEl<n>;
   std::vector<double> ea((size_t)(N + 1) * E::SIZE), eb((size_t)(N + 1) * E::SIZE);
@@ -50,6 +50,7 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
     riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
                         vf + (size_t)k * VF_SIZE, vn, vn + NX * NX, k == N - 1, 1.0, NX);
     if (!rw->ok) return 0;
+    closed_loop_record<n>(ctx, *rw, acl + (size_t)k * ACL_SIZE<n>);   // as k_scan_gains does in its last pass
   }
   return 1;
 }
@@ -210,11 +211,13 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto terminal = [&](const double* xx) { double c = 0; for (int i = 0; i < NX; ++i) { const double d = xx[N * NX + i] - par[N * NP + HSQP_P_XDES + i]; c += 0.5 * dm.Qf[i] * d * d; } return c; };
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
-  if (cent && g_scan) { if (!scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data())) return HSQP_ERR_NUMERIC; rw->ok = 1; }
+  std::vector<double> acl(cent && g_scan ? (size_t)N * ACL_SIZE<CNX> : 0);
+  if (cent && g_scan) { if (!scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data())) return HSQP_ERR_NUMERIC; rw->ok = 1; }
   else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
-  if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
+  if (cent && g_scan) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
+  else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();
   for (int k = 0; k < N; ++k)

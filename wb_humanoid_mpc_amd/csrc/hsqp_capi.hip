@@ -164,7 +164,7 @@ __global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double
 template <int n>
 __global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
                                                             const double* __restrict__ qp, const double* __restrict__ el, const double* __restrict__ vf_in,
-                                                            double* __restrict__ ric, int N, int* __restrict__ status, double* __restrict__ vf) {
+                                                            double* __restrict__ ric, int N, int* __restrict__ status, double* __restrict__ vf, double* __restrict__ acl) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
@@ -178,14 +178,15 @@ __global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __re
     const int st = (q[QP_NUT] < 0.0 ? 1 : 0) | (w.ok ? 0 : 2);
     if (st) atomicOr(&status[b], st);
   }
+  if (acl) closed_loop_record<n>(ctx, w, acl + (size_t)node * ACL_SIZE<n>);   // the last pass: closed loop of this stage for the roll-out
 }
 template <int n>
-__global__ __launch_bounds__(RIC_THREADS) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
-                                                              const double* __restrict__ ric, int N, double* __restrict__ dx) {
+__global__ __launch_bounds__(RIC_THREADS) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ acl,
+                                                              int N, double* __restrict__ dx) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
-  riccati_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, qp + (size_t)b * N * QP_SIZE, ric + (size_t)b * N * RIC_SIZE, N, dx + (size_t)b * (N + 1) * NX);
+  closed_loop_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, acl + (size_t)b * N * ACL_SIZE<n>, N, dx + (size_t)b * (N + 1) * NX);
 }
 
 // ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
@@ -438,6 +439,7 @@ struct hsqp_handle {
   bool uniform_grid = true, has_events = false;
   double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
   double* d_vf2 = nullptr;        // scan path: value functions of the refinement pass (the KKT check then reads these)
+  double* d_acl = nullptr;        // scan path: closed loop [B][N][ACL_SIZE] of every stage for the roll-out (allocated when the scan is first used)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   double* d_stepinfo = nullptr;   // [B][N][4] per-node {armijo, |dx|^2, |du|^2}
@@ -497,7 +499,7 @@ void hsqp_destroy(hsqp_handle* h) {
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
                   h->d_unew, h->d_misc, h->d_kkt, h->d_ginf, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
-                  h->d_el[0], h->d_el[1], h->d_vf2};
+                  h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -775,11 +777,15 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
           if (hipMalloc(pv, bytes) != hipSuccess) { *pv = nullptr; h->err = "hipMalloc failed (value functions of the scan, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
         }
+      if (!h->d_acl) {
+        const size_t bytes = (size_t)h->st.max_batch * h->st.max_nodes * ACL_SIZE<CNX> * 8;
+        if (hipMalloc(&h->d_acl, bytes) != hipSuccess) { h->d_acl = nullptr; h->err = "hipMalloc failed (closed loop of the scan path, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+      }
       hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
-                         (const double*)nullptr, h->d_ric, N, h->d_status, h->d_vf);
+                         (const double*)nullptr, h->d_ric, N, h->d_status, h->d_vf, (double*)nullptr);
       hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
-                         (const double*)h->d_vf, h->d_ric, N, h->d_status, want_kkt ? h->d_vf2 : (double*)nullptr);
-      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_ric, N, h->d_dx);
+                         (const double*)h->d_vf, h->d_ric, N, h->d_status, want_kkt ? h->d_vf2 : (double*)nullptr, h->d_acl);
+      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);
     } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
       hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                          h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);

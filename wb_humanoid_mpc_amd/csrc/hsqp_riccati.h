@@ -457,6 +457,99 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
   }
 }
 
+// ---- closed-loop roll-out of the parallel-in-time path (hsqp_scan.h).  There the gains of all stages are formed in parallel (one
+// workgroup per stage), so each workgroup can also afford the closed loop A_cl = A~ + B~ K, b_cl = b~ + B~ k of its stage: the serial
+// roll-out is then ONE mat-vec phase per stage (dx+ = A_cl dx + b_cl) instead of the three of riccati_forward, which applies A~, B~, K
+// separately because forming A_cl inside the serial backward sweep would put it on that sweep's critical path.
+template <int NXE>
+constexpr int ACL_SIZE = ((NXE * NXE + NXE + 7) / 8) * 8;   // [NXE][NXE] A_cl, [NXE] b_cl
+
+// after riccati_backward(..., N = 1, ...): the stage's A~, B~, b~ and its gains are still in the workspace
+template <int NXE>
+HSQP_HD void closed_loop_record(const Ctx& ctx, const RicWS& w, double* acl) {
+  WG_FOR(ctx, it, NXE * NXE + NXE) {
+    if (it < NXE * NXE) {
+      const int i = it / NXE, j = it % NXE;
+      double s = w.A2[0][i][j];
+#pragma unroll
+      for (int m = 0; m < NUT; ++m) s += w.B[i][m] * w.Em[m][EM_G + j];
+      acl[it] = s;
+    } else {
+      const int i = it - NXE * NXE;
+      double s = w.bt2[0][i];
+#pragma unroll
+      for (int m = 0; m < NUT; ++m) s += w.B[i][m] * w.kv[m];
+      acl[it] = s;
+    }
+  }
+}
+
+// dx [N+1][58]: dx_0 = x_init - x_0, dx+ = A_cl dx + b_cl on the leading NXE states; the padding states keep dx (A~ = I there).
+template <int NXE>
+HSQP_HD void closed_loop_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* acl, int N, double* dx_out) {
+  WG_FOR(ctx, i, NX) {
+    const double d = x_init[i] - x[i];
+    w.dx[i] = d;
+    dx_out[i] = d;
+  }
+  WG_SYNC(ctx);
+  constexpr int NC = (NXE + 3) / 4;
+  double* part = w.SA[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads >= 4 * NXE) {
+    // item it < 4 NXE owns the columns p + 4c of row it >> 2; the slice of stage k + 1 is fetched while stage k is being combined
+    const int it = ctx.tid, row = it >> 2, p = it & 3;
+    const bool live = it < 4 * NXE;
+    double a[NC], an[NC], sc = 0.0, scn = 0.0;
+    auto fetch = [&](int k, double* av, double& s1) {
+      const double* r = acl + (size_t)k * ACL_SIZE<NXE>;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; av[c] = (live && cc < NXE) ? r[row * NXE + cc] : 0.0; }
+      s1 = (live && p == 0) ? r[NXE * NXE + row] : 0.0;
+    };
+    fetch(0, an, scn);
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c] = an[c];
+      sc = scn;
+      if (k + 1 < N) fetch(k + 1, an, scn);
+      if (live) {
+        double s = sc;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[c] * w.dx[cc]; }
+        part[it] = s;
+      }
+      WG_SYNC(ctx);
+      if (it < NX) {
+        const double* p1 = &part[4 * (it < NXE ? it : 0)];
+        const double s = it < NXE ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[it];
+        w.dx[it] = s;
+        dx_out[(size_t)(k + 1) * NX + it] = s;
+      }
+      WG_SYNC(ctx);
+    }
+    return;
+  }
+#endif
+  for (int k = 0; k < N; ++k) {
+    const double* r = acl + (size_t)k * ACL_SIZE<NXE>;
+    WG_FOR(ctx, it, 4 * NXE) {
+      const int row = it >> 2, p = it & 3;
+      double s = p == 0 ? r[NXE * NXE + row] : 0.0;
+      for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += r[row * NXE + cc] * w.dx[cc]; }
+      part[it] = s;
+    }
+    WG_SYNC(ctx);
+    WG_FOR(ctx, i, NX) {
+      const double* p1 = &part[4 * (i < NXE ? i : 0)];
+      const double s = i < NXE ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[i];
+      w.dx[i] = s;
+      dx_out[(size_t)(k + 1) * NX + i] = s;
+    }
+    WG_SYNC(ctx);
+  }
+}
+
 // Per-node recovery of the inputs and the step of length alpha (parallel over all nodes of all instances):
 //   ut = K dx + k,  du = Px dx + Pu ut + Pe,  x_new = x + alpha dx,  u_new = u + alpha du.
 struct StepWS {
