@@ -103,6 +103,62 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
   }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same elimination with the matrix in REGISTERS (device, combination step): lane i of a wave holds row i — the n columns of M and
+// a share NO of the right-hand-side columns — and NW waves each eliminate M redundantly (identical arithmetic, identical pivots) on
+// their own share, so a step needs no barrier, no LDS traffic and no dynamic register index: the pivot row is a LANE, its elements come
+// through v_readlane with that (wave-uniform) lane number, the pivot search is a scalar maximum over n readlanes of the packed
+// (magnitude | lane) candidates, and each lane's multiplier is its own element of column j.  Rows are never swapped: a used row stays
+// in its lane and remembers which solution row it is.  G: [n][ld] in LDS = [M | right-hand sides]; X[r][c] (leading dimension ldx)
+// receives the solution row r of right-hand-side column c < nrhs.  Steps: ~0.9 k cycles instead of 3.8 k for the LDS form.
+template <int n, int ld, int nrhs, int NW>
+__device__ inline void gauss_jordan_rows(const Ctx& ctx, const double* G, double* X, int ldx, int* okflag) {
+  constexpr int NO = (nrhs + NW - 1) / NW;
+  const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
+  if (wave >= NW) return;
+  const int row = lane < n ? lane : n - 1;
+  const int c0 = wave * NO;
+  double m[n], o[NO];
+#pragma clang loop unroll(full)
+  for (int c = 0; c < n; ++c) m[c] = G[row * ld + c];
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NO; ++c) o[c] = G[row * ld + n + (c0 + c < nrhs ? c0 + c : nrhs - 1)];
+  double mx = 0.0;
+#pragma clang loop unroll(full)
+  for (int c = 0; c < n; ++c) mx = fmax(mx, fabs(m[c]));
+  const double rscale = mx > 0.0 ? 1.0 / mx : 1.0;
+  bool used = lane >= n;          // the padding lanes never become pivots
+  int mycol = 0;
+  double dpiv = 1.0;
+  bool good = true;
+#pragma clang loop unroll(full)
+  for (int j = 0; j < n; ++j) {
+    // candidates: the magnitude as a float with its low 6 bits replaced by the lane number; used rows offer 0
+    const unsigned cand = used ? 0u : ((__float_as_uint((float)(fabs(m[j]) * rscale)) & ~63u) | (unsigned)lane);
+    unsigned best = 0u;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < n; ++i) { const unsigned ci = (unsigned)__builtin_amdgcn_readlane((int)cand, i); best = ci > best ? ci : best; }
+    const int p = (int)(best & 63u);
+    double pv = readlane_f64(m[j], p);
+    if (!(fabs(pv) > 1e-300)) { good = false; pv = 1.0; }
+    const double rpv = fast_rcp(pv);
+    const bool isp = lane == p;
+    const double f = (isp || lane >= n) ? 0.0 : m[j] * rpv;
+    if (isp) { used = true; mycol = j; dpiv = pv; }
+#pragma clang loop unroll(full)
+    for (int c = j + 1; c < n; ++c) m[c] -= f * readlane_f64(m[c], p);
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NO; ++c) o[c] -= f * readlane_f64(o[c], p);
+  }
+  if (lane < n) {
+    const double rd = 1.0 / dpiv;
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NO; ++c) if (c0 + c < nrhs) X[mycol * ldx + c0 + c] = o[c] * rd;
+  }
+  if (!good && ctx.tid == 0) *okflag = 0;
+}
+#endif
+
 // ---- stage -> element
 template <int n>
 struct ScanInitWS {
@@ -217,12 +273,22 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   WG_FOR(ctx, i, n) w.G[i][i] += 1.0;
   WG_SYNC(ctx);
   PH_TICK(ctx, 21);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads >= 256) {
+    if (ctx.tid == 0) w.gj.ok = 1;
+    gauss_jordan_rows<n, LG, 2 * n + 1, 4>(ctx, &w.G[0][0], &w.X[0][0], 2 * n + 2, &w.gj.ok);
+    WG_FOR(ctx, r, n) w.X[r][2 * n + 1] = 0.0;
+    PH_TICK(ctx, 22);
+  } else
+#endif
+  {
   gauss_jordan<n, LG, 3 * n + 1, true>(ctx, &w.G[0][0], w.gj);
   PH_TICK(ctx, 22);
   WG_FOR(ctx, i, n * (2 * n + 2)) {
     const int r = i / (2 * n + 2), c = i % (2 * n + 2);
     const int p = w.gj.piv[r];
     w.X[r][c] = c <= 2 * n ? w.G[p][n + c] / w.G[p][r] : 0.0;
+  }
   }
   WG_SYNC(ctx);   // G is dead from here on (out aliases it)
   PH_TICK(ctx, 23);
