@@ -111,7 +111,7 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
 // (magnitude | lane) candidates, and each lane's multiplier is its own element of column j.  Rows are never swapped: a used row stays
 // in its lane and remembers which solution row it is.  G: [n][ld] in LDS = [M | right-hand sides]; X[r][c] (leading dimension ldx)
 // receives the solution row r of right-hand-side column c < nrhs.  Steps: ~0.9 k cycles instead of 3.8 k for the LDS form.
-template <int n, int ld, int nrhs, int NW>
+template <int n, int ld, int nrhs, int NW, bool PIVOT = true>
 __device__ inline void gauss_jordan_rows(const Ctx& ctx, const double* G, double* X, int ldx, int* okflag) {
   constexpr int NO = (nrhs + NW - 1) / NW;
   const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
@@ -134,11 +134,14 @@ __device__ inline void gauss_jordan_rows(const Ctx& ctx, const double* G, double
 #pragma clang loop unroll(full)
   for (int j = 0; j < n; ++j) {
     // candidates: the magnitude as a float with its low 6 bits replaced by the lane number; used rows offer 0
-    const unsigned cand = used ? 0u : ((__float_as_uint((float)(fabs(m[j]) * rscale)) & ~63u) | (unsigned)lane);
-    unsigned best = 0u;
+    int p = j;                    // PIVOT = false: diagonal pivots (symmetric positive definite M)
+    if (PIVOT) {
+      const unsigned cand = used ? 0u : ((__float_as_uint((float)(fabs(m[j]) * rscale)) & ~63u) | (unsigned)lane);
+      unsigned best = 0u;
 #pragma clang loop unroll(full)
-    for (int i = 0; i < n; ++i) { const unsigned ci = (unsigned)__builtin_amdgcn_readlane((int)cand, i); best = ci > best ? ci : best; }
-    const int p = (int)(best & 63u);
+      for (int i = 0; i < n; ++i) { const unsigned ci = (unsigned)__builtin_amdgcn_readlane((int)cand, i); best = ci > best ? ci : best; }
+      p = (int)(best & 63u);
+    }
     double pv = readlane_f64(m[j], p);
     if (!(fabs(pv) > 1e-300)) { good = false; pv = 1.0; }
     const double rpv = fast_rcp(pv);
@@ -201,13 +204,21 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     }
   }
   WG_SYNC(ctx);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads >= 128) {
+    int okflag = 1;   // R~ is positive definite by construction (the serial sweep reports a failed Lam; here a bad pivot only degrades the element)
+    gauss_jordan_rows<NUT, LG, NUT, 2, false>(ctx, &w.G[0][0], &w.Ri[0][0], NUT + 1, &okflag);
+  } else
+#endif
+  {
   gauss_jordan<NUT, LG, 2 * NUT, false>(ctx, &w.G[0][0], w.gj);
   WG_FOR(ctx, i, NUT * NUT) { const int r = i / NUT, c = i % NUT; w.Ri[r][c] = w.G[r][NUT + c] / w.G[r][r]; }
+  }
   WG_SYNC(ctx);
   {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
     const XtyJob jobs[2] = {xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1),
                             xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1)};
-    wg_xty_jobs(ctx, jobs, 2);
+    wg_xty_jobs<true>(ctx, jobs, 2);
     WG_FOR(ctx, r, NUT) { double s = 0.0; for (int l = 0; l < NUT; ++l) s += w.Ri[r][l] * w.rv[l]; w.wr[r] = s; }
   }
   WG_SYNC(ctx);
@@ -215,7 +226,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     const XtyJob jobs[3] = {xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WP[0][0], n + 1, el + E::A, n, q + QP_A, NX, -1.0),
                             xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1, el + E::C, n),
                             xty_job(n, n, NUT, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1, el + E::J, n, q + QP_Q, NX, -1.0)};
-    wg_xty_jobs(ctx, jobs, 3);
+    wg_xty_jobs<true>(ctx, jobs, 3);
     WG_FOR(ctx, i, 2 * n + (E::SIZE - E::ETA - n)) {
       if (i < n) { double s = q[QP_BV + i]; for (int l = 0; l < NUT; ++l) s -= w.BT[l][i] * w.wr[l]; el[E::B + i] = s; }
       else if (i < 2 * n) { const int r = i - n; double s = q[QP_QV + r]; for (int l = 0; l < NUT; ++l) s -= w.Pm[l][r] * w.wr[l]; el[E::ETA + r] = -s; }
@@ -296,7 +307,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     const XtyJob jobs[3] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], 2 * n + 2, out + E::A, n),
                             xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], 2 * n + 2, &w.T[0][0], LD),
                             xty_job(n, n, n, &w.J2[0][0], LD, &w.X[0][0], 2 * n + 2, &w.V[0][0], LD)};
-    wg_xty_jobs(ctx, jobs, 3);
+    wg_xty_jobs<true>(ctx, jobs, 3);
     WG_FOR(ctx, i, 2 * n) {
       if (i < n) { double s = 0.0; for (int l = 0; l < n; ++l) s += w.X[i][n + l] * w.y[l]; w.z[i] = s; }
       else { const int r = i - n; double s = w.b2[r]; for (int l = 0; l < n; ++l) s += w.A2T[l][r] * w.X[l][2 * n]; out[E::B + r] = s; }
@@ -308,7 +319,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
     XtyJob jc = xty_job(n, n, n, &w.T[0][0], 1, &w.A2T[0][0], LD, &w.out.Co[0][0], LD, e2 + E::C, n);
     jc.sx1 = LD;
     const XtyJob jobs[2] = {jc, xty_job(n, n, n, &w.A1[0][0], LD, &w.V[0][0], LD, &w.out.Jo[0][0], LD, e1 + E::J, n)};
-    wg_xty_jobs(ctx, jobs, 2);
+    wg_xty_jobs<true>(ctx, jobs, 2);
     WG_FOR(ctx, r, n) { double s = w.y[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.z[l]; w.t[r] = s; }
   }
   WG_SYNC(ctx);
