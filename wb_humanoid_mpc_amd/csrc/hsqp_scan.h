@@ -109,10 +109,11 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
 // their own share, so a step needs no barrier, no LDS traffic and no dynamic register index: the pivot row is a LANE, its elements come
 // through v_readlane with that (wave-uniform) lane number, the pivot search is a scalar maximum over n readlanes of the packed
 // (magnitude | lane) candidates, and each lane's multiplier is its own element of column j.  Rows are never swapped: a used row stays
-// in its lane and remembers which solution row it is.  G: [n][ld] in LDS = [M | right-hand sides]; X[r][c] (leading dimension ldx)
+// in its lane and remembers which solution row it is.  X[r][c] (leading dimension ldx)
 // receives the solution row r of right-hand-side column c < nrhs.  Steps: ~0.9 k cycles instead of 3.8 k for the LDS form.
-template <int n, int ld, int nrhs, int NW, bool PIVOT = true>
-__device__ inline void gauss_jordan_rows(const Ctx& ctx, const double* G, double* X, int ldx, int* okflag) {
+// load_m(row, c) / load_r(row, c): element of M / of the right-hand sides (from LDS or global memory).
+template <int n, int nrhs, int NW, bool PIVOT, class LoadM, class LoadR>
+__device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR load_r, double* X, int ldx, int* okflag) {
   constexpr int NO = (nrhs + NW - 1) / NW;
   const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
   if (wave >= NW) return;
@@ -120,9 +121,9 @@ __device__ inline void gauss_jordan_rows(const Ctx& ctx, const double* G, double
   const int c0 = wave * NO;
   double m[n], o[NO];
 #pragma clang loop unroll(full)
-  for (int c = 0; c < n; ++c) m[c] = G[row * ld + c];
+  for (int c = 0; c < n; ++c) m[c] = load_m(row, c);
 #pragma clang loop unroll(full)
-  for (int c = 0; c < NO; ++c) o[c] = G[row * ld + n + (c0 + c < nrhs ? c0 + c : nrhs - 1)];
+  for (int c = 0; c < NO; ++c) o[c] = load_r(row, c0 + c < nrhs ? c0 + c : nrhs - 1);
   double mx = 0.0;
 #pragma clang loop unroll(full)
   for (int c = 0; c < n; ++c) mx = fmax(mx, fabs(m[c]));
@@ -207,7 +208,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads >= 128) {
     int okflag = 1;   // R~ is positive definite by construction (the serial sweep reports a failed Lam; here a bad pivot only degrades the element)
-    gauss_jordan_rows<NUT, LG, NUT, 2, false>(ctx, &w.G[0][0], &w.Ri[0][0], NUT + 1, &okflag);
+    gauss_jordan_rows<NUT, NUT, 2, false>(ctx, [&](int r, int c) { return w.G[r][c]; }, [&](int r, int c) { return w.G[r][NUT + c]; }, &w.Ri[0][0], NUT + 1, &okflag);
   } else
 #endif
   {
@@ -239,100 +240,133 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
 // ---- combination of two elements
 template <int n>
 struct ScanCombWS {
-  static constexpr int LD = n + 1, LG = 3 * n + 2;
+  static constexpr int LD = n + 1, LX = 2 * n + 2;
+  double Mb[n][LD];                   // M = I + C1 J2; once the elimination has read it: V = J2 XA
+  double J2[n][LD];                   // J2; once T and t are formed: A1
+  double A2T[n][LD];
   union {
-    double G[n][LG];                  // [M | A1 | C1 | b1 + C1 eta2]
-    struct { double Co[n][LD], Jo[n][LD]; } out;   // results before symmetrisation (G is dead by then)
+    double C1[n][LD];                 // staging of C1 for the product that forms M (the elimination reads C1 from global memory)
+    double X[n][LX];                  // [XA | XC | xb . ] in natural row order; XA is overwritten by T = A2 XC
   };
-  double A1[n][LD], C1[n][LD], A2T[n][LD], J2[n][LD];
-  double X[n][2 * n + 2];             // [XA | XC | xb] in natural row order
-  double T[n][LD], V[n][LD];          // A2 XC, J2 XA
-  double b1[n], eta1[n], b2[n], eta2[n], y[n], z[n], t[n];
-  GjWS gj;
+  double b1[n], eta1[n], b2[n], eta2[n], y[n], z[n], t[n], rh[n];
+  int ok;
 };
 
-// e1 (i -> j), e2 (j -> k) -> out (i -> k); returns through *ok whether every pivot was usable
+// e1 (i -> j), e2 (j -> k) -> out (i -> k); returns through *ok whether every pivot was usable.
+// 137 KB of LDS for n = 58: the augmented matrix [M | A1 | C1 | rhs] of the elimination lives in registers (gauss_jordan_rows), the
+// symmetric results C and J are formed as symmetric tile jobs straight into the output element.
 template <int n>
 HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, const double* e2, double* out, int* ok) {
   using E = ScanEl<n>;
-  constexpr int LD = ScanCombWS<n>::LD, LG = ScanCombWS<n>::LG;
+  constexpr int LD = ScanCombWS<n>::LD, LX = ScanCombWS<n>::LX;
   PH_TICK(ctx, 126);
-  WG_FOR(ctx, i, 4 * n * n + 4 * n) {
-    if (i < n * n) { const int r = i / n, c = i % n; const double v = e1[E::A + i]; w.A1[r][c] = v; w.G[r][n + c] = v; }
-    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; const double v = e1[E::C + j]; w.C1[r][c] = v; w.G[r][2 * n + c] = v; }
+  WG_FOR(ctx, i, 3 * n * n + 4 * n + 1) {
+    if (i < n * n) { const int r = i / n, c = i % n; w.C1[r][c] = e1[E::C + i]; }
+    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; w.J2[r][c] = e2[E::J + j]; }
     else if (i < 3 * n * n) { const int j = i - 2 * n * n, r = j / n, c = j % n; w.A2T[c][r] = e2[E::A + j]; }
-    else if (i < 4 * n * n) { const int j = i - 3 * n * n, r = j / n, c = j % n; w.J2[r][c] = e2[E::J + j]; }
-    else {
-      const int j = i - 4 * n * n, r = j % n;
+    else if (i < 3 * n * n + 4 * n) {
+      const int j = i - 3 * n * n, r = j % n;
       if (j < n) w.b1[r] = e1[E::B + r];
       else if (j < 2 * n) w.eta1[r] = e1[E::ETA + r];
       else if (j < 3 * n) w.b2[r] = e2[E::B + r];
       else w.eta2[r] = e2[E::ETA + r];
-    }
+    } else w.ok = 1;
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 20);
-  {  // M = I + C1 J2 (C1 symmetric: X = C1), right-hand side b1 + C1 eta2, y = eta2 - J2 b1
-    const XtyJob job = xty_job(n, n, n, &w.C1[0][0], LD, &w.J2[0][0], LD, &w.G[0][0], LG);
-    wg_xty_jobs(ctx, &job, 1);
+  {  // M - I = C1 J2 (C1 symmetric: X = C1), right-hand side b1 + C1 eta2, y = eta2 - J2 b1
+    const XtyJob job = xty_job(n, n, n, &w.C1[0][0], LD, &w.J2[0][0], LD, &w.Mb[0][0], LD);
+    wg_xty_jobs<true>(ctx, &job, 1);
     WG_FOR(ctx, i, 2 * n) {
-      if (i < n) { double s = w.b1[i]; for (int l = 0; l < n; ++l) s += w.C1[i][l] * w.eta2[l]; w.G[i][3 * n] = s; w.G[i][3 * n + 1] = 0.0; }
+      if (i < n) { double s = w.b1[i]; for (int l = 0; l < n; ++l) s += w.C1[i][l] * w.eta2[l]; w.rh[i] = s; }
       else { const int r = i - n; double s = w.eta2[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.b1[l]; w.y[r] = s; }
     }
   }
-  WG_SYNC(ctx);
-  WG_FOR(ctx, i, n) w.G[i][i] += 1.0;
-  WG_SYNC(ctx);
+  WG_SYNC(ctx);   // the staging of C1 is dead from here on (X aliases it)
   PH_TICK(ctx, 21);
+  // [XA | XC | xb] = M^-1 [A1 | C1 | rhs]
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (ctx.nthreads >= 256) {
-    if (ctx.tid == 0) w.gj.ok = 1;
-    gauss_jordan_rows<n, LG, 2 * n + 1, 4>(ctx, &w.G[0][0], &w.X[0][0], 2 * n + 2, &w.gj.ok);
+  {   // k_scan_combine runs with 512 threads (8 waves)
+    constexpr int NW = n > 40 ? 8 : 4;
+    gauss_jordan_rows<n, 2 * n + 1, NW, true>(
+        ctx, [&](int r, int c) { return w.Mb[r][c] + (r == c ? 1.0 : 0.0); },
+        [&](int r, int c) { return c < n ? e1[E::A + r * n + c] : (c < 2 * n ? e1[E::C + r * n + (c - n)] : w.rh[r]); }, &w.X[0][0], LX, &w.ok);
     WG_FOR(ctx, r, n) w.X[r][2 * n + 1] = 0.0;
-    PH_TICK(ctx, 22);
-  } else
-#endif
+  }
+#else
   {
-  gauss_jordan<n, LG, 3 * n + 1, true>(ctx, &w.G[0][0], w.gj);
+    constexpr int LG = 3 * n + 2;
+    std::vector<double> Gv((size_t)n * LG);
+    GjWS gj;
+    WG_FOR(ctx, i, n * LG) {
+      const int r = i / LG, c = i % LG;
+      Gv[i] = c < n ? w.Mb[r][c] + (r == c ? 1.0 : 0.0) : (c < 2 * n ? e1[E::A + r * n + (c - n)] : (c < 3 * n ? e1[E::C + r * n + (c - 2 * n)] : (c == 3 * n ? w.rh[r] : 0.0)));
+    }
+    gauss_jordan<n, LG, 3 * n + 1, true>(ctx, Gv.data(), gj);
+    WG_FOR(ctx, i, n * LX) {
+      const int r = i / LX, c = i % LX;
+      const int p = gj.piv[r];
+      w.X[r][c] = c <= 2 * n ? Gv[(size_t)p * LG + n + c] / Gv[(size_t)p * LG + r] : 0.0;
+    }
+    if (!gj.ok) w.ok = 0;
+  }
+#endif
+  WG_SYNC(ctx);
   PH_TICK(ctx, 22);
-  WG_FOR(ctx, i, n * (2 * n + 2)) {
-    const int r = i / (2 * n + 2), c = i % (2 * n + 2);
-    const int p = w.gj.piv[r];
-    w.X[r][c] = c <= 2 * n ? w.G[p][n + c] / w.G[p][r] : 0.0;
-  }
-  }
-  WG_SYNC(ctx);   // G is dead from here on (out aliases it)
-  PH_TICK(ctx, 23);
-  {  // A = A2 XA (to the output), T = A2 XC, V = J2 XA;  z = XC y, b = A2 xb + b2
-    const XtyJob jobs[3] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], 2 * n + 2, out + E::A, n),
-                            xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], 2 * n + 2, &w.T[0][0], LD),
-                            xty_job(n, n, n, &w.J2[0][0], LD, &w.X[0][0], 2 * n + 2, &w.V[0][0], LD)};
-    wg_xty_jobs<true>(ctx, jobs, 3);
+  {  // A = A2 XA (to the output), V = J2 XA (over M);  z = XC y, b = A2 xb + b2
+    const XtyJob jobs[2] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], LX, out + E::A, n),
+                            xty_job(n, n, n, &w.J2[0][0], LD, &w.X[0][0], LX, &w.Mb[0][0], LD)};
+    wg_xty_jobs<true>(ctx, jobs, 2);
     WG_FOR(ctx, i, 2 * n) {
       if (i < n) { double s = 0.0; for (int l = 0; l < n; ++l) s += w.X[i][n + l] * w.y[l]; w.z[i] = s; }
       else { const int r = i - n; double s = w.b2[r]; for (int l = 0; l < n; ++l) s += w.A2T[l][r] * w.X[l][2 * n]; out[E::B + r] = s; }
     }
   }
   WG_SYNC(ctx);
-  PH_TICK(ctx, 24);
-  {  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]), J = A1' V + J1;  t = y - J2 z
-    XtyJob jc = xty_job(n, n, n, &w.T[0][0], 1, &w.A2T[0][0], LD, &w.out.Co[0][0], LD, e2 + E::C, n);
-    jc.sx1 = LD;
-    const XtyJob jobs[2] = {jc, xty_job(n, n, n, &w.A1[0][0], LD, &w.V[0][0], LD, &w.out.Jo[0][0], LD, e1 + E::J, n)};
-    wg_xty_jobs<true>(ctx, jobs, 2);
+  PH_TICK(ctx, 23);
+  // T = A2 XC over XA (dead);  t = y - J2 z;  A1 is fetched meanwhile and lands in the J2 buffer after the barrier
+  constexpr int NPA1 = (n * n + 511) / 512;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double ta1[NPA1];
+  const bool hoist = ctx.nthreads >= 512;
+  if (hoist) {
+#pragma unroll
+    for (int j = 0; j < NPA1; ++j) { const int e = ctx.tid + j * ctx.nthreads; ta1[j] = e1[E::A + (e < n * n ? e : 0)]; }
+  }
+#else
+  const bool hoist = false;
+#endif
+  {
+    const XtyJob job = xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], LX, &w.X[0][0], LX);
+    wg_xty_jobs<true>(ctx, &job, 1);
     WG_FOR(ctx, r, n) { double s = w.y[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.z[l]; w.t[r] = s; }
+  }
+  WG_SYNC(ctx);   // J2 is dead
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (hoist) {
+#pragma unroll
+    for (int j = 0; j < NPA1; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < n * n) w.J2[e / n][e % n] = ta1[j]; }
+  }
+#endif
+  if (!hoist) { WG_FOR(ctx, e, n * n) w.J2[e / n][e % n] = e1[E::A + e]; }
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 24);
+  {  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]), J = A1' V + J1: both symmetric -> tiles on / above the diagonal, mirrored, straight
+     // to the output element;  eta = eta1 + A1' t
+    XtyJob jc = xty_job(n, n, n, &w.X[0][0], 1, &w.A2T[0][0], LD, out + E::C, n, e2 + E::C, n);
+    jc.sx1 = LX;
+    XtyJob jj = xty_job(n, n, n, &w.J2[0][0], LD, &w.Mb[0][0], LD, out + E::J, n, e1 + E::J, n);
+    jc.sym = 1; jj.sym = 1;
+    const XtyJob jobs[2] = {jc, jj};
+    wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_C_GLOBAL>(ctx, jobs, 2);
+    WG_FOR(ctx, i, n + (E::SIZE - E::ETA - n) + 1) {
+      if (i < n) { double s = w.eta1[i]; for (int l = 0; l < n; ++l) s += w.J2[l][i] * w.t[l]; out[E::ETA + i] = s; }
+      else if (i < n + (E::SIZE - E::ETA - n)) out[E::ETA + n + (i - n)] = 0.0;
+      else if (!w.ok) *ok = 0;
+    }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 25);
-  WG_FOR(ctx, i, 2 * n * n + n + (E::SIZE - E::ETA - n) + 1) {
-    if (i < n * n) { const int r = i / n, c = i % n; out[E::C + i] = 0.5 * (w.out.Co[r][c] + w.out.Co[c][r]); }
-    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; out[E::J + j] = 0.5 * (w.out.Jo[r][c] + w.out.Jo[c][r]); }
-    else if (i < 2 * n * n + n) { const int r = i - 2 * n * n; double s = w.eta1[r]; for (int l = 0; l < n; ++l) s += w.A1[l][r] * w.t[l]; out[E::ETA + r] = s; }
-    else if (i < 2 * n * n + n + (E::SIZE - E::ETA - n)) out[E::ETA + n + (i - 2 * n * n - n)] = 0.0;
-    else if (!w.gj.ok) *ok = 0;
-  }
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 26);
 }
 
 }  // namespace hsqp
