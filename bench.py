@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--gait", default="walk", help="gait of the synthetic schedule (config 5: slow_walk)")
     ap.add_argument("--no-perturb", action="store_true", help="config 3: the unperturbed initial state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--riccati", default="auto", choices=["auto", "serial", "parallel"],
+                    help="backward sweep: auto (serial; scan for a centroidal problem with <= 2 instances), serial, parallel (the associative scan over the stages, hsqp_scan.h)")
     ap.add_argument("--global-batch", type=int, default=256, help="strong-scaling leg (N > 1): instances of the one global batch")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling / data-path leg")
     ap.add_argument("--force-strong", action="store_true", help="run the data-path leg on one GPU too (scatter / gather degenerate to copies): exercises hsqp_upload_device / hsqp_download_device")
@@ -254,7 +256,7 @@ def main():
                                                     seed=shard_seed(BENCH_SEED, rank))
     else:
         x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=args.gait, perturb=not args.no_perturb, seed=shard_seed(BENCH_SEED, rank))
-    solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank)
+    solver = HipSqpSolver(model, max_nodes=N, max_batch=B, device=local_rank, riccati=args.riccati)
     solver.upload(x0, x, u, par, dt)      # inputs resident in HBM before the timed region
 
     def sync():
@@ -298,9 +300,10 @@ def main():
         nodes = B * N
         f_rk4, f_gn, f_proj, f_ric = CENT_F if cent else (F_RK4, F_GN, F_PROJ, F_RIC)
         f_node, bytes_node = f_rk4 + f_gn + f_proj + f_ric, CENT_BYTES_NODE if cent else BYTES_NODE
+        scan_used = args.riccati == "parallel" or (args.riccati == "auto" and cent and B <= 2 and N >= 48)
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
         kern = {"lq_approximation(k_lq)": (kms[0], f_rk4 + f_gn, "k_lq_cent" if cent else "k_lq<true>"), "projection(k_project)": (kms[1], f_proj, "k_project"),
-                ("backward_sweep(k_scan_*: parallel-in-time scan)" if cent and B <= 2 and N >= 48 else "riccati(k_riccati)"): (kms[2], f_ric, "k_riccati")}
+                ("backward_sweep(k_scan_*: parallel-in-time scan)" if scan_used else "riccati(k_riccati)"): (kms[2], f_ric, "k_riccati")}
         dom = max(kern, key=lambda n: kern[n][0])
         dom_ms, dom_flops, dom_key = kern[dom]
         traffic = pmc_traffic(dom_key) if (B, N) == (256, 100) and not cent else None
@@ -313,7 +316,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config {cfg}: G1 {'centroidal' if cent else 'whole-body'} MPC, N={N}, dt={dt}, gait {args.gait}, {B} {'perturbed ' if not args.no_perturb else ''}instances per GPU, "
                                    "1 SQP iteration per step (LQ + projection + Riccati + full step + performance index), cold-start trajectory",
-                       "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                       "batch_per_gpu": B, "global_batch": B * world, "nodes": N, "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "backward_sweep": "parallel-in-time scan over the stages (hsqp_scan.h)" if scan_used else "serial Riccati recursion"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE) from the committed rocprofv3 --pmc "

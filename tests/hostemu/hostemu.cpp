@@ -14,11 +14,12 @@
 
 using namespace hsqp;
 
+static int g_scan_refinements = 2;   // whole-body scan: refinement passes (emu_set_scan_refinements)
 static int g_scan = 0;   // centroidal formulation: backward sweep by the parallel scan (hsqp_scan.h) instead of the serial recursion
 
 // the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
 template <int n>
-static int scan_backward(const DevModel& dm, int N, const double* x, const double* par, const double* qp, double* ric, double* vf, double* acl) {
+static int scan_backward(const DevModel& dm, int N, const double* x, const double* par, const double* qp, double* ric, double* vf, double* acl, int refinements) {
   Ctx ctx{0, 1, nullptr};
   using E = ScanEl<n>;
   std::vector<double> ea((size_t)(N + 1) * E::SIZE), eb((size_t)(N + 1) * E::SIZE);
@@ -36,21 +37,22 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
     ea.swap(eb);
   }
   if (!ok) return 0;
-  // one stage of the Riccati code per node, started from the scanned value function of node k + 1 (S = J, s = -eta) ...
-  std::vector<double> vf1((size_t)(N + 1) * VF_SIZE);
-  for (int k = 0; k < N; ++k) {
-    const double* en = &ea[(size_t)(k + 1) * E::SIZE];
-    riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
-                        vf1.data() + (size_t)k * VF_SIZE, en + E::J, en + E::ETA, k == N - 1, -1.0);
-    if (!rw->ok) return 0;
-  }
-  // ... and once more from the value functions of that pass (refinement: the exact Riccati map contracts the scan's rounding error)
-  for (int k = 0; k < N; ++k) {
-    const double* vn = vf1.data() + (size_t)(k + 1) * VF_SIZE;
-    riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
-                        vf + (size_t)k * VF_SIZE, vn, vn + NX * NX, k == N - 1, 1.0, NX);
-    if (!rw->ok) return 0;
-    closed_loop_record<n>(ctx, *rw, acl + (size_t)k * ACL_SIZE<n>);   // as k_scan_gains does in its last pass
+  // one stage of the Riccati code per node, started from the scanned value function of node k + 1 (S = J, s = -eta), then `refinements`
+  // times more from the value functions of the previous pass (the exact Riccati map contracts the scan's rounding error); the last
+  // pass also leaves the closed loop of every stage for the roll-out (k_scan_gains / launch_scan in hsqp_capi.hip)
+  std::vector<double> va((size_t)(N + 1) * VF_SIZE), vb((size_t)(N + 1) * VF_SIZE);
+  for (int pass = 0; pass <= refinements; ++pass) {
+    const bool lastp = pass == refinements;
+    double* vout = lastp ? vf : ((pass & 1) ? vb.data() : va.data());
+    const double* vin = pass == 0 ? nullptr : (((pass - 1) & 1) ? vb.data() : va.data());
+    for (int k = 0; k < N; ++k) {
+      const double* en = &ea[(size_t)(k + 1) * E::SIZE];
+      const double* vn = vin ? vin + (size_t)(k + 1) * VF_SIZE : nullptr;
+      riccati_backward<n>(ctx, *rw, dm.Qf, x + (size_t)N * NX, par + (size_t)N * NP, qp + (size_t)k * QP_SIZE, ric + (size_t)k * RIC_SIZE, 1,
+                          vout + (size_t)k * VF_SIZE, vn ? vn : en + E::J, vn ? vn + NX * NX : en + E::ETA, k == N - 1, vn ? 1.0 : -1.0, vn ? NX : n);
+      if (!rw->ok) return 0;
+      if (lastp) closed_loop_record<n>(ctx, *rw, acl + (size_t)k * ACL_SIZE<n>);
+    }
   }
   return 1;
 }
@@ -58,6 +60,7 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
 extern "C" {
 
 void emu_set_scan(int on) { g_scan = on; }
+void emu_set_scan_refinements(int r) { g_scan_refinements = r; }
 
 // Gauss-Jordan of hsqp_scan.h on a 35 x 106 system [M | RHS] (row-major, leading dimension 106; the shape of the combination step):
 // X = M^-1 RHS (35 x 71); returns ok
@@ -211,12 +214,17 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto terminal = [&](const double* xx) { double c = 0; for (int i = 0; i < NX; ++i) { const double d = xx[N * NX + i] - par[N * NP + HSQP_P_XDES + i]; c += 0.5 * dm.Qf[i] * d * d; } return c; };
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
-  std::vector<double> acl(cent && g_scan ? (size_t)N * ACL_SIZE<CNX> : 0);
-  if (cent && g_scan) { if (!scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data())) return HSQP_ERR_NUMERIC; rw->ok = 1; }
+  std::vector<double> acl(g_scan ? (size_t)N * ACL_SIZE<NX> : 0);
+  if (g_scan) {   // whole-body: two refinement passes (HSQP_SCAN_WB_REFINEMENTS in hsqp_capi.hip)
+    const int okk = cent ? scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), 1) : scan_backward<NX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), g_scan_refinements);
+    if (!okk) return HSQP_ERR_NUMERIC;
+    rw->ok = 1;
+  }
   else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
   if (cent && g_scan) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
+  else if (g_scan) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
   else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();

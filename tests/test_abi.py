@@ -73,14 +73,19 @@ def test_product_sources_never_reference_the_oracle():
 
 
 def test_parallel_riccati_flag_is_validated_before_the_device_is_touched(model):
-    """HSQP_FLAG_PARALLEL_RICCATI needs the centroidal formulation and excludes HSQP_FLAG_SERIAL_RICCATI: BAD_ARG, also without a GPU."""
+    """HSQP_FLAG_PARALLEL_RICCATI excludes HSQP_FLAG_SERIAL_RICCATI: BAD_ARG, also without a GPU; on its own it is valid for both formulations
+    (whole-body: opt-in only, csrc/hsqp_scan.h)."""
     import ctypes as C
     from wb_humanoid_mpc_amd import _abi, load_model, solver
     lib = solver.load_library()
     h = C.c_void_p()
-    st = _abi.Settings(max_nodes=4, max_batch=1, device=0, flags=_abi.FLAG_PARALLEL_RICCATI)
-    assert lib.hsqp_create(C.byref(model.desc), C.byref(st), C.byref(h)) == _abi.ERR_BAD_ARG
     cm = load_model(formulation="centroidal")
-    st = _abi.Settings(max_nodes=4, max_batch=1, device=0, flags=_abi.FLAG_PARALLEL_RICCATI | _abi.FLAG_SERIAL_RICCATI)
-    assert lib.hsqp_create(C.byref(cm.desc), C.byref(st), C.byref(h)) == _abi.ERR_BAD_ARG
-    assert b"PARALLEL_RICCATI" in lib.hsqp_last_error(None)
+    for m in (model, cm):
+        st = _abi.Settings(max_nodes=4, max_batch=1, device=0, flags=_abi.FLAG_PARALLEL_RICCATI | _abi.FLAG_SERIAL_RICCATI)
+        assert lib.hsqp_create(C.byref(m.desc), C.byref(st), C.byref(h)) == _abi.ERR_BAD_ARG
+        assert b"PARALLEL_RICCATI" in lib.hsqp_last_error(None)
+        st = _abi.Settings(max_nodes=4, max_batch=1, device=0, flags=_abi.FLAG_PARALLEL_RICCATI)
+        rc = lib.hsqp_create(C.byref(m.desc), C.byref(st), C.byref(h))
+        assert rc != _abi.ERR_BAD_ARG            # no GPU here: HSQP_ERR_NO_DEVICE; on a GPU box: HSQP_OK
+        if rc == 0:
+            lib.hsqp_destroy(h)

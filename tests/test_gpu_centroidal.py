@@ -210,10 +210,3 @@ def test_parallel_in_time_backward_sweep_equals_the_serial_recursion(cmodel, cor
         assert_perf(b["perf_after"][i], a["perf_after"][i], f"scan vs serial, instance {i}")
     r = coracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=4)
     assert_step(b, r, 0, "scan vs oracle")
-
-
-def test_parallel_riccati_flag_needs_the_centroidal_formulation(model):
-    from wb_humanoid_mpc_amd.solver import HipSqpSolver, HsqpError
-    with pytest.raises(HsqpError) as e:
-        HipSqpSolver(model, max_nodes=4, max_batch=1, riccati="parallel")
-    assert e.value.code == _abi.ERR_BAD_ARG

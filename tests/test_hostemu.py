@@ -94,3 +94,28 @@ def test_phases_are_free_of_intra_phase_dependencies(model, emu, gait, n):
         res.append((dx, du, qp, pb, pa))
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("gait,n", [("walk", 16), ("run", 37)])
+def test_whole_body_parallel_scan_backward_sweep_equals_the_serial_recursion(model, emu, gait, n):
+    """hsqp_scan.h at n = 58 (elements of all stages, ceil(log2(N+1)) levels of combinations, single-stage gains with two refinement
+    passes, closed-loop roll-out) against the serial recursion of the same kernel sources.  Tolerance as declared for the device
+    (tests/test_gpu_parity.py): a few 1e-9 of the step's scale — cond(I + C1 J2) reaches 1e9 on the whole-body problem."""
+    lib, h = emu
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=5)
+    res = []
+    for scan in (0, 1):
+        lib.emu_set_scan(scan)
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        qp = np.zeros((n, lib.emu_qp_size()))
+        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
+        lib.emu_set_scan(0)
+        assert rc == 0
+        res.append((dx, du, kkt, pa))
+    (dx0, du0, kkt0, pa0), (dx1, du1, kkt1, pa1) = res
+    sc = max(1.0, np.abs(dx0).max(), np.abs(du0).max())
+    err = max(np.abs(dx1 - dx0).max(), np.abs(du1 - du0).max())
+    assert err <= 5e-9 * sc, (err, sc)
+    assert kkt1[0] <= 1e-9 * sc * 100 and kkt1[1] <= 1e-10 * sc   # stationarity with the scanned value functions as costates (gradient scale >> step scale)
+    assert np.allclose(pa1, pa0, rtol=1e-8, atol=1e-12)

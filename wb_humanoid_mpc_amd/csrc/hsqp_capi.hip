@@ -447,7 +447,7 @@ struct hsqp_handle {
   int* d_counts = nullptr;
   hsqp_linesearch_settings ls_settings;
   double* d_el[2] = {nullptr, nullptr};   // scan elements (allocated when the parallel-in-time sweep is first used)
-  size_t el_capacity = 0;                 // in elements
+  size_t el_capacity = 0;                 // in doubles per buffer
   void* d_stage = nullptr;        // grow-only staging area for the small per-call inputs (reference, policy queries)
   size_t stage_bytes = 0;
   bool ls_ran = false;
@@ -481,6 +481,48 @@ static void* stage_area(hsqp_handle* h, size_t bytes) {
   return h->d_stage;
 }
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+constexpr int HSQP_SCAN_WB_REFINEMENTS = 2;   // whole-body elements are worse conditioned (cond(I + C1 J2) up to 1e9): two contractions by the exact Riccati map
+// parallel-in-time backward sweep (hsqp_scan.h): elements of all stages, ceil(log2(N+1)) scan levels, single-stage gains (from the
+// scanned value functions, then `refinements` times from the value functions of the previous gains pass), closed-loop roll-out
+template <int n>
+static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refinements) {
+  constexpr int SZ = ScanEl<n>::SIZE;
+  const int nodes = B * N;
+  const size_t need = (size_t)B * (N + 1) * SZ;
+  if (need > h->el_capacity) {
+    for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
+    h->el_capacity = 0;
+    for (auto& p : h->d_el)
+      if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
+    h->el_capacity = need;
+  }
+  hipLaunchKernelGGL(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
+  int cur = 0;
+  for (int d = 1; d < N + 1; d *= 2) {
+    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status, h->d_prof + 256);
+    cur = 1 - cur;
+  }
+  for (double** pv : {&h->d_vf, &h->d_vf2})
+    if (!*pv) {
+      const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
+      if (hipMalloc(pv, bytes) != hipSuccess) { *pv = nullptr; h->err = "hipMalloc failed (value functions of the scan, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+    }
+  if (!h->d_acl) {
+    const size_t bytes = (size_t)h->st.max_batch * h->st.max_nodes * ACL_SIZE<n> * 8;
+    if (hipMalloc(&h->d_acl, bytes) != hipSuccess) { h->d_acl = nullptr; h->err = "hipMalloc failed (closed loop of the scan path, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+  }
+  // the gains passes ping-pong between the two value-function buffers; the LAST pass writes d_vf2 (what the KKT check reads) and the closed loop
+  double* vbuf[2] = {(refinements & 1) ? h->d_vf : h->d_vf2, (refinements & 1) ? h->d_vf2 : h->d_vf};
+  for (int pass = 0; pass <= refinements; ++pass) {
+    const bool lastp = pass == refinements;
+    hipLaunchKernelGGL(k_scan_gains<n>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
+                       pass == 0 ? (const double*)nullptr : (const double*)vbuf[(pass - 1) & 1], h->d_ric, N, h->d_status,
+                       (lastp && !want_kkt) ? (double*)nullptr : vbuf[pass & 1], lastp ? h->d_acl : (double*)nullptr);
+  }
+  hipLaunchKernelGGL(k_scan_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);
+  return HSQP_OK;
+}
 
 extern "C" {
 
@@ -537,8 +579,8 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (!model || !settings || !out) { g_create_error = "null argument"; return HSQP_ERR_BAD_ARG; }
   *out = nullptr;
   if (settings->max_nodes < 1 || settings->max_batch < 1) { g_create_error = "max_nodes and max_batch must be >= 1"; return HSQP_ERR_BAD_ARG; }
-  if ((settings->flags & HSQP_FLAG_PARALLEL_RICCATI) && (model->formulation != HSQP_FORM_CENTROIDAL || (settings->flags & HSQP_FLAG_SERIAL_RICCATI))) {
-    g_create_error = "HSQP_FLAG_PARALLEL_RICCATI needs the centroidal formulation and excludes HSQP_FLAG_SERIAL_RICCATI";
+  if ((settings->flags & HSQP_FLAG_PARALLEL_RICCATI) && (settings->flags & HSQP_FLAG_SERIAL_RICCATI)) {
+    g_create_error = "HSQP_FLAG_PARALLEL_RICCATI excludes HSQP_FLAG_SERIAL_RICCATI";
     return HSQP_ERR_BAD_ARG;
   }
   int ndev = 0;
@@ -583,6 +625,10 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_combine<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanCombWS<CNX>));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_gains<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_forward<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_init<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanInitWS<NX>));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_combine<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanCombWS<NX>));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_gains<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_forward<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess || a5 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   *out = h;
   g_create_error.clear();
@@ -753,39 +799,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
     }
-    const bool scan = cent && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    // automatic choice only for the centroidal formulation: the whole-body scan agrees with the serial recursion to ~1e-9 of the step's
+    // scale only (cond(I + C1 J2) up to 1e9), which is outside the parity tolerance of the default path -> opt-in (HSQP_FLAG_PARALLEL_RICCATI)
+    const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (cent && B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
     if (scan) {
-      // parallel-in-time backward sweep (hsqp_scan.h): elements of all stages, ceil(log2(N+1)) scan levels, single-stage gains, roll-out
-      constexpr int SZ = ScanEl<CNX>::SIZE;
-      const size_t need = (size_t)B * (N + 1);
-      if (need > h->el_capacity) {
-        for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
-        h->el_capacity = 0;
-        for (auto& p : h->d_el)
-          if (hipMalloc(&p, need * SZ * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
-        h->el_capacity = need;
-      }
-      hipLaunchKernelGGL(k_scan_init<CNX>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<CNX>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
-      int cur = 0;
-      for (int d = 1; d < N + 1; d *= 2) {
-        hipLaunchKernelGGL(k_scan_combine<CNX>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<CNX>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status, h->d_prof + 256);
-        cur = 1 - cur;
-      }
-      // gains in two passes: from the scanned value functions (which also yields S_k of every node), then once more from those
-      for (double** pv : {&h->d_vf, &h->d_vf2})
-        if (!*pv) {
-          const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
-          if (hipMalloc(pv, bytes) != hipSuccess) { *pv = nullptr; h->err = "hipMalloc failed (value functions of the scan, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
-        }
-      if (!h->d_acl) {
-        const size_t bytes = (size_t)h->st.max_batch * h->st.max_nodes * ACL_SIZE<CNX> * 8;
-        if (hipMalloc(&h->d_acl, bytes) != hipSuccess) { h->d_acl = nullptr; h->err = "hipMalloc failed (closed loop of the scan path, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
-      }
-      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
-                         (const double*)nullptr, h->d_ric, N, h->d_status, h->d_vf, (double*)nullptr);
-      hipLaunchKernelGGL(k_scan_gains<CNX>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
-                         (const double*)h->d_vf, h->d_ric, N, h->d_status, want_kkt ? h->d_vf2 : (double*)nullptr, h->d_acl);
-      hipLaunchKernelGGL(k_scan_forward<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);
+      const int rc = cent ? launch_scan<CNX>(h, B, N, want_kkt, 1) : launch_scan<NX>(h, B, N, want_kkt, HSQP_SCAN_WB_REFINEMENTS);
+      if (rc != HSQP_OK) return rc;
     } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
       hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                          h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);

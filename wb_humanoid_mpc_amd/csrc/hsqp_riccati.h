@@ -522,7 +522,7 @@ HSQP_HD void closed_loop_forward(const Ctx& ctx, RicWS& w, const double* x_init,
       WG_SYNC(ctx);
       if (it < NX) {
         const double* p1 = &part[4 * (it < NXE ? it : 0)];
-        const double s = it < NXE ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[it];
+        const double s = (NXE == NX || it < NXE) ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[NXE == NX ? 0 : it];
         w.dx[it] = s;
         dx_out[(size_t)(k + 1) * NX + it] = s;
       }
@@ -542,7 +542,7 @@ HSQP_HD void closed_loop_forward(const Ctx& ctx, RicWS& w, const double* x_init,
     WG_SYNC(ctx);
     WG_FOR(ctx, i, NX) {
       const double* p1 = &part[4 * (i < NXE ? i : 0)];
-      const double s = i < NXE ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[i];
+      const double s = (NXE == NX || i < NXE) ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[NXE == NX ? 0 : i];
       w.dx[i] = s;
       dx_out[(size_t)(k + 1) * NX + i] = s;
     }
