@@ -130,13 +130,16 @@ typedef struct hsqp_model_desc {
 } hsqp_model_desc;
 
 #define HSQP_FLAG_LINESEARCH 1   /* hsqp_solve runs the filter line search (as the reference's SqpSolver does) instead of alpha = 1 */
-/* Backward sweep of the stage QP.  Default: the serial Riccati recursion, one workgroup per instance; for the centroidal
- * formulation with at most HSQP_SCAN_AUTO_BATCH instances and at least HSQP_SCAN_AUTO_MIN_NODES shooting intervals the
- * parallel-in-time sweep (associative scan over the stages, ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because one
- * or two serial chains leave the device idle (N = 100: 0.78 vs 1.59 ms).  Its result agrees with the serial recursion's to ~1e-11
- * of the step's scale on well-conditioned problems (3e-8 observed on an instance whose serial KKT residual is itself 1e-8). */
+/* Backward sweep of the stage QP.  Default: the serial Riccati recursion, one workgroup per instance.  With at most
+ * HSQP_SCAN_AUTO_BATCH instances and at least HSQP_SCAN_AUTO_MIN_NODES shooting intervals (both formulations) the parallel-in-time
+ * sweep (associative scan over the stages, ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because one or two serial
+ * chains leave the device idle (N = 100: centroidal 0.39 vs 0.81 ms, whole-body 1.0 vs 1.67 ms).  Its result agrees with the serial
+ * recursion's to ~1e-11 of the step's scale on the QPs of a cold start or of a tracking MPC; it degrades on far-from-feasible
+ * line-search iterates (cond(I + C1 J2) up to 1e9), so every scan result is GATED by the KKT residual of the QP (5e-11 max(1, |g|_inf),
+ * twenty times tighter than BASELINE.md's criterion for a QP solution) and the iteration is redone with the serial recursion when it
+ * fails: hsqp_scan_fallbacks() counts those. */
 #define HSQP_FLAG_SERIAL_RICCATI 2     /* always the serial recursion                                              */
-#define HSQP_FLAG_PARALLEL_RICCATI 4   /* always the scan (centroidal formulation only; hsqp_create fails otherwise) */
+#define HSQP_FLAG_PARALLEL_RICCATI 4   /* the scan for every batch size and horizon (still gated); excludes HSQP_FLAG_SERIAL_RICCATI */
 #define HSQP_SCAN_AUTO_BATCH 2
 #define HSQP_SCAN_AUTO_MIN_NODES 48
 typedef struct hsqp_settings {
@@ -300,6 +303,8 @@ int hsqp_joint_torques(hsqp_handle* h, int n, const double* x /*[n][58]*/, const
 int hsqp_evaluate_policy(hsqp_handle* h, const double* s /*[B]*/, double* x /*[B][58]*/, double* u /*[B][35]*/, double* tau /*[B][23]*/);
 
 const char* hsqp_last_error(const hsqp_handle* h);   /* h may be NULL: last creation error */
+/* Iterations since hsqp_create whose parallel-in-time sweep failed the KKT gate and were redone with the serial recursion (-1: h is NULL). */
+long long hsqp_scan_fallbacks(const hsqp_handle* h);
 const char* hsqp_version(void);
 int hsqp_device_count(void);
 

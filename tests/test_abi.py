@@ -21,7 +21,7 @@ def _header_functions():
 def test_header_declares_the_expected_entry_points():
     assert _header_functions() == sorted([
         "hsqp_create", "hsqp_destroy", "hsqp_solve", "hsqp_upload", "hsqp_iterate_device", "hsqp_download",
-        "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_version", "hsqp_device_count",
+        "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_scan_fallbacks", "hsqp_version", "hsqp_device_count",
         "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference", "hsqp_joint_torques", "hsqp_evaluate_policy",
         "hsqp_upload_device", "hsqp_download_device"])
 

@@ -109,13 +109,17 @@ def test_first_linesearch_iterations_at_full_size_equal_the_oracle(model, cmodel
             ls = (o.cent_linesearch if cent else o.linesearch)(dt, xo, uo, r["dx"], r["du"], par[0], r["armijo"], threads=threads)
             assert out["alpha"][0] == ls["alpha"] and out["step_type"][0] == ls["step_type"], (it, out["alpha"][0], ls["alpha"])
             # iteration 1 from the cold start: BASELINE.md §6 as is.  DECLARED RELAXATION for iterations 2 and 3: they linearise about the
-            # first accepted trial point, which is far from feasible (|du| 600 - 1000 N on these QPs); measured error 6.5e-7 (config 2,
-            # parallel-in-time sweep) and 2.2e-8 (config 3) = 1.1e-9 / 6e-11 of the step, allowed: 1e-8 + 2e-9 |step|_inf
-            lim = TRAJ_ABS + (0.0 if it == 0 else 2e-9 * max(np.abs(r["dx"]).max(), np.abs(r["du"]).max()))
+            # first accepted trial point, which is far from feasible (|du| 600 - 1000 N on these QPs); measured error 1.6e-7 (config 2)
+            # and 5.4e-8 (config 3) = 3e-10 / 7e-11 of the step, allowed: 1e-8 + 1e-9 |step|_inf.  On these iterates the parallel-in-time
+            # sweep fails its KKT gate (stationarity 1e-5 .. 1e-4) and the iteration is redone with the serial recursion: asserted below.
+            lim = TRAJ_ABS + (0.0 if it == 0 else 1e-9 * max(np.abs(r["dx"]).max(), np.abs(r["du"]).max()))
             assert np.abs(out["x"][0] - ls["x"]).max() <= lim and np.abs(out["u"][0] - ls["u"]).max() <= lim, it
             assert_perf(out["perf_after"][0], ls["perf"], f"{name} iteration {it}", rel=1e-10 if it == 0 else 1e-9)   # same relaxation (measured 2.4e-10)
             xs, us = out["x"], out["u"]
             xo, uo = out["x"][0], out["u"][0]      # the oracle follows the device's trajectory: errors are per iteration, not compounded
+        # one instance on 100 nodes takes the parallel-in-time sweep: accepted on the cold-start QP, rejected by the gate on the two
+        # ill-conditioned iterates that follow
+        assert s.scan_fallbacks() == 2, s.scan_fallbacks()
     finally:
         s.close()
 

@@ -439,6 +439,7 @@ struct hsqp_handle {
   bool uniform_grid = true, has_events = false;
   double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
   double* d_vf2 = nullptr;        // scan path: value functions of the refinement pass (the KKT check then reads these)
+  long long scan_fallbacks = 0;   // iterations whose scan result failed the KKT gate and were redone with the serial recursion
   double* d_acl = nullptr;        // scan path: closed loop [B][N][ACL_SIZE] of every stage for the roll-out (allocated when the scan is first used)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
@@ -482,6 +483,11 @@ static void* stage_area(hsqp_handle* h, size_t bytes) {
 }
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// KKT gate of the parallel-in-time sweep, relative to max(1, |g|_inf).  BASELINE.md §6 asks 1e-9 of a QP solution; on ill-conditioned QPs a
+// residual of that size still leaves the step five digits off (measured: 3e-10 .. 5e-10 on the far-from-feasible line-search iterates of
+// configs 2 and 3, where the scan's trajectories differ from the oracle's by 1e-3), while the scan reaches 2.5e-13 (config 2) and
+// 1.3e-11 (config 3) where it is accurate.  The gate sits between the two populations.
+constexpr double HSQP_SCAN_GATE_REL = 5e-11;
 constexpr int HSQP_SCAN_WB_REFINEMENTS = 2;   // whole-body elements are worse conditioned (cond(I + C1 J2) up to 1e9): two contractions by the exact Riccati map
 // parallel-in-time backward sweep (hsqp_scan.h): elements of all stages, ceil(log2(N+1)) scan levels, single-stage gains (from the
 // scanned value functions, then `refinements` times from the value functions of the previous gains pass), closed-loop roll-out
@@ -533,6 +539,8 @@ int hsqp_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+long long hsqp_scan_fallbacks(const hsqp_handle* h) { return h ? h->scan_fallbacks : -1; }
 
 const char* hsqp_last_error(const hsqp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -799,29 +807,62 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
     }
-    // automatic choice only for the centroidal formulation: the whole-body scan agrees with the serial recursion to ~1e-9 of the step's
-    // scale only (cond(I + C1 J2) up to 1e9), which is outside the parity tolerance of the default path -> opt-in (HSQP_FLAG_PARALLEL_RICCATI)
-    const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (cent && B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
-    if (scan) {
-      const int rc = cent ? launch_scan<CNX>(h, B, N, want_kkt, 1) : launch_scan<NX>(h, B, N, want_kkt, HSQP_SCAN_WB_REFINEMENTS);
-      if (rc != HSQP_OK) return rc;
-    } else if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
-      hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                         h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
-    else
-      hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                         h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, want_kkt ? h->d_vf : (double*)nullptr);
-    if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
-    if (cent)
-      hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                         h->d_xnew, h->d_unew, h->d_stepinfo);
-    else   // whole-body: the step and its value pass are one kernel (k_step_value)
-      hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
-                         h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
-    if (want_kkt) {
+    // The backward sweep: serial recursion, or — one or two instances on a long horizon, or on request — the associative scan over the
+    // stages (hsqp_scan.h).  The scan inverts I + C1 J2 of partial horizons (condition number up to 1e5 centroidal, 1e9 whole-body): on
+    // the QPs of a cold start or of a tracking MPC it reproduces the serial recursion to 1e-11 of the step's scale, on a far-from-
+    // feasible line-search iterate it can lose five digits.  Its result is therefore GATED: the KKT residual of the QP is evaluated
+    // (k_kkt, one small kernel + one 3 B-double read-back) and, if a residual exceeds HSQP_SCAN_GATE_REL max(1, |g|_inf), the
+    // iteration is redone with the serial recursion (hsqp_scan_fallbacks counts these).
+    const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    auto launch_sweep = [&](bool use_scan, bool need_vf) -> int {
+      if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
+      if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
+        hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr);
+      else
+        hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr);
+      return HSQP_OK;
+    };
+    auto launch_step = [&]() {
+      if (cent)
+        hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+                           h->d_xnew, h->d_unew, h->d_stepinfo);
+      else   // whole-body: the step and its value pass are one kernel (k_step_value)
+        hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
+                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
+    };
+    auto launch_kkt = [&](bool from_scan) -> int {
       HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
       HCHECK(hipMemsetAsync(h->d_ginf, 0, (size_t)B * 8, h->stream));
-      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+      return HSQP_OK;
+    };
+    { const int rc = launch_sweep(scan, want_kkt || scan); if (rc != HSQP_OK) return rc; }
+    if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
+    launch_step();
+    if (scan) {
+      { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
+      std::vector<double> hk((size_t)3 * B);
+      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, (size_t)B * 2 * 8, hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipMemcpyAsync(hk.data() + 2 * B, h->d_ginf, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipStreamSynchronize(h->stream));
+      bool accept = true;
+      for (int b = 0; b < B; ++b) {
+        const double lim = HSQP_SCAN_GATE_REL * (hk[2 * B + b] > 1.0 ? hk[2 * B + b] : 1.0);
+        if (!(hk[2 * b] <= lim && hk[2 * b + 1] <= lim)) accept = false;
+      }
+      if (!accept) {
+        ++h->scan_fallbacks;
+        if (want_kkt && !h->d_vf) { h->err = "internal: value-function buffer missing"; return HSQP_ERR_HIP; }
+        { const int rc = launch_sweep(false, want_kkt != 0); if (rc != HSQP_OK) return rc; }
+        if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
+        launch_step();
+        if (want_kkt) { const int rc = launch_kkt(false); if (rc != HSQP_OK) return rc; }
+      }
+    } else if (want_kkt) {
+      const int rc = launch_kkt(false);
+      if (rc != HSQP_OK) return rc;
     }
     if (cent)
       hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,

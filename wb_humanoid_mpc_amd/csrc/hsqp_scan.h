@@ -254,7 +254,7 @@ struct ScanCombWS {
 
 // e1 (i -> j), e2 (j -> k) -> out (i -> k); returns through *ok whether every pivot was usable.
 // 137 KB of LDS for n = 58: the augmented matrix [M | A1 | C1 | rhs] of the elimination lives in registers (gauss_jordan_rows), the
-// symmetric results C and J are formed as symmetric tile jobs straight into the output element.
+// two symmetric results are staged for their symmetrisation in buffers that are dead by then.
 template <int n>
 HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, const double* e2, double* out, int* ok) {
   using E = ScanEl<n>;
@@ -351,22 +351,32 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   if (!hoist) { WG_FOR(ctx, e, n * n) w.J2[e / n][e % n] = e1[E::A + e]; }
   WG_SYNC(ctx);
   PH_TICK(ctx, 24);
-  {  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]), J = A1' V + J1: both symmetric -> tiles on / above the diagonal, mirrored, straight
-     // to the output element;  eta = eta1 + A1' t
-    XtyJob jc = xty_job(n, n, n, &w.X[0][0], 1, &w.A2T[0][0], LD, out + E::C, n, e2 + E::C, n);
+  // C = T A2' + C2 (X^T Y with X[l][i] = T[i][l]) and J = A1' V + J1 are symmetric in exact arithmetic, but the computed X carries the
+  // rounding of an elimination whose condition number reaches 1e5 (centroidal) .. 1e9 (whole-body): the ANTISYMMETRIC part of that error
+  // is removed by averaging the two triangles, which is worth three digits on ill-conditioned iterates (measured: input error 1.3e-4
+  // vs 2e-7 on the line-search iterations of config 2) — so both products are formed in full and symmetrised, one after the other
+  // through the two buffers that are free by then: the XC columns of X (T is formed, z and b are out), then A2'.
+  {
+    XtyJob jc = xty_job(n, n, n, &w.X[0][0], 1, &w.A2T[0][0], LD, &w.X[0][n], LX, e2 + E::C, n);
     jc.sx1 = LX;
-    XtyJob jj = xty_job(n, n, n, &w.J2[0][0], LD, &w.Mb[0][0], LD, out + E::J, n, e1 + E::J, n);
-    jc.sym = 1; jj.sym = 1;
-    const XtyJob jobs[2] = {jc, jj};
-    wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_C_GLOBAL>(ctx, jobs, 2);
-    WG_FOR(ctx, i, n + (E::SIZE - E::ETA - n) + 1) {
-      if (i < n) { double s = w.eta1[i]; for (int l = 0; l < n; ++l) s += w.J2[l][i] * w.t[l]; out[E::ETA + i] = s; }
-      else if (i < n + (E::SIZE - E::ETA - n)) out[E::ETA + n + (i - n)] = 0.0;
-      else if (!w.ok) *ok = 0;
-    }
+    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, &jc, 1);
+    WG_FOR(ctx, i, n) { double s = w.eta1[i]; for (int l = 0; l < n; ++l) s += w.J2[l][i] * w.t[l]; out[E::ETA + i] = s; }
+  }
+  WG_SYNC(ctx);   // A2' is dead
+  {
+    const XtyJob jj = xty_job(n, n, n, &w.J2[0][0], LD, &w.Mb[0][0], LD, &w.A2T[0][0], LD, e1 + E::J, n);
+    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, &jj, 1);
+    WG_FOR(ctx, i, n * n) { const int r = i / n, c = i % n; out[E::C + i] = 0.5 * (w.X[r][n + c] + w.X[c][n + r]); }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 25);
+  WG_FOR(ctx, i, n * n + (E::SIZE - E::ETA - n) + 1) {
+    if (i < n * n) { const int r = i / n, c = i % n; out[E::J + i] = 0.5 * (w.A2T[r][c] + w.A2T[c][r]); }
+    else if (i < n * n + (E::SIZE - E::ETA - n)) out[E::ETA + n + (i - n * n)] = 0.0;
+    else if (!w.ok) *ok = 0;
+  }
+  WG_SYNC(ctx);
+  PH_TICK(ctx, 26);
 }
 
 }  // namespace hsqp

@@ -52,6 +52,8 @@ def load_library():
     lib.hsqp_last_kernel_ms.argtypes = [C.c_void_p, _dp]
     lib.hsqp_last_error.argtypes = [C.c_void_p]
     lib.hsqp_last_error.restype = C.c_char_p
+    lib.hsqp_scan_fallbacks.argtypes = [C.c_void_p]
+    lib.hsqp_scan_fallbacks.restype = C.c_longlong
     lib.hsqp_version.restype = C.c_char_p
     lib.hsqp_joint_torques.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.hsqp_evaluate_policy.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
@@ -69,7 +71,7 @@ def _c(a):
 class HipSqpSolver:
     def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False, riccati="auto"):
         """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step.
-        riccati: "auto" (serial recursion; parallel-in-time scan for a centroidal problem with <= 2 instances and >= 48 nodes),
+        riccati: "auto" (serial recursion; KKT-gated parallel-in-time scan for <= 2 instances on >= 48 nodes),
         "serial", "parallel"."""
         self.lib = load_library()
         self.model = model
@@ -243,6 +245,10 @@ class HipSqpSolver:
         ms = np.zeros(5)
         self._check(self.lib.hsqp_last_kernel_ms(self.h, ms.ctypes.data_as(_dp)))
         return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
+
+    def scan_fallbacks(self):
+        """Iterations whose parallel-in-time sweep failed the KKT gate and were redone with the serial recursion (hsqp_scan_fallbacks)."""
+        return int(self.lib.hsqp_scan_fallbacks(self.h))
 
     # ---- the step after the solve: MPC_MRT_Interface::evaluatePolicy + computeJointTorques (WBMpcMrtJointController.cpp:136-147)
     def evaluate_policy(self, s):
