@@ -130,7 +130,8 @@ __global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restr
 }
 
 // ---- parallel-in-time backward sweep (hsqp_scan.h).  Elements: [B][N + 1][ScanEl<n>::SIZE], two buffers (ping-pong per level).
-constexpr int SCAN_INIT_THREADS = 256, SCAN_COMB_THREADS = 512;
+constexpr int SCAN_INIT_THREADS = 256, SCAN_COMB_THREADS = 512, SCAN_FWD_THREADS = 256;
+static_assert(4 * NX <= SCAN_FWD_THREADS, "closed_loop_forward: one item per thread");
 template <int n>
 __global__ __launch_bounds__(SCAN_INIT_THREADS) void k_scan_init(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
                                                                  const double* __restrict__ qp, int N, double* __restrict__ el) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __re
   if (acl) closed_loop_record<n>(ctx, w, acl + (size_t)node * ACL_SIZE<n>);   // the last pass: closed loop of this stage for the roll-out
 }
 template <int n>
-__global__ __launch_bounds__(RIC_THREADS) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ acl,
+__global__ __launch_bounds__(SCAN_FWD_THREADS) void k_scan_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ acl,
                                                               int N, double* __restrict__ dx) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
@@ -526,7 +527,7 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
                        pass == 0 ? (const double*)nullptr : (const double*)vbuf[(pass - 1) & 1], h->d_ric, N, h->d_status,
                        (lastp && !want_kkt) ? (double*)nullptr : vbuf[pass & 1], lastp ? h->d_acl : (double*)nullptr);
   }
-  hipLaunchKernelGGL(k_scan_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);
+  hipLaunchKernelGGL(k_scan_forward<n>, dim3(B), dim3(SCAN_FWD_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);   // 4 n <= 256 items per stage: four waves
   return HSQP_OK;
 }
 

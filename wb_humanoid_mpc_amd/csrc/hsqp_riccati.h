@@ -497,36 +497,43 @@ HSQP_HD void closed_loop_forward(const Ctx& ctx, RicWS& w, const double* x_init,
   double* part = w.SA[0];
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads >= 4 * NXE) {
-    // item it < 4 NXE owns the columns p + 4c of row it >> 2; the slice of stage k + 1 is fetched while stage k is being combined
+    // item it < 4 NXE owns the columns p + 4c of row it >> 2.  The closed loops were written by N different workgroups a moment ago, so a
+    // stage's slice comes from the far caches (1 - 2 us) while a stage takes 0.4 us: the slices are fetched PF stages ahead into a ring of
+    // register sets (the loop is unrolled by PF so that every set has fixed registers)
+    constexpr int PF = 4;
     const int it = ctx.tid, row = it >> 2, p = it & 3;
     const bool live = it < 4 * NXE;
-    double a[NC], an[NC], sc = 0.0, scn = 0.0;
+    double a[PF][NC], sc[PF];
     auto fetch = [&](int k, double* av, double& s1) {
       const double* r = acl + (size_t)k * ACL_SIZE<NXE>;
 #pragma unroll
       for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; av[c] = (live && cc < NXE) ? r[row * NXE + cc] : 0.0; }
       s1 = (live && p == 0) ? r[NXE * NXE + row] : 0.0;
     };
-    fetch(0, an, scn);
-    for (int k = 0; k < N; ++k) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) a[c] = an[c];
-      sc = scn;
-      if (k + 1 < N) fetch(k + 1, an, scn);
-      if (live) {
-        double s = sc;
+    for (int u = 0; u < PF; ++u) { if (u < N) fetch(u, a[u], sc[u]); }
+    for (int k0 = 0; k0 < N; k0 += PF) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[c] * w.dx[cc]; }
-        part[it] = s;
+      for (int u = 0; u < PF; ++u) {
+        const int k = k0 + u;
+        if (k < N) {
+          if (live) {
+            double s = sc[u];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[u][c] * w.dx[cc]; }
+            part[it] = s;
+          }
+          if (k + PF < N) fetch(k + PF, a[u], sc[u]);
+          WG_SYNC(ctx);
+          if (it < NX) {
+            const double* p1 = &part[4 * (it < NXE ? it : 0)];
+            const double s = (NXE == NX || it < NXE) ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[NXE == NX ? 0 : it];
+            w.dx[it] = s;
+            dx_out[(size_t)(k + 1) * NX + it] = s;
+          }
+          WG_SYNC(ctx);
+        }
       }
-      WG_SYNC(ctx);
-      if (it < NX) {
-        const double* p1 = &part[4 * (it < NXE ? it : 0)];
-        const double s = (NXE == NX || it < NXE) ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[NXE == NX ? 0 : it];
-        w.dx[it] = s;
-        dx_out[(size_t)(k + 1) * NX + it] = s;
-      }
-      WG_SYNC(ctx);
     }
     return;
   }

@@ -107,11 +107,24 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
 // The same elimination with the matrix in REGISTERS (device, combination step): lane i of a wave holds row i — the n columns of M and
 // a share NO of the right-hand-side columns — and NW waves each eliminate M redundantly (identical arithmetic, identical pivots) on
 // their own share, so a step needs no barrier, no LDS traffic and no dynamic register index: the pivot row is a LANE, its elements come
-// through v_readlane with that (wave-uniform) lane number, the pivot search is a scalar maximum over n readlanes of the packed
+// through v_readlane with that (wave-uniform) lane number, the pivot search is a DPP wave maximum of the packed
 // (magnitude | lane) candidates, and each lane's multiplier is its own element of column j.  Rows are never swapped: a used row stays
 // in its lane and remembers which solution row it is.  X[r][c] (leading dimension ldx)
 // receives the solution row r of right-hand-side column c < nrhs.  Steps: ~0.9 k cycles instead of 3.8 k for the LDS form.
 // load_m(row, c) / load_r(row, c): element of M / of the right-hand sides (from LDS or global memory).
+// maximum of an unsigned value over the 64 lanes of the wave (wave-uniform result): Hillis-Steele inside the rows of 16 lanes with DPP
+// row shifts, then the two row broadcasts of the GFX9 DPP set; a lane without a source keeps 0, the identity of the unsigned maximum
+__device__ inline unsigned wave_umax(unsigned v) {
+  auto step = [](unsigned x, int y) { return x > (unsigned)y ? x : (unsigned)y; };
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8   -> lane 15 of a row: the row's maximum
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = step(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3 -> lane 63: all
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int n, int nrhs, int NW, bool PIVOT, class LoadM, class LoadR>
 __device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR load_r, double* X, int ldx, int* okflag) {
   constexpr int NO = (nrhs + NW - 1) / NW;
@@ -138,10 +151,7 @@ __device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR loa
     int p = j;                    // PIVOT = false: diagonal pivots (symmetric positive definite M)
     if (PIVOT) {
       const unsigned cand = used ? 0u : ((__float_as_uint((float)(fabs(m[j]) * rscale)) & ~63u) | (unsigned)lane);
-      unsigned best = 0u;
-#pragma clang loop unroll(full)
-      for (int i = 0; i < n; ++i) { const unsigned ci = (unsigned)__builtin_amdgcn_readlane((int)cand, i); best = ci > best ? ci : best; }
-      p = (int)(best & 63u);
+      p = (int)(wave_umax(cand) & 63u);
     }
     double pv = readlane_f64(m[j], p);
     if (!(fabs(pv) > 1e-300)) { good = false; pv = 1.0; }
