@@ -300,7 +300,7 @@ def main():
         nodes = B * N
         f_rk4, f_gn, f_proj, f_ric = CENT_F if cent else (F_RK4, F_GN, F_PROJ, F_RIC)
         f_node, bytes_node = f_rk4 + f_gn + f_proj + f_ric, CENT_BYTES_NODE if cent else BYTES_NODE
-        scan_used = args.riccati == "parallel" or (args.riccati == "auto" and cent and B <= 2 and N >= 48)
+        scan_used = args.riccati == "parallel" or (args.riccati == "auto" and B <= 2 and N >= 48)   # HSQP_SCAN_AUTO_BATCH / _MIN_NODES (include/hsqp.h)
         # dominant kernel of one step, its algorithmic work and measured duration (HIP events on the library's stream)
         kern = {"lq_approximation(k_lq)": (kms[0], f_rk4 + f_gn, "k_lq_cent" if cent else "k_lq<true>"), "projection(k_project)": (kms[1], f_proj, "k_project"),
                 ("backward_sweep(k_scan_*: parallel-in-time scan)" if scan_used else "riccati(k_riccati)"): (kms[2], f_ric, "k_riccati")}

@@ -135,9 +135,9 @@ typedef struct hsqp_model_desc {
  * sweep (associative scan over the stages, ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because one or two serial
  * chains leave the device idle (N = 100: centroidal 0.39 vs 0.81 ms, whole-body 1.0 vs 1.67 ms).  Its result agrees with the serial
  * recursion's to ~1e-11 of the step's scale on the QPs of a cold start or of a tracking MPC; it degrades on far-from-feasible
- * line-search iterates (cond(I + C1 J2) up to 1e9), so every scan result is GATED by the KKT residual of the QP (5e-11 max(1, |g|_inf),
- * twenty times tighter than BASELINE.md's criterion for a QP solution) and the iteration is redone with the serial recursion when it
- * fails: hsqp_scan_fallbacks() counts those. */
+ * line-search iterates and on badly scaled QPs (cond(I + C1 J2) up to 1e9), so every scan result is GATED by the KKT residual of the
+ * QP (min(1e-9 max(1, |g|_inf), 2e-8)) and the iteration is redone with the serial recursion when it fails: hsqp_scan_fallbacks()
+ * counts those. */
 #define HSQP_FLAG_SERIAL_RICCATI 2     /* always the serial recursion                                              */
 #define HSQP_FLAG_PARALLEL_RICCATI 4   /* the scan for every batch size and horizon (still gated); excludes HSQP_FLAG_SERIAL_RICCATI */
 #define HSQP_SCAN_AUTO_BATCH 2

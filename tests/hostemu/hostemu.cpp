@@ -14,7 +14,7 @@
 
 using namespace hsqp;
 
-static int g_scan_refinements = 2;   // whole-body scan: refinement passes (emu_set_scan_refinements)
+static int g_scan_refinements = 0;   // whole-body scan: refinement passes (HSQP_SCAN_WB_REFINEMENTS in hsqp_capi.hip; emu_set_scan_refinements)
 static int g_scan = 0;   // centroidal formulation: backward sweep by the parallel scan (hsqp_scan.h) instead of the serial recursion
 
 // the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
@@ -215,7 +215,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
   std::vector<double> acl(g_scan ? (size_t)N * ACL_SIZE<NX> : 0);
-  if (g_scan) {   // whole-body: two refinement passes (HSQP_SCAN_WB_REFINEMENTS in hsqp_capi.hip)
+  if (g_scan) {
     const int okk = cent ? scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), 1) : scan_backward<NX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), g_scan_refinements);
     if (!okk) return HSQP_ERR_NUMERIC;
     rw->ok = 1;

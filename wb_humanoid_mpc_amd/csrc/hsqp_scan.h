@@ -103,6 +103,15 @@ HSQP_HD void gauss_jordan(const Ctx& ctx, double* G, GjWS& g) {
   }
 }
 
+// LDS mailbox of gauss_jordan_pipeline (below)
+struct GjPipe {
+  static constexpr int CH = 8;
+  double f[2][CH][64];     // multiplier of row (lane) i at step j of the chunk (0 for the pivot row itself and for the padding lanes)
+  int piv[2][CH];          // pivot lane of the step
+  int mycol[64];           // which solution row the lane's row became
+  double rdiag[64];        // 1 / its pivot
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // The same elimination with the matrix in REGISTERS (device, combination step): lane i of a wave holds row i — the n columns of M and
 // a share NO of the right-hand-side columns — and NW waves each eliminate M redundantly (identical arithmetic, identical pivots) on
@@ -170,6 +179,80 @@ __device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR loa
     for (int c = 0; c < NO; ++c) if (c0 + c < nrhs) X[mycol * ldx + c0 + c] = o[c] * rd;
   }
   if (!good && ctx.tid == 0) *okflag = 0;
+}
+
+// The same elimination as a PIPELINE over the waves of an 8-wave workgroup (combination step).  In gauss_jordan_rows every wave repeats
+// the elimination of M (two thirds of its instructions at n = 58); here wave 0 alone eliminates M, CH steps at a time, and publishes
+// per step the pivot lane and every row's multiplier (LDS, double-buffered per chunk); the other seven waves hold only right-hand-side
+// columns and apply the chunk wave 0 finished one barrier earlier: o[c] -= f_row * (pivot row's o[c], by v_readlane).  One barrier per
+// chunk, both sides take about the same time per step (M: 58 - j column updates on one wave; right-hand sides: 17 on each of seven).
+
+template <int n, int nrhs, class LoadM, class LoadR>
+__device__ inline void gauss_jordan_pipeline(const Ctx& ctx, GjPipe& g, LoadM load_m, LoadR load_r, double* X, int ldx, int* okflag) {
+  constexpr int CH = GjPipe::CH, NCHK = (n + CH - 1) / CH, NRW = 7, NO = (nrhs + NRW - 1) / NRW;
+  const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
+  const int row = lane < n ? lane : n - 1;
+  const int c0 = (wave - 1) * NO;
+  double m[n], o[NO];
+  double rscale = 1.0, dpiv = 1.0;
+  bool used = lane >= n, good = true;
+  int mycol = 0;
+  if (wave == 0) {
+#pragma clang loop unroll(full)
+    for (int c = 0; c < n; ++c) m[c] = load_m(row, c);
+    double mx = 0.0;
+#pragma clang loop unroll(full)
+    for (int c = 0; c < n; ++c) mx = fmax(mx, fabs(m[c]));
+    rscale = mx > 0.0 ? 1.0 / mx : 1.0;
+  } else {
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NO; ++c) o[c] = load_r(row, c0 + c < nrhs ? c0 + c : nrhs - 1);
+  }
+#pragma clang loop unroll(full)
+  for (int k = 0; k <= NCHK; ++k) {
+    if (wave == 0) {
+      if (k < NCHK) {
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < CH; ++jj) {
+          const int j = k * CH + jj;
+          if (j < n) {
+            const unsigned cand = used ? 0u : ((__float_as_uint((float)(fabs(m[j]) * rscale)) & ~63u) | (unsigned)lane);
+            const int p = (int)(wave_umax(cand) & 63u);
+            double pv = readlane_f64(m[j], p);
+            if (!(fabs(pv) > 1e-300)) { good = false; pv = 1.0; }
+            const double rpv = fast_rcp(pv);
+            const bool isp = lane == p;
+            const double f = (isp || lane >= n) ? 0.0 : m[j] * rpv;
+            if (isp) { used = true; mycol = j; dpiv = pv; }
+            g.f[k & 1][jj][lane] = f;
+            if (lane == 0) g.piv[k & 1][jj] = p;
+#pragma clang loop unroll(full)
+            for (int c = j + 1; c < n; ++c) m[c] -= f * readlane_f64(m[c], p);
+          }
+        }
+        if (k == NCHK - 1) {
+          g.mycol[lane] = mycol;
+          g.rdiag[lane] = 1.0 / dpiv;
+          if (!good && lane == 0) *okflag = 0;
+        }
+      }
+    } else if (k > 0) {
+      const int kc = k - 1, nst = (kc + 1) * CH <= n ? CH : n - kc * CH;
+      for (int jj = 0; jj < nst; ++jj) {
+        const int p = __builtin_amdgcn_readfirstlane(g.piv[kc & 1][jj]);
+        const double f = g.f[kc & 1][jj][lane];
+#pragma clang loop unroll(full)
+        for (int c = 0; c < NO; ++c) o[c] -= f * readlane_f64(o[c], p);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave > 0 && lane < n) {
+    const int r = g.mycol[lane];
+    const double rd = g.rdiag[lane];
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NO; ++c) if (c0 + c < nrhs) X[r * ldx + c0 + c] = o[c] * rd;
+  }
 }
 #endif
 
@@ -260,6 +343,7 @@ struct ScanCombWS {
   };
   double b1[n], eta1[n], b2[n], eta2[n], y[n], z[n], t[n], rh[n];
   int ok;
+  GjPipe gp;
 };
 
 // e1 (i -> j), e2 (j -> k) -> out (i -> k); returns through *ok whether every pivot was usable.
@@ -297,9 +381,8 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   // [XA | XC | xb] = M^-1 [A1 | C1 | rhs]
 #if defined(__HIP_DEVICE_COMPILE__)
   {   // k_scan_combine runs with 512 threads (8 waves)
-    constexpr int NW = n > 40 ? 8 : 4;
-    gauss_jordan_rows<n, 2 * n + 1, NW, true>(
-        ctx, [&](int r, int c) { return w.Mb[r][c] + (r == c ? 1.0 : 0.0); },
+    gauss_jordan_pipeline<n, 2 * n + 1>(
+        ctx, w.gp, [&](int r, int c) { return w.Mb[r][c] + (r == c ? 1.0 : 0.0); },
         [&](int r, int c) { return c < n ? e1[E::A + r * n + c] : (c < 2 * n ? e1[E::C + r * n + (c - n)] : w.rh[r]); }, &w.X[0][0], LX, &w.ok);
     WG_FOR(ctx, r, n) w.X[r][2 * n + 1] = 0.0;
   }
