@@ -555,7 +555,7 @@ void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
-                  h->d_unew, h->d_misc, h->d_kkt, h->d_ginf, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
+                  h->d_unew, h->d_misc, h->d_kkt, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
                   h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
@@ -622,11 +622,12 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_qp, B * N * (size_t)QP_SIZE * 8}, {(void**)&h->d_ric, B * N * (size_t)RIC_SIZE * 8},
       {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
-      {(void**)&h->d_kkt, B * 2 * 8}, {(void**)&h->d_ginf, B * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
+      {(void**)&h->d_kkt, B * 3 * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
       {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
       {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
   for (const Alloc& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
+  h->d_ginf = h->d_kkt + 2 * B;   // one block [kkt (2 per instance of max_batch) | |g|_inf]: one memset, one read-back for the scan's gate
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
   if (hipMemset(h->d_prof, 0, 4 * 128 * sizeof(long long)) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
@@ -840,8 +841,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                            h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
-      HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)B * 2 * 8, h->stream));
-      HCHECK(hipMemsetAsync(h->d_ginf, 0, (size_t)B * 8, h->stream));
+      HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)h->st.max_batch * 3 * 8, h->stream));   // kkt and |g|_inf are one block
       hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       return HSQP_OK;
     };
@@ -850,13 +850,14 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     launch_step();
     if (scan) {
       { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
-      std::vector<double> hk((size_t)3 * B);
-      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, (size_t)B * 2 * 8, hipMemcpyDeviceToHost, h->stream));
-      HCHECK(hipMemcpyAsync(hk.data() + 2 * B, h->d_ginf, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+      const int Bm = h->st.max_batch;
+      std::vector<double> hk((size_t)3 * Bm);
+      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, (size_t)Bm * 3 * 8, hipMemcpyDeviceToHost, h->stream));
       HCHECK(hipStreamSynchronize(h->stream));
       bool accept = true;
       for (int b = 0; b < B; ++b) {
-        const double rel = HSQP_SCAN_GATE_REL * (hk[2 * B + b] > 1.0 ? hk[2 * B + b] : 1.0), lim = rel < HSQP_SCAN_GATE_ABS ? rel : HSQP_SCAN_GATE_ABS;
+        const double gi = hk[2 * Bm + b];
+        const double rel = HSQP_SCAN_GATE_REL * (gi > 1.0 ? gi : 1.0), lim = rel < HSQP_SCAN_GATE_ABS ? rel : HSQP_SCAN_GATE_ABS;
         if (!(hk[2 * b] <= lim && hk[2 * b + 1] <= lim)) accept = false;
       }
       if (!accept) {
