@@ -1,7 +1,7 @@
 // Parallel-in-time backward sweep of the stage QP (BASELINE north star: "the serial Riccati recursion run as a cyclic-reduction /
 // parallel-scan over stages"): the value functions S_k, s_k of all nodes from an associative scan over conditional value functions
-// instead of N dependent Riccati stages.  Used for single-instance problems of the centroidal formulation, where the serial chain
-// of N = 100 stages leaves all but one CU idle (config 2: 1.6 of 2.2 ms).
+// instead of N dependent Riccati stages.  Used for one or two instances on a long horizon (both formulations: n = 35 and n = 58), where
+// the serial chain of N = 100 stages leaves all but one or two CUs idle (config 3: 1.67 of 1.93 ms; config 2: 0.81 of 1.29 ms).
 //
 // Formulation (Särkkä & García-Fernández, "Temporal parallelization of dynamic programming and linear quadratic control",
 // IEEE TAC 2023; algebra restated and checked in oracle/parallel_scan.py): an element (A, b, C, eta, J) of the interval i -> j stands
@@ -15,12 +15,16 @@
 //
 // Kernels (hsqp_capi.hip): k_scan_init (one workgroup per node: stage -> element), k_scan_combine (one per node and level:
 // Hillis-Steele suffix scan, ceil(log2(N+1)) levels, ping-pong element buffers), k_scan_gains (one per node: ONE stage of the
-// existing Riccati code started from S_{k+1}, s_{k+1} -> K, k and S_k for the KKT check), k_scan_forward (the mat-vec
-// roll-out dx+ = A~ dx + B~ (K dx + k) + b~, riccati_forward).  The record the step / KKT kernels read is the one k_riccati writes.
+// existing Riccati code started from S_{k+1}, s_{k+1} -> K, k, S_k for the KKT check, and the stage's closed loop), k_scan_forward
+// (the roll-out dx+ = A_cl dx + b_cl, closed_loop_forward in hsqp_riccati.h).  The record the step / KKT kernels read is the one
+// k_riccati writes.
 //
-// Numerics: M is solved by Gauss-Jordan elimination with row pivoting.  On the projected QPs of the centroidal problem
-// cond(M) <= 1e5 and the scan reproduces the serial recursion to 1e-11 of the step's scale; on the whole-body problem cond(M)
-// reaches 1e9 (5e-8 / 1.4e-6 agreement, tests/test_parallel_scan.py), so the whole-body path keeps the serial recursion.
+// Numerics: M is solved by Gauss-Jordan elimination with scaled row pivoting, in registers (gauss_jordan_pipeline below; the LDS form
+// gauss_jordan is what the host build runs); the symmetric results are symmetrised by averaging, which removes the antisymmetric part
+// of the elimination's error.  cond(M) <= 1e5 on the projected QPs of the centroidal problem, up to 1e9 on the whole-body problem: on
+// the QPs of a cold start / a tracking MPC the scan reproduces the serial recursion to 1e-11 .. 1e-10 of the step's scale, on
+// far-from-feasible line-search iterates it loses up to five digits — hsqp_iterate_device therefore gates every scan result by the KKT
+// residual of the QP and falls back to the serial recursion (hsqp_capi.hip: HSQP_SCAN_GATE_*).
 #pragma once
 #include "hsqp_riccati.h"
 
