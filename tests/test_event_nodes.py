@@ -216,6 +216,37 @@ def test_device_on_the_event_grid_equals_the_oracle(model, oracle):
 
 
 @pytest.mark.gpu
+def test_parallel_in_time_sweep_on_a_long_event_grid(model):
+    """One instance on a 1.8 s walk horizon (>= 48 intervals, several of them events): the default path takes the parallel-in-time
+    sweep, whose stage elements treat an event interval like any other stage (A~ = I, B~ = 0, R~ = I): against the serial recursion,
+    with the KKT gate's verdict — the scan's result if accepted (<= 2e-10 of the step's scale from the serial one), else the serial
+    recursion's bit for bit."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dts, node_times, _, _ = walk_problem_with_events(model, horizon=1.8)
+    N = len(dts)
+    assert N >= 48 and (dts == 0.0).sum() >= 4
+    outs = {}
+    for mode in ("auto", "serial"):
+        s = HipSqpSolver(model, max_nodes=N, max_batch=1, riccati=mode)
+        try:
+            outs[mode] = s.run(x0[None], x[None], u[None], par[None], dts)
+            outs[mode]["fallbacks"] = s.scan_fallbacks()
+        finally:
+            s.close()
+    a, b = outs["serial"], outs["auto"]
+    ev = np.flatnonzero(dts == 0.0)
+    assert not b["du"][:, ev].any()
+    if b["fallbacks"]:
+        assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["du"], b["du"])
+    else:
+        sc = max(1.0, np.abs(a["dx"]).max(), np.abs(a["du"]).max())
+        err = max(np.abs(a["dx"] - b["dx"]).max(), np.abs(a["du"] - b["du"]).max())
+        assert err <= 2e-10 * sc, (err, sc)
+        assert_perf(b["perf_after"][0], a["perf_after"][0], "scan vs serial on the event grid", rel=1e-9)
+    print(f"event grid N={N}: fallbacks {b['fallbacks']}")
+
+
+@pytest.mark.gpu
 def test_device_centroidal_event_grid_equals_the_oracle(cmodel, coracle):
     from wb_humanoid_mpc_amd.reference import build_centroidal_node_params, centroidal_velocity_command_targets
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
