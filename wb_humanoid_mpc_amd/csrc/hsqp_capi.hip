@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void k_ls_retake(const double* __restrict__ x, 
 
 // ---- KKT residual of the projected QP (reporting only, not part of an SQP step): one workgroup per (instance, node), the
 //      per-instance maxima by atomic max on the bit patterns of the (non-negative) residuals
-__global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+__global__ __launch_bounds__(256) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
                                              const double* __restrict__ vf, const double* __restrict__ dx, const double* __restrict__ ut, int N,
                                              double* __restrict__ kkt, double* __restrict__ ginf) {
   __shared__ KktWS w;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(128) void k_kkt(const double* __restrict__ x_init, 
   {
     const double* q = qp + (size_t)node * QP_SIZE;
     const int i = threadIdx.x;
-    gred[i] = i < NX ? fabs(q[QP_QV + i]) : (i < NX + NUT ? fabs(q[QP_RV + i - NX]) : 0.0);
+    if (i < 128) gred[i] = i < NX ? fabs(q[QP_QV + i]) : (i < NX + NUT ? fabs(q[QP_RV + i - NX]) : 0.0);
     __syncthreads();
     if (i == 0) {
       double m = 0.0;
@@ -842,7 +842,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     };
     auto launch_kkt = [&](bool from_scan) -> int {
       HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)h->st.max_batch * 3 * 8, h->stream));   // kkt and |g|_inf are one block
-      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(128), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       return HSQP_OK;
     };
     { const int rc = launch_sweep(scan, want_kkt || scan); if (rc != HSQP_OK) return rc; }

@@ -643,6 +643,7 @@ HSQP_HD bool ls_decide(const LsSettings& st, const hsqp_perf& base, const hsqp_p
 // out2 = {stationarity, primal} of this node.
 struct KktWS {
   double dx[NX], dxn[NX], ut[NUT], lam[NX], lamn[NX], res[2 * NX + NUT];
+  double part[4 * (2 * NX + NUT)];   // four partial sums per row (short chains: the kernel is latency-bound at small batches)
 };
 HSQP_HD void kkt_node(const Ctx& ctx, KktWS& w, const double* q, const double* vfk, const double* vfn, const double* dxk, const double* dxn,
                       const double* utk, const double* dx0 /*null unless k == 0*/, double* out2) {
@@ -652,34 +653,58 @@ HSQP_HD void kkt_node(const Ctx& ctx, KktWS& w, const double* q, const double* v
     else w.ut[i - 2 * NX] = utk[i - 2 * NX];
   }
   WG_SYNC(ctx);
-  WG_FOR(ctx, i, 2 * NX) {
+  // lam = S dx + s, lam+ = S+ dx+ + s+ : item = (row, quarter of the columns); S is stored symmetric to the bit, so the column read
+  // vf[j][r] is used (consecutive rows in consecutive lanes: coalesced)
+  constexpr int LQ = (NX + 3) / 4, LU = (NUT + 3) / 4;
+  WG_FOR(ctx, it, 4 * 2 * NX) {
+    const int p = it / (2 * NX), i = it % (2 * NX);
     const bool nxt = i >= NX;
     const int r = nxt ? i - NX : i;
     const double* vf = nxt ? vfn : vfk;
     const double* d = nxt ? w.dxn : w.dx;
-    double l = vf[NX * NX + r];
-    for (int j = 0; j < NX; ++j) l += vf[r * NX + j] * d[j];
-    if (nxt) w.lamn[r] = l; else w.lam[r] = l;
+    double l = p == 0 ? vf[NX * NX + r] : 0.0;
+#pragma unroll
+    for (int t = 0; t < LQ; ++t) { const int j = p * LQ + t; if (j < NX) l += vf[j * NX + r] * d[j]; }
+    w.part[4 * i + p] = l;
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, i, 2 * NX) {
+    const double* pp = &w.part[4 * i];
+    const double l = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+    if (i >= NX) w.lamn[i - NX] = l; else w.lam[i] = l;
+  }
+  WG_SYNC(ctx);
+  WG_FOR(ctx, it, 4 * (2 * NX + NUT)) {
+    const int p = it / (2 * NX + NUT), i = it % (2 * NX + NUT);
+    double a = 0.0;
+    if (i < NX) {              // x-stationarity (Q~ symmetric to the bit: coalesced column reads)
+      if (p == 0) a = q[QP_QV + i] - w.lam[i];
+#pragma unroll
+      for (int t = 0; t < LQ; ++t) { const int j = p * LQ + t; if (j < NX) a += q[QP_Q + j * NX + i] * w.dx[j] + q[QP_A + j * NX + i] * w.lamn[j]; }
+#pragma unroll
+      for (int t = 0; t < LU; ++t) { const int j = p * LU + t; if (j < NUT) a += q[QP_P + j * NX + i] * w.ut[j]; }
+    } else if (i < NX + NUT) { // u-stationarity
+      const int r = i - NX;
+      if (p == 0) a = q[QP_RV + r];
+#pragma unroll
+      for (int t = 0; t < LQ; ++t) { const int j = p * LQ + t; if (j < NX) a += q[QP_P + r * NX + j] * w.dx[j] + q[QP_B + j * NUT + r] * w.lamn[j]; }
+#pragma unroll
+      for (int t = 0; t < LU; ++t) { const int j = p * LU + t; if (j < NUT) a += q[QP_R + j * NUT + r] * w.ut[j]; }
+    } else {                   // dynamics
+      const int r = i - NX - NUT;
+      if (p == 0) a = w.dxn[r] - q[QP_BV + r];
+#pragma unroll
+      for (int t = 0; t < LQ; ++t) { const int j = p * LQ + t; if (j < NX) a -= q[QP_A + r * NX + j] * w.dx[j]; }
+#pragma unroll
+      for (int t = 0; t < LU; ++t) { const int j = p * LU + t; if (j < NUT) a -= q[QP_B + r * NUT + j] * w.ut[j]; }
+    }
+    w.part[4 * i + p] = a;
   }
   WG_SYNC(ctx);
   WG_FOR(ctx, i, 2 * NX + NUT) {
-    double a;
-    if (i < NX) {              // x-stationarity
-      a = q[QP_QV + i] - w.lam[i];
-      for (int j = 0; j < NX; ++j) a += q[QP_Q + i * NX + j] * w.dx[j] + q[QP_A + j * NX + i] * w.lamn[j];
-      for (int j = 0; j < NUT; ++j) a += q[QP_P + j * NX + i] * w.ut[j];
-    } else if (i < NX + NUT) { // u-stationarity
-      const int r = i - NX;
-      a = q[QP_RV + r];
-      for (int j = 0; j < NX; ++j) a += q[QP_P + r * NX + j] * w.dx[j] + q[QP_B + j * NUT + r] * w.lamn[j];
-      for (int j = 0; j < NUT; ++j) a += q[QP_R + r * NUT + j] * w.ut[j];
-    } else {                   // dynamics
-      const int r = i - NX - NUT;
-      a = w.dxn[r] - q[QP_BV + r];
-      for (int j = 0; j < NX; ++j) a -= q[QP_A + r * NX + j] * w.dx[j];
-      for (int j = 0; j < NUT; ++j) a -= q[QP_B + r * NUT + j] * w.ut[j];
-      if (dx0) { const double a0 = fabs(w.dx[r] - dx0[r]); a = (a0 != a0 || a0 > fabs(a)) ? a0 : fabs(a); }
-    }
+    const double* pp = &w.part[4 * i];
+    double a = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+    if (i >= NX + NUT && dx0) { const int r = i - NX - NUT; const double a0 = fabs(w.dx[r] - dx0[r]); a = (a0 != a0 || a0 > fabs(a)) ? a0 : fabs(a); }
     w.res[i] = fabs(a);
   }
   WG_SYNC(ctx);
