@@ -444,6 +444,7 @@ struct hsqp_handle {
   double* d_acl = nullptr;        // scan path: closed loop [B][N][ACL_SIZE] of every stage for the roll-out (allocated when the scan is first used)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
+  int* d_scanst = nullptr;   // flags of the scan kernels (bad pivot, rank-deficient D, failed Lam) of the current attempt: part of the gate, behind d_ginf
   double* d_stepinfo = nullptr;   // [B][N][4] per-node {armijo, |dx|^2, |du|^2}
   LsState* d_ls = nullptr;
   int* d_counts = nullptr;
@@ -513,7 +514,7 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
   hipLaunchKernelGGL(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
   int cur = 0;
   for (int d = 1; d < N + 1; d *= 2) {
-    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_status, h->d_prof + 256);
+    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_scanst, h->d_prof + 256);
     cur = 1 - cur;
   }
   for (double** pv : {&h->d_vf, &h->d_vf2})
@@ -530,7 +531,7 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
   for (int pass = 0; pass <= refinements; ++pass) {
     const bool lastp = pass == refinements;
     hipLaunchKernelGGL(k_scan_gains<n>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
-                       pass == 0 ? (const double*)nullptr : (const double*)vbuf[(pass - 1) & 1], h->d_ric, N, h->d_status,
+                       pass == 0 ? (const double*)nullptr : (const double*)vbuf[(pass - 1) & 1], h->d_ric, N, h->d_scanst,
                        (lastp && !want_kkt) ? (double*)nullptr : vbuf[pass & 1], lastp ? h->d_acl : (double*)nullptr);
   }
   hipLaunchKernelGGL(k_scan_forward<n>, dim3(B), dim3(SCAN_FWD_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);   // 4 n <= 256 items per stage: four waves
@@ -622,12 +623,13 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_qp, B * N * (size_t)QP_SIZE * 8}, {(void**)&h->d_ric, B * N * (size_t)RIC_SIZE * 8},
       {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
-      {(void**)&h->d_kkt, B * 3 * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
+      {(void**)&h->d_kkt, B * 3 * 8 + ((B * sizeof(int) + 7) / 8) * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
       {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
       {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
   for (const Alloc& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
-  h->d_ginf = h->d_kkt + 2 * B;   // one block [kkt (2 per instance of max_batch) | |g|_inf]: one memset, one read-back for the scan's gate
+  h->d_ginf = h->d_kkt + 2 * B;   // one block [kkt (2 per instance of max_batch) | |g|_inf | flags of the scan kernels]: one memset, one read-back for the scan's gate
+  h->d_scanst = reinterpret_cast<int*>(h->d_kkt + 3 * B);
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
   if (hipMemset(h->d_prof, 0, 4 * 128 * sizeof(long long)) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
@@ -822,6 +824,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // (k_kkt, one small kernel + one 3 B-double read-back) and, if a residual exceeds the gate (HSQP_SCAN_GATE_REL / _ABS above), the
     // iteration is redone with the serial recursion (hsqp_scan_fallbacks counts these).
     const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    const int Bm = h->st.max_batch;
+    const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
     auto launch_sweep = [&](bool use_scan, bool need_vf) -> int {
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
@@ -841,21 +845,23 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                            h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
-      HCHECK(hipMemsetAsync(h->d_kkt, 0, (size_t)h->st.max_batch * 3 * 8, h->stream));   // kkt and |g|_inf are one block
+      if (!from_scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // kkt, |g|_inf (and the scan flags) are one block; the scan path has zeroed it before its kernels
       hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       return HSQP_OK;
     };
+    if (scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // also the flags the scan kernels OR into
     { const int rc = launch_sweep(scan, want_kkt || scan); if (rc != HSQP_OK) return rc; }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
     launch_step();
     if (scan) {
       { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
-      const int Bm = h->st.max_batch;
-      std::vector<double> hk((size_t)3 * Bm);
-      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, (size_t)Bm * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+      std::vector<double> hk(gate_bytes / 8);
+      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, gate_bytes, hipMemcpyDeviceToHost, h->stream));
       HCHECK(hipStreamSynchronize(h->stream));
+      const int* flags = reinterpret_cast<const int*>(hk.data() + 3 * Bm);
       bool accept = true;
       for (int b = 0; b < B; ++b) {
+        if (flags[b]) accept = false;   // a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported (d_status)
         const double gi = hk[2 * Bm + b];
         const double rel = HSQP_SCAN_GATE_REL * (gi > 1.0 ? gi : 1.0), lim = rel < HSQP_SCAN_GATE_ABS ? rel : HSQP_SCAN_GATE_ABS;
         if (!(hk[2 * b] <= lim && hk[2 * b + 1] <= lim)) accept = false;
