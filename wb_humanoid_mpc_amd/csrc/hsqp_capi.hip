@@ -440,6 +440,7 @@ struct hsqp_handle {
   bool uniform_grid = true, has_events = false;
   double* d_vf = nullptr;         // [B][N+1][VF_SIZE] value function of the last Riccati sweep (allocated when a KKT check is first asked for)
   double* d_vf2 = nullptr;        // scan path: value functions of the refinement pass (the KKT check then reads these)
+  double* h_gate = nullptr;       // pinned host copy of the gate block [kkt | |g|_inf | scan flags]
   long long scan_fallbacks = 0;   // iterations whose scan result failed the KKT gate and were redone with the serial recursion
   double* d_acl = nullptr;        // scan path: closed loop [B][N][ACL_SIZE] of every stage for the roll-out (allocated when the scan is first used)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
@@ -560,6 +561,7 @@ void hsqp_destroy(hsqp_handle* h) {
                   h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
+  if (h->h_gate) (void)hipHostFree(h->h_gate);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -628,6 +630,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
   for (const Alloc& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
+  if (hipHostMalloc((void**)&h->h_gate, B * 3 * 8 + ((B * sizeof(int) + 7) / 8) * 8) != hipSuccess) { h->h_gate = nullptr; return fail(HSQP_ERR_OOM, "hipHostMalloc failed (gate block)"); }
   h->d_ginf = h->d_kkt + 2 * B;   // one block [kkt (2 per instance of max_batch) | |g|_inf | flags of the scan kernels]: one memset, one read-back for the scan's gate
   h->d_scanst = reinterpret_cast<int*>(h->d_kkt + 3 * B);
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
@@ -853,12 +856,30 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     { const int rc = launch_sweep(scan, want_kkt || scan); if (rc != HSQP_OK) return rc; }
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
     launch_step();
-    if (scan) {
+    if (scan) {   // the gate's inputs: KKT residuals, |g|_inf and the scan kernels' flags travel to pinned host memory while the kernels below run
       { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
-      std::vector<double> hk(gate_bytes / 8);
-      HCHECK(hipMemcpyAsync(hk.data(), h->d_kkt, gate_bytes, hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipMemcpyAsync(h->h_gate, h->d_kkt, gate_bytes, hipMemcpyDeviceToHost, h->stream));
+    } else if (want_kkt) {
+      const int rc = launch_kkt(false);
+      if (rc != HSQP_OK) return rc;
+    }
+    auto launch_perf = [&]() {   // value pass of the centroidal trial, performance indices before / after, line-search state of the full-step trial
+      if (cent)
+        hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
+                           (const LsState*)nullptr);
+      hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
+                         (const LsState*)nullptr);
+      hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
+                         (const LsState*)nullptr);
+      hipLaunchKernelGGL(k_ls_init, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_stepinfo, h->d_x, h->d_dx, h->d_par, N, h->d_ls);
+    };
+    launch_perf();   // speculatively on the scan's step: the gate is read only now, so the host round trip hides behind these kernels
+    const bool ev4_early = last && !linesearch;
+    if (ev4_early) HCHECK(hipEventRecord(h->ev[4], h->stream));
+    if (scan) {
       HCHECK(hipStreamSynchronize(h->stream));
-      const int* flags = reinterpret_cast<const int*>(hk.data() + 3 * Bm);
+      const double* hk = h->h_gate;
+      const int* flags = reinterpret_cast<const int*>(hk + 3 * Bm);
       bool accept = true;
       for (int b = 0; b < B; ++b) {
         if (flags[b]) accept = false;   // a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported (d_status)
@@ -873,19 +894,10 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));
         launch_step();
         if (want_kkt) { const int rc = launch_kkt(false); if (rc != HSQP_OK) return rc; }
+        launch_perf();
+        if (ev4_early) HCHECK(hipEventRecord(h->ev[4], h->stream));
       }
-    } else if (want_kkt) {
-      const int rc = launch_kkt(false);
-      if (rc != HSQP_OK) return rc;
     }
-    if (cent)
-      hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
-                         (const LsState*)nullptr);
-    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
-                       (const LsState*)nullptr);
-    hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
-                       (const LsState*)nullptr);
-    hipLaunchKernelGGL(k_ls_init, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_stepinfo, h->d_x, h->d_dx, h->d_par, N, h->d_ls);
     if (linesearch) {
       // back-tracking: decide the pending trials on the device, shorten the rejected steps, re-evaluate only those instances
       LsSettings lst{h->ls_settings.g_max, h->ls_settings.g_min, h->ls_settings.gamma_c, h->ls_settings.armijo_factor, h->ls_settings.alpha_decay,
@@ -916,7 +928,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       if (still_active) { h->err = "line search: trials exhausted with instances still undecided (internal error)"; return HSQP_ERR_NUMERIC; }
     }
     h->ls_ran = linesearch != 0;
-    if (last) HCHECK(hipEventRecord(h->ev[4], h->stream));
+    if (last && !ev4_early) HCHECK(hipEventRecord(h->ev[4], h->stream));
     if (take_step && !last) {
       HCHECK(hipMemcpyAsync(h->d_x, h->d_xnew, (size_t)B * (N + 1) * NX * 8, hipMemcpyDeviceToDevice, h->stream));
       HCHECK(hipMemcpyAsync(h->d_u, h->d_unew, (size_t)B * N * NU * 8, hipMemcpyDeviceToDevice, h->stream));
