@@ -358,17 +358,34 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   using E = ScanEl<n>;
   constexpr int LD = ScanCombWS<n>::LD, LX = ScanCombWS<n>::LX;
   PH_TICK(ctx, 126);
-  WG_FOR(ctx, i, 3 * n * n + 4 * n + 1) {
-    if (i < n * n) { const int r = i / n, c = i % n; w.C1[r][c] = e1[E::C + i]; }
-    else if (i < 2 * n * n) { const int j = i - n * n, r = j / n, c = j % n; w.J2[r][c] = e2[E::J + j]; }
-    else if (i < 3 * n * n) { const int j = i - 2 * n * n, r = j / n, c = j % n; w.A2T[c][r] = e2[E::A + j]; }
-    else if (i < 3 * n * n + 4 * n) {
-      const int j = i - 3 * n * n, r = j % n;
+  // item = (column c, row group g of NG): walks down its column of the three matrices with constant strides (no division per element;
+  // a wave reads 64 consecutive words of a row); eight loads in flight before the first store
+  {
+    constexpr int NG = 8, RPG = (n + NG - 1) / NG;
+    WG_FOR(ctx, it, 64 * NG) {
+      const int c = it & 63, g = it >> 6;
+      if (c < n) {
+        double t[3][RPG];
+#pragma unroll
+        for (int k = 0; k < RPG; ++k) {
+          const int r = g + NG * k, rr = r < n ? r : n - 1;
+          t[0][k] = e1[E::C + rr * n + c]; t[1][k] = e2[E::J + rr * n + c]; t[2][k] = e2[E::A + rr * n + c];
+        }
+#pragma unroll
+        for (int k = 0; k < RPG; ++k) {
+          const int r = g + NG * k;
+          if (r < n) { w.C1[r][c] = t[0][k]; w.J2[r][c] = t[1][k]; w.A2T[c][r] = t[2][k]; }
+        }
+      }
+    }
+    WG_FOR(ctx, j, 4 * n + 1) {
+      const int r = j % n;
       if (j < n) w.b1[r] = e1[E::B + r];
       else if (j < 2 * n) w.eta1[r] = e1[E::ETA + r];
       else if (j < 3 * n) w.b2[r] = e2[E::B + r];
-      else w.eta2[r] = e2[E::ETA + r];
-    } else w.ok = 1;
+      else if (j < 4 * n) w.eta2[r] = e2[E::ETA + r];
+      else w.ok = 1;
+    }
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 20);
