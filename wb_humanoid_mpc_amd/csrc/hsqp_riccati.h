@@ -29,6 +29,14 @@ constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) |
 constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// DPP quad permute of a double (two 32-bit moves): CTRL = the four 2-bit source selectors of a quad, e.g. 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
+template <int CTRL>
+__device__ inline double quad_perm_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
 __device__ inline double readlane_f64(double v, int lane) {
   const long long b = __double_as_longlong(v);
@@ -517,20 +525,23 @@ HSQP_HD void closed_loop_forward(const Ctx& ctx, RicWS& w, const double* x_init,
       for (int u = 0; u < PF; ++u) {
         const int k = k0 + u;
         if (k < N) {
-          if (live) {
-            double s = sc[u];
+          // ONE barrier per stage: the four partial sums of a row sit in four adjacent lanes and are added with two DPP quad
+          // permutes (no LDS round trip); dx is double-buffered (dx / sv) so that the next stage's reads do not race this stage's writes
+          const double* dcur = (k & 1) ? w.sv : w.dx;
+          double* dnxt = (k & 1) ? w.dx : w.sv;
+          double s = sc[u];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[u][c] * w.dx[cc]; }
-            part[it] = s;
+          for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[u][c] * dcur[cc]; }
+          s += quad_perm_f64<0xB1>(s);     // lanes (0,1) (2,3) of the quad exchange
+          s += quad_perm_f64<0x4E>(s);     // halves of the quad exchange: every lane of the quad holds the row's sum
+          if (live && p == 0) { dnxt[row] = s; dx_out[(size_t)(k + 1) * NX + row] = s; }
+          if (NXE < NX && it >= 4 * NXE && it < 4 * NXE + (NX - NXE)) {   // padding states keep dx (A~ = I there)
+            const int r = NXE + it - 4 * NXE;
+            const double v = dcur[r];
+            dnxt[r] = v;
+            dx_out[(size_t)(k + 1) * NX + r] = v;
           }
           if (k + PF < N) fetch(k + PF, a[u], sc[u]);
-          WG_SYNC(ctx);
-          if (it < NX) {
-            const double* p1 = &part[4 * (it < NXE ? it : 0)];
-            const double s = (NXE == NX || it < NXE) ? (p1[0] + p1[1]) + (p1[2] + p1[3]) : w.dx[NXE == NX ? 0 : it];
-            w.dx[it] = s;
-            dx_out[(size_t)(k + 1) * NX + it] = s;
-          }
           WG_SYNC(ctx);
         }
       }
