@@ -403,32 +403,37 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
       for (int c = 0; c < NCB; ++c) bq[c] = bqn[c];
       sc = scn;
       if (k + 1 < N) fetch(k + 1, an, bqn, scn);
-      if (it < NR1) {
-        double s = 0.0;
+      // TWO barriers per stage: the four partial sums of a row sit in four adjacent lanes and are added by DPP quad permutes (no LDS
+      // round trip for them); only ut = k + K dx (23 numbers every row needs) and the new dx go through LDS; dx is double-buffered
+      // (dx / sv) so that the next stage's reads do not race this stage's writes
+      const double* dcur = (k & 1) ? w.sv : w.dx;
+      double* dnxt = (k & 1) ? w.dx : w.sv;
+      double s1 = 0.0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s += a[c] * w.dx[cc]; }
-        part1[it] = s;
+      for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s1 += a[c] * dcur[cc]; }
+      if (rowK) {          // row of K: ut_j = k_j + K_j dx
+        double s = s1;
+        s += quad_perm_f64<0xB1>(s);
+        s += quad_perm_f64<0x4E>(s);
+        if (p == 0) w.zv[row - NX] = s;
       } else if (isk) w.kv[it - NR1] = sc;
       WG_SYNC(ctx);
-      if (rowA) {
-        double s = 0.0;
+      {
+        double s = rowA ? s1 + (p == 0 ? sc : 0.0) : 0.0;      // A~ dx slice (+ b~ on the first lane of the quad)
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
           const int j = p + 4 * c, jc = j < NUT ? j : NUT - 1;
-          const double* pj = &part1[4 * (NX + jc)];
-          const double utj = w.kv[jc] + ((pj[0] + pj[1]) + (pj[2] + pj[3]));
-          s += (j < NUT) ? bq[c] * utj : 0.0;
+          const double utj = w.kv[jc] + w.zv[jc];
+          s += (rowA && j < NUT) ? bq[c] * utj : 0.0;
         }
-        part2[it] = (p == 0 ? sc : 0.0) + s;      // b~ rides on the first partial sum
-      }
-      WG_SYNC(ctx);
-      if (it < NX) {
-        const double* p1 = &part1[4 * it];
-        const double* p2 = &part2[4 * it];
-        // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
-        const double s = (NXE == NX || it < NXE) ? ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p2[0] + p2[1]) + (p2[2] + p2[3])) : w.dx[it];
-        w.dx[it] = s;
-        dx_out[(size_t)(k + 1) * NX + it] = s;
+        s += quad_perm_f64<0xB1>(s);
+        s += quad_perm_f64<0x4E>(s);
+        if (rowA && p == 0) {
+          // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
+          const double v = (NXE == NX || row < NXE) ? s : dcur[row];
+          dnxt[row] = v;
+          dx_out[(size_t)(k + 1) * NX + row] = v;
+        }
       }
       WG_SYNC(ctx);
     }
