@@ -190,7 +190,7 @@ def strong_scaling_leg(args, torch, group, model_local, rank, local_rank, world,
                                                 "iteration incl. the KKT check, hsqp_download_device, RCCL gather of x / u / performance / KKT to rank 0"},
                "gathered_solution_equals_single_gpu_solve": same, "kkt_residual_max": float(gathered["kkt"].max().item()),
                "note": "BASELINE config 4 as written (256 instances over the GPUs); bounded by the serial Riccati sweep: one workgroup per instance, "
-                       "~23 us per stage whatever the batch (DESIGN.md §6)"}
+                       "~17 us per stage whatever the batch (DESIGN.md §6)"}
     solver.close()
     return out
 
