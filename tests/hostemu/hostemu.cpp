@@ -59,6 +59,7 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
 
 extern "C" {
 
+int emu_scan_gate_accepts(double r_stat, double r_prim, double g_inf, int flags) { return scan_gate_accepts(r_stat, r_prim, g_inf, flags) ? 1 : 0; }
 void emu_set_scan(int on) { g_scan = on; }
 void emu_set_scan_refinements(int r) { g_scan_refinements = r; }
 

@@ -118,11 +118,30 @@ def test_whole_body_parallel_scan_backward_sweep_equals_the_serial_recursion(mod
     (dx0, du0, kkt0, pa0), (dx1, du1, kkt1, pa1) = res
     sc = max(1.0, np.abs(dx0).max(), np.abs(du0).max())
     err = max(np.abs(dx1 - dx0).max(), np.abs(du1 - du0).max())
-    gate_abs = 2e-8
+    lib.emu_scan_gate_accepts.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+    accepted = bool(lib.emu_scan_gate_accepts(kkt1[0], kkt1[1], 1e5, 0))   # |g|_inf of these QPs is 1e4 .. 1e5: the absolute bound decides
     if accurate:
         assert err <= 1e-9 * sc, (err, sc)
-        assert kkt1[0] <= gate_abs and kkt1[1] <= 1e-12 * sc
+        assert accepted and kkt1[1] <= 1e-12 * sc
         assert np.allclose(pa1, pa0, rtol=1e-8, atol=1e-12)
     else:
         assert err <= 1e-6 * sc, (err, sc)          # still a usable SQP direction ...
-        assert kkt1[0] > gate_abs, kkt1             # ... but flagged: the gate's criterion sees it
+        assert not accepted, kkt1                   # ... but flagged: the gate's criterion sees it
+
+
+def test_scan_gate_decisions(emu):
+    """scan_gate_accepts (hsqp_scan.h) on the measured populations: accurate scans pass, inaccurate ones, flagged ones and NaN do not."""
+    lib, _ = emu
+    lib.emu_scan_gate_accepts.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+    gate = lambda *a: bool(lib.emu_scan_gate_accepts(*a))  # noqa: E731
+    assert gate(3.07e-11, 1.4e-15, 122.0, 0)            # config 2, cold start
+    assert gate(1.07e-9, 7.2e-14, 38.1, 0)              # config 3, cold start
+    assert gate(3.4e-9, 3.1e-14, 5e3, 0)                # perturbed walk instance
+    assert not gate(7.8e-6, 2.1e-14, 2.71e4, 0)         # config 2, far-from-feasible line-search iterate (3e-10 of |g|_inf!)
+    assert not gate(1.85e-4, 1.1e-13, 3.38e5, 0)        # config 3, the same
+    assert not gate(1.6e-7, 4.4e-14, 1e5, 0)            # randomly perturbed run-gait QP
+    assert not gate(2e-9, 1e-14, 0.1, 0)                # small gradient scale: BASELINE.md's 1e-9 max(1, |g|_inf) binds
+    assert gate(5e-10, 1e-14, 0.1, 0)
+    assert not gate(1e-12, 3e-8, 50.0, 0)               # primal residual
+    assert not gate(1e-12, 1e-14, 50.0, 2)              # a bad pivot inside the scan
+    assert not gate(float("nan"), 1e-14, 50.0, 0) and not gate(1e-12, 1e-14, float("nan"), 0)

@@ -486,13 +486,7 @@ static void* stage_area(hsqp_handle* h, size_t bytes) {
 }
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// KKT gate of the parallel-in-time sweep: the stationarity / primal residuals of the QP must be below BOTH HSQP_SCAN_GATE_REL max(1, |g|_inf)
-// (BASELINE.md §6's criterion for a QP solution) and HSQP_SCAN_GATE_ABS.  The absolute bound is what separates the two populations seen on
-// this problem (the QP's units are fixed by the model): where the scan reproduces the serial recursion to <= 2e-10 of the step's scale its
-// stationarity is 3e-11 .. 3.4e-9 (configs 2, 3, perturbed walk instances, N = 16 .. 100); where it loses digits — far-from-feasible
-// line-search iterates, randomly perturbed run-gait QPs with |du| ~ 1e3 — it is 1.6e-7 .. 2e-4 (step errors 1e-8 .. 1e-5 of the scale),
-// while the residual relative to |g|_inf still looks harmless there (3e-10) because |g|_inf is 1e4 .. 1e5.
-constexpr double HSQP_SCAN_GATE_REL = 1e-9, HSQP_SCAN_GATE_ABS = 2e-8;
+// (the KKT gate of the parallel-in-time sweep: scan_gate_accepts, hsqp_scan.h)
 // Refinement passes of the gains (one more stage of the exact Riccati map from the value functions of the previous pass).  Centroidal: one
 // pass gains a digit (1e-11 -> 1e-12 of the step's scale).  Whole-body: none — the closed loop of that problem has slow modes (positions
 // integrate velocities over dt = 0.02), so the map barely contracts an error in S: 0, 1, 2 or 3 passes all leave 1.4e-11 .. 8e-11
@@ -824,7 +818,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // stages (hsqp_scan.h).  The scan inverts I + C1 J2 of partial horizons (condition number up to 1e5 centroidal, 1e9 whole-body): on
     // the QPs of a cold start or of a tracking MPC it reproduces the serial recursion to 1e-11 of the step's scale, on a far-from-
     // feasible line-search iterate it can lose five digits.  Its result is therefore GATED: the KKT residual of the QP is evaluated
-    // (k_kkt, one small kernel + one 3 B-double read-back) and, if a residual exceeds the gate (HSQP_SCAN_GATE_REL / _ABS above), the
+    // (k_kkt, one small kernel + one 3 B-double read-back) and, if a residual exceeds the gate (scan_gate_accepts, hsqp_scan.h), the
     // iteration is redone with the serial recursion (hsqp_scan_fallbacks counts these).
     const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
     const int Bm = h->st.max_batch;
@@ -882,10 +876,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       const int* flags = reinterpret_cast<const int*>(hk + 3 * Bm);
       bool accept = true;
       for (int b = 0; b < B; ++b) {
-        if (flags[b]) accept = false;   // a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported (d_status)
-        const double gi = hk[2 * Bm + b];
-        const double rel = HSQP_SCAN_GATE_REL * (gi > 1.0 ? gi : 1.0), lim = rel < HSQP_SCAN_GATE_ABS ? rel : HSQP_SCAN_GATE_ABS;
-        if (!(hk[2 * b] <= lim && hk[2 * b + 1] <= lim)) accept = false;
+        // (a flag = a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported in d_status)
+        if (!scan_gate_accepts(hk[2 * b], hk[2 * b + 1], hk[2 * Bm + b], flags[b])) accept = false;
       }
       if (!accept) {
         ++h->scan_fallbacks;
