@@ -476,21 +476,26 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
     double* dst = c < NX ? qp + QP_A + c : (c < NTW ? qp + QP_B + (c - NX) : qp + QP_BV);
     const int st = c < NX ? NX : (c < NTW ? NUT : 1);
-    for (int r = g; r < NX; r += NCG) {
-      const bool base = cent ? r < 12 : ((r < 6) || (r >= NV && r < NV + 6));
-      if (base) continue;
-      double s;
-      if (cent) s = r < HSQP_CNX ? dt * w.Tm[r][c] : 0.0;            // input 12 + (r - 12) = r
-      else {
-        const int j = r < NV ? r - 6 : r - NV - 6;
-        s = (r < NV ? 0.5 * dt * dt : dt) * w.Tm[12 + j][c];
+    if (!cent) {
+      // joint j: q_j+ = q_j + dt v_j + dt^2/2 qdd_j (row 6 + j), v_j+ = v_j + dt qdd_j (row NV + 6 + j), qdd_j = input 12 + j: both rows
+      // are scaled copies of row 12 + j of T, read once
+      const double hq = 0.5 * dt * dt;
+      for (int j = g; j < NJ; j += NCG) {
+        const int rq = 6 + j, rv = NV + 6 + j;
+        const double t = w.Tm[12 + j][c];
+        double sq = hq * t, sv = dt * t;
+        if (c < NX) { sq += (c == rq ? 1.0 : 0.0) + (c == rv ? dt : 0.0); sv += (c == rv ? 1.0 : 0.0); }
+        else if (c == NTW) { sq += w.bvec[rq]; sv += w.bvec[rv]; }
+        dst[rq * st] = sq;
+        dst[rv * st] = sv;
       }
-      if (c < NX) {
-        double a = (r == c) ? 1.0 : 0.0;
-        if (!cent && r < NV && c == NV + r) a += dt;
-        s += a;
-      } else if (c == NTW) s += w.bvec[r];
-      dst[r * st] = s;
+    } else {
+      for (int r = 12 + g; r < NX; r += NCG) {   // rows 12..34: q_j+ = q_j + dt qd_j (input r); rows 35..57: padding states (identity)
+        double s = r < HSQP_CNX ? dt * w.Tm[r][c] : 0.0;
+        if (c < NX) s += (r == c) ? 1.0 : 0.0;
+        else if (c == NTW) s += w.bvec[r];
+        dst[r * st] = s;
+      }
     }
   }
   WG_SYNC(ctx);  // PV dead: Jt aliases it
