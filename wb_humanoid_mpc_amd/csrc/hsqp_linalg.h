@@ -165,6 +165,14 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
 #define XTY_PROF_T(name) ((void)0)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
+// DPP quad permute of a double (two 32-bit moves): CTRL = the four 2-bit source selectors of a quad, e.g. 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
+template <int CTRL>
+__device__ inline double quad_perm_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) * hsqp_gcptr;
 typedef double __attribute__((address_space(1))) * hsqp_gptr;

@@ -311,6 +311,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     //     R(:,c) -= beta (v . R(:,c)) v  with  v . y = x . y - alpha y_k ;  column k itself is recorded in V
     WG_FOR(ctx, it, NE_MAX * (NU + 1)) {
       const int c = it / (NU + 1), i = it % (NU + 1);
+      if (c < k && it != 0) continue;            // finished columns: whole waves drop out as k grows (item 0 keeps the step's bookkeeping)
       const double p0 = w.qr.part[k][0], p1 = w.qr.part[k][1], p2 = w.qr.part[k][2], p3 = w.qr.part[k][3], rkk = w.qr.yk[k];
       const double q0 = w.qr.part[c][0], q1 = w.qr.part[c][1], q2 = w.qr.part[c][2], q3 = w.qr.part[c][3], ykc = w.qr.yk[c];
       const double xi = w.qr.Rm[i][k], rc = w.qr.Rm[i][c];
@@ -353,6 +354,43 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // Q^T = H_{ned-1} ... H_0 of the free inputs: one column per item, the column lives in registers while the reflectors are
   // applied; it belongs to the ORIGINAL input index ub[c].  Rows 0..ned-1 are Q1^T (-> Q1T), rows ned.. are Q2^T = Pu^T, written
   // straight into Tm; the columns of the eliminated inputs are zero
+#if defined(__HIP_DEVICE_COMPILE__)
+  // device: FOUR adjacent lanes per column, lane p holds the entries i = p + 4 t; the dot product with a reflector is closed by two DPP
+  // quad permutes (the one-lane-per-column form below keeps 35 lanes of one wave busy for 12 x 105 dependent operations)
+  if (ctx.tid < 4 * (NU + 1)) {
+    constexpr int NT4 = (NU + 4) / 4;            // 9 entries per lane cover i = 0..35 (V has NU + 1 columns, the last one zero)
+    const int c = ctx.tid >> 2, p = ctx.tid & 3;
+    const bool livec = c < nub;                  // c == NU (the 36th quad) and the eliminated inputs: zero columns
+    double col[NT4];
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) col[t] = (p + 4 * t == c && livec) ? 1.0 : 0.0;
+    for (int k = 0; k < ned; ++k) {
+      double vk[NT4], sdot = 0.0;
+#pragma unroll
+      for (int t = 0; t < NT4; ++t) { const int i = p + 4 * t; vk[t] = i <= NU ? w.qr.V[k][i < NU + 1 ? i : NU] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < NT4; ++t) sdot += vk[t] * col[t];
+      sdot += quad_perm_f64<0xB1>(sdot);
+      sdot += quad_perm_f64<0x4E>(sdot);
+      sdot *= w.qr.beta[k];
+#pragma unroll
+      for (int t = 0; t < NT4; ++t) col[t] -= sdot * vk[t];
+    }
+    if (c < NU) {
+      const int uc = w.ub[c];
+#pragma unroll
+      for (int t = 0; t < NT4; ++t) {
+        const int i = p + 4 * t;
+        if (i < NU) {
+          if (i < ned) w.qr.Q1T[i][uc] = col[t];
+          const int cc = i - ned;
+          if (cc >= 0 && cc < nut) w.Tm[uc][NX + cc] = col[t];
+        }
+      }
+      for (int cc = nut + p; cc < NUT; cc += 4) w.Tm[uc][NX + cc] = 0.0;
+    }
+  }
+#else
   WG_FOR(ctx, c, NU) {
     double col[NU];
 #pragma unroll
@@ -375,6 +413,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
 #pragma unroll
     for (int cc = 0; cc < NUT; ++cc) if (cc >= nut) w.Tm[uc][NX + cc] = 0.0;
   }
+#endif
   WG_SYNC(ctx);
   PH_TICK(ctx, 2);
   // ---- staging of the record's [A|B] rows and of the (transposed) input block of the residual rows r0 .. r0+nr.  Device: the

@@ -29,14 +29,6 @@ constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) |
 constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// DPP quad permute of a double (two 32-bit moves): CTRL = the four 2-bit source selectors of a quad, e.g. 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
-template <int CTRL>
-__device__ inline double quad_perm_f64(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 // a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
 __device__ inline double readlane_f64(double v, int lane) {
   const long long b = __double_as_longlong(v);
