@@ -173,6 +173,12 @@ __device__ inline double quad_perm_f64(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
+__device__ inline double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) * hsqp_gcptr;
 typedef double __attribute__((address_space(1))) * hsqp_gptr;

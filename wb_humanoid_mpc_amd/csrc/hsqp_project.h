@@ -291,6 +291,56 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     if (i < NU) w.eu[i] = w.urow[i] >= 0 ? -w.CDe[w.urow[i]][NZ] : 0.0; }   // an eliminated input is fixed at -e of its unit row
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // device: the whole factorisation in the registers of ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of the
+  // 36 x 16 matrix (36 registers); the pivot column comes through v_readlane with compile-time lane numbers (its elements are then
+  // wave-uniform), norm, dot product and update are lane-local.  Same arithmetic per element as the two-phase form below (which the host
+  // build runs), summation order aside.
+  if (ctx.tid < 64) {
+    const int c = ctx.tid & (LDR - 1);
+    const bool owner = ctx.tid < LDR;
+    double e[NU + 1];
+#pragma unroll
+    for (int i = 0; i <= NU; ++i) e[i] = w.qr.Rm[i][c];
+#pragma unroll
+    for (int k = 0; k < NE_MAX; ++k) {
+      if (k < ned) {
+        double x[NU + 1];
+#pragma unroll
+        for (int i = k; i <= NU; ++i) x[i] = readlane_f64(e[i], k);
+        double n4[4] = {0.0, 0.0, 0.0, 0.0}, d4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = k; i <= NU; ++i) { n4[i & 3] += x[i] * x[i]; d4[i & 3] += x[i] * e[i]; }
+        const double nrm2 = (n4[0] + n4[1]) + (n4[2] + n4[3]), rkk = x[k];
+        const double rs = inv_sqrt(nrm2 > 1e-300 ? nrm2 : 1e-300);
+        const double nrm = nrm2 * rs;
+        const double alpha = rkk >= 0.0 ? -nrm : nrm;
+        const double hv = nrm2 - alpha * rkk;      // = |v|^2 / 2
+        const double beta = hv > 1e-300 ? fast_rcp(hv) : 0.0;
+        const double sdot = beta * (((d4[0] + d4[1]) + (d4[2] + d4[3])) - alpha * e[k]);
+        if (ctx.tid == 0) {
+          w.qr.beta[k] = beta;
+          w.qr.Rdiag[k] = alpha;
+          w.qr.rinv[k] = rkk >= 0.0 ? -rs : rs;
+          if (!(nrm >= 1e-12)) w.ok = 0;
+        }
+        if (owner && c == k) {
+#pragma unroll
+          for (int i = 0; i <= NU; ++i) w.qr.V[k][i] = i < k ? 0.0 : (i == k ? x[k] - alpha : x[i]);
+        } else if (c > k) {
+          e[k] -= sdot * (x[k] - alpha);
+#pragma unroll
+          for (int i = k + 1; i <= NU; ++i) e[i] -= sdot * x[i];
+        }
+      }
+    }
+    if (owner) {   // R1 above the diagonal (the W phase reads Rm[j][i], j < i)
+#pragma unroll
+      for (int j = 0; j < NE_MAX; ++j) if (j < c) w.qr.Rm[j][c] = e[j];
+    }
+  }
+  WG_SYNC(ctx);
+#else
   // Both phases run on fixed item grids with unconditional loads (columns >= ne and row 35 are zero padding), so a
   // phase is one LDS round trip; masks are applied to values, not to control flow.
   for (int k = 0; k < ned; ++k) {
@@ -334,6 +384,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
     WG_SYNC(ctx);
   }
+#endif
   PH_TICK(ctx, 9);
   // ---- W = R1^-T [C | e'] over the dense rows: forward substitution per column, the column kept in registers (rows >= ned:
   //      rinv = 0 -> 0).  Last use of the equality rows: Tm may be written from the next phase on.

@@ -28,14 +28,6 @@ constexpr int LDB = 24;                        // leading dimension of the 23-wi
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
 constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
-__device__ inline double readlane_f64(double v, int lane) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-#endif
 constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
   double S[NX][NX];                            // alive through the whole stage: S A~ is formed during the factorisation
