@@ -253,6 +253,23 @@ def test_config3_exactly_against_the_oracle(model, oracle, riccati):
     assert fallbacks == 0
 
 
+def test_parallel_in_time_sweep_is_repeatable(model):
+    """The scan's elimination is a pipeline over the waves of a workgroup (one wave eliminates M and posts the multipliers, seven apply
+    them a chunk behind): a missing barrier or a mailbox race would show as run-to-run differences — twenty repeated solves of two
+    instances (202 workgroups per level) must agree bit for bit."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=100, batch=2, gait="walk", perturb=True)
+    s = HipSqpSolver(model, max_nodes=100, max_batch=2)
+    try:
+        ref = s.run(x0, x, u, par, dt)
+        for _ in range(20):
+            out = s.run(x0, x, u, par, dt)
+            assert np.array_equal(out["dx"], ref["dx"]) and np.array_equal(out["du"], ref["du"])
+        assert s.scan_fallbacks() == 0
+    finally:
+        s.close()
+
+
 def test_kkt_gate_sends_an_ill_conditioned_qp_back_to_the_serial_recursion(model):
     """A randomly perturbed run-gait QP (|du| ~ 1e3; tests/test_hostemu.py shows the scan 3e-8 of the step's scale off on its like) in
     the automatic range of the parallel-in-time sweep: the KKT gate rejects the scan's result and the iteration is redone with the
