@@ -43,7 +43,8 @@ constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 51 KB workspace: three workgroups of four waves per CU
 static_assert(PROJ_THREADS >= 256 && PROJ_THREADS % 64 == 0, "project_node hoists its staging loads assuming >= 256 threads; the Gram tiles are dealt to waves 0..3");
 constexpr int RIC_THREADS = 512;
-constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (22 KB workspace)
+constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (19.2 KB workspace: 8 one-wave workgroups per CU)
+static_assert(sizeof(LqWST<false>) <= 163840 / 8, "value-only workspace: eight workgroups per CU");
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 

@@ -47,10 +47,10 @@ struct StageWST {
     struct { double In[NB][10], f[NB][6]; };   // spatial inertia about O and net force per body (from the inertia phase on)
   };
   union {
-    double BB[D ? NB : 1][36];     // per-body BB (dead once the composites are formed)
-    double G[D ? 6 : 1][96];       // d ab / d[x;u], columns 0..92 used (written after the composites)
+    double BB[D ? NB : 1][D ? 36 : 1];     // per-body BB (dead once the composites are formed)
+    double G[D ? 6 : 1][D ? 96 : 1];       // d ab / d[x;u], columns 0..92 used (written after the composites)
   };
-  double Ic[D ? NB : 1][10], fc[D ? NB : 1][6], BBc[D ? NB : 1][36];
+  double Ic[D ? NB : 1][10], fc[D ? NB : 1][6], BBc[D ? NB : 1][D ? 36 : 1];   // (the value-only workspace carries no derivative storage: 8 workgroups / CU)
   double rP[2][3];                 // contact points relative to O
   double Fx[2][6];                 // contact wrenches about O {moment, force}
   // ---- results

@@ -20,6 +20,7 @@ constexpr int ROW_FOOT = 0, ROW_FRIC = 30, ROW_MXY = 38, ROW_COLL = 46;
 
 template <bool D>
 struct NodeWST {
+  static constexpr bool DERIV = D;
   double x[NX], u[NU], par[NP];
   double xnom[NX], unom[NU];
   int contact[2];
@@ -30,7 +31,7 @@ struct NodeWST {
   double Rf[2][9];               // contact frame rotation
   double pts[10][3];             // collision points rel. to O (order of DevModel::coll_body)
   double hfric[2], hmxy[2][4], hcoll[16];
-  double scale[NRS];             // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive
+  double scale[D ? NRS : 1];     // sqrt(p'') (or sqrt(w)*ip) per row slot, 0 if the slot is inactive (derivative rows only)
   double rho[NRS];
   double eqv[NE_MAX];
   union {
@@ -186,7 +187,7 @@ HSQP_HD void node_scalars(const Ctx& ctx, const DevModel& dm, const SW& ws, NW& 
           if (p.d2 > 0.0) { sc = sqrt(p.d2); rho = p.d1 / sc; }
         }
       }
-      nw.scale[s] = sc;
+      if (NW::DERIV) nw.scale[s] = sc;
       nw.rho[s] = rho;
     } else {
       const int r = s - NRS;
