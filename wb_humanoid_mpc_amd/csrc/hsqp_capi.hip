@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_ls_retake(const double* __restrict__ x, 
 
 // ---- KKT residual of the projected QP (reporting only, not part of an SQP step): one workgroup per (instance, node), the
 //      per-instance maxima by atomic max on the bit patterns of the (non-negative) residuals
-__global__ __launch_bounds__(256) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+__global__ __launch_bounds__(256, 4) void k_kkt(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
                                              const double* __restrict__ vf, const double* __restrict__ dx, const double* __restrict__ ut, int N,
                                              double* __restrict__ kkt, double* __restrict__ ginf) {
   __shared__ KktWS w;
