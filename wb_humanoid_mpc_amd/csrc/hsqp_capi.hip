@@ -215,12 +215,13 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
                                                                           const double* __restrict__ dx, const double* __restrict__ x, const double* __restrict__ u,
                                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, double alpha,
                                                                           double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
-                                                                          double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc) {
+                                                                          double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc, long long* prof) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   LqWST<false>& w = *reinterpret_cast<LqWST<false>*>(hsqp_smem);
   static_assert(sizeof(StepWS) <= sizeof(w.st), "the step scratch aliases the stage workspace");
   StepWS& sw = *reinterpret_cast<StepWS*>(&w.st);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};   // phase profile (profile builds): slot 3, labelled k_lq<false>
+  PH_TICK(ctx, 126);
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, sw, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
             du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4);
@@ -840,7 +841,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
                            h->d_xnew, h->d_unew, h->d_stepinfo);
       else   // whole-body: the step and its value pass are one kernel (k_step_value)
         hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
-                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc);
+                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
       if (!from_scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // kkt, |g|_inf (and the scan flags) are one block; the scan path has zeroed it before its kernels
