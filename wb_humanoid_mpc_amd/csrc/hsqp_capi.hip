@@ -900,24 +900,30 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       // reason the loop ends; hsqp_set_linesearch keeps it <= HSQP_LS_MAX_TRIALS
       const int max_trials = ls_max_trials(h->ls_settings);
       int still_active = 0;
-      for (int trial = 0; trial < max_trials; ++trial) {
-        HCHECK(hipMemsetAsync(h->d_counts, 0, 2 * sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
-        int counts[2];
+      // Two trials per host round trip: the follow-up of a rejected trial (shortened trajectory, its value pass, its performance index) is
+      // launched WITHOUT waiting for the verdict — every one of these kernels leaves the instances alone whose search is over (LsState::
+      // active / dirty), so after an accepted trial they are no-ops of a few microseconds, and the host reads the counters of the second
+      // decision only.  (One synchronisation per trial cost 40 us each at one instance — review item of round 1.)
+      constexpr int LS_SPECULATIVE = 2;
+      for (int trial = 0; trial < max_trials;) {
+        int counts[2] = {0, 0};
+        for (int r = 0; r < LS_SPECULATIVE && trial < max_trials; ++r, ++trial) {
+          HCHECK(hipMemsetAsync(h->d_counts, 0, 2 * sizeof(int), h->stream));
+          hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
+          hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
+          if (cent)
+            hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
+                               h->d_misc, (const LsState*)h->d_ls);
+          else
+            hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+                               N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
+          hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
+                             (const LsState*)h->d_ls);
+        }
         HCHECK(hipMemcpyAsync(counts, h->d_counts, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
         HCHECK(hipStreamSynchronize(h->stream));
-        if (counts[0] > 0)
-          hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
         still_active = counts[1];
         if (counts[1] == 0) break;
-        if (cent)
-          hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
-                             h->d_misc, (const LsState*)h->d_ls);
-        else
-          hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
-                             N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
-        hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
-                           (const LsState*)h->d_ls);
       }
       if (still_active) { h->err = "line search: trials exhausted with instances still undecided (internal error)"; return HSQP_ERR_NUMERIC; }
     }
