@@ -318,6 +318,7 @@ def test_whole_body_parallel_in_time_sweep_against_the_serial_recursion(model, n
     for i in range(batch):
         sc = max(1.0, np.abs(a["dx"][i]).max(), np.abs(a["du"][i]).max())
         err = max(np.abs(a["dx"][i] - b["dx"][i]).max(), np.abs(a["du"][i] - b["du"][i]).max())
+        print(f"N={n} B={batch} instance {i}: scan vs serial {err:.3e} = {err / sc:.2e} of the step's scale {sc:.3g}, kkt {b['kkt'][i]}")
         assert err <= 2e-10 * sc, f"instance {i}: scan vs serial {err:.3e} = {err / sc:.2e} of the step's scale {sc:.3g}"
         assert_kkt(b["kkt"][i], b["grad_inf"][i], f"scan, instance {i}")     # what the gate checks (gradient of the projected QP)
         assert_perf(b["perf_after"][i], a["perf_after"][i], f"scan vs serial, instance {i}", rel=1e-9)
