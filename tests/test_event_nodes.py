@@ -17,17 +17,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _dp = C.POINTER(C.c_double)
 
 
-def walk_problem_with_events(model, horizon=0.6, perturb_seed=None, gait="walk", t_start=-0.45):
+def walk_problem_with_events(model, horizon=0.6, perturb_seed=None, gait="walk", t_start=-0.45, t0=0.0):
     """A walk horizon whose mode switches fall INSIDE intervals of the nominal grid: (x0, x, u, par, dts, node_times, schedule, targets)."""
     dt = model.sqp["dt"]
-    schedule = tile_gait(model.gaits[gait], t_start, 3.0)
+    schedule = tile_gait(model.gaits[gait], t_start, 3.0 + t0)
     x0 = model.initial_state.copy()
     if perturb_seed is not None:
         rng = np.random.default_rng(perturb_seed)
         x0[6:6 + model.nj] += 0.03 * rng.standard_normal(model.nj)
         x0[6 + model.nj:] += 0.05 * rng.standard_normal(6 + model.nj)
-    targets = velocity_command_targets(model, (0.3, 0.0, 0.7925, 0.0), 0.0, x0, horizon)
-    dts, node_times = event_grid(0.0, horizon, dt, schedule.event_times)
+    targets = velocity_command_targets(model, (0.3, 0.0, 0.7925, 0.0), t0, x0, horizon)
+    dts, node_times = event_grid(t0, t0 + horizon, dt, schedule.event_times)
     par = build_node_params_at(model, schedule, targets, node_times)
     x, u = cold_start(model, x0, par)
     if perturb_seed is not None:      # leave the cold start so that the jump defects are non-zero
@@ -122,6 +122,41 @@ def test_kernel_sources_on_the_event_grid_equal_the_oracle(model, oracle, emu, s
     emu.emu_destroy(h)
 
 
+def first_interval_event_problem(model, perturb_seed=7):
+    """A horizon that starts 5e-5 s BEFORE a mode switch: the switch lies within dt_min of the initial time, so ocs2's grid replaces
+    the initial node by the pre-event node and the FIRST interval is the event (dt_nodes[0] = 0).  In a receding-horizon run this
+    happens about once per hundred switches."""
+    sched = tile_gait(model.gaits["walk"], -0.45, 4.0)
+    e = [t for t in sched.event_times if t > 0.1][0]
+    prob = walk_problem_with_events(model, perturb_seed=perturb_seed, t0=e - 5e-5)
+    assert prob[4][0] == 0.0 and (prob[4] == 0.0).sum() >= 2
+    return prob
+
+
+def test_kernel_sources_with_an_event_as_the_first_interval(model, oracle, emu):
+    x0, x, u, par, dts, _, _, _ = first_interval_event_problem(model)
+    n = len(dts)
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(emu.emu_create(C.byref(model.desc), err, 256))
+    assert h.value, err.value
+    P = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+    xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+    kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+    d = np.ascontiguousarray(dts)
+    assert emu.emu_sqp_iteration(h, n, C.c_double(0.0), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), None, P(d)) == 0
+    oracle.set_grid(dts)
+    try:
+        r = oracle.sqp_iteration(0.0, x0, x, u, par, threads=4)
+    finally:
+        oracle.set_grid(None)
+    scale = max(np.abs(r["dx"]).max(), np.abs(r["du"]).max())
+    assert np.abs(dx - r["dx"]).max() <= TRAJ_ABS + 1e-10 * scale and np.abs(du - r["du"]).max() <= TRAJ_ABS + 1e-10 * scale
+    assert not du[0].any() and np.allclose(dx[1], dx[0] + (x[0] - x[1]), atol=1e-12)     # node 0 is the identity jump
+    assert np.allclose(dx[0], x0 - x[0], atol=0)
+    assert kkt[1] <= 1e-9
+    emu.emu_destroy(h)
+
+
 def test_event_grid_phases_are_race_free(model):
     """The reverse-order host build (every phase executes its items backwards) reproduces the forward build bit for bit on the
     event grid too (jump_node_qp and the dt = 0 paths of the LQ / value phases)."""
@@ -163,6 +198,8 @@ def test_policy_interpolation_on_a_grid_with_events(emu, rng):
         ku, au = (k, a) if k <= N - 2 else (N - 2, 1.0)
         if dts[ku] == 0.0:
             au = 1.0
+        elif ku + 1 <= N - 1 and dts[ku + 1] == 0.0:
+            au = 0.0          # node ku + 1 is a pre-event node: the input before it is held up to the switch
         np.testing.assert_allclose(u, (1 - au) * ut[ku] + au * ut[ku + 1], atol=1e-12)
 
 
@@ -206,11 +243,46 @@ def test_device_on_the_event_grid_equals_the_oracle(model, oracle):
         xs, us, tau = s.evaluate_policy(np.array([te - 1e-3, te, te + 1e-3]))
         assert np.all(np.isfinite(tau))
         np.testing.assert_allclose(xs[1], out2["x"][1, ev[0] + 1], atol=1e-12)       # at the event time: the post-event node
-        # an event as the first or last interval is rejected
+        # an event as the last interval is rejected — before anything is copied: the handle holds no half-uploaded problem afterwards
         bad = dts.copy(); bad[-1] = 0.0
         with pytest.raises(HsqpError) as e:
             s.run(x0, x, u, par, bad)
         assert e.value.code == _abi.ERR_BAD_ARG
+        with pytest.raises(HsqpError) as e:
+            s.iterate(1)
+        assert e.value.code == _abi.ERR_BAD_ARG
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_device_with_an_event_as_the_first_interval(model, oracle):
+    """dt_nodes[0] = 0 (a mode switch within dt_min after the initial time) is a legal ocs2 grid: accepted and solved like any other
+    event stage (it used to be rejected, which threw out of the MPC loop about once per hundred switches)."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dts, node_times, sched, targets = first_interval_event_problem(model)
+    N = len(dts)
+    s = HipSqpSolver(model, max_nodes=N, max_batch=1)
+    try:
+        out = s.run(x0[None], x[None], u[None], par[None], dts)
+        oracle.set_grid(dts)
+        try:
+            r = oracle.sqp_iteration(0.0, x0, x, u, par, threads=os.cpu_count() or 4)
+        finally:
+            oracle.set_grid(None)
+        assert_step(out, r, 0, "event as the first interval")
+        assert_perf(out["perf_after"][0], r["perf_after"], "after")
+        assert_kkt(out["kkt"][0], out["grad_inf"][0], "first-interval event")
+        assert not out["du"][0, 0].any()
+        # the device-generated table on the same grid, and the policy at the very start (the post-event node)
+        t0 = node_times[0]
+        s.upload_reference(x0[None], x[None], u[None], dts, t0, *pack_reference([sched], [targets]), swing_config(model), node_times=node_times)
+        np.testing.assert_allclose(s.device_params()[0], par, rtol=0, atol=1e-12)
+        s.iterate(1, take_step=True)
+        out2 = s.download()
+        xs, us, tau = s.evaluate_policy(np.array([0.0]))
+        np.testing.assert_allclose(xs[0], out2["x"][0, 1], atol=1e-12)
+        assert np.all(np.isfinite(tau))
     finally:
         s.close()
 

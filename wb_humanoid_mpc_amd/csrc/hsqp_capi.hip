@@ -688,13 +688,12 @@ static int set_grid(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
       const double d = h->h_dt[b * N + k];
       if (!(d >= 0.0) || d > 1e6) { h->err = "dt_nodes: interval lengths must be finite and >= 0"; return HSQP_ERR_BAD_ARG; }
       if (d == 0.0) {
-        if (k == N - 1 || k == 0) { h->err = "dt_nodes: the first and the last interval cannot be events (dt = 0)"; return HSQP_ERR_BAD_ARG; }
+        // the FIRST interval may be an event: a mode switch within dt_min after the initial time replaces the initial node
+        // (timeDiscretizationWithEvents), and the identity-jump stage works at node 0 like anywhere else
+        if (k == N - 1) { h->err = "dt_nodes: the last interval cannot be an event (dt = 0)"; return HSQP_ERR_BAD_ARG; }
         h->has_events = true;
       }
     }
-  if (h->has_events && h->hdm.formulation == HSQP_FORM_CENTROIDAL && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (p->batch <= HSQP_SCAN_AUTO_BATCH && p->n_nodes >= HSQP_SCAN_AUTO_MIN_NODES && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI)))) {
-    // the scan's stage elements invert R~ of every stage; an event stage has R~ = I, so it is fine — nothing to reject
-  }
   if (!device_src) HCHECK(hipMemcpyAsync(h->d_dt, h->h_dt.data(), B * N * 8, hipMemcpyHostToDevice, h->stream));
   return HSQP_OK;
 }
@@ -710,11 +709,13 @@ static int upload_impl(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
   HCHECK(hipSetDevice(h->device));
   const size_t B = p->batch, N = p->n_nodes;
   const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  // the grid is validated BEFORE any trajectory copy is queued; a rejected problem leaves no half-uploaded state behind
+  h->have_problem = false; h->have_solution = false;
+  { const int rc = set_grid(h, p, device_src); if (rc != HSQP_OK) return rc; }
   HCHECK(hipMemcpyAsync(h->d_xinit, p->x_init, B * NX * 8, kind, h->stream));
   HCHECK(hipMemcpyAsync(h->d_x, p->x_traj, B * (N + 1) * NX * 8, kind, h->stream));
   HCHECK(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, kind, h->stream));
   HCHECK(hipMemcpyAsync(h->d_par, p->node_params, B * (N + 1) * NP * 8, kind, h->stream));
-  { const int rc = set_grid(h, p, device_src); if (rc != HSQP_OK) return rc; }
   HCHECK(hipStreamSynchronize(h->stream));
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
@@ -761,6 +762,7 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   double* d_ts = reinterpret_cast<double*>(base + o_ts);
   double* d_nt = r->node_times ? reinterpret_cast<double*>(base + o_nt) : nullptr;
   auto release = []() {};
+  h->have_problem = false; h->have_solution = false;   // a failure below leaves no half-uploaded problem behind
   int rc = set_grid(h, p, false);
   if (rc != HSQP_OK) return rc;
   auto step = [&](hipError_t e, const char* what) { if (rc == HSQP_OK && e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = HSQP_ERR_HIP; } };

@@ -95,6 +95,9 @@ HSQP_HD void policy_interpolate_grid(const Ctx& ctx, const double* xt, const dou
   double au = ax;
   if (ku > N - 2) { ku = N - 2 > 0 ? N - 2 : 0; au = N >= 2 ? 1.0 : 0.0; }
   if (N >= 2 && dts[ku] == 0.0) au = 1.0;
+  // node ku + 1 is a PRE-event node when interval ku + 1 is an event: it carries no optimised input of its own (du = 0 there;
+  // upstream multiple_shooting::toPrimalSolution gives it the input of the node before), so the input is held up to the switch
+  else if (N >= 2 && ku + 1 <= N - 1 && dts[ku + 1] == 0.0) au = 0.0;
   WG_FOR(ctx, i, NX + NU) {
     if (i < NX) x[i] = (1.0 - ax) * xt[(size_t)kx * NX + i] + ax * xt[(size_t)(kx + 1) * NX + i];
     else { const int c = i - NX; u[c] = N >= 2 ? (1.0 - au) * ut[(size_t)ku * NU + c] + au * ut[(size_t)(ku + 1) * NU + c] : ut[c]; }

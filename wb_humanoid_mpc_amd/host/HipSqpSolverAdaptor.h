@@ -85,7 +85,10 @@ class HipSqpSolverAdaptor final : public SolverBase {
   void reset() override { primal_.clear(); log_.clear(); numIterations_ = 0; benchmarks_ = HipSqpBenchmarks(); }
   size_t getNumIterations() const override { return numIterations_; }
   scalar_t getFinalTime() const override { return primal_.timeTrajectory_.empty() ? 0.0 : primal_.timeTrajectory_.back(); }
-  const PerformanceIndex& getPerformanceIndeces() const override { return log_.back(); }
+  const PerformanceIndex& getPerformanceIndeces() const override {
+    if (log_.empty()) throw std::runtime_error("[HipSqpSolverAdaptor] No performance log yet, no problem solved yet?");
+    return log_.back();
+  }
   const std::vector<PerformanceIndex>& getIterationsLog() const override {
     if (log_.empty()) throw std::runtime_error("[HipSqpSolverAdaptor] No performance log yet, no problem solved yet?");
     return log_;
@@ -101,6 +104,25 @@ class HipSqpSolverAdaptor final : public SolverBase {
     for (size_t i : primal_.postEventIndices_) if (i < n) out->postEventIndices_.push_back(i);
     out->modeSchedule_ = primal_.modeSchedule_;
     out->controllerPtr_.reset(new FeedforwardController(out->timeTrajectory_, out->inputTrajectory_));
+  }
+  // ---- the rest of SolverBase's pure-virtual query interface.  Upstream SqpSolver answers these the same way: it throws "not
+  //      implemented" for the value function, the Hamiltonian, the Lagrangian and the multipliers (ocs2_sqp/SqpSolver.h); the
+  //      optimal control problem lives on the device here (hsqp_model_desc), so there is no host OptimalControlProblem to hand out.
+  const OptimalControlProblem& getOptimalControlProblem() const override {
+    throw std::runtime_error("[HipSqpSolverAdaptor] getOptimalControlProblem() not available: the problem definition is device code (hsqp_model_desc)");
+  }
+  const DualSolution* getDualSolution() const override { return nullptr; }   // upstream SqpSolver: nullptr as well (no dual solution)
+  ScalarFunctionQuadraticApproximation getValueFunction(scalar_t, const vector_t&) const override {
+    throw std::runtime_error("[HipSqpSolverAdaptor] getValueFunction() not implemented");
+  }
+  ScalarFunctionQuadraticApproximation getHamiltonian(scalar_t, const vector_t&, const vector_t&) override {
+    throw std::runtime_error("[HipSqpSolverAdaptor] getHamiltonian() not implemented");
+  }
+  vector_t getStateInputEqualityConstraintLagrangian(scalar_t, const vector_t&) const override {
+    throw std::runtime_error("[HipSqpSolverAdaptor] getStateInputEqualityConstraintLagrangian() not implemented");
+  }
+  MultiplierCollection getSolutionMultipliers(scalar_t) const override {
+    throw std::runtime_error("[HipSqpSolverAdaptor] getSolutionMultipliers() not implemented");
   }
   /** SqpSolver::getBenchmarks() of the fork. */
   const HipSqpBenchmarks& getBenchmarks() const { return benchmarks_; }
@@ -131,6 +153,20 @@ class HipSqpSolverAdaptor final : public SolverBase {
     for (int k = 0; k < n; ++k) out[k] = (1.0 - a) * v[i - 1][k] + a * v[i][k];
   }
 
+  // upstream SqpSolver: an external controller is ignored ("runImpl(initTime, initState, finalTime)"); an external primal solution
+  // replaces the warm start
+  void runImpl(scalar_t initTime, const vector_t& initState, scalar_t finalTime, const ControllerBase* /*externalControllerPtr*/) override {
+    runImpl(initTime, initState, finalTime);
+  }
+  void runImpl(scalar_t initTime, const vector_t& initState, scalar_t finalTime, const PrimalSolution& primalSolution) override {
+    primal_.clear();
+    primal_.timeTrajectory_ = primalSolution.timeTrajectory_;
+    primal_.stateTrajectory_ = primalSolution.stateTrajectory_;
+    primal_.inputTrajectory_ = primalSolution.inputTrajectory_;
+    primal_.postEventIndices_ = primalSolution.postEventIndices_;
+    primal_.modeSchedule_ = primalSolution.modeSchedule_;
+    runImpl(initTime, initState, finalTime);
+  }
   void runImpl(scalar_t initTime, const vector_t& initState, scalar_t finalTime) override {
     const int nx = cfg_.stateDim;
     if ((int)initState.size() != nx) throw std::runtime_error("[HipSqpSolverAdaptor] initial state has the wrong dimension");
@@ -206,7 +242,12 @@ class HipSqpSolverAdaptor final : public SolverBase {
       ++numIterations_;
       if (std::sqrt(dxn) < settings_.deltaTol && std::sqrt(dun) < settings_.deltaTol) break;   // upstream: step below deltaTol -> converged
     }
-    // 5. primal solution: inputs stamped at every node, the last one repeated (upstream PrimalSolution convention)
+    // 5. primal solution: inputs stamped at every node, the last one repeated (upstream PrimalSolution convention).  A pre-event node
+    //    has no input of its own (its stage is the identity jump, du = 0): upstream multiple_shooting::toPrimalSolution copies the
+    //    input of the node before it, so that the controller, the next warm start and the policy hold the last optimised input up
+    //    to the switch instead of blending towards a stale one.
+    for (int k = 1; k < N; ++k)
+      if (dts[k] == 0.0) std::copy_n(&u[(size_t)(k - 1) * HSQP_NU], HSQP_NU, &u[(size_t)k * HSQP_NU]);
     primal_.clear();
     primal_.timeTrajectory_ = times;
     primal_.modeSchedule_ = ms;
