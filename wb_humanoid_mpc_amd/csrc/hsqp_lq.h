@@ -118,6 +118,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
   for (int s = 0; s < 4; ++s) {
     PH_TICK(ctx, 1);
     rk4_stage_inputs(ctx, w, s, dt);
+    PH_TICK(ctx, 27);
     // the stage Jacobians of stages 2..4 go straight to the record (they are only chained later); stage 1 stays in LDS
     // for the node terms and is copied out
     stage_eval<DERIV>(ctx, dm, w.st, (DERIV && s > 0) ? rec + REC_GS + s * 6 * LDJ : nullptr);
@@ -183,6 +184,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     else rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
   }
   WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
+  PH_TICK(ctx, 33);
   // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
   const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
   {   // stage Jacobians back from the record (written by this workgroup, L2-resident), 9 loads in flight per item
@@ -195,6 +197,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 34);
   for (int s = 1; s < 4; ++s) {
     const double c = s == 1 ? c2 : (s == 2 ? c3 : c4);
     const double cprev = s == 2 ? c2 : c3;  // coefficient of stage s-1 (used for s >= 2)

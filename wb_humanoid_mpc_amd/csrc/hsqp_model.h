@@ -44,11 +44,13 @@ struct StageWST {
       double Mq[NB][9];            //   Rfix * Rot(axis, q): joint rotation in the parent body frame
       double pa[NB][6];            //   joint offset and joint axis in the parent body frame (copied next to Mq: they sit on the walk's serial path)
     };
-    struct { double In[NB][10], f[NB][6]; };   // spatial inertia about O and net force per body (from the inertia phase on)
+    // spatial inertia about O and net force per body (from the inertia phase on).  Derivative pass: turned IN PLACE into suffix sums
+    // over the depth-first order (row NB = 0), so that the composite of body i is row i minus row i + subtree_size[i]
+    struct { double In[NB + 1][10], f[NB + 1][6]; };
   };
   union {
-    double BB[D ? NB : 1][D ? 36 : 1];     // per-body BB (dead once the composites are formed)
-    double G[D ? 6 : 1][D ? 96 : 1];       // d ab / d[x;u], columns 0..92 used (written after the composites)
+    double BB[D ? NB + 1 : 1][D ? 36 : 1];   // per-body BB, then its suffix sums like In / f (dead once the composites are formed)
+    double G[D ? 6 : 1][D ? 96 : 1];         // d ab / d[x;u], columns 0..92 used (written after the composites)
   };
   double Ic[D ? NB : 1][10], fc[D ? NB : 1][6], BBc[D ? NB : 1][D ? 36 : 1];   // (the value-only workspace carries no derivative storage: 8 workgroups / CU)
   double rP[2][3];                 // contact points relative to O
@@ -151,6 +153,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     for (int k = 0; k < 3; ++k) { ws.pa[i][k] = dm.pfix[i][k]; ws.pa[i][3 + k] = dm.axis_p[i][k]; }
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 28);
   // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
   // only on row r of R_p, so every chain is walked by three independent items (one per row), each from the base
   // down its whole ancestor path (the shared waist bodies are recomputed, not exchanged): no barrier inside the tree.
@@ -225,6 +228,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     ws.vl[jc][k] = s;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 29);
   // ---- phase F3: Sd_i = v_i x S_i
   WG_FOR(ctx, it, NJC * 6) {
     const int jc = it / 6, k = it % 6, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
@@ -235,6 +239,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     ws.Sd[jc][k] = s;
   }
   WG_SYNC(ctx);
+  PH_TICK(ctx, 30);
   // ---- phase F4: link accelerations (gravity trick, base acceleration unknown -> 0):
   // a_i = a_0 + sum_a (S_a qdd_a + Sd_a qd_a); the euler joints enter with zero acceleration
   WG_FOR(ctx, it, NJC * 6) {
@@ -308,30 +313,44 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     }
     WG_SYNC(ctx);
     PH_TICK(ctx, 23);
-    // composites over subtrees, comp_i = sum of own_j over the depth-first range [i, i + sub_i), in ONE phase: an item
-    // (chain, quantity) runs down the whole range of the chain's first body and records the running sum at the bodies of
-    // the chain itself, which lead the range (the rest of the range are the subtrees of the chains hanging off it; their
-    // composites are formed by their own items from the same `own` data, so no item reads another item's result).  The
-    // loads have contiguous, sum-independent addresses; only the additions are chained.
-    WG_FOR(ctx, it, (ws.n_chains + 1) * 52) {
-      const int ch = it / 52, e = it % 52;
+    // composites over subtrees: comp_i = sum of own_j over the depth-first range [i, i + sub_i) = Sfx[i] - Sfx[i + sub_i] with the
+    // suffix sums Sfx[j] = sum_{l >= j} own_l, formed IN PLACE by 52 items (one per quantity: 10 inertia entries, 6 force entries, 36
+    // entries of BB): 24 independent loads, a chain of 23 additions in registers, 25 stores (row NB = 0); a second phase takes the
+    // differences with unit-stride loads.  (The range-sum form — one item per (chain, quantity) with masked block loads — was the
+    // longest phase of the kernel: 7.8 k cycles per stage; differences taken by the consumers while they load doubled the column phase.)
+    WG_FOR(ctx, e, 52) {
+      double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
+      const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
+      double v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) v[j] = own[j * st];
+      double sfx = 0.0;
+      own[NB * st] = 0.0;
+#pragma unroll
+      for (int j = NB - 1; j >= 0; --j) { sfx += v[j]; own[j * st] = sfx; }
+    }
+    WG_SYNC(ctx);
+    // differences: an item = (quantity, half of the bodies), fully unrolled over its 12 bodies so that all loads are in flight
+    // together (a rolled item loop pays two dependent LDS round trips per body: 7 k cycles per stage)
+    static_assert(NB == 24, "two groups of twelve bodies");
+    WG_FOR(ctx, it, 2 * 52) {
+      const int e = it % 52, i0 = (it / 52) * 12;
       const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
       double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
       const int st = e < 10 ? 10 : (e < 16 ? 6 : 36);
-      const int b0 = ws.chain_start[ch], len = ws.chain_len[ch], sz = ws.sub[b0];
-      double s = 0.0;
-      // blocks of 8 from the far end of the range: the 8 loads of a block are issued together (clamped index, masked use)
-      for (int n0 = sz; n0 > 0; n0 -= 8) {
-        double v[8];
+      unsigned long long s8;
+      unsigned int s4;
+      memcpy(&s8, &ws.sub[i0], 8);
+      memcpy(&s4, &ws.sub[i0 + 8], 4);
+      double a[12], b[12];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const int n = n0 - 1 - t; v[t] = own[(b0 + (n >= 0 ? n : 0)) * st]; }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int n = n0 - 1 - t;
-          s += n >= 0 ? v[t] : 0.0;
-          if (n >= 0 && n < len) comp[(b0 + n) * st] = s;
-        }
+      for (int j = 0; j < 12; ++j) {
+        const int sz = j < 8 ? (int)((s8 >> (8 * j)) & 0xffull) : (int)((s4 >> (8 * (j - 8))) & 0xffu);
+        a[j] = own[(i0 + j) * st];
+        b[j] = own[(i0 + j + sz) * st];
       }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) comp[(i0 + j) * st] = a[j] - b[j];
     }
   } else {
     WG_FOR(ctx, e, 16) {
@@ -346,12 +365,14 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   WG_FOR(ctx, it, 1) {
     double Fext[6];
     for (int k = 0; k < 6; ++k) Fext[k] = ws.Fx[0][k] + ws.Fx[1][k];
-    for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ws.fc[0][k];
-    const double* I6 = ws.Ic[0] + 4;
+    const double* ftot = ws.fc[0];
+    const double* Itot = ws.Ic[0];
+    for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ftot[k];
+    const double* I6 = Itot + 4;
     const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
     m3_inverse(Ib, ws.Iinv);
     m3_mulv(ws.Iinv, ws.Ftil, ws.y);
-    const double minv = 1.0 / ws.Ic[0][0];
+    const double minv = 1.0 / Itot[0];
     for (int k = 0; k < 3; ++k) ws.ab[k] = ws.Ftil[3 + k] * minv;
     m3_mulv(ws.Einv, ws.y, ws.ab + 3);
   }

@@ -371,6 +371,7 @@ HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS&
       CDe[(r0 + 6) * LDJ + col] = dm.gain_pos_z * dq[2] + dm.gain_linvel_z * dq[8] + dm.gain_linacc_z * dq[14];
     }
   }
+  PH_TICK(ctx, 31);
   // ---- friction, moment XY and collision rows, one item per (row slot, column)
   WG_FOR(ctx, it, (NRS - ROW_FRIC) * LDJ) {
     const int s = ROW_FRIC + it / LDJ, col = it % LDJ;
@@ -423,6 +424,7 @@ HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS&
     }
     Jout[s * LDJ + col] = val;
   }
+  PH_TICK(ctx, 32);
   // ---- diagonal part
   WG_FOR(ctx, i, LDJ) {
     double d = 0.0, g = 0.0;
