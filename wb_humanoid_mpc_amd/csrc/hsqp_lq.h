@@ -107,7 +107,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
 #else
   const DevModel& dm = dm_global;
 #endif
-  stage_topology(ctx, dm, w.st);
+  stage_topology(ctx, dm, w.st, /*sync*/ false);   // one phase with the node's inputs: the two global round trips overlap
   WG_FOR(ctx, i, NX + NU + NP + NX) {
     if (i < NX) { if (!PRELOADED) w.nw.x[i] = x[i]; }
     else if (i < NX + NU) { if (!PRELOADED) w.nw.u[i - NX] = u[i - NX]; }

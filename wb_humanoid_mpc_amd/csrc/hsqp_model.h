@@ -35,14 +35,14 @@ struct StageWST {
   double E[9];       // E[3*r+c]: column c = world axis of euler rate c (z, y, x)
   double Einv[9];
   // ---- revolute coordinates jc = 0..25 (euler z,y,x, then joints); generalized coordinate = 3 + jc
-  double S[NJC][6], Sd[NJC][6], Sdd[D ? NJC : 1][6];
+  double S[NJC + 1][6], Sd[NJC][6], Sdd[D ? NJC : 1][6];   // S[NJC]: dump row of the placement walk
   double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
   // ---- bodies
-  double R[NB][9], r[NB][3];       // world rotation, origin relative to the base origin O
+  double R[NB + 1][9], r[NB + 1][3];   // world rotation, origin relative to the base origin O (row NB: dump row of the placement walk)
   union {
     struct {                       // placement walk (phases F0-F1):
-      double Mq[NB][9];            //   Rfix * Rot(axis, q): joint rotation in the parent body frame
-      double pa[NB][6];            //   joint offset and joint axis in the parent body frame (copied next to Mq: they sit on the walk's serial path)
+      double Mq[NB + 1][9];        //   Rfix * Rot(axis, q): joint rotation in the parent body frame (row NB: identity, the padded steps of the walk)
+      double pa[NB + 1][6];        //   joint offset and joint axis in the parent body frame (copied next to Mq: they sit on the walk's serial path; row NB: zero)
     };
     // spatial inertia about O and net force per body (from the inertia phase on).  Derivative pass: turned IN PLACE into suffix sums
     // over the depth-first order (row NB = 0), so that the composite of body i is row i minus row i + subtree_size[i]
@@ -124,7 +124,7 @@ HSQP_HD unsigned long long anc_packed(const unsigned char* row) {
 HSQP_HD int anc_at(unsigned long long pk, int n) { return (int)((pk >> (8 * n)) & 0xffull); }
 
 template <class SW>
-HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
+HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws, bool sync = true) {
   WG_FOR(ctx, i, NB * NANC + NB) {
     if (i < NB * NANC) ws.anc[i / NANC][i % NANC] = dm.anc[i / NANC][i % NANC];
     else {
@@ -134,7 +134,7 @@ HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
       if (b == 0) ws.n_chains = dm.n_chains;
     }
   }
-  WG_SYNC(ctx);
+  if (sync) WG_SYNC(ctx);
 }
 
 // Gout (optional, row stride LDJ, may be global memory): if given, the Jacobian goes there instead of ws.G (columns
@@ -142,12 +142,17 @@ HSQP_HD void stage_topology(const Ctx& ctx, const DevModel& dm, SW& ws) {
 template <bool DERIV>
 HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws, double* Gout = nullptr) {
   // ---- phase F0: trigonometry, parallel over the 26 angles (joint rotations in the parent frame; euler cos/sin)
-  WG_FOR(ctx, it, NB + 2) {
+  WG_FOR(ctx, it, NB + 3) {
+    if (it == NB + 2) {   // the identity joint the placement walk takes on the padded steps of a path
+      for (int k = 0; k < 9; ++k) ws.Mq[NB][k] = (k % 4 == 0) ? 1.0 : 0.0;
+      for (int k = 0; k < 6; ++k) ws.pa[NB][k] = 0.0;
+      continue;
+    }
     double sn, cs;
-    if (it < 3) { sincos(ws.q[3 + it], &sn, &cs); ws.ecs[it][0] = cs; ws.ecs[it][1] = sn; continue; }
+    sincos(ws.q[3 + it], &sn, &cs);   // one evaluation for both roles: angle 3 + it is euler angle it (it < 3) or joint it - 3
+    if (it < 3) { ws.ecs[it][0] = cs; ws.ecs[it][1] = sn; continue; }
     const int i = it - 2;
     double Rq[9];
-    sincos(ws.q[5 + i], &sn, &cs);
     rot_axis_cs(dm.axis[i], cs, sn, Rq);
     m3_mul(dm.Rfix[i], Rq, ws.Mq[i]);
     for (int k = 0; k < 3; ++k) { ws.pa[i][k] = dm.pfix[i][k]; ws.pa[i][3 + k] = dm.axis_p[i][k]; }
@@ -157,9 +162,12 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
   // only on row r of R_p, so every chain is walked by three independent items (one per row), each from the base
   // down its whole ancestor path (the shared waist bodies are recomputed, not exchanged): no barrier inside the tree.
-  WG_FOR(ctx, it, ws.n_chains * 3 + 4) {
+  // The euler item sits at a wave boundary (item 64 of a two-wave workgroup): it runs beside the walk, not after it.
+  const int n_walk = ws.n_chains * 3 + 3, it_euler = n_walk <= 64 ? 64 : n_walk;
+  WG_FOR(ctx, it, it_euler + 1) {
+    if (it >= n_walk && it != it_euler) continue;
     const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
-    if (it == ws.n_chains * 3 + 3) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
+    if (it == it_euler) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
       const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
       for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
       m3_inverse(ws.E, ws.Einv);
@@ -182,11 +190,15 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     const int b0 = ws.chain_start[ch], end = b0 + ws.chain_len[ch] - 1, na = ws.n_anc[end];
     double rp = 0.0;
     // fully unrolled over the (padded) path: the index and operand loads do not depend on the running row, only the
-    // multiply-adds are chained
+    // multiply-adds are chained.  No branch and no select on the data: a padded step multiplies by the identity joint (row NB of
+    // Mq / pa: the running row comes back bit for bit), and what is not to be kept — padded steps, ancestors that belong to another
+    // chain — is stored to the dump rows (R[NB], r[NB], S[NJC]).
     const unsigned long long pk1 = anc_packed(ws.anc[end]);
 #pragma unroll
     for (int n = 0; n < NANC; ++n) {
-      const int i = anc_at(pk1, n);
+      const int ia = anc_at(pk1, n);
+      const int i = n < na ? ia : NB;
+      const int d = (n < na && ia >= b0) ? ia : NB;
       const double* M = ws.Mq[i];
       const double* pa = ws.pa[i];
       const double rn0 = Rp[0] * M[0] + Rp[1] * M[3] + Rp[2] * M[6];
@@ -194,10 +206,8 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
       const double rn2 = Rp[0] * M[2] + Rp[1] * M[5] + Rp[2] * M[8];
       const double rr = rp + Rp[0] * pa[0] + Rp[1] * pa[1] + Rp[2] * pa[2];
       const double w = Rp[0] * pa[3] + Rp[1] * pa[4] + Rp[2] * pa[5];
-      if (n < na) {
-        if (i >= b0) { ws.R[i][3 * r] = rn0; ws.R[i][3 * r + 1] = rn1; ws.R[i][3 * r + 2] = rn2; ws.r[i][r] = rr; ws.S[i + 2][r] = w; }
-        Rp[0] = rn0; Rp[1] = rn1; Rp[2] = rn2; rp = rr;
-      }
+      ws.R[d][3 * r] = rn0; ws.R[d][3 * r + 1] = rn1; ws.R[d][3 * r + 2] = rn2; ws.r[d][r] = rr; ws.S[d + 2][r] = w;
+      Rp[0] = rn0; Rp[1] = rn1; Rp[2] = rn2; rp = rr;
     }
   }
   WG_SYNC(ctx);
@@ -263,17 +273,21 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   WG_SYNC(ctx);
   PH_TICK(ctx, 21);
   // ---- per-body spatial inertia about O and net force
-  WG_FOR(ctx, it, NB + 2 + (DERIV ? NJC : 0)) {
-    if (it >= NB + 2) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
-      const int jc = it - NB - 2;
+  // derivative pass (two waves): the bodies on wave 0, the contact points and Sdd from item 64 on — different roles in one wave run
+  // one after the other, on two waves side by side
+  constexpr int IT_C = DERIV ? 64 : NB;
+  WG_FOR(ctx, it, IT_C + 2 + (DERIV ? NJC : 0)) {
+    if (it >= NB && it < IT_C) continue;
+    if (it >= IT_C + 2) {   // Sdd = a x S + v x Sd (only the derivative columns need it)
+      const int jc = it - IT_C - 2;
       double t1[6], t2[6];
       mxm(ws.al[jc], ws.S[jc], t1);
       mxm(ws.vl[jc], ws.Sd[jc], t2);
       for (int k = 0; k < 6; ++k) ws.Sdd[jc][k] = t1[k] + t2[k];
       continue;
     }
-    if (it >= NB) {   // contact point of foot f relative to O and its wrench about O {moment, force} (off the serial totals phase)
-      const int f = it - NB, b = dm.contact_body[f];
+    if (it >= IT_C) {   // contact point of foot f relative to O and its wrench about O {moment, force} (off the serial totals phase)
+      const int f = it - IT_C, b = dm.contact_body[f];
       double rr[3], mom[3];
       m3_mulv(ws.R[b], dm.contact_p[f], rr);
       for (int k = 0; k < 3; ++k) { rr[k] += ws.r[b][k]; ws.rP[f][k] = rr[k]; }
@@ -380,11 +394,17 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   PH_TICK(ctx, 25);
   if (!DERIV) return;
   // ---- Jacobian columns: items (jc, kind in {q, qd, qdd}) and the 12 wrench components
-  WG_FOR(ctx, it, NJC * 3 + 12) {
+  // Kind-major item order, the q-columns (by far the longest) alone on wave 0, everything else from item 64 on: lanes of one wave
+  // that take different branches run them one after the other, so a (jc, kind)-interleaved order made BOTH waves execute all
+  // three column kinds
+  static_assert(NJC <= 64 && 64 + NJC + NJ + 12 + 54 <= 192, "item layout of the Jacobian-column phase");
+  WG_FOR(ctx, it, 64 + NJC + NJ + 12) {
     double rhs[3], lin[3];
     int col;
-    if (it < NJC * 3) {
-      const int jc = it / 3, kind = it % 3;
+    if (it >= NJC && it < 64) continue;
+    if (it < 64 + NJC + NJ) {
+      const int kind = it < NJC ? 0 : (it < 64 + NJC ? 1 : 2);
+      const int jc = kind == 0 ? it : (kind == 1 ? it - 64 : 3 + it - 64 - NJC);
       const int bi = jc < 3 ? 0 : jc - 2;
       const double* Sx = ws.S[jc];
       const double* Ic = ws.Ic[bi];
@@ -432,7 +452,6 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
         for (int k = 0; k < 6; ++k) dF[k] = 2.0 * t1[k] + t2[k];
         for (int k = 0; k < 3; ++k) rhs[k] = -dF[k];
       } else {
-        if (jc < 3) continue;
         col = NX + 12 + (jc - 3);
         inertia_apply(Ic, Sx, dF);
         for (int k = 0; k < 3; ++k) rhs[k] = -dF[k];
@@ -440,7 +459,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
       const double minv = 1.0 / ws.Ic[0][0];
       for (int k = 0; k < 3; ++k) lin[k] = -dF[3 + k] * minv;
     } else {
-      const int wi = it - NJC * 3, f = wi / 6, k6 = wi % 6;
+      const int wi = it - 64 - NJC - NJ, f = wi / 6, k6 = wi % 6;
       col = NX + wi;
       double e[3] = {0.0, 0.0, 0.0};
       e[k6 % 3] = 1.0;
@@ -459,8 +478,9 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     else for (int k = 0; k < 3; ++k) { ws.G[k][col] = lin[k]; ws.G[3 + k][col] = ang[k]; }
   }
   // columns with identically zero derivative: base position (0..2) and base linear velocity (29..31)
-  WG_FOR(ctx, it, 6 * 9) {
-    const int r = it / 9, c = it % 9;
+  WG_FOR(ctx, itz, 64 + 6 * 9) {
+    if (itz < 64) continue;
+    const int it = itz - 64, r = it / 9, c = it % 9;
     const int col = c < 3 ? c : (c < 6 ? NV + (c - 3) : NZ + (c - 6));
     if (Gout) Gout[r * LDJ + col] = 0.0;
     else if (col < NZ) ws.G[r][col] = 0.0;
