@@ -36,7 +36,7 @@ struct StageWST {
   double Einv[9];
   // ---- revolute coordinates jc = 0..25 (euler z,y,x, then joints); generalized coordinate = 3 + jc
   double S[NJC + 1][6], Sd[NJC][6], Sdd[D ? NJC : 1][6];   // S[NJC]: dump row of the placement walk
-  double vl[NJC][6], al[NJC][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc
+  double vl[NJC + 1][6], al[NJC + 1][6];   // spatial velocity / (gravity-trick) acceleration of the link after joint jc (row NJC: dump row of the walks)
   // ---- bodies
   double R[NB + 1][9], r[NB + 1][3];   // world rotation, origin relative to the base origin O (row NB: dump row of the placement walk)
   union {
@@ -212,30 +212,32 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 20);
-  // ---- phase F2: linear part of the joint axes S_i = {w_i, r_i x w_i} and the link velocities as sums over the
-  // ancestor path, v_i = v_base + sum_a S_a qd_a (one item per component)
-  WG_FOR(ctx, it, NJC * 6) {
-    const int jc = it / 6, k = it % 6, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  // ---- phase F2: linear part of the joint axes S_i = {w_i, r_i x w_i} and the link velocities v_i = v_base + sum_a S_a qd_a.  One item
+  // per (chain, component) walks down the ancestor path of the chain's last body and records the running sum at the bodies of its own
+  // chain (the shared ancestors are re-summed, not exchanged; other chains' bodies and the padded steps go to the dump rows): 48 items
+  // of 8 steps instead of one 8-step sum per (body, component) — 156 items, three wave rounds.
+  WG_FOR(ctx, it, ws.n_chains * 6 + 18) {
+    const int k = it % 6, k1 = (k + 1) % 3, k2 = (k + 2) % 3, ch = it / 6 - 3;
+    // the base (= the third euler link): angular part from the euler rates, linear part = base linear velocity
     double s;
-    if (k < 3) { s = ws.S[0][k] * ws.v[3]; if (jc >= 1) s += ws.S[1][k] * ws.v[4]; if (jc >= 2) s += ws.S[2][k] * ws.v[5]; }
+    if (k < 3) { s = ws.S[0][k] * ws.v[3]; if (ch >= -2) s += ws.S[1][k] * ws.v[4]; if (ch >= -1) s += ws.S[2][k] * ws.v[5]; }
     else s = ws.v[k - 3];
-    if (jc >= 3) {
-      const int i = jc - 2, na = ws.n_anc[i];
-      double sa = 0.0;
-      const unsigned long long pk2 = anc_packed(ws.anc[i]);
+    if (ch < 0) { ws.vl[ch + 3][k] = s; continue; }      // the euler links jc = 0, 1, 2
+    const int b0 = ws.chain_start[ch], end = b0 + ws.chain_len[ch] - 1, na = ws.n_anc[end];
+    const unsigned long long pk2 = anc_packed(ws.anc[end]);
 #pragma unroll
-      for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself: the last term is always the own axis
-        // branch-free: sa = p1 S[j1] - p2 S[j2] with (p1, j1, p2, j2) = (1, k, 0, k) for the angular rows, (r[k1], k2, r[k2], k1) for the linear
-        const int a = anc_at(pk2, n);
-        const double r1 = ws.r[a][k1], r2 = ws.r[a][k2];
-        const double s1 = ws.S[a + 2][k < 3 ? k : k2], s2 = ws.S[a + 2][k < 3 ? k : k1];
-        const double qa = ws.v[5 + a];
-        sa = (k < 3 ? 1.0 : r1) * s1 - (k < 3 ? 0.0 : r2) * s2;
-        s += (n < na ? qa : 0.0) * sa;
-      }
-      if (k >= 3) ws.S[jc][k] = sa;
+    for (int n = 0; n < NANC; ++n) {   // the path is padded with the body itself
+      // branch-free: sa = p1 S[j1] - p2 S[j2] with (p1, j1, p2, j2) = (1, k, 0, k) for the angular rows, (r[k1], k2, r[k2], k1) for the linear
+      const int a = anc_at(pk2, n);
+      const int d = (n < na && a >= b0) ? a + 2 : NJC;
+      const double r1 = ws.r[a][k1], r2 = ws.r[a][k2];
+      const double s1 = ws.S[a + 2][k < 3 ? k : k2], s2 = ws.S[a + 2][k < 3 ? k : k1];
+      const double qa = ws.v[5 + a];
+      const double sa = (k < 3 ? 1.0 : r1) * s1 - (k < 3 ? 0.0 : r2) * s2;
+      s += (n < na ? qa : 0.0) * sa;
+      ws.S[d][k] = sa;                        // (an angular item rewrites the value it read: no branch)
+      ws.vl[d][k] = s;
     }
-    ws.vl[jc][k] = s;
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 29);
@@ -251,24 +253,24 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   WG_SYNC(ctx);
   PH_TICK(ctx, 30);
   // ---- phase F4: link accelerations (gravity trick, base acceleration unknown -> 0):
-  // a_i = a_0 + sum_a (S_a qdd_a + Sd_a qd_a); the euler joints enter with zero acceleration
-  WG_FOR(ctx, it, NJC * 6) {
-    const int jc = it / 6, k = it % 6;
+  // a_i = a_0 + sum_a (S_a qdd_a + Sd_a qd_a); the euler joints enter with zero acceleration.  Walked like F2.
+  WG_FOR(ctx, it, ws.n_chains * 6 + 18) {
+    const int k = it % 6, ch = it / 6 - 3;
     double s = k == 5 ? dm.gravity : 0.0;
     s += ws.Sd[0][k] * ws.v[3];
-    if (jc >= 1) s += ws.Sd[1][k] * ws.v[4];
-    if (jc >= 2) s += ws.Sd[2][k] * ws.v[5];
-    if (jc >= 3) {
-      const int i = jc - 2, na = ws.n_anc[i];
-      const unsigned long long pk4 = anc_packed(ws.anc[i]);
+    if (ch >= -2) s += ws.Sd[1][k] * ws.v[4];
+    if (ch >= -1) s += ws.Sd[2][k] * ws.v[5];
+    if (ch < 0) { ws.al[ch + 3][k] = s; continue; }
+    const int b0 = ws.chain_start[ch], end = b0 + ws.chain_len[ch] - 1, na = ws.n_anc[end];
+    const unsigned long long pk4 = anc_packed(ws.anc[end]);
 #pragma unroll
-      for (int n = 0; n < NANC; ++n) {
-        const int a = anc_at(pk4, n);
-        const double t = ws.S[a + 2][k] * ws.qddj[a - 1] + ws.Sd[a + 2][k] * ws.v[5 + a];
-        s += n < na ? t : 0.0;
-      }
+    for (int n = 0; n < NANC; ++n) {
+      const int a = anc_at(pk4, n);
+      const int d = (n < na && a >= b0) ? a + 2 : NJC;
+      const double t = ws.S[a + 2][k] * ws.qddj[a - 1] + ws.Sd[a + 2][k] * ws.v[5 + a];
+      s += n < na ? t : 0.0;
+      ws.al[d][k] = s;
     }
-    ws.al[jc][k] = s;
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 21);
