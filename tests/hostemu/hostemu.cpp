@@ -123,13 +123,14 @@ void emu_lq_node(void* h, const double* x, const double* u, const double* xnext,
 // dense blocks from a record: AB[58*93], H[93*93], g[93], CDe[14*94]
 void emu_expand(const double* rec, double dt, double* AB, double* H, double* g, double* CDe) {
   expand_AB(rec, dt, AB);
+  const int nrows = (int)rec[REC_NROWS];   // compact residual rows (hsqp_node.h); rows beyond them are not part of the model
   for (int a = 0; a < NZ; ++a) {
     double ga = rec[REC_GD + a];
-    for (int r = 0; r < NRS; ++r) ga += rec[REC_J + r * LDJ + a] * rec[REC_RHO + r];
+    for (int r = 0; r < nrows; ++r) ga += rec[REC_J + r * LDJ + a] * rec[REC_RHO + r];
     g[a] = ga;
     for (int b = 0; b < NZ; ++b) {
       double s = a == b ? rec[REC_D + a] : 0.0;
-      for (int r = 0; r < NRS; ++r) s += rec[REC_J + r * LDJ + a] * rec[REC_J + r * LDJ + b];
+      for (int r = 0; r < nrows; ++r) s += rec[REC_J + r * LDJ + a] * rec[REC_J + r * LDJ + b];
       H[a * NZ + b] = s;
     }
   }

@@ -1105,16 +1105,17 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
       out.assign(nodes * (isH ? NZ * NZ : NZ), 0.0);
       for (size_t n = 0; n < nodes; ++n) {
         const double* r = &rec[n * REC_SIZE];
+        const int nrows = (int)r[REC_NROWS];
         for (int a = 0; a < NZ; ++a) {
           if (isH) {
             for (int b = 0; b < NZ; ++b) {
               double s = a == b ? r[REC_D + a] : 0.0;
-              for (int k = 0; k < NRS; ++k) s += r[REC_J + k * LDJ + a] * r[REC_J + k * LDJ + b];
+              for (int k = 0; k < nrows; ++k) s += r[REC_J + k * LDJ + a] * r[REC_J + k * LDJ + b];
               out[n * NZ * NZ + a * NZ + b] = s;
             }
           } else {
             double s = r[REC_GD + a];
-            for (int k = 0; k < NRS; ++k) s += r[REC_J + k * LDJ + a] * r[REC_RHO + k];
+            for (int k = 0; k < nrows; ++k) s += r[REC_J + k * LDJ + a] * r[REC_RHO + k];
             out[n * NZ + a] = s;
           }
         }

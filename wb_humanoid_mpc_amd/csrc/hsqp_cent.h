@@ -506,6 +506,7 @@ HSQP_HD void cent_write_terms(const DevModel& dm, const CentOut<T>& o, const dou
   misc[0] = (double)o.ne; misc[1] = dt * cost; misc[2] = dt * eq;
   misc[4] = (double)o.contact[0]; misc[5] = (double)o.contact[1]; misc[6] = (double)o.eq_off[0]; misc[7] = (double)o.eq_off[1];
   if (!rec) return;
+  rec[REC_NROWS] = (double)NRS;   // this kernel fills every row slot (no compaction)
   for (int s = 0; s < NRS; ++s) rec[REC_RHO + s] = sdt * o.rho[s];
   const double shift = -(o.hfric_d1[0] + o.hfric_d1[1]) * dm.friction_hess_shift;   // hessianDiagonalShift on every state and input
   for (int i = 0; i < LDJ; ++i) {

@@ -23,8 +23,9 @@ constexpr int REC_RHO = REC_J + NRS * LDJ;        // [NRS]
 constexpr int REC_D = REC_RHO + NRS;              // [LDJ]        Hessian diagonal (x dt)
 constexpr int REC_GD = REC_D + LDJ;               // [LDJ]        gradient, diagonal part (x dt)
 constexpr int REC_CDE = REC_GD + LDJ;             // [NE_MAX][LDJ] rows [C|D|e]
-constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [8]  ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt)
-constexpr int REC_FLOW = REC_MISC + 8;            // [64] xdot at (x,u)
+constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [16] ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt), contact flags (2), first equality row of each foot (2), [8] = NROWS
+constexpr int REC_NROWS = REC_MISC + 8;           //      residual rows in use (compact layout, hsqp_node.h); the rows up to the end of their 24-row pass are zero
+constexpr int REC_FLOW = REC_MISC + 16;           // [64] xdot at (x,u)
 constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel)
 constexpr int REC_SIZE = REC_GS + 4 * 6 * LDJ;
 
@@ -134,20 +135,17 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
       PH_TICK(ctx, 4);
       node_scalars(ctx, dm, w.st, w.nw);
       PH_TICK(ctx, 5);
-      if constexpr (DERIV) node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J, rec + REC_CDE);
-      PH_TICK(ctx, 6);
-      if (DERIV) WG_FOR(ctx, i, 64 + NRS) {
-        if (i < 64) {
+      if constexpr (DERIV) {
+        WG_FOR(ctx, i, 64) {   // (no barrier needed before the next phase: record writes only)
           double f = 0.0;
           if (i < NV) f = w.nw.x[NV + i];
           else if (i < NV + 6) f = w.st.ab[i - NV];
           else if (i < NX) f = w.nw.u[12 + i - NV - 6];
           rec[REC_FLOW + i] = f;
-        } else {
-          rec[REC_RHO + i - 64] = sqrt(dt) * w.nw.rho[i - 64];
         }
+        node_derivatives(ctx, dm, w.st, w.nw, dt, rec + REC_J, rec + REC_CDE, rec + REC_RHO);
       }
-      WG_SYNC(ctx);
+      PH_TICK(ctx, 6);
     }
   }
   PH_TICK(ctx, 7);
@@ -170,7 +168,8 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     for (int i = 0; i < NX; ++i) dyn += w.bvec[i] * w.bvec[i];
     for (int r = 0; r < w.nw.ne; ++r) eq += w.nw.eqv[r] * w.nw.eqv[r];
     misc[0] = (double)w.nw.ne;
-    misc[1] = dt * w.nw.cost;
+    misc[1] = dt * node_cost(w.nw);
+    if (DERIV) misc[8] = (double)w.nw.nrows;   // (DERIV: misc = rec + REC_MISC, 16 wide)
     misc[2] = dt * eq;
     misc[3] = (dt > 0.0 ? dt : 1.0) * dyn;   // an event interval (dt = 0, identity jump map) counts its defect unscaled
     // structure of the equality rows for the projection: a swing foot's zero-wrench rows are unit rows of D (and have C = 0)

@@ -162,21 +162,21 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   // ---- phase F1: placements.  Row r of R_i = R_p Mq_i and component r of r_i = r_p + R_p pfix_i, w_i = R_p axis_i depend
   // only on row r of R_p, so every chain is walked by three independent items (one per row), each from the base
   // down its whole ancestor path (the shared waist bodies are recomputed, not exchanged): no barrier inside the tree.
-  // The euler item sits at a wave boundary (item 64 of a two-wave workgroup): it runs beside the walk, not after it.
-  const int n_walk = ws.n_chains * 3 + 3, it_euler = n_walk <= 64 ? 64 : n_walk;
-  WG_FOR(ctx, it, it_euler + 1) {
-    if (it >= n_walk && it != it_euler) continue;
-    const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
-    if (it == it_euler) {   // euler-rate axes E = [wz wy wx], its inverse, the three euler joints
-      const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
-      for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
-      m3_inverse(ws.E, ws.Einv);
-      for (int k = 0; k < 3; ++k) {
-        ws.S[0][k] = wz[k]; ws.S[1][k] = wy[k]; ws.S[2][k] = wx[k];
-        ws.S[0][3 + k] = 0.0; ws.S[1][3 + k] = 0.0; ws.S[2][3 + k] = 0.0;
-      }
-      continue;
+  // The euler item (E, its inverse, the axes of the three euler joints) is a loop of its own at a wave boundary (item 64 of a
+  // two-wave workgroup): it runs beside the walk, not after it.
+  WG_FOR(ctx, ite, 65) {
+    if (ite != 64) continue;
+    const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1];
+    const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
+    for (int r = 0; r < 3; ++r) { ws.E[3 * r] = wz[r]; ws.E[3 * r + 1] = wy[r]; ws.E[3 * r + 2] = wx[r]; }
+    m3_inverse(ws.E, ws.Einv);
+    for (int k = 0; k < 3; ++k) {
+      ws.S[0][k] = wz[k]; ws.S[1][k] = wy[k]; ws.S[2][k] = wx[k];
+      ws.S[0][3 + k] = 0.0; ws.S[1][3 + k] = 0.0; ws.S[2][3 + k] = 0.0;
     }
+  }
+  WG_FOR(ctx, it, ws.n_chains * 3 + 3) {
+    const double cz = ws.ecs[0][0], sz = ws.ecs[0][1], cy = ws.ecs[1][0], sy = ws.ecs[1][1], cx = ws.ecs[2][0], sx = ws.ecs[2][1];
     const int r = it % 3, ch = it / 3;
     double Rp[3];   // row r of R0 = Rz Ry Rx
     if (r == 0) { Rp[0] = cz * cy; Rp[1] = cz * sy * sx - sz * cx; Rp[2] = cz * sy * cx + sz * sx; }

@@ -64,6 +64,7 @@ struct ProjWS {
     double CDe[NE_MAX][LDJ];     // the equality rows, until W = R1^-T [C|e] is formed (Tm is written after that)
   };
   int ne, nut, ok;
+  int nrows;                     // residual rows of the record in use (REC_NROWS); the third pass is skipped when they fit two
   // deflation of the unit rows of D (a swing foot's zero-wrench constraints W_f = 0 fix six inputs outright): the Householder
   // QR only sees the dense rows (ned of them) restricted to the free inputs (nub of them)
   int ned, nub;
@@ -268,6 +269,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         w.ok = 1;
         w.ned = ne_ - nel;
         w.nub = NU - nel;
+        w.nrows = (int)rec[REC_NROWS];
       }
     }
   }
@@ -616,15 +618,20 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   project_rows(NRP, NRP);
   WG_SYNC(ctx);
   PH_TICK(ctx, 11);
-  load_ju(2 * NRP, NRS - 2 * NRP);
+  // the third pass only if rows beyond the first two passes are in use (the whole-body LQ kernel writes its rows compactly: 46 in
+  // double support, 38 in single support; the collision rows, which would make it 54 / 62, are absent unless one of them is active)
+  const bool pass3 = w.nrows > 2 * NRP;
+  if (pass3) load_ju(2 * NRP, NRS - 2 * NRP);
   gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
-  store_ju(2 * NRP, NRS - 2 * NRP);
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 15);
-  project_rows(2 * NRP, NRS - 2 * NRP);
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 7);
-  gram_rows<false, NRS - 2 * NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  if (pass3) {
+    store_ju(2 * NRP, NRS - 2 * NRP);
+    WG_SYNC(ctx);
+    PH_TICK(ctx, 15);
+    project_rows(2 * NRP, NRS - 2 * NRP);
+    WG_SYNC(ctx);
+    PH_TICK(ctx, 7);
+    gram_rows<false, NRS - 2 * NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  }
   // the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the diagonal part of the gradient, straight from Tm
   gram_rows<true, NU>(ctx, g, &w.Tm[0][0], LDTM, &w.d[NX], &w.gd[NX]);
   PH_TICK(ctx, 12);
