@@ -34,6 +34,7 @@ namespace {
 #define HSQP_LQV_WPE 2
 #endif
 constexpr int LQ_THREADS = HSQP_LQ_THREADS;
+
 #ifndef HSQP_PROJ_THREADS
 #define HSQP_PROJ_THREADS 256
 #endif

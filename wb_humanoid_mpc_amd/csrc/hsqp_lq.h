@@ -42,13 +42,8 @@ struct LqWST {
 #else
   NoDevModelCopy dml;
 #endif
-  union {
-    StageWST<D> st;
-    struct {
-      double Gs[D ? 3 : 1][D ? 6 : 1][LDJ];   // stage Jacobians of stages 2..4 (stage 1 is Ab[0])
-      double Ab[D ? 4 : 1][D ? 6 : 1][LDJ];
-    } ch;              // RK4 chain workspace: aliases the stage workspace, which is dead after stage 4
-  };
+  StageWST<D> st;
+  double blk[D ? 3 : 1][2][6][6];   // RK4 chain: the blocks G_s[:, v_b] and G_s[:, q_b] of stages 2..4 (everything else of the chain lives in registers)
   NodeWST<D> nw;
   double vs[4][NV];    // velocity part of the stage states
   double as[4][6];     // base accelerations of the stages
@@ -87,6 +82,54 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
   for (int k = 0; k < 6; ++k) s += Gs[r][c0 + k] * Abt[k][col];
   if (col >= NX + 12) s += Gs[r][c0 + 6 + (col - NX - 12)];
   return s;
+}
+
+// The RK4 sensitivity chain of ONE column of [A|B] (see lq_node): Ab_1 = G_1, Ab_s = direct(G_s) + c_s G_s[:, v_b] Ab_{s-1} + c_s c_{s-1} G_s[:, q_b] Ab_{s-2};
+// P6 = dt^2/6 (Ab_1 + Ab_2 + Ab_3), V6 = dt/6 (Ab_1 + 2 Ab_2 + 2 Ab_3 + Ab_4) -> rec[REC_PV].  gs = rec + REC_GS: the stage Jacobians as the
+// column phases wrote them; the own-column entries of a stage and its selection partners are fetched one stage ahead of their use.
+HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* rec) {
+  const bool vcol = col >= NV && col < NX, acol = col >= NX + 12 && col < NZ;
+  const int j = col - NX - 12;
+  const int iA = col < NZ ? col : 0, iB = vcol ? col - NV : (acol ? NV + 6 + j : iA), iC = acol ? 6 + j : iA;
+  const double live = col < NZ ? 1.0 : 0.0;
+  const double cs[3] = {0.5 * dt, 0.5 * dt, dt};
+  double a2[6], a1[6], P[6], V[6];   // Ab_{s-2}, Ab_{s-1}
+  double gA[6], gB[6], gC[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { a1[r] = live * gs[r * LDJ + iA]; a2[r] = 0.0; P[r] = a1[r]; V[r] = a1[r]; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { gA[r] = gs[(6 + r) * LDJ + iA]; gB[r] = gs[(6 + r) * LDJ + iB]; gC[r] = gs[(6 + r) * LDJ + iC]; }
+#pragma unroll
+  for (int sg = 0; sg < 3; ++sg) {
+    const double c = cs[sg], cprev = sg == 0 ? 0.0 : cs[sg - 1];
+    const double wB = (vcol || acol) ? c : 0.0, wC = (acol && sg >= 1) ? c * cprev : 0.0;
+    double an[6], nA[6], nB[6], nC[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);   // keep the ILP scheduler from hoisting the block loads of all three stages to the top (1.3 KB of spills per lane)
+#endif
+    if (sg < 2) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { nA[r] = gs[((sg + 2) * 6 + r) * LDJ + iA]; nB[r] = gs[((sg + 2) * 6 + r) * LDJ + iB]; nC[r] = gs[((sg + 2) * 6 + r) * LDJ + iC]; }
+    }
+#pragma unroll 2
+    for (int r = 0; r < 6; ++r) {   // (two rows at a time: fully unrolled, the scheduler fetches all 72 block entries first and spills)
+      const double v = live * gA[r] + wB * gB[r] + wC * gC[r];
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { s1 += blk[sg][0][r][k] * a1[k]; s2 += blk[sg][1][r][k] * a2[k]; }
+      an[r] = v + c * (s1 + cprev * s2);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      a2[r] = a1[r]; a1[r] = an[r];
+      if (sg < 2) { P[r] += an[r]; V[r] += 2.0 * an[r]; gA[r] = nA[r]; gB[r] = nB[r]; gC[r] = nC[r]; } else V[r] += an[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    rec[REC_PV + r * LDJ + col] = live * (dt * dt / 6.0 * P[r]);
+    rec[REC_PV + (6 + r) * LDJ + col] = live * (dt / 6.0 * V[r]);
+  }
 }
 
 // Full LQ data of node (x, u, x_next, par) -> record `rec` (global memory); misc[0..3] = {ne, dt*cost, dt*|eq|^2, dt*|b|^2}.
@@ -177,65 +220,25 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     misc[6] = (double)w.nw.eq_off[0]; misc[7] = (double)w.nw.eq_off[1];
   }
   if constexpr (DERIV) {
-  // ---- write d, gd (the equality rows went straight to the record)
-  WG_FOR(ctx, i, 2 * LDJ) {
+  // ---- d, gd to the record; the chain's shared blocks G_s[:, v_b], G_s[:, q_b] (s = 2..4) from the record (written by this
+  //      workgroup, L2-resident) to LDS
+  WG_FOR(ctx, i, 2 * LDJ + 3 * 72) {
     if (i < LDJ) rec[REC_D + i] = w.nw.d[i];
-    else rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
-  }
-  WG_SYNC(ctx);  // the stage workspace is dead from here on: Ab aliases it
-  PH_TICK(ctx, 33);
-  // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz
-  const double c2 = 0.5 * dt, c3 = 0.5 * dt, c4 = dt;
-  {   // stage Jacobians back from the record (written by this workgroup, L2-resident), 9 loads in flight per item
-    constexpr int ng = 4 * 6 * LDJ, nbg = nbatches(ng, 9);
-    WG_FOR(ctx, b, nbg) {
-      copy_batch<9>(b, ng, rec + REC_GS, [&](int i, double g) {
-        if (i < 6 * LDJ) w.ch.Ab[0][i / LDJ][i % LDJ] = g;
-        else w.ch.Gs[i / (6 * LDJ) - 1][(i / LDJ) % 6][i % LDJ] = g;
-      });
+    else if (i < 2 * LDJ) rec[REC_GD + i - LDJ] = w.nw.gd[i - LDJ];
+    else {
+      const int e = i - 2 * LDJ, sg = e / 72, which = (e / 36) % 2, r = (e / 6) % 6, k = e % 6;
+      w.blk[sg][which][r][k] = rec[REC_GS + ((sg + 1) * 6 + r) * LDJ + (which == 0 ? NV : 0) + k];
     }
   }
+  // ---- chain the stage Jacobians:  Ab_s = d a_b(x_s, u) / dz = G_s dz_s/dz.  dz_s/dz only couples a COLUMN of Ab_s with the same
+  // column of Ab_{s-1}, Ab_{s-2} (through the 6 x 6 blocks of G_s that multiply d v_b and d q_b) and with a few columns of G_s (the
+  // selection structure), so one item per column runs the whole chain in registers and writes its column of P6, V6: one phase
+  // (round 2: LDS copies of all four G_s, a direct-part phase and a matrix-core job per stage — eight barriers, 22 k cycles).
   WG_SYNC(ctx);
-  PH_TICK(ctx, 34);
-  for (int s = 1; s < 4; ++s) {
-    const double c = s == 1 ? c2 : (s == 2 ? c3 : c4);
-    const double cprev = s == 2 ? c2 : c3;  // coefficient of stage s-1 (used for s >= 2)
-    // direct part: G_s composed with the selection structure of d z_s / d z
-    WG_FOR(ctx, i, 6 * LDJ) {
-      const int r = i / LDJ, col = i % LDJ;
-      const double* G = w.ch.Gs[s - 1][r];
-      double val = 0.0;
-      if (col < NZ) {
-        val = G[col];
-        if (col >= NV && col < NX) val += c * G[col - NV];
-        if (col >= NX + 12) {
-          val += c * G[NV + 6 + (col - NX - 12)];
-          if (s >= 2) val += c * cprev * G[6 + (col - NX - 12)];
-        }
-      }
-      w.ch.Ab[s][r][col] = val;
-    }
-    WG_SYNC(ctx);
-    // chained part on the matrix cores: Ab_s += c G_s[:, v_b] Ab_{s-1} + c c_{s-1} G_s[:, q_b] Ab_{s-2}  (6x6 by 6x96 products;
-    // X^T Y with X read through an element stride: X[l][r] = G_s[r][c0 + l])
-    {
-      XtyJob job = xty_job(6, LDJ, 6, &w.ch.Gs[s - 1][0][NV], 1, &w.ch.Ab[s - 1][0][0], LDJ, &w.ch.Ab[s][0][0], LDJ, &w.ch.Ab[s][0][0], LDJ, c);
-      job.sx1 = LDJ;
-      if (s >= 2) { job.L2 = 6; job.X2 = &w.ch.Gs[s - 1][0][0]; job.ldx2 = 1; job.sx2 = LDJ; job.Y2 = &w.ch.Ab[s - 2][0][0]; job.ldy2 = LDJ; job.sign2 = cprev; }
-      wg_xty_jobs<true>(ctx, &job, 1);
-    }
-    WG_SYNC(ctx);
-  }
+#ifndef HSQP_NO_CHAIN
+  WG_FOR(ctx, col, LDJ) lq_chain_column(w.blk, rec + REC_GS, col, dt, rec);
+#endif
   PH_TICK(ctx, 8);
-  WG_FOR(ctx, i, 2 * 6 * LDJ) {
-    const int which = i / (6 * LDJ), r = (i / LDJ) % 6, col = i % LDJ;
-    double v;
-    if (which == 0) v = dt * dt / 6.0 * (w.ch.Ab[0][r][col] + w.ch.Ab[1][r][col] + w.ch.Ab[2][r][col]);
-    else v = dt / 6.0 * (w.ch.Ab[0][r][col] + 2.0 * w.ch.Ab[1][r][col] + 2.0 * w.ch.Ab[2][r][col] + w.ch.Ab[3][r][col]);
-    rec[REC_PV + i] = v;
-  }
-  WG_SYNC(ctx);
-  PH_TICK(ctx, 9);
   }
 }
 
