@@ -54,6 +54,25 @@ def usable_cores():
     return max(1, min(n, int(quota + 0.5))) if quota else n, n, quota
 
 
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo among the CPUs this process may run on: SMT siblings count once."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, pkg = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and cpu in allowed:
+                seen.add((pkg, int(v)))
+        return len(seen) or None
+    except (OSError, ValueError):
+        return None
+
+
 class CpuBaseline:
     def __init__(self, model):
         self.lib = C.CDLL(build())
