@@ -178,6 +178,18 @@ class Oracle:
         self.lib.orc_performance(self.h, u.shape[0], C.c_double(dt), _p(x), _p(u), _p(par), threads, C.byref(p))
         return dict(merit=p.merit, cost=p.cost, dynamics_sse=p.dynamics_sse, equality_sse=p.equality_sse)
 
+    def friction_cone(self, F):
+        """(h, dh[3], d2h[3,3], hessianDiagonalShift) of the friction cone at the contact force F — the function the LQ code calls."""
+        h, sh, dh, d2 = C.c_double(0.0), C.c_double(0.0), np.zeros(3), np.zeros((3, 3))
+        self.lib.orc_friction_cone(self.h, _p(_c(F)), C.byref(h), _p(dh), _p(d2), C.byref(sh))
+        return h.value, dh, d2, sh.value
+
+    def nominal(self, x, par):
+        """(xnom[58], unom[35]): the quadratic cost's nominal state (arm-swing reference on the current yaw) and weight-compensating input."""
+        xn, un = np.zeros(_abi.NX), np.zeros(_abi.NU)
+        self.lib.orc_nominal(self.h, _p(_c(x)), _p(_c(par)), _p(xn), _p(un))
+        return xn, un
+
     def penalty(self, kind, mu, delta, h):
         d1, d2 = C.c_double(), C.c_double()
         p = self.lib.orc_penalty(kind, C.c_double(mu), C.c_double(delta), C.c_double(h), C.byref(d1), C.byref(d2))

@@ -463,6 +463,17 @@ void nominal(const Oracle& o, const double* x, const double* par, double* xnom, 
 // Stage cost + equality constraints at (x,u): value only (lq = nullptr) or with the
 // Gauss-Newton / penalty quadratic model.  Returns l (unscaled); fills lq->H,g (unscaled) and C,D,e.
 // Terms and their order follow WBMpcInterface::setupOptimalControlProblem (humanoid_nmpc/humanoid_wb_mpc/src/WBMpcInterface.cpp:131-199).
+// Friction cone h(F) = mu (Fz + gripperForce) - sqrt(Fx^2 + Fy^2 + regularization) of one contact force F (world = contact frame,
+// t_R_w = I) with its first and second derivatives: FrictionForceConeConstraint.cpp:141-185 (coneConstraint, computeConeLocalDerivatives).
+static void friction_cone(const hsqp_model_desc& md, const double* F, double& h, double dh[3], double d2[3][3]) {
+  const double Fx = F[0], Fy = F[1], Fz = F[2];
+  const double T2 = Fx * Fx + Fy * Fy + md.friction_reg, Tn = std::sqrt(T2), T32 = Tn * T2;
+  h = md.friction_mu * (Fz + md.friction_grip) - Tn;
+  dh[0] = -Fx / Tn; dh[1] = -Fy / Tn; dh[2] = md.friction_mu;
+  const double d[3][3] = {{-(Fy * Fy + md.friction_reg) / T32, Fx * Fy / T32, 0.0}, {Fx * Fy / T32, -(Fx * Fx + md.friction_reg) / T32, 0.0}, {0.0, 0.0, 0.0}};
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) d2[a][b] = d[a][b];
+}
+
 double stage_terms(const Oracle& o, const double* x, const double* u, const double* par, NodeLQ* lq, double* eq_out, int* ne_out) {
   const hsqp_model_desc& md = o.md;
   const bool contact[2] = {par[HSQP_P_CONTACT] > 0.5, par[HSQP_P_CONTACT + 1] > 0.5};
@@ -533,16 +544,11 @@ double stage_terms(const Oracle& o, const double* x, const double* u, const doub
   for (int f = 0; f < 2; ++f) {
     // --- friction cone soft constraint (active in contact): FrictionForceConeConstraint.cpp:78-224, relaxed barrier
     if (contact[f]) {
-      const double Fx = u[6 * f], Fy = u[6 * f + 1], Fz = u[6 * f + 2];
-      const double T2 = Fx * Fx + Fy * Fy + md.friction_reg, Tn = std::sqrt(T2), T32 = Tn * T2;
-      const double h = md.friction_mu * (Fz + md.friction_grip) - Tn;
+      double h, dh[3], d2[3][3];
+      friction_cone(md, u + 6 * f, h, dh, d2);     // (pinned against the reference-compiled constraint: tests/test_ref_terms.py)
       const Pen p = relaxed_barrier(md.friction_barrier.mu, md.friction_barrier.delta, h);
       cost += p.p;
       if (lq) {
-        const double dh[3] = {-Fx / Tn, -Fy / Tn, md.friction_mu};
-        double d2[3][3] = {{-(Fy * Fy + md.friction_reg) / T32, Fx * Fy / T32, 0.0},
-                           {Fx * Fy / T32, -(Fx * Fx + md.friction_reg) / T32, 0.0},
-                           {0.0, 0.0, 0.0}};
         const int o0 = NX + 6 * f;
         for (int a = 0; a < 3; ++a) {
           g[o0 + a] += p.d1 * dh[a];
@@ -1197,6 +1203,16 @@ void orc_performance(void* h, int N, double dt, const double* x, const double* u
   performance(*static_cast<Oracle*>(h), N, dt, x, u, par, threads, out);
 }
 
+// the nominal state / input the quadratic cost uses at (x, node parameters): StateInputQuadraticCost::getStateInputDeviation's xNominal, uNominal
+void orc_nominal(void* hh, const double* x, const double* par, double* xnom, double* unom) { nominal(*static_cast<Oracle*>(hh), x, par, xnom, unom); }
+// the friction-cone value / derivatives the LQ code uses, and the Hessian diagonal shift it applies to every state and input
+void orc_friction_cone(void* hh, const double* F, double* h, double* dh, double* d2, double* shift) {
+  const Oracle& o = *static_cast<Oracle*>(hh);
+  double d[3][3];
+  friction_cone(o.md, F, *h, dh, d);
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) d2[3 * a + b] = d[a][b];
+  *shift = o.md.friction_hess_shift;
+}
 double orc_penalty(int kind, double mu, double delta, double hval, double* d1, double* d2) {
   const Pen p = kind == 0 ? relaxed_barrier(mu, delta, hval) : pwp_barrier(mu, delta, hval);
   if (d1) *d1 = p.d1;

@@ -1,5 +1,6 @@
-// STAND-IN (test infrastructure) for <ocs2_core/Types.h> of upstream leggedrobotics/ocs2: the scalar / array aliases the
-// reference files compiled by oracle/Makefile (_ref target) use.  scalar_t is double upstream too.
+// STAND-IN (test infrastructure) for <ocs2_core/Types.h> of upstream leggedrobotics/ocs2: the scalar / vector / matrix aliases and the
+// function-approximation PODs the reference files compiled by oracle/Makefile (_ref targets) use.  scalar_t is double upstream too;
+// vector_t / matrix_t are Eigen::VectorXd / MatrixXd upstream, the Eigen stand-in of this directory here.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -13,12 +14,16 @@
 #include <tuple>
 #include <utility>
 #include <vector>
-namespace Eigen {   // only named by alias templates of humanoid_common_mpc/common/Types.h; never instantiated here
-template <class S, int R, int C> class Matrix;
-template <class S> class Quaternion;
-}  // namespace Eigen
+#include <Eigen/Core>
 namespace ocs2 {
 using scalar_t = double;
 using scalar_array_t = std::vector<scalar_t>;
 using size_array_t = std::vector<size_t>;
+using vector_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, 1>;
+using matrix_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic>;
+using vector_array_t = std::vector<vector_t>;
+using matrix_array_t = std::vector<matrix_t>;
+// upstream ocs2_core/Types.h: value + first (+ second) derivatives of a vector-valued function of (x, u)
+struct VectorFunctionLinearApproximation { vector_t f; matrix_t dfdx, dfdu; };
+struct VectorFunctionQuadraticApproximation { vector_t f; matrix_t dfdx, dfdu; matrix_array_t dfdxx, dfdux, dfduu; };
 }  // namespace ocs2

@@ -1,5 +1,26 @@
 // STAND-IN (test infrastructure) for <ocs2_core/automatic_differentiation/Types.h>: upstream ad_scalar_t is
-// CppAD::AD<CppAD::cg::CG<double>>; the files compiled here only name it in alias declarations.
+// CppAD::AD<CppAD::cg::CG<double>>.  Here it is a plain number wrapper, complete enough that the reference's explicit template
+// instantiations for ad_scalar_t compile; nothing is ever evaluated through it.
 #pragma once
 #include <ocs2_core/Types.h>
-namespace ocs2 { struct ad_scalar_t; }
+namespace ocs2 {
+struct ad_scalar_t {
+  double v = 0.0;
+  ad_scalar_t() = default;
+  ad_scalar_t(double x) : v(x) {}
+  ad_scalar_t(int x) : v(x) {}
+  ad_scalar_t& operator+=(const ad_scalar_t& o) { v += o.v; return *this; }
+  ad_scalar_t& operator-=(const ad_scalar_t& o) { v -= o.v; return *this; }
+  ad_scalar_t& operator*=(const ad_scalar_t& o) { v *= o.v; return *this; }
+  ad_scalar_t& operator/=(const ad_scalar_t& o) { v /= o.v; return *this; }
+  ad_scalar_t operator-() const { return ad_scalar_t(-v); }
+  // hidden friend: found by argument-dependent lookup only, so that an unqualified sqrt(double) in namespace ocs2 still means std::sqrt
+  friend ad_scalar_t sqrt(const ad_scalar_t& a) { return ad_scalar_t(std::sqrt(a.v)); }
+};
+inline ad_scalar_t operator+(ad_scalar_t a, const ad_scalar_t& b) { return a += b; }
+inline ad_scalar_t operator-(ad_scalar_t a, const ad_scalar_t& b) { return a -= b; }
+inline ad_scalar_t operator*(ad_scalar_t a, const ad_scalar_t& b) { return a *= b; }
+inline ad_scalar_t operator/(ad_scalar_t a, const ad_scalar_t& b) { return a /= b; }
+inline bool operator<(const ad_scalar_t& a, const ad_scalar_t& b) { return a.v < b.v; }
+inline bool operator>(const ad_scalar_t& a, const ad_scalar_t& b) { return a.v > b.v; }
+}  // namespace ocs2

@@ -1,0 +1,93 @@
+"""TEST INFRASTRUCTURE: ctypes front-end of oracle/_ref/libref_terms.so — more of the REFERENCE'S OWN code compiled in place from
+/root/reference (oracle/Makefile target `ref`, oracle/ref_terms_driver.cpp): the whole-body robot model's index maps, the friction-cone
+and zero-wrench constraints, the switched-model reference manager (contact flags, gait phase, arm-swing reference), the end-effector
+weights loader.  Only tests/ and tests/golden/make_ref_terms_golden.py import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_ref", "libref_terms.so")
+_dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+
+def available():
+    if os.path.exists(LIB):
+        return True
+    if os.path.isdir("/root/reference/humanoid_nmpc/humanoid_common_mpc/src/constraint"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        return os.path.exists(LIB)
+    return False
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class RefTerms:
+    def __init__(self, nj=23):
+        if not available():
+            raise RuntimeError("oracle/_ref/libref_terms.so is missing and /root/reference is not mounted")
+        self.lib = C.CDLL(LIB)
+        self.nj = nj
+        self.nx, self.nu = 2 * (6 + nj), 12 + nj
+
+    def layout(self):
+        out = (C.c_int * 12)()
+        self.lib.ref_wb_layout(self.nj, out)
+        keys = ["state_dim", "input_dim", "base_start", "joint_start", "joint_velocity_start", "gen_coordinates_dim", "wrench_start_0", "wrench_start_1",
+                "force_start_0", "force_start_1", "moment_start_0", "moment_start_1"]
+        return dict(zip(keys, list(out)))
+
+    def accessors(self, x, u):
+        nj = self.nj
+        sizes = [("base_pose", 6), ("joint_angles", nj), ("base_lin_vel", 3), ("base_vel", 6), ("joint_velocities", nj), ("gen_coordinates", 6 + nj),
+                 ("gen_velocities", 6 + nj), ("wrench_0", 6), ("wrench_1", 6), ("force_0", 3), ("moment_1", 3)]
+        out = np.zeros(sum(n for _, n in sizes))
+        self.lib.ref_wb_accessors(nj, _d(x).ctypes.data_as(_dp), _d(u).ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+        res, o = {}, 0
+        for k, n in sizes:
+            res[k] = out[o:o + n].copy(); o += n
+        return res
+
+    def friction_cone(self, cfg, contact, event_times, mode_sequence, time, x, u):
+        """cfg = (frictionCoefficient, regularization, gripperForce, hessianDiagonalShift) -> dict(f, dfdu, dfduu, dfdxx_diag, active)."""
+        ev, seq = _d(event_times), _i(mode_sequence)
+        f, dfdu, dfduu, dxx = np.zeros(1), np.zeros(self.nu), np.zeros((self.nu, self.nu)), np.zeros(self.nx)
+        act = C.c_int(0)
+        rc = self.lib.ref_friction_cone(self.nj, _d(cfg).ctypes.data_as(_dp), int(contact), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip), C.c_double(time),
+                                        _d(x).ctypes.data_as(_dp), _d(u).ctypes.data_as(_dp), f.ctypes.data_as(_dp), dfdu.ctypes.data_as(_dp), dfduu.ctypes.data_as(_dp),
+                                        dxx.ctypes.data_as(_dp), C.byref(act))
+        assert rc == 0, rc
+        return dict(f=f[0], dfdu=dfdu, dfduu=dfduu, dfdxx_diag=dxx, active=bool(act.value))
+
+    def zero_wrench(self, contact, event_times, mode_sequence, time, x, u):
+        ev, seq = _d(event_times), _i(mode_sequence)
+        f, dfdu = np.zeros(6), np.zeros((6, self.nu))
+        act = C.c_int(0)
+        rc = self.lib.ref_zero_wrench(self.nj, int(contact), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip), C.c_double(time), _d(x).ctypes.data_as(_dp),
+                                      _d(u).ctypes.data_as(_dp), f.ctypes.data_as(_dp), dfdu.ctypes.data_as(_dp), C.byref(act))
+        assert rc == 0, rc
+        return dict(f=f, dfdu=dfdu, active=bool(act.value))
+
+    def desired_state(self, arm_joints, event_times, mode_sequence, target_times, target_states, arm_swing, t0, tf, state, time):
+        """(xnom[nx], phase variable, contact flags) after preSolverRun(t0, tf, state)."""
+        ev, seq, tt, ts = _d(event_times), _i(mode_sequence), _d(target_times), _d(target_states)
+        xn, ph, fl = np.zeros(self.nx), C.c_double(0.0), (C.c_int * 2)()
+        rc = self.lib.ref_desired_state(self.nj, _i(arm_joints).ctypes.data_as(_ip), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip), len(tt), tt.ctypes.data_as(_dp),
+                                        ts.ctypes.data_as(_dp), int(bool(arm_swing)), C.c_double(t0), C.c_double(tf), _d(state).ctypes.data_as(_dp), C.c_double(time),
+                                        xn.ctypes.data_as(_dp), C.byref(ph), fl)
+        assert rc == 0, rc
+        return xn, ph.value, (bool(fl[0]), bool(fl[1]))
+
+    def foot_weights(self, task_file, prefix):
+        w = np.zeros(18)
+        rc = self.lib.ref_foot_weights(task_file.encode(), prefix.encode(), w.ctypes.data_as(_dp))
+        assert rc == 0, rc
+        return w

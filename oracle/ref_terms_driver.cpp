@@ -1,0 +1,169 @@
+// =====================================================================================
+// TEST INFRASTRUCTURE — C entry points over more of the REFERENCE'S OWN code, compiled from /root/reference in place (oracle/Makefile,
+// target _ref/libref_terms.so) against the stand-in third-party headers of oracle/ref_stubs/ (a minimal Eigen, ocs2 interfaces, Boost
+// property tree).  Only tests/ and tests/golden/make_ref_terms_golden.py load the library.  What it pins:
+//   a1   humanoid_wb_mpc/include/humanoid_wb_mpc/common/WBAccelMpcRobotModel.h:47-245       state / input layout and accessors
+//   a5   humanoid_common_mpc/src/reference_manager/SwitchedModelReferenceManager.cpp:55-152  getContactFlags, getPhaseVariable,
+//        getDesiredState (arm-swing reference on the CURRENT yaw), modifyReferences (gait schedule window + swing planner update)
+//   a11  humanoid_common_mpc/src/constraint/ZeroWrenchConstraint.cpp:59-84                  value, dfdu
+//   a12  humanoid_common_mpc/src/constraint/FrictionForceConeConstraint.cpp:78-224          value, dfdu, dfduu, dfdxx (diagonal shift)
+//   a7   humanoid_wb_mpc/src/cost/EndEffectorDynamicsCostHelpers.cpp:41-108                 EndEffectorDynamicsWeights::getWeights (the weight
+//        overwrite quirk) + toVector, read from the reference's own task.info through the stand-in INFO parser
+// =====================================================================================
+#include <cstring>
+
+#include "humanoid_common_mpc/constraint/FrictionForceConeConstraint.h"
+#include "humanoid_common_mpc/constraint/ZeroWrenchConstraint.h"
+#include "humanoid_common_mpc/reference_manager/SwitchedModelReferenceManager.h"
+#include "humanoid_wb_mpc/common/WBAccelMpcRobotModel.h"
+#include "humanoid_wb_mpc/cost/EndEffectorDynamicsCostHelpers.h"
+
+using namespace ocs2;
+using namespace ocs2::humanoid;
+
+namespace {
+struct SettingsArgs { int nj = 23; int arm[4] = {0, 0, 0, 0}; } g_args;
+}
+
+namespace ocs2::humanoid {
+// declared by the reference's headers, defined in files that need Boost / Pinocchio for real: never called by this driver, or (the
+// ModelSettings constructor, whose real body parses the URDF through Pinocchio) given the few fields the compiled code reads
+ModeSchedule loadModeSchedule(const std::string&, const std::string&, bool) { throw std::runtime_error("stand-in"); }
+ModeSequenceTemplate loadModeSequenceTemplate(const std::string&, const std::string&, bool) { throw std::runtime_error("stand-in"); }
+std::ostream& operator<<(std::ostream& stream, const ModeSequenceTemplate&) { return stream; }
+ModelSettings::ModelSettings(const std::string&, const std::string&, const std::string&, bool) {
+  mpc_joint_dim = static_cast<size_t>(g_args.nj);
+  full_joint_dim = mpc_joint_dim;
+  j_l_shoulder_y_index = g_args.arm[0]; j_r_shoulder_y_index = g_args.arm[1]; j_l_elbow_y_index = g_args.arm[2]; j_r_elbow_y_index = g_args.arm[3];
+  phaseTransitionStanceTime = 0.4;
+}
+}  // namespace ocs2::humanoid
+
+namespace {
+struct World {
+  World(int nj, const int arm[4]) : settings((g_args.nj = nj, std::memcpy(g_args.arm, arm, sizeof(g_args.arm)), std::string()), "", ""), model(settings) {}
+  ModelSettings settings;
+  WBAccelMpcRobotModel<scalar_t> model;
+};
+vector_t to_vec(const double* p, int n) { vector_t v(n); for (int i = 0; i < n; ++i) v(i) = p[i]; return v; }
+class NoPreComp final : public PreComputation {};
+
+std::unique_ptr<SwitchedModelReferenceManager> make_manager(World& w, int n_events, const double* event_times, const int* mode_sequence) {
+  // a GaitSchedule whose getModeSchedule(...) returns exactly the given schedule on the window the manager asks for: the initial mode
+  // schedule IS the given one (no template is inserted; the default template only tiles beyond its last event)
+  auto gait = std::make_shared<GaitSchedule>(ModeSchedule(std::vector<scalar_t>(event_times, event_times + n_events), std::vector<size_t>(mode_sequence, mode_sequence + n_events + 1)),
+                                             ModeSequenceTemplate({0.0, 0.5}, {STANCE}), 0.4);
+  SwingTrajectoryPlanner::Config c;
+  auto swing = std::make_shared<SwingTrajectoryPlanner>(c, 2);
+  return std::make_unique<SwitchedModelReferenceManager>(gait, swing, PinocchioInterface(), w.model);
+}
+}  // namespace
+
+extern "C" {
+
+// out[12] = state dim, input dim, base start, joint start, joint-velocity start, gen. coordinates dim, wrench start of contacts 0 / 1, force
+// start 0 / 1, moment start 0 / 1
+void ref_wb_layout(int nj, int* out) {
+  const int arm[4] = {0, 0, 0, 0};
+  World w(nj, arm);
+  out[0] = (int)w.model.getStateDim(); out[1] = (int)w.model.getInputDim(); out[2] = (int)w.model.getBaseStartindex(); out[3] = (int)w.model.getJointStartindex();
+  out[4] = (int)w.model.getJointVelocitiesStartindex(); out[5] = (int)w.model.getGenCoordinatesDim();
+  for (int c = 0; c < 2; ++c) { out[6 + c] = (int)w.model.getContactWrenchStartIndices(c); out[8 + c] = (int)w.model.getContactForceStartIndices(c); out[10 + c] = (int)w.model.getContactMomentStartIndices(c); }
+}
+
+// the accessors on a state / input pair: out = [basePose 6 | jointAngles nj | baseComLinearVelocity 3 | baseComVelocity 6 | jointVelocities nj |
+//                                               generalized coordinates 6+nj | generalized velocities 6+nj | wrench0 6 | wrench1 6 | force0 3 | moment1 3]
+void ref_wb_accessors(int nj, const double* x, const double* u, double* out) {
+  const int arm[4] = {0, 0, 0, 0};
+  World w(nj, arm);
+  const vector_t xs = to_vec(x, (int)w.model.getStateDim()), us = to_vec(u, (int)w.model.getInputDim());
+  int o = 0;
+  auto put = [&](const Eigen::Dyn<scalar_t>& v) { for (Eigen::Index i = 0; i < v.size(); ++i) out[o++] = v(i); };
+  put(w.model.getBasePose(xs)); put(w.model.getJointAngles(xs)); put(w.model.getBaseComLinearVelocity(xs)); put(w.model.getBaseComVelocity(xs));
+  put(w.model.getJointVelocities(xs, us)); put(w.model.getGeneralizedCoordinates(xs)); put(w.model.getGeneralizedVelocities(xs, us));
+  put(w.model.getContactWrench(us, 0)); put(w.model.getContactWrench(us, 1)); put(w.model.getContactForce(us, 0)); put(w.model.getContactMoment(us, 1));
+}
+
+// FrictionForceConeConstraint of contact `contact`: cfg = {frictionCoefficient, regularization, gripperForce, hessianDiagonalShift}.
+// f[1], dfdu[nu], dfduu[nu*nu], dfdxx_diag[nx] (its dfdxx is diagonal: the shift), active = isActive(time) on the given mode schedule.
+int ref_friction_cone(int nj, const double cfg[4], int contact, int n_events, const double* event_times, const int* mode_sequence, double time, const double* x,
+                      const double* u, double* f, double* dfdu, double* dfduu, double* dfdxx_diag, int* active) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    mgr->setModeSchedule(ModeSchedule(std::vector<scalar_t>(event_times, event_times + n_events), std::vector<size_t>(mode_sequence, mode_sequence + n_events + 1)));
+    const FrictionForceConeConstraint::Config c(cfg[0], cfg[1], cfg[2], cfg[3]);
+    FrictionForceConeConstraint con(*mgr, c, contact, w.model);
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    const vector_t xs = to_vec(x, nx), us = to_vec(u, nu);
+    const auto q = con.getQuadraticApproximation(time, xs, us, NoPreComp());
+    const auto l = con.getLinearApproximation(time, xs, us, NoPreComp());
+    f[0] = q.f(0);
+    if (con.getValue(time, xs, us, NoPreComp())(0) != q.f(0) || l.f(0) != q.f(0)) return 2;
+    for (int i = 0; i < nu; ++i) { dfdu[i] = q.dfdu(0, i); if (l.dfdu(0, i) != q.dfdu(0, i)) return 2; }
+    for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) dfduu[i * nu + j] = q.dfduu[0](i, j);
+    for (int i = 0; i < nx; ++i) {
+      dfdxx_diag[i] = q.dfdxx[0](i, i);
+      for (int j = 0; j < nx; ++j) if (i != j && q.dfdxx[0](i, j) != 0.0) return 3;
+    }
+    for (int i = 0; i < nx; ++i) if (q.dfdx(0, i) != 0.0) return 3;
+    *active = con.isActive(time) ? 1 : 0;
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_friction_cone: " << e.what() << "\n"; return 1; }
+}
+
+// ZeroWrenchConstraint of contact `contact`: f[6], dfdu[6*nu] (dfdx is zero), active = isActive(time) (= NOT in contact)
+int ref_zero_wrench(int nj, int contact, int n_events, const double* event_times, const int* mode_sequence, double time, const double* x, const double* u,
+                    double* f, double* dfdu, int* active) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    mgr->setModeSchedule(ModeSchedule(std::vector<scalar_t>(event_times, event_times + n_events), std::vector<size_t>(mode_sequence, mode_sequence + n_events + 1)));
+    ZeroWrenchConstraint con(*mgr, contact, w.model);
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    const vector_t xs = to_vec(x, nx), us = to_vec(u, nu);
+    const auto l = con.getLinearApproximation(time, xs, us, NoPreComp());
+    if ((int)con.getNumConstraints(time) != 6) return 2;
+    for (int r = 0; r < 6; ++r) { f[r] = l.f(r); for (int i = 0; i < nu; ++i) dfdu[r * nu + i] = l.dfdu(r, i); }
+    for (int r = 0; r < 6; ++r) for (int i = 0; i < nx; ++i) if (l.dfdx(r, i) != 0.0) return 3;
+    *active = con.isActive(time) ? 1 : 0;
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_zero_wrench: " << e.what() << "\n"; return 1; }
+}
+
+// SwitchedModelReferenceManager: preSolverRun(t0, tf, state) (-> modifyReferences: gait-schedule window, swing planner update), then at
+// `time`: getDesiredState(targets, state, time) -> xnom[nx], getPhaseVariable -> *phase, getContactFlags -> flags[2].
+int ref_desired_state(int nj, const int arm[4], int n_events, const double* event_times, const int* mode_sequence, int n_knots, const double* tt,
+                      const double* ts, int arm_swing, double t0, double tf, const double* state, double time, double* xnom, double* phase, int* flags) {
+  try {
+    World w(nj, arm);
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    const int nx = (int)w.model.getStateDim();
+    TargetTrajectories targets;
+    for (int k = 0; k < n_knots; ++k) { targets.timeTrajectory.push_back(tt[k]); targets.stateTrajectory.push_back(to_vec(ts + (size_t)k * nx, nx)); }
+    mgr->setTargetTrajectories(targets);
+    mgr->setArmSwingReferenceActive(arm_swing != 0);
+    const vector_t xs = to_vec(state, nx);
+    mgr->preSolverRun(t0, tf, xs);
+    const vector_t xn = mgr->getDesiredState(mgr->getTargetTrajectories(), xs, time);
+    for (int i = 0; i < nx; ++i) xnom[i] = xn(i);
+    *phase = mgr->getPhaseVariable(time);
+    const contact_flag_t fl = mgr->getContactFlags(time);
+    flags[0] = fl[0]; flags[1] = fl[1];
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_desired_state: " << e.what() << "\n"; return 1; }
+}
+
+// EndEffectorDynamicsWeights::getWeights(taskFile, prefix).toVector() -> w18
+int ref_foot_weights(const char* task_file, const char* prefix, double* w18) {
+  try {
+    EndEffectorDynamicsWeights w = EndEffectorDynamicsWeights::getWeights(task_file, prefix, false);
+    const auto v = w.toVector();
+    for (int i = 0; i < 18; ++i) w18[i] = v(i);
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_foot_weights: " << e.what() << "\n"; return 1; }
+}
+
+}  // extern "C"
