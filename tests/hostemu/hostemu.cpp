@@ -114,6 +114,7 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 // LQ record of one node (REC_SIZE doubles) + dense expansions for comparison with the oracle
 int emu_rec_size() { return REC_SIZE; }
 int emu_rec_misc_offset() { return REC_MISC; }
+int emu_rec_flow_offset() { return REC_FLOW; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};

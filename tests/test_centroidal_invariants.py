@@ -26,8 +26,7 @@ def emu_flow(cmodel):
     err = C.create_string_buffer(256)
     h = C.c_void_p(lib.emu_create(C.byref(cmodel.desc), err, 256))
     assert h.value, err.value
-    RS, mo = lib.emu_rec_size(), lib.emu_rec_misc_offset()
-    flow_off = mo + 8          # REC_FLOW follows the 8 misc doubles (hsqp_lq.h)
+    RS, flow_off = lib.emu_rec_size(), lib.emu_rec_flow_offset()
 
     def flow(x35, u, par, dt=0.02):
         x = np.zeros(NX)
