@@ -255,7 +255,20 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* problem, const hsq
 #define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
 #define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */
 #define HSQP_ITER_LINESEARCH 4   /* filter line search on the step length instead of the plain full step     */
+/* n_iterations is an upper bound: stop as soon as EVERY instance has converged the way ocs2's SqpSolver::checkConvergence does on the
+ * step — alpha |dx| and alpha |du| below delta_tol (PRIMAL), or no step length accepted (STEPSIZE).  One small read-back per iteration
+ * (the line-search state); the trajectories never leave the device.  hsqp_last_iterations() tells how many were run, hsqp_iteration_log()
+ * returns the performance index / step length / step type each of them ended with (sqpIteration > 1 of the reference in ONE call). */
+#define HSQP_ITER_UNTIL_CONVERGED 8
 int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags);
+int hsqp_last_iterations(const hsqp_handle* h);     /* iterations the last hsqp_iterate_device call ran (-1: h is NULL) */
+/* Per-iteration record of the last hsqp_iterate_device call with HSQP_ITER_UNTIL_CONVERGED: iteration in [0, hsqp_last_iterations),
+ * any output may be NULL; perf = performance index after that iteration's (line-searched) step. */
+int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf /*[B]*/, double* alpha /*[B]*/, int32_t* step_type /*[B]*/);
+/* Change the quadratic cost weights of a live handle (the reference's centroidal node retunes Q / R at run time through its gains
+ * receiver: humanoid_centroidal_mpc_ros2 GainsReceiver): diagonal Q[58], R[35], Qf[58] in the layout of hsqp_model_desc; NULL keeps
+ * the current values.  Takes effect with the next iteration. */
+int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf);
 /* Line-search settings of the handle (defaults: task.info g_max 1e-2, g_min 1e-6, deltaTol 1e-4; upstream gamma_c 1e-6,
  * armijoFactor 1e-4, alpha_decay 0.5, alpha_min 1e-4). */
 void hsqp_linesearch_defaults(hsqp_linesearch_settings* s);

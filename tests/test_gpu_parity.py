@@ -407,3 +407,65 @@ def test_receding_horizon_loop_with_device_parameters(model):
         assert np.all(viol[1:] < viol[:-1]) and np.all(viol[-1] < 0.6 * viol[0])
     finally:
         s.close()
+
+
+def test_until_converged_runs_the_iterations_of_repeated_single_calls(model):
+    """HSQP_ITER_UNTIL_CONVERGED (sqpIteration > 1 in ONE device call): the same trajectory, iteration log and count as
+    driving single iterations from the host and applying ocs2's step-size test there; a generous deltaTol ends the loop early."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=12, batch=3, gait="stance", perturb=True, seed=5)
+    s = HipSqpSolver(model, max_nodes=12, max_batch=3)
+    try:
+        s.upload(x0, x, u, par, dt)
+        n = s.iterate(4, take_step=True, kkt=True, linesearch=True, until_converged=True)
+        assert n == 4                                  # far from converged at deltaTol = 1e-4
+        out = s.download()
+        logs = [s.iteration_log(i) for i in range(n)]
+        # the same through single-iteration calls with a host round trip in between
+        xs, us = x.copy(), u.copy()
+        for i in range(n):
+            s.upload(x0, xs, us, par, dt)
+            s.iterate(1, take_step=True, kkt=True, linesearch=True)
+            o = s.download()
+            xs, us = o["x"], o["u"]
+            assert np.array_equal(logs[i][1], o["alpha"]) and np.array_equal(logs[i][2], o["step_type"])
+            assert all(abs(logs[i][0][b]["cost"] - o["perf_after"][b]["cost"]) <= 1e-9 * max(1.0, abs(o["perf_after"][b]["cost"])) for b in range(3))
+        assert np.array_equal(out["x"], xs) and np.array_equal(out["u"], us)
+        # early exit: with a huge deltaTol every instance is "converged" after the first iteration
+        s.set_linesearch(delta_tol=1e6)
+        s.upload(x0, x, u, par, dt)
+        assert s.iterate(5, take_step=True, linesearch=True, until_converged=True) == 1
+        with pytest.raises(Exception):
+            s.iteration_log(1)
+    finally:
+        s.close()
+
+
+def test_update_weights_equals_a_handle_created_with_them(model):
+    """hsqp_update_weights (the gains receiver's hook): a live handle whose Q / R / Qf were replaced solves like a
+    handle created with those weights."""
+    import copy
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver, HsqpError
+    x0, x, u, par, dt = make_problem(model, n_nodes=10, batch=2, perturb=True, seed=9)
+    Q = np.array(model.desc.Q) * np.linspace(0.5, 2.0, _abi.NX)
+    R = np.array(model.desc.R) * 3.0
+    Qf = np.array(model.desc.Qf) * 0.25
+    s = HipSqpSolver(model, max_nodes=10, max_batch=2)
+    try:
+        base = s.run(x0, x, u, par, dt)
+        s.update_weights(Q, R, Qf)
+        got = s.run(x0, x, u, par, dt)
+        with pytest.raises(HsqpError):
+            s.update_weights(Q=-Q)
+    finally:
+        s.close()
+    m2 = copy.copy(model)
+    m2.desc = type(model.desc).from_buffer_copy(model.desc)
+    m2.desc.Q[:], m2.desc.R[:], m2.desc.Qf[:] = Q.tolist(), R.tolist(), Qf.tolist()
+    s2 = HipSqpSolver(m2, max_nodes=10, max_batch=2)
+    try:
+        want = s2.run(x0, x, u, par, dt)
+    finally:
+        s2.close()
+    assert np.array_equal(got["dx"], want["dx"]) and np.array_equal(got["du"], want["du"])
+    assert not np.array_equal(got["dx"], base["dx"])

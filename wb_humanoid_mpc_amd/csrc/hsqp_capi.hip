@@ -463,6 +463,9 @@ struct hsqp_handle {
   double dt = 0.0;
   bool have_problem = false, have_solution = false;
   double kernel_ms[5] = {0, 0, 0, 0, 0};
+  int last_iterations = 0;
+  struct IterLog { std::vector<hsqp_perf> perf; std::vector<double> alpha; std::vector<int> type; };
+  std::vector<IterLog> iter_log;   // HSQP_ITER_UNTIL_CONVERGED: what every iteration of the last call ended with
   std::string err;
 };
 
@@ -803,8 +806,14 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
   const int nodes = B * N;
   const bool cent = h->hdm.formulation == HSQP_FORM_CENTROIDAL;
   HCHECK(hipMemsetAsync(h->d_status, 0, (size_t)B * sizeof(int), h->stream));   // once per call: the kernels OR into it
-  for (int it = 0; it < n_iterations; ++it) {
-    const bool last = it == n_iterations - 1;
+  const bool until_converged = (flags & HSQP_ITER_UNTIL_CONVERGED) != 0;
+  h->iter_log.clear();
+  h->last_iterations = 0;
+  double ms_sum[4] = {0.0, 0.0, 0.0, 0.0};
+  bool converged = false;
+  for (int it = 0; it < n_iterations && !converged; ++it) {
+    // (until_converged: any iteration may turn out to be the last one, so each is bracketed by the timing events and its times are summed)
+    const bool last = it == n_iterations - 1 || until_converged;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     if (cent)
       hipLaunchKernelGGL(k_lq_cent, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
@@ -932,18 +941,79 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     }
     h->ls_ran = linesearch != 0;
     if (last && !ev4_early) HCHECK(hipEventRecord(h->ev[4], h->stream));
-    if (take_step && !last) {
+    h->last_iterations = it + 1;
+    if (until_converged) {
+      // SqpSolver::checkConvergence on the step (upstream ocs2_sqp): STEPSIZE (no step length accepted) or PRIMAL (alpha |dx| and
+      // alpha |du| below deltaTol) for EVERY instance ends the loop; the record of the iteration goes to the log
+      hsqp_handle::IterLog rec;
+      rec.perf.resize(B); rec.alpha.resize(B); rec.type.resize(B);
+      std::vector<LsState> ls(B);
+      HCHECK(hipMemcpyAsync(ls.data(), h->d_ls, (size_t)B * sizeof(LsState), hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipMemcpyAsync(rec.perf.data(), h->d_perf_after, (size_t)B * sizeof(hsqp_perf), hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipStreamSynchronize(h->stream));
+      converged = true;
+      for (int b = 0; b < B; ++b) {
+        rec.alpha[b] = linesearch ? ls[b].alpha : 1.0;
+        rec.type[b] = linesearch ? ls[b].step_type : HSQP_STEP_FULL;
+        const bool zero_step = linesearch && ls[b].step_type == HSQP_STEP_ZERO;
+        const bool primal = rec.alpha[b] * ls[b].dxnorm < h->ls_settings.delta_tol && rec.alpha[b] * ls[b].dunorm < h->ls_settings.delta_tol;
+        if (!zero_step && !primal) converged = false;
+      }
+      h->iter_log.push_back(std::move(rec));
+      float msi[4];
+      for (int i = 0; i < 4; ++i) { HCHECK(hipEventElapsedTime(&msi[i], h->ev[i], h->ev[i + 1])); ms_sum[i] += msi[i]; }
+    }
+    const bool more = it + 1 < n_iterations && !converged;
+    if (take_step && more) {
       HCHECK(hipMemcpyAsync(h->d_x, h->d_xnew, (size_t)B * (N + 1) * NX * 8, hipMemcpyDeviceToDevice, h->stream));
       HCHECK(hipMemcpyAsync(h->d_u, h->d_unew, (size_t)B * N * NU * 8, hipMemcpyDeviceToDevice, h->stream));
     }
   }
   HCHECK(hipGetLastError());
   HCHECK(hipStreamSynchronize(h->stream));
-  float ms[4];
-  for (int i = 0; i < 4; ++i) HCHECK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-  h->kernel_ms[0] = ms[0]; h->kernel_ms[1] = ms[1]; h->kernel_ms[2] = ms[2]; h->kernel_ms[3] = ms[3];
-  h->kernel_ms[4] = ms[0] + ms[1] + ms[2] + ms[3];
+  if (until_converged) {
+    for (int i = 0; i < 4; ++i) h->kernel_ms[i] = ms_sum[i];
+  } else {
+    float ms[4];
+    for (int i = 0; i < 4; ++i) HCHECK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    for (int i = 0; i < 4; ++i) h->kernel_ms[i] = ms[i];
+  }
+  h->kernel_ms[4] = h->kernel_ms[0] + h->kernel_ms[1] + h->kernel_ms[2] + h->kernel_ms[3];
   h->have_solution = true;
+  return HSQP_OK;
+}
+
+int hsqp_last_iterations(const hsqp_handle* h) { return h ? h->last_iterations : -1; }
+
+int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf, double* alpha, int32_t* step_type) {
+  if (!h || iteration < 0 || iteration >= (int)h->iter_log.size()) return HSQP_ERR_BAD_ARG;
+  const hsqp_handle::IterLog& r = h->iter_log[iteration];
+  for (size_t b = 0; b < r.perf.size(); ++b) {
+    if (perf) perf[b] = r.perf[b];
+    if (alpha) alpha[b] = r.alpha[b];
+    if (step_type) step_type[b] = r.type[b];
+  }
+  return HSQP_OK;
+}
+
+int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  for (const double* w : {Q, R, Qf}) {
+    if (!w) continue;
+    const int n = w == R ? NU : NX;
+    for (int i = 0; i < n; ++i)
+      if (!(w[i] >= 0.0) || !std::isfinite(w[i])) { h->err = "hsqp_update_weights: weights must be finite and >= 0"; return HSQP_ERR_BAD_ARG; }
+  }
+  if (h->hdm.formulation == HSQP_FORM_CENTROIDAL)
+    for (const double* w : {Q, Qf})
+      for (int i = HSQP_CNX; w && i < NX; ++i)
+        if (w[i] != 0.0) { h->err = "hsqp_update_weights: centroidal Q / Qf beyond the 35 centroidal states must be zero"; return HSQP_ERR_BAD_ARG; }
+  HCHECK(hipSetDevice(h->device));
+  if (Q) { memcpy(h->hdm.Q, Q, NX * 8); memcpy(h->md.Q, Q, NX * 8); }
+  if (R) { memcpy(h->hdm.R, R, NU * 8); memcpy(h->md.R, R, NU * 8); }
+  if (Qf) { memcpy(h->hdm.Qf, Qf, NX * 8); memcpy(h->md.Qf, Qf, NX * 8); }
+  HCHECK(hipStreamSynchronize(h->stream));   // no kernel of an earlier call may still be reading the image
+  HCHECK(hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice));
   return HSQP_OK;
 }
 

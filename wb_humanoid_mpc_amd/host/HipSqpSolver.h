@@ -75,13 +75,16 @@ class HipSqpSolver {
    */
   void runWithReference(int nodes, double dt, const double* xInit, const double* xTraj, const double* uTraj, const hsqp_reference& ref,
                         bool takeStepWithLinesearch = false, const double* dtNodes = nullptr /* non-uniform grid with event nodes: [batch][nodes] interval
-                        lengths (0 = event), together with ref.node_times */) {
+                        lengths (0 = event), together with ref.node_times */,
+                        int maxIterations = 1 /* sqp::Settings::sqpIteration: all of them in ONE device call, ended early by ocs2's step-size test */) {
     const int batch = ref.batch;
     hsqp_problem p{batch, nodes, dt, xInit, xTraj, uTraj, nullptr, dtNodes};
     int rc = hsqp_upload_reference(h_, &p, &ref);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_upload_reference failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
-    rc = hsqp_iterate_device(h_, 1, HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0));
+    rc = hsqp_iterate_device(h_, maxIterations < 1 ? 1 : maxIterations,
+                             HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0) | HSQP_ITER_UNTIL_CONVERGED);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_iterate_device failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
+    iterations_ = hsqp_last_iterations(h_);
     solution_.batch = batch; solution_.nodes = nodes;
     solution_.stateTrajectory.assign((size_t)batch * (nodes + 1) * HSQP_NX, 0.0);
     solution_.inputTrajectory.assign((size_t)batch * nodes * HSQP_NU, 0.0);
@@ -119,6 +122,16 @@ class HipSqpSolver {
     if (hsqp_set_linesearch(h_, &ls) != HSQP_OK) throw std::runtime_error(std::string("[HipSqpSolver] ") + hsqp_last_error(h_));
   }
   Benchmarks getBenchmarks() const { return bench_; }
+  /** SQP iterations the last runWithReference ran, and what iteration `it` of them ended with (instance 0 .. batch-1). */
+  int getNumIterations() const { return iterations_; }
+  void getIterationLog(int it, std::vector<hsqp_perf>& perf, std::vector<double>& alpha, std::vector<int32_t>& stepType) const {
+    perf.assign(solution_.batch, hsqp_perf{}); alpha.assign(solution_.batch, 0.0); stepType.assign(solution_.batch, HSQP_STEP_ZERO);
+    if (hsqp_iteration_log(h_, it, perf.data(), alpha.data(), stepType.data()) != HSQP_OK) throw std::runtime_error("[HipSqpSolver] no such iteration in the log");
+  }
+  /** Live weight update (the centroidal node's gains receiver): diagonal Q / R / Qf, nullptr keeps the current one. */
+  void updateWeights(const double* Q, const double* R, const double* Qf) {
+    if (hsqp_update_weights(h_, Q, R, Qf) != HSQP_OK) throw std::runtime_error(std::string("[HipSqpSolver] ") + hsqp_last_error(h_));
+  }
   hsqp_handle* handle() { return h_; }
 
  private:
@@ -128,6 +141,7 @@ class HipSqpSolver {
   std::vector<double> kkt_, stepSize_;
   std::vector<int32_t> stepType_;
   Benchmarks bench_;
+  int iterations_ = 0;
 };
 
 }  // namespace hsqp_host

@@ -221,26 +221,27 @@ class HipSqpSolverAdaptor final : public SolverBase {
     r.event_times = ms.eventTimes.data(); r.mode_sequence = modes.data(); r.n_knots = (int32_t)tt.timeTrajectory.size();
     r.target_times = tt.timeTrajectory.data(); r.target_states = knots.data(); r.swing = cfg_.swing; r.terrain_height = cfg_.terrainHeight;
     r.arm_swing = cfg_.armSwingReference ? 1 : 0; r.node_times = cfg_.eventNodes ? nodeTimes.data() : nullptr;
-    // 4. SQP iterations with the filter line search
+    // 4. SQP iterations with the filter line search: ONE upload and ONE device call for all sqpIteration of them (the trajectories stay in
+    //    HBM between the iterations; the loop ends early by SqpSolver::checkConvergence's step-size test, evaluated per iteration from a
+    //    small read-back of the line-search state)
     log_.clear();
-    numIterations_ = 0;
-    for (size_t it = 0; it < settings_.sqpIteration; ++it) {
-      impl_.runWithReference(N, settings_.dt, x0.data(), x.data(), u.data(), r, /*line search*/ true, cfg_.eventNodes ? dts.data() : nullptr);
+    impl_.runWithReference(N, settings_.dt, x0.data(), x.data(), u.data(), r, /*line search*/ true, cfg_.eventNodes ? dts.data() : nullptr,
+                           (int)std::max<size_t>(settings_.sqpIteration, 1));
+    {
       const hsqp_host::PrimalSolution& s = impl_.getPrimalSolution();
-      double dxn = 0.0, dun = 0.0;
-      for (size_t i = 0; i < x.size(); ++i) { const double d = s.stateTrajectory[i] - x[i]; dxn += d * d; }
-      for (size_t i = 0; i < u.size(); ++i) { const double d = s.inputTrajectory[i] - u[i]; dun += d * d; }
       x = s.stateTrajectory; u = s.inputTrajectory;
-      const hsqp_perf& p = impl_.getPerformanceIndeces()[0];
-      PerformanceIndex pi;
-      pi.merit = p.merit; pi.cost = p.cost; pi.dynamicsViolationSSE = p.dynamics_sse; pi.equalityConstraintsSSE = p.equality_sse;
-      log_.push_back(pi);
-      stepSize_ = impl_.getStepSizes()[0]; stepType_ = impl_.getStepTypes()[0];
-      const hsqp_host::Benchmarks b = impl_.getBenchmarks();
+      numIterations_ = (size_t)impl_.getNumIterations();
+      std::vector<hsqp_perf> perf; std::vector<double> alpha; std::vector<int32_t> type;
+      for (size_t it = 0; it < numIterations_; ++it) {
+        impl_.getIterationLog((int)it, perf, alpha, type);
+        PerformanceIndex pi;
+        pi.merit = perf[0].merit; pi.cost = perf[0].cost; pi.dynamicsViolationSSE = perf[0].dynamics_sse; pi.equalityConstraintsSSE = perf[0].equality_sse;
+        log_.push_back(pi);
+        stepSize_ = alpha[0]; stepType_ = type[0];
+      }
+      const hsqp_host::Benchmarks b = impl_.getBenchmarks();   // summed over the iterations of the call
       benchmarks_.linearQuadraticApproximationTime += b.linearQuadraticApproximationTime; benchmarks_.solveQpTime += b.solveQpTime;
-      benchmarks_.linesearchTime += b.linesearchTime; benchmarks_.computeControllerTime += b.computeControllerTime; benchmarks_.numCalls += 1;
-      ++numIterations_;
-      if (std::sqrt(dxn) < settings_.deltaTol && std::sqrt(dun) < settings_.deltaTol) break;   // upstream: step below deltaTol -> converged
+      benchmarks_.linesearchTime += b.linesearchTime; benchmarks_.computeControllerTime += b.computeControllerTime; benchmarks_.numCalls += numIterations_;
     }
     // 5. primal solution: inputs stamped at every node, the last one repeated (upstream PrimalSolution convention).  A pre-event node
     //    has no input of its own (its stage is the identity jump, du = 0): upstream multiple_shooting::toPrimalSolution copies the

@@ -44,6 +44,9 @@ def load_library():
     lib.hsqp_upload.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
     lib.hsqp_upload_reference.argtypes = [C.c_void_p, C.POINTER(_abi.Problem), C.POINTER(_abi.Reference)]
     lib.hsqp_iterate_device.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hsqp_last_iterations.argtypes = [C.c_void_p]
+    lib.hsqp_iteration_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(_abi.Perf), _dp, C.POINTER(C.c_int32)]
+    lib.hsqp_update_weights.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.hsqp_download.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
     lib.hsqp_upload_device.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
     lib.hsqp_download_device.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
@@ -202,8 +205,24 @@ class HipSqpSolver:
             raise HsqpError(n, self.lib.hsqp_last_error(self.h).decode())
         return a
 
-    def iterate(self, n_iterations=1, take_step=False, kkt=False, linesearch=False):
-        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0) | (4 if linesearch else 0)))
+    def iterate(self, n_iterations=1, take_step=False, kkt=False, linesearch=False, until_converged=False):
+        """until_converged: n_iterations is an upper bound; the call ends when every instance's step is below deltaTol (or no step length
+        was accepted): ocs2's SqpSolver::checkConvergence.  Returns the number of iterations run."""
+        self._check(self.lib.hsqp_iterate_device(self.h, n_iterations, (1 if take_step else 0) | (2 if kkt else 0) | (4 if linesearch else 0) |
+                                                 (8 if until_converged else 0)))
+        return int(self.lib.hsqp_last_iterations(self.h))
+
+    def iteration_log(self, iteration):
+        """(perf[B], alpha[B], step_type[B]) iteration `iteration` of the last until_converged call ended with."""
+        B, _ = self._shape
+        perf, alpha, st = (_abi.Perf * B)(), np.zeros(B), np.zeros(B, dtype=np.int32)
+        self._check(self.lib.hsqp_iteration_log(self.h, iteration, perf, alpha.ctypes.data_as(_dp), st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return self._perf(perf), alpha, st
+
+    def update_weights(self, Q=None, R=None, Qf=None):
+        """hsqp_update_weights: new diagonal Q[58] / R[35] / Qf[58] of the live handle (None keeps the current one)."""
+        arrs = [None if a is None else _c(a) for a in (Q, R, Qf)]
+        self._check(self.lib.hsqp_update_weights(self.h, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]))
 
     # ---- sqp::Settings of the line search (task.info sqp block + upstream defaults)
     def linesearch_settings(self):
