@@ -8,6 +8,7 @@
 #include <iostream>
 
 #include "HipSqpSolverAdaptor.h"
+#include "HipSqpModelIO.h"
 
 using namespace ocs2;
 using namespace ocs2::humanoid;
@@ -44,7 +45,13 @@ class FixedReferenceManager final : public ReferenceManagerInterface {
 int main(int argc, char** argv) {
   if (argc != 4) { std::fprintf(stderr, "usage: adaptor_driver model.bin case.txt out.txt\n"); return 2; }
   HipSqpAdaptorConfig cfg;
-  {
+  // the problem image: the exported JSON read by the C++ loader (host/HipSqpModelIO.h — no Python in the loop), or a raw struct dump
+  const std::string modelPath = argv[1];
+  const bool fromJson = modelPath.size() > 5 && modelPath.substr(modelPath.size() - 5) == ".json";
+  if (fromJson) {
+    try { cfg.model = hsqp_host::loadModelDesc(modelPath); cfg.swing = hsqp_host::loadSwingConfig(modelPath); }
+    catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 2; }
+  } else {
     std::ifstream f(argv[1], std::ios::binary);
     f.read(reinterpret_cast<char*>(&cfg.model), sizeof(cfg.model));
     if (!f) { std::fprintf(stderr, "cannot read the model description\n"); return 2; }
@@ -53,8 +60,13 @@ int main(int argc, char** argv) {
   int stateDim, nEvents, nKnots, calls, eventNodes, maxNodes;
   double dt, horizon, period, t0;
   in >> stateDim >> dt >> horizon >> period >> t0 >> calls >> eventNodes >> maxNodes;
-  double* sw = &cfg.swing.lift_off_velocity;
-  for (int i = 0; i < 8; ++i) in >> sw[i];
+  {
+    hsqp_swing_config fileSwing;
+    double* sw = &fileSwing.lift_off_velocity;
+    for (int i = 0; i < 8; ++i) in >> sw[i];
+    if (fromJson) { if (std::memcmp(&fileSwing, &cfg.swing, sizeof(fileSwing)) != 0) { std::fprintf(stderr, "swing configuration of the image differs from the case file\n"); return 2; } }
+    else cfg.swing = fileSwing;
+  }
   auto rm = std::make_shared<FixedReferenceManager>();
   in >> nEvents;
   rm->ms.eventTimes.resize(nEvents); rm->ms.modeSequence.resize(nEvents + 1);

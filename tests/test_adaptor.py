@@ -86,7 +86,9 @@ def test_adaptor_receding_horizon_equals_the_ctypes_path(tmp_path, model, cmodel
     targets = (centroidal_velocity_command_targets if cent else velocity_command_targets)(m, (0.3, 0.0, 0.7925, 0.0), 0.0, x0, 3.0)
     write_case(tmp_path, m, schedule, targets, x0, horizon, period, calls, nx)
     exe = build_driver(tmp_path)
-    r = subprocess.run([str(exe), str(tmp_path / "model.bin"), str(tmp_path / "case.txt"), str(tmp_path / "out.txt")], capture_output=True, text=True)
+    # the model description comes from the exported image through the C++ loader (host/HipSqpModelIO.h): no Python-made struct in the loop
+    image = os.path.join(LIBDIR, "data", "g1_centroidal.json" if cent else "g1_wb.json")
+    r = subprocess.run([str(exe), image, str(tmp_path / "case.txt"), str(tmp_path / "out.txt")], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "ok calls=3 preSolverRun=3" in r.stdout and "LQ Approximation" in r.stdout
     got = read_output(tmp_path / "out.txt", nx)
