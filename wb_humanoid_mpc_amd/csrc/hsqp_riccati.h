@@ -567,6 +567,81 @@ struct StepWS {
 // armijoDescentMetric on the projected cost), |dx|^2, |du|^2} of this node.
 HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double* rk, const double* dx, const double* x, const double* u,
                        double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ctx.nthreads == 64) {
+    // One-wave kernels (k_step, k_step_value): the phase-by-phase form below exposes four dependent HBM round trips (dx; the rows of K;
+    // the rows of Px / Pu; q~, r~ of the descent metric) on a node whose arithmetic is a few hundred multiply-adds.  Here EVERY global
+    // load of the node is issued before the first use (93 doubles per lane in registers), so the node pays one round trip; the sums run in
+    // the order of the phase form (matvec_part), the results are bit-identical to it.
+    const int l = ctx.tid;
+    constexpr int NCX = (NX + 3) / 4, NCU = (NUT + 3) / 4;
+    const double dxl = l < NX ? dx[l] : 0.0, xl = l < NX ? x[l] : 0.0;
+    const double ul = l < NU ? u[l] : 0.0, pel = l < NU ? q[QP_PE + l] : 0.0, kvl = l < NUT ? rk[RIC_KV + l] : 0.0;
+    const double qvl = (info && l < NX) ? q[QP_QV + l] : 0.0, rvl = (info && l < NUT) ? q[QP_RV + l] : 0.0;
+    double kk[2][NCX], px[3][NCX], pu[3][NCU];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = l + 64 * j, r = it >> 2, pp = it & 3;
+#pragma unroll
+      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; kk[j][c] = (it < NUT * 4 && cc < NX) ? rk[RIC_K + r * NX + cc] : 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int it = l + 64 * j, r = it >> 2, pp = it & 3;
+#pragma unroll
+      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; px[j][c] = (it < NU * 4 && cc < NX) ? q[QP_PX + r * NX + cc] : 0.0; }
+#pragma unroll
+      for (int c = 0; c < NCU; ++c) { const int cc = pp + 4 * c; pu[j][c] = (it < NU * 4 && cc < NUT) ? q[QP_PU + r * NUT + cc] : 0.0; }
+    }
+    if (l < NX) { w.dx[l] = dxl; x_new[l] = xl + alpha * dxl; }
+    WG_SYNC(ctx);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = l + 64 * j, pp = it & 3;
+      if (it < NUT * 4) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; if (cc < NX) sacc += kk[j][c] * w.dx[cc]; }
+        w.part[it] = sacc;
+      }
+    }
+    WG_SYNC(ctx);
+    if (l < NUT) { const double v = kvl + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3])); w.ut[l] = v; ut_out[l] = v; }
+    WG_SYNC(ctx);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int it = l + 64 * j, pp = it & 3;
+      if (it < NU * 4) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; if (cc < NX) s1 += px[j][c] * w.dx[cc]; }
+#pragma unroll
+        for (int c = 0; c < NCU; ++c) { const int cc = pp + 4 * c; if (cc < NUT) s2 += pu[j][c] * w.ut[cc]; }
+        w.part[it] = s1 + s2;
+      }
+    }
+    WG_SYNC(ctx);
+    if (l < NU) {
+      const double sv = pel + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3]));
+      du_out[l] = sv; u_new[l] = ul + alpha * sv; w.du[l] = sv;
+    }
+    WG_SYNC(ctx);
+    if (info) {
+      // (the phase form sums these serially in one lane each; the same serial order here, from LDS copies of q~, r~)
+      if (l < NX) w.part[l] = qvl;
+      if (l < NUT) w.part[NX + l] = rvl;
+      WG_SYNC(ctx);
+      if (l < 3) {
+        double sacc = 0.0;
+        if (l == 0) { for (int i = 0; i < NX; ++i) sacc += w.part[i] * w.dx[i]; for (int j = 0; j < NUT; ++j) sacc += w.part[NX + j] * w.ut[j]; }
+        else if (l == 1) { for (int i = 0; i < NX; ++i) sacc += w.dx[i] * w.dx[i]; }
+        else { for (int i = 0; i < NU; ++i) sacc += w.du[i] * w.du[i]; }
+        info[l] = sacc;
+      }
+    }
+    return;
+  }
+#endif
   WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
   WG_SYNC(ctx);
   WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_K + (it >> 2) * NX, w.dx, it & 3);
