@@ -142,6 +142,15 @@ typedef struct hsqp_model_desc {
 #define HSQP_FLAG_PARALLEL_RICCATI 4   /* the scan for every batch size and horizon (still gated); excludes HSQP_FLAG_SERIAL_RICCATI */
 #define HSQP_SCAN_AUTO_BATCH 2
 #define HSQP_SCAN_AUTO_MIN_NODES 48
+/* Two-level (segmented) sweep for the batches in between (csrc/hsqp_segment.h) — OPT-IN.  One workgroup per instance leaves 256 - B CUs idle
+ * during the N dependent stages (BASELINE config 4 as written puts 32 instances on each of 8 GPUs: 1.72 of the 2.48 ms of a step).  With this
+ * flag the horizon of every instance is cut into P = 7 (or 3) segments: segment elements (Riccati recursion from J = 0 + prepended closed
+ * loops) on B P workgroups, a suffix scan over the P + 1 elements, ordinary recursions per segment from the boundary value functions, the
+ * roll-out: 1.14 ms per sweep at 32 instances.  Gated like the scan — by the KKT residual of the segments' last stages — with the serial
+ * recursion as fallback (hsqp_scan_fallbacks counts; after a rejection the handle backs off for 1, 3, 7, .. iterations).  DECLARED RELAXATION
+ * of BASELINE.md §6: its step differs from the serial recursion's by 4e-11 .. 4e-10 of the step's scale (measured on perturbed config-4
+ * batches: up to 7e-8 absolute where the bound on trajectories is 1e-8), which is why no default path takes it. */
+#define HSQP_FLAG_SEGMENTED_RICCATI 8  /* excludes HSQP_FLAG_SERIAL_RICCATI and HSQP_FLAG_PARALLEL_RICCATI */
 typedef struct hsqp_settings {
   int32_t max_nodes;            /* N_max: shooting intervals per instance                                */
   int32_t max_batch;            /* independent MPC instances per call on this device                     */

@@ -75,3 +75,82 @@ def solve_qp(stages, QN, qN, dx0):
         us.append(u)
         dx.append(A @ dx[-1] + B @ u + b)
     return np.array(dx), np.array(us), S, s, levels
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Two-level (segmented) sweep — the strong-scaling form for 2 < B <= 128 instances per GPU: the horizon is cut into
+# P segments; (1) every segment's element by PREPENDING its stages one at a time, (2) a suffix scan over the P segment elements and
+# the terminal element gives the value function at every segment boundary, (3) an ordinary Riccati recursion per segment from its
+# boundary value function gives the gains, (4) the usual roll-out.  (1) and (3) are parallel over segments.
+#
+# Prepending stage k (x+ = A x + B u + b, cost Q, P, R, q, r) to the element (A2, b2, C2, eta2, J2) of k+1 .. end: the stage's
+# element has C1 = B R^-1 B' of rank nu, so M^-1 = (I + C1 J2)^-1 follows from the Riccati gain solve with S = J2, s = -eta2:
+#     Lam = R + B' S B,  G = P + B' S A,  g = r + B' (S b + s),  K = -Lam^-1 G,  k = -Lam^-1 g
+#     M^-1 A1 = A + B K = Acl,   M^-1 (b1 + C1 eta2) = b + B k = bcl,   M^-1 C1 = B Lam^-1 B'
+#     J <- Q + A' S A - G' Lam^-1 G,   eta <- -(q + A' (S b + s) - G' Lam^-1 g)            (the Riccati step itself)
+#     A <- A2 Acl,   b <- A2 bcl + b2,   C <- A2 B Lam^-1 B' A2' + C2
+def prepend_stage(st, e2):
+    A2, b2, C2, eta2, J2 = e2
+    A, B, b, Q, P, R, q, r = (st[k] for k in ("A", "B", "b", "Q", "P", "R", "q", "r"))
+    S, s = J2, -eta2
+    Lam = R + B.T @ S @ B
+    G = P + B.T @ S @ A
+    sb = S @ b + s
+    g = r + B.T @ sb
+    L = np.linalg.cholesky(Lam)
+    Z = np.linalg.solve(L, G)
+    z = np.linalg.solve(L, g)
+    K = -np.linalg.solve(L.T, Z)
+    kv = -np.linalg.solve(L.T, z)
+    J = Q + A.T @ S @ A - Z.T @ Z
+    eta = -(q + A.T @ sb - Z.T @ z)
+    Acl, bcl = A + B @ K, b + B @ kv
+    W = A2 @ np.linalg.solve(L, B.T).T          # A2 B L^-T
+    return (A2 @ Acl, A2 @ bcl + b2, W @ W.T + C2, eta, 0.5 * (J + J.T))
+
+
+def identity_element(n):
+    return (np.eye(n), np.zeros(n), np.zeros((n, n)), np.zeros(n), np.zeros((n, n)))
+
+
+def riccati_segment(stages, S, s):
+    """Ordinary backward recursion over `stages` from the value function (S, s) at their end: gains (K, k) per stage and (S, s) at the start."""
+    gains = []
+    for st in reversed(stages):
+        A, B, b, Q, P, R, q, r = (st[k] for k in ("A", "B", "b", "Q", "P", "R", "q", "r"))
+        Lam = R + B.T @ S @ B
+        G = P + B.T @ S @ A
+        sb = S @ b + s
+        g = r + B.T @ sb
+        K = -np.linalg.solve(Lam, G)
+        kv = -np.linalg.solve(Lam, g)
+        S, s = Q + A.T @ S @ A + G.T @ K, q + A.T @ sb + G.T @ kv
+        S = 0.5 * (S + S.T)
+        gains.append((K, kv))
+    return gains[::-1], S, s
+
+
+def solve_qp_segmented(stages, QN, qN, dx0, n_segments):
+    """Returns dx, u, the boundary indices, the boundary value functions and the number of scan levels over the segments."""
+    N, n = len(stages), QN.shape[0]
+    bounds = [round(p * N / n_segments) for p in range(n_segments + 1)]
+    # (1) segment elements, independent of each other
+    elems = []
+    for p in range(n_segments):
+        e = identity_element(n)
+        for k in range(bounds[p + 1] - 1, bounds[p] - 1, -1):
+            e = prepend_stage(stages[k], e)
+        elems.append(e)
+    # (2) suffix scan over the segment elements + the terminal element: value function at every boundary
+    suf, levels = suffix_scan(elems + [terminal_element(QN, qN)])
+    # (3) gains per segment from the value function at its END, (4) roll-out
+    gains = []
+    for p in range(n_segments):
+        g, _, _ = riccati_segment(stages[bounds[p]:bounds[p + 1]], suf[p + 1][4], -suf[p + 1][3])
+        gains += g
+    dx, us = [np.asarray(dx0, dtype=float)], []
+    for st, (K, kv) in zip(stages, gains):
+        u = K @ dx[-1] + kv
+        us.append(u)
+        dx.append(st["A"] @ dx[-1] + st["B"] @ u + st["b"])
+    return np.array(dx), np.array(us), bounds, [(e[4], -e[3]) for e in suf], levels

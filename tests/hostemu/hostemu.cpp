@@ -11,6 +11,7 @@
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_scan.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_segment.h"
 
 using namespace hsqp;
 
@@ -57,8 +58,70 @@ static int scan_backward(const DevModel& dm, int N, const double* x, const doubl
   return 1;
 }
 
+static int g_segments = 0;   // > 0: backward sweep by the two-level (segmented) form of hsqp_segment.h with this many segments
+
+// the segmented backward sweep through the kernel sources, pass by pass as launch_segmented (hsqp_capi.hip) runs it
+template <int n>
+static int segmented_backward(const DevModel& dm, int N, int P, const double* x, const double* par, const double* qp, double* ric, double* vf) {
+  Ctx ctx{0, 1, nullptr};
+  using E = ScanEl<n>;
+  std::vector<double> ea((size_t)(P + 1) * E::SIZE), eb((size_t)(P + 1) * E::SIZE), ric2((size_t)N * RIC_SIZE), linv((size_t)N * LDB * LDB), vf0((size_t)P * VF_SIZE);
+  std::vector<double> zero((size_t)NX * NX + NX, 0.0);
+  auto rw = std::make_unique<RicWS>();
+  auto aw = std::make_unique<SegAccWS>();
+  auto cw = std::make_unique<ScanCombWS<n>>();
+  const double* xN = x + (size_t)N * NX;
+  const double* parN = par + (size_t)N * NP;
+  for (int p = 0; p < P; ++p) {
+    const int k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
+    riccati_backward<n>(ctx, *rw, dm.Qf, xN, parN, qp + (size_t)k0 * QP_SIZE, &ric2[(size_t)k0 * RIC_SIZE], L, &vf0[(size_t)p * VF_SIZE], zero.data(), zero.data() + n * n,
+                        false, 1.0, n, &linv[(size_t)k0 * LDB * LDB], 1);
+    if (!rw->ok) return 0;
+    seg_accumulate<n>(ctx, *aw, qp + (size_t)k0 * QP_SIZE, &ric2[(size_t)k0 * RIC_SIZE], &linv[(size_t)k0 * LDB * LDB], L, &vf0[(size_t)p * VF_SIZE], &ea[(size_t)p * E::SIZE]);
+  }
+  scan_terminal_element<n>(ctx, &ea[(size_t)P * E::SIZE], dm.Qf, xN, parN);
+  int ok = 1;
+  for (int d = 1; d < P + 1; d *= 2) {
+    for (int k = 0; k <= P; ++k) {
+      if (k + d <= P) scan_combine<n>(ctx, *cw, &ea[(size_t)k * E::SIZE], &ea[(size_t)(k + d) * E::SIZE], &eb[(size_t)k * E::SIZE], &ok);
+      else std::copy(&ea[(size_t)k * E::SIZE], &ea[(size_t)(k + 1) * E::SIZE], &eb[(size_t)k * E::SIZE]);
+    }
+    ea.swap(eb);
+  }
+  if (!ok) return 0;
+  for (int p = 0; p < P; ++p) {
+    const int k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
+    const double* en = &ea[(size_t)(p + 1) * E::SIZE];
+    riccati_backward<n>(ctx, *rw, dm.Qf, xN, parN, qp + (size_t)k0 * QP_SIZE, ric + (size_t)k0 * RIC_SIZE, L, vf + (size_t)k0 * VF_SIZE, en + E::J, en + E::ETA, p == P - 1, -1.0, n);
+    if (!rw->ok) return 0;
+  }
+  return 1;
+}
+
 extern "C" {
 
+void emu_set_segments(int P) { g_segments = P; }
+// debug / test access to the pieces of the two-level sweep (n = 58): the element of the stage range [k0, k0 + L) of a QP record array, and
+// the combination of two elements (ScanEl<58> layout)
+int emu_el_size58() { return ScanEl<NX>::SIZE; }
+int emu_segment_element58(void* h, const double* qp, int k0, int L, double* el) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  Ctx ctx{0, 1, nullptr};
+  std::vector<double> ric2((size_t)L * RIC_SIZE), linv((size_t)L * LDB * LDB), vf0(VF_SIZE), zero((size_t)NX * NX + NX, 0.0), xN(NX, 0.0), parN(NP, 0.0);
+  auto rw = std::make_unique<RicWS>();
+  auto aw = std::make_unique<SegAccWS>();
+  riccati_backward<NX>(ctx, *rw, dm.Qf, xN.data(), parN.data(), qp + (size_t)k0 * QP_SIZE, ric2.data(), L, vf0.data(), zero.data(), zero.data() + NX * NX, false, 1.0, NX, linv.data(), 1);
+  if (!rw->ok) return 0;
+  seg_accumulate<NX>(ctx, *aw, qp + (size_t)k0 * QP_SIZE, ric2.data(), linv.data(), L, vf0.data(), el);
+  return 1;
+}
+int emu_scan_combine58(const double* e1, const double* e2, double* out) {
+  Ctx ctx{0, 1, nullptr};
+  auto cw = std::make_unique<ScanCombWS<NX>>();
+  int ok = 1;
+  scan_combine<NX>(ctx, *cw, e1, e2, out, &ok);
+  return ok;
+}
 int emu_scan_gate_accepts(double r_stat, double r_prim, double g_inf, int flags) { return scan_gate_accepts(r_stat, r_prim, g_inf, flags) ? 1 : 0; }
 void emu_set_scan(int on) { g_scan = on; }
 void emu_set_scan_refinements(int r) { g_scan_refinements = r; }
@@ -218,7 +281,12 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   pb[0] += terminal(x);
   std::vector<double> vf((size_t)(N + 1) * VF_SIZE);
   std::vector<double> acl(g_scan ? (size_t)N * ACL_SIZE<NX> : 0);
-  if (g_scan) {
+  if (g_segments > 0) {
+    const int okk = cent ? segmented_backward<CNX>(dm, N, g_segments, x, par, qp.data(), ric.data(), vf.data()) : segmented_backward<NX>(dm, N, g_segments, x, par, qp.data(), ric.data(), vf.data());
+    if (!okk) return HSQP_ERR_NUMERIC;
+    rw->ok = 1;
+  }
+  else if (g_scan) {
     const int okk = cent ? scan_backward<CNX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), 1) : scan_backward<NX>(dm, N, x, par, qp.data(), ric.data(), vf.data(), acl.data(), g_scan_refinements);
     if (!okk) return HSQP_ERR_NUMERIC;
     rw->ok = 1;
@@ -226,8 +294,8 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
-  if (cent && g_scan) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
-  else if (g_scan) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
+  if (cent && g_scan && !g_segments) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
+  else if (g_scan && !g_segments) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
   else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
   auto sw = std::make_unique<StepWS>();

@@ -469,3 +469,63 @@ def test_update_weights_equals_a_handle_created_with_them(model):
         s2.close()
     assert np.array_equal(got["dx"], want["dx"]) and np.array_equal(got["du"], want["du"])
     assert not np.array_equal(got["dx"], base["dx"])
+
+
+SEG_REL = 1e-9   # declared relaxation of the OPT-IN two-level sweep: measured 4e-11 .. 4e-10 of the step's scale from the serial recursion (include/hsqp.h)
+
+
+@pytest.mark.parametrize("B,N,seed", [(3, 28, 77), (32, 100, 3), (32, 100, 1), (16, 60, 77), (8, 100, 77)])
+def test_two_level_sweep_against_the_serial_recursion(model, oracle, B, N, seed):
+    """The opt-in segmented (two-level) sweep of hsqp_segment.h (HSQP_FLAG_SEGMENTED_RICCATI; BASELINE config 4 as written puts 32 instances on
+    each of 8 GPUs): the step within SEG_REL of its scale of the serial recursion's (seed 1 is the worst batch of tools/gpu_seg_fuzz.py:
+    3.6e-10), the same performance index, the KKT residual of the QP at the gate's bound, no fallback on these walk-gait batches, bit-repeatable;
+    one instance of the small case also against the oracle."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=seed)
+    outs = {}
+    for md in ("serial", "segmented", "again"):
+        s = HipSqpSolver(model, max_nodes=N, max_batch=B, riccati="serial" if md == "serial" else "segmented")
+        try:
+            s.upload(x0, x, u, par, dt)
+            s.iterate(1, take_step=True, kkt=True)
+            outs[md] = s.download()
+            outs[md]["fallbacks"] = s.scan_fallbacks()
+        finally:
+            s.close()
+    a, b = outs["serial"], outs["segmented"]
+    assert b["fallbacks"] == 0
+    assert np.array_equal(b["dx"], outs["again"]["dx"]) and np.array_equal(b["du"], outs["again"]["du"])     # no atomics, fixed combine order
+    sc = max(1.0, np.abs(a["dx"]).max(), np.abs(a["du"]).max())
+    err = max(np.abs(a["dx"] - b["dx"]).max(), np.abs(a["du"] - b["du"]).max())
+    print(f"two-level sweep B={B} N={N} seed {seed}: |step - serial| = {err:.2e} ({err / sc:.1e} of the scale), KKT {b['kkt'].max():.1e} (serial {a['kkt'].max():.1e})")
+    assert err <= SEG_REL * sc
+    assert not np.array_equal(a["dx"], b["dx"])          # it really is the other algorithm
+    for i in range(B):
+        assert b["kkt"][i].max() <= 1e-7, f"instance {i}: KKT residual {b['kkt'][i].max():.2e} passed the gate"
+        assert_perf(b["perf_after"][i], a["perf_after"][i], f"instance {i}", rel=1e-9)
+    if B <= 4:
+        r = oracle.sqp_iteration(dt, x0[1], x[1], u[1], par[1], threads=os.cpu_count() or 4)
+        assert_step(b, r, 1, "two-level sweep vs oracle", rel=SEG_REL)    # the declared relaxation of the opt-in sweep
+
+
+def test_two_level_sweep_gate_rejects_and_backs_off(cmodel):
+    """A perturbed centroidal batch (|S| ~ 4e6: the combination of its segment elements loses digits) fails the gate — the KKT residual of the
+    segments' last stages —, the iteration is redone with the serial recursion (bit for bit the serial handle's result), and the handle
+    backs off instead of paying sweep + fallback every iteration."""
+    from wb_humanoid_mpc_amd.reference import make_centroidal_problem
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 8, 100
+    x0, x, u, par, dt = make_centroidal_problem(cmodel, n_nodes=N, batch=B, perturb=True)
+    res = {}
+    for md in ("serial", "segmented"):
+        s = HipSqpSolver(cmodel, max_nodes=N, max_batch=B, riccati=md)
+        try:
+            s.upload(x0, x, u, par, dt)
+            for _ in range(6):
+                s.iterate(1)
+            s.iterate(1, kkt=True)
+            res[md] = (s.download(), s.scan_fallbacks())
+        finally:
+            s.close()
+    assert res["serial"][1] == 0 and 1 <= res["segmented"][1] <= 3            # rejected, then 1 + 3 iterations of back-off, rejected again, ...
+    assert np.array_equal(res["segmented"][0]["dx"], res["serial"][0]["dx"]) and np.array_equal(res["segmented"][0]["du"], res["serial"][0]["du"])

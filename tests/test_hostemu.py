@@ -145,3 +145,43 @@ def test_scan_gate_decisions(emu):
     assert not gate(1e-12, 3e-8, 50.0, 0)               # primal residual
     assert not gate(1e-12, 1e-14, 50.0, 2)              # a bad pivot inside the scan
     assert not gate(float("nan"), 1e-14, 50.0, 0) and not gate(1e-12, 1e-14, float("nan"), 0)
+
+
+@pytest.mark.parametrize("form,gait,n,segments", [("wb", "walk", 24, 3), ("wb", "run", 33, 7), ("wb", "walk", 60, 7), ("centroidal", "walk", 40, 7)])
+def test_two_level_sweep_of_the_kernel_sources_equals_the_serial_recursion(model, cmodel, emu, form, gait, n, segments):
+    """hsqp_segment.h through the host build, pass by pass as launch_segmented runs it (segment elements = Riccati recursion from J = 0 +
+    prepended closed loops, suffix scan over the segment elements with the scan's combination, exact recursions per segment from the
+    boundary value functions): the step of the serial recursion to 1e-10 of its scale, and the forward / reverse item orders agree bit for bit."""
+    from test_oracle_centroidal_ocp import perturbed_centroidal_problem
+    cent = form == "centroidal"
+    m = cmodel if cent else model
+    x0, x, u, par, dt = (perturbed_centroidal_problem if cent else perturbed_problem)(m, n, gait, seed=5)
+    outs = {}
+    for lib_name in ("libhsqp_hostemu.so", "libhsqp_hostemu_rev.so"):
+        L = C.CDLL(os.path.join(HERE, "hostemu", lib_name))
+        L.emu_create.restype = C.c_void_p
+        err = C.create_string_buffer(256)
+        hh = C.c_void_p(L.emu_create(C.byref(m.desc), err, 256))
+        for P_ in ((0, segments) if lib_name.endswith("emu.so") else (segments,)):
+            L.emu_set_segments(P_)
+            xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+            kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+            assert L.emu_sqp_iteration(hh, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), None, None) == 0
+            outs[(lib_name, P_)] = (dx.copy(), du.copy(), kkt.copy())
+        L.emu_set_segments(0)
+    ser, seg, rev = outs[("libhsqp_hostemu.so", 0)], outs[("libhsqp_hostemu.so", segments)], outs[("libhsqp_hostemu_rev.so", segments)]
+    sc = max(1.0, np.abs(ser[0]).max(), np.abs(ser[1]).max())
+    err = max(np.abs(seg[0] - ser[0]).max(), np.abs(seg[1] - ser[1]).max())
+    # the device's gate: the KKT residual of the segments' last stages (= the maximum over all stages up to rounding, which is what the host
+    # build evaluates) against the scan's bounds; an accepted sweep must be accurate, a rejected one is redone with the serial recursion
+    L.emu_scan_gate_accepts.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+    accepted = L.emu_scan_gate_accepts(seg[2][0], seg[2][1], 1e9, 0) == 1
+    print(f"{form} {gait} N={n} P={segments}: |step - serial| = {err:.2e} ({err / sc:.1e} of the scale), KKT {seg[2][0]:.1e} / {seg[2][1]:.1e} -> {'accepted' if accepted else 'rejected'}")
+    # (The run-gait QP with |du| ~ 1e3 is the hard case: its segment elements equal the numpy prototype's to 1e-12, but the scan's Gauss-Jordan
+    # combination of two of them — cond(I + C1 J2) ~ 1e9 — loses digits that numpy's LU keeps: 2.5e-9 of the scale instead of 2e-12.)
+    if accepted:
+        assert err <= 2e-10 * sc
+    else:
+        assert gait == "run"
+    assert err <= 1e-8 * sc
+    assert np.array_equal(seg[0], rev[0]) and np.array_equal(seg[1], rev[1])   # race check

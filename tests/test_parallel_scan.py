@@ -80,3 +80,39 @@ def test_scan_reproduces_the_serial_riccati_solution(model, cmodel, form, gait, 
     # the value functions of the scan are symmetric positive semi-definite like the Riccati ones
     assert all(np.linalg.eigvalsh(Sk).min() >= -1e-9 * max(1.0, np.abs(Sk).max()) for Sk in S)
     lib.emu_destroy(h)
+
+
+@pytest.mark.parametrize("form,gait,n,segments", [("wb", "walk", 40, 4), ("wb", "run", 33, 8), ("wb", "walk", 100, 8), ("centroidal", "walk", 100, 5)])
+def test_segmented_sweep_reproduces_the_serial_riccati_solution(model, cmodel, form, gait, n, segments):
+    """The two-level sweep of DESIGN.md §6 (segment elements by prepending stages — rank-nu Woodbury = the Riccati gain solve —, a suffix
+    scan over the segment elements, ordinary recursions per segment from the boundary value functions) against the serial recursion."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu"), "all"])
+    lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
+    lib.emu_create.restype = C.c_void_p
+    cent = form == "centroidal"
+    m = cmodel if cent else model
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(m.desc), err, 256))
+    x0, x, u, par, dt = (perturbed_centroidal_problem if cent else perturbed_problem)(m, n, gait, seed=5)
+    xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+    kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+    qp = np.zeros((n, lib.emu_qp_size()))
+    assert lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None) == 0
+    nxe = _abi.CNX if cent else NX
+    Qf = np.array(m.raw["Qf"])
+    stages = stages_from_records(qp, nxe)
+    qN = Qf * (x[n, :nxe] - par[n, :nxe])
+    sdx, sut, bounds, vf, levels = parallel_scan.solve_qp_segmented(stages, np.diag(Qf), qN, (x0 - x[0])[:nxe], segments)
+    assert levels == math.ceil(math.log2(segments + 1)) and bounds[0] == 0 and bounds[-1] == n
+    sc = max(1.0, np.abs(dx).max(), np.abs(du).max())
+    err_x = np.abs(sdx - dx[:, :nxe]).max() / sc
+    # the prepend form equals the generic combination of the stage's element with the accumulated one
+    e2 = parallel_scan.identity_element(nxe)
+    for k in (n - 1, n - 2, n - 3):
+        a = parallel_scan.prepend_stage(stages[k], e2)
+        b = parallel_scan.combine(parallel_scan.stage_element(**stages[k]), e2)
+        for u_, v_ in zip(a, b):
+            assert np.abs(u_ - v_).max() <= 1e-9 * max(1.0, np.abs(v_).max())
+        e2 = a
+    print(f"{form} {gait} N={n} P={segments}: |dx - serial| / scale = {err_x:.2e}")
+    assert err_x <= TOL[form]

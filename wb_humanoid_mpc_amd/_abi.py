@@ -101,4 +101,5 @@ class LinesearchSettings(C.Structure):
 STEP_COST, STEP_DUAL, STEP_CONSTRAINT, STEP_ZERO, STEP_FULL = 0, 1, 2, 3, 4
 FLAG_LINESEARCH = 1
 FLAG_SERIAL_RICCATI, FLAG_PARALLEL_RICCATI, SCAN_AUTO_BATCH, SCAN_AUTO_MIN_NODES = 2, 4, 2, 48
+FLAG_SEGMENTED_RICCATI = 8   # the two-level (segmented) sweep (csrc/hsqp_segment.h): opt-in, declared relaxation of the trajectory tolerance
 BLK_PARAMS = 11

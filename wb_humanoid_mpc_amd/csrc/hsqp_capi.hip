@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -15,6 +17,7 @@
 #include "hsqp_policy.h"
 #include "hsqp_cent.h"
 #include "hsqp_scan.h"
+#include "hsqp_segment.h"
 
 using namespace hsqp;
 
@@ -192,6 +195,71 @@ __global__ __launch_bounds__(SCAN_FWD_THREADS) void k_scan_forward(const double*
   closed_loop_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, acl + (size_t)b * N * ACL_SIZE<n>, N, dx + (size_t)b * (N + 1) * NX);
 }
 
+// ---- two-level (segmented) backward sweep (hsqp_segment.h): B P workgroups, segment p of instance b covers the stages [p N / P, (p + 1) N / P)
+constexpr int SEG_ACC_THREADS = 512;
+// 1a: Riccati recursion over the segment from J = 0, eta = 0 (zero: n x n + n zeros): gains and (L^-1)^T of every stage, (J, s) at its first node
+template <int n>
+__global__ __launch_bounds__(RIC_THREADS) void k_seg_elem_ric(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+                                                              const double* __restrict__ qp, const double* __restrict__ zero, double* __restrict__ ric_tmp,
+                                                              double* __restrict__ linv, double* __restrict__ vf0, int N, int P, int* __restrict__ status) {
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const size_t s0 = (size_t)b * N + k0;
+  riccati_backward<n>(ctx, w, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, qp + s0 * QP_SIZE, ric_tmp + s0 * RIC_SIZE, L,
+                      vf0 + (size_t)seg * VF_SIZE, zero, zero + n * n, false, 1.0, n, linv + s0 * LDB * LDB, 1);
+  if (threadIdx.x == 0 && !w.ok) atomicOr(&status[b], 2);
+}
+// 1b: the (A, b, C) part of the segment's element by prepending its stages; el: [B][P + 1][ScanEl<n>::SIZE]
+template <int n>
+__global__ __launch_bounds__(SEG_ACC_THREADS) void k_seg_accumulate(const double* __restrict__ qp, const double* __restrict__ ric_tmp, const double* __restrict__ linv,
+                                                                   const double* __restrict__ vf0, int N, int P, double* __restrict__ el) {
+  SegAccWS& w = *reinterpret_cast<SegAccWS*>(hsqp_smem);
+  const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const size_t s0 = (size_t)b * N + k0;
+  seg_accumulate<n>(ctx, w, qp + s0 * QP_SIZE, ric_tmp + s0 * RIC_SIZE, linv + s0 * LDB * LDB, L, vf0 + (size_t)seg * VF_SIZE,
+                    el + ((size_t)b * (P + 1) + p) * ScanEl<n>::SIZE);
+}
+// the terminal cost as element P of every instance
+template <int n>
+__global__ __launch_bounds__(256) void k_seg_terminal(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par, int N, int P,
+                                                      double* __restrict__ el) {
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  scan_terminal_element<n>(ctx, el + ((size_t)b * (P + 1) + P) * ScanEl<n>::SIZE, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP);
+}
+// 3: the gains of the segment's stages from the value function at its end (suffix element p + 1 of the scanned array)
+template <int n>
+__global__ __launch_bounds__(RIC_THREADS) void k_seg_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+                                                             const double* __restrict__ qp, const double* __restrict__ el, double* __restrict__ ric, int N, int P,
+                                                             int* __restrict__ status, double* __restrict__ vf, int vf_mode) {
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const size_t s0 = (size_t)b * N + k0;
+  const double* en = el + ((size_t)b * (P + 1) + p + 1) * ScanEl<n>::SIZE;
+  int mybad = 0;
+  for (int k = threadIdx.x; k < L; k += blockDim.x)
+    if (qp[(s0 + k) * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
+  const int bad = __syncthreads_or(mybad);
+  // vf: this segment writes the value functions of its nodes k0 .. k0 + L - 1 (vf_mode 0: all — the KKT report; 2: its first node and its last
+  // stage's node — what the gate's boundary stages need); the last segment also the terminal node
+  riccati_backward<n>(ctx, w, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, qp + s0 * QP_SIZE, ric + s0 * RIC_SIZE, L,
+                      vf ? vf + ((size_t)b * (N + 1) + k0) * VF_SIZE : nullptr, en + ScanEl<n>::J, en + ScanEl<n>::ETA, p == P - 1, -1.0, n, nullptr, vf_mode);
+  if (threadIdx.x == 0) { const int st = (bad ? 1 : 0) | (w.ok ? 0 : 2); if (st) atomicOr(&status[b], st); }
+}
+// 4: the roll-out alone (k_riccati runs it behind its backward sweep)
+template <int NXE>
+__global__ __launch_bounds__(RIC_THREADS) void k_ric_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+                                                             const double* __restrict__ ric, int N, double* __restrict__ dx) {
+  RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
+  const int b = blockIdx.x;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, qp + (size_t)b * N * QP_SIZE, ric + (size_t)b * N * RIC_SIZE, N,
+                       dx + (size_t)b * (N + 1) * NX);
+}
+
 // ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
 __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, const double* __restrict__ ric, const double* __restrict__ dx,
                                              const double* __restrict__ x, const double* __restrict__ u, int N, double alpha,
@@ -329,6 +397,37 @@ __global__ __launch_bounds__(256, 4) void k_kkt(const double* __restrict__ x_ini
   }
 }
 
+// ---- gate of the two-level sweep: the KKT residual of the LAST stage of every segment but the last one.  Inside a segment the gains come
+//      from an exact recursion started at the segment's end, so its stages are stationary up to rounding; what the scanned boundary value
+//      functions got wrong shows at stage k_p - 1, whose gains were derived from the scanned suffix p while its successor costate is the
+//      value function segment p's own recursion arrives at (vf: written by k_seg_riccati for exactly these nodes).  B (P - 1) workgroups
+//      instead of the B N of k_kkt (135 us at 32 x 100 nodes).
+__global__ __launch_bounds__(256, 4) void k_kkt_boundaries(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
+                                                        const double* __restrict__ vf, const double* __restrict__ dx, const double* __restrict__ ut, int N, int P,
+                                                        double* __restrict__ kkt, double* __restrict__ ginf) {
+  __shared__ KktWS w;
+  __shared__ double r2[2], gred[128];
+  const int b = blockIdx.x / (P - 1), p = 1 + blockIdx.x % (P - 1), k = seg_bound(p, N, P) - 1;
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const double* vfb = vf + (size_t)b * (N + 1) * VF_SIZE;
+  const double* dxb = dx + (size_t)b * (N + 1) * NX;
+  const size_t node = (size_t)b * N + k;
+  (void)x_init; (void)x;   // (k >= 1 here: the initial-condition residual belongs to stage 0, which is no boundary stage)
+  kkt_node(ctx, w, qp + node * QP_SIZE, vfb + (size_t)k * VF_SIZE, vfb + (size_t)(k + 1) * VF_SIZE, dxb + (size_t)k * NX, dxb + (size_t)(k + 1) * NX, ut + node * NUT, nullptr, r2);
+  if (threadIdx.x < 2) atomicMax(reinterpret_cast<unsigned long long*>(kkt + 2 * b + threadIdx.x), (unsigned long long)__double_as_longlong(r2[threadIdx.x]));
+  {
+    const double* q = qp + node * QP_SIZE;
+    const int i = threadIdx.x;
+    if (i < 128) gred[i] = i < NX ? fabs(q[QP_QV + i]) : (i < NX + NUT ? fabs(q[QP_RV + i - NX]) : 0.0);
+    __syncthreads();
+    if (i == 0) {
+      double m = 0.0;
+      for (int l = 0; l < 128; ++l) m = (gred[l] != gred[l]) ? HUGE_VAL : fmax(m, gred[l]);
+      atomicMax(reinterpret_cast<unsigned long long*>(ginf + b), (unsigned long long)__double_as_longlong(m));
+    }
+  }
+}
+
 // ---- per-node parameter table from the compact per-instance reference: one thread per (instance, node)
 __global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, hsqp_swing_config cfg, double terrain, int arm_swing, int max_events,
                                                const int* __restrict__ n_events, const double* __restrict__ ev, const int* __restrict__ seq, int n_knots,
@@ -446,6 +545,10 @@ struct hsqp_handle {
   double* h_gate = nullptr;       // pinned host copy of the gate block [kkt | |g|_inf | scan flags]
   long long scan_fallbacks = 0;   // iterations whose scan result failed the KKT gate and were redone with the serial recursion
   double* d_acl = nullptr;        // scan path: closed loop [B][N][ACL_SIZE] of every stage for the roll-out (allocated when the scan is first used)
+  // segmented sweep (allocated when first used): gains of the J = 0 recursions, (L^-1)^T of every stage, (J, s) at the segment starts, zeros
+  double *d_ric2 = nullptr, *d_linv = nullptr, *d_vf0 = nullptr, *d_zero = nullptr;
+  size_t vf0_capacity = 0;
+  int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected two-level sweep the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   int* d_scanst = nullptr;   // flags of the scan kernels (bad pivot, rank-deficient D, failed Lam) of the current attempt: part of the gate, behind d_ginf
@@ -539,6 +642,68 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
   return HSQP_OK;
 }
 
+// segment count of the two-level sweep for B instances on N intervals (0: not applicable).  OPT-IN (HSQP_FLAG_SEGMENTED_RICCATI): measured on
+// perturbed config-4 batches of 32 (tools/gpu_seg_fuzz.py) its step is 4e-11 .. 4e-10 of the step's scale (up to 7e-8 absolute) from the serial
+// recursion's — the combination of two long-segment elements solves with cond(I + C1 J2) ~ 1e9 — which is outside BASELINE.md §6's 1e-8 on
+// trajectories, so the default path never takes it; a caller that accepts the declared error asks for it.  P + 1 elements per instance go
+// through the suffix scan: P + 1 a power of two wastes no level, B (P + 1) <= 256 workgroups run a level in one round, and every level costs
+// accuracy, hence P <= 7 (B = 32: P = 7, three levels of 256 workgroups).
+static int segment_count(const hsqp_handle* h, int B, int N) {
+  if (!(h->st.flags & HSQP_FLAG_SEGMENTED_RICCATI)) return 0;
+  const int cap = std::min(std::min(256 / std::max(B, 1) - 1, N / 4), 7);
+  if (cap < 1) return 0;
+  int e = 2;
+  while (2 * e <= cap + 1) e *= 2;
+  return e - 1 >= 3 ? e - 1 : 0;   // 3 or 7 segments; fewer do not pay
+}
+
+// two-level sweep (hsqp_segment.h): segment elements, suffix scan over them, gains per segment, roll-out
+template <int n>
+static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
+  constexpr int SZ = ScanEl<n>::SIZE;
+  const size_t need = (size_t)B * (P + 1) * SZ;
+  if (need > h->el_capacity) {
+    for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
+    h->el_capacity = 0;
+    for (auto& p : h->d_el)
+      if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (segment elements)"; return HSQP_ERR_OOM; }
+    h->el_capacity = need;
+  }
+  const size_t BN = (size_t)h->st.max_batch * h->st.max_nodes;
+  if (!h->d_ric2 && hipMalloc(&h->d_ric2, BN * RIC_SIZE * 8) != hipSuccess) { h->d_ric2 = nullptr; h->err = "hipMalloc failed (segmented sweep: gains)"; return HSQP_ERR_OOM; }
+  if (!h->d_linv && hipMalloc(&h->d_linv, BN * LDB * LDB * 8) != hipSuccess) { h->d_linv = nullptr; h->err = "hipMalloc failed (segmented sweep: factors)"; return HSQP_ERR_OOM; }
+  if (!h->d_zero) {
+    if (hipMalloc(&h->d_zero, (NX * NX + NX) * 8) != hipSuccess) { h->d_zero = nullptr; h->err = "hipMalloc failed"; return HSQP_ERR_OOM; }
+    if (hipMemsetAsync(h->d_zero, 0, (NX * NX + NX) * 8, h->stream) != hipSuccess) { h->err = "memset failed"; return HSQP_ERR_HIP; }
+  }
+  if ((size_t)B * P > h->vf0_capacity) {
+    if (h->d_vf0) (void)hipFree(h->d_vf0);
+    h->d_vf0 = nullptr; h->vf0_capacity = 0;
+    if (hipMalloc(&h->d_vf0, (size_t)B * P * VF_SIZE * 8) != hipSuccess) { h->d_vf0 = nullptr; h->err = "hipMalloc failed (segmented sweep: boundary value functions)"; return HSQP_ERR_OOM; }
+    h->vf0_capacity = (size_t)B * P;
+  }
+  if (!h->d_vf2) {   // (the gate needs the value functions of the boundary stages' nodes; want_vf: of every node, for the KKT report)
+    const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
+    if (hipMalloc(&h->d_vf2, bytes) != hipSuccess) { h->d_vf2 = nullptr; h->err = "hipMalloc failed (value functions of the segmented sweep, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+  }
+  const int segs = B * P;
+  hipLaunchKernelGGL(k_seg_elem_ric<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_zero, h->d_ric2,
+                     h->d_linv, h->d_vf0, N, P, h->d_scanst);
+  hipLaunchKernelGGL(k_seg_accumulate<n>, dim3(segs), dim3(SEG_ACC_THREADS), sizeof(SegAccWS), h->stream, (const double*)h->d_qp, (const double*)h->d_ric2,
+                     (const double*)h->d_linv, (const double*)h->d_vf0, N, P, h->d_el[0]);
+  hipLaunchKernelGGL(k_seg_terminal<n>, dim3(B), dim3(256), 0, h->stream, h->d_dm, h->d_x, h->d_par, N, P, h->d_el[0]);
+  int cur = 0;
+  for (int d = 1; d < P + 1; d *= 2) {
+    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (P + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], P, d, h->d_scanst,
+                       (long long*)nullptr);
+    cur = 1 - cur;
+  }
+  hipLaunchKernelGGL(k_seg_riccati<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_el[cur], h->d_ric, N, P,
+                     h->d_scanst, h->d_vf2, want_vf ? 0 : 2);
+  hipLaunchKernelGGL(k_ric_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_ric, N, h->d_dx);
+  return HSQP_OK;
+}
+
 extern "C" {
 
 const char* hsqp_version(void) { return "hsqp-hip 0.2 (gfx950, f64)"; }
@@ -558,7 +723,7 @@ void hsqp_destroy(hsqp_handle* h) {
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
                   h->d_unew, h->d_misc, h->d_kkt, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
-                  h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl};
+                  h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl, h->d_ric2, h->d_linv, h->d_vf0, h->d_zero};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (h->h_gate) (void)hipHostFree(h->h_gate);
@@ -599,6 +764,10 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (settings->max_nodes < 1 || settings->max_batch < 1) { g_create_error = "max_nodes and max_batch must be >= 1"; return HSQP_ERR_BAD_ARG; }
   if ((settings->flags & HSQP_FLAG_PARALLEL_RICCATI) && (settings->flags & HSQP_FLAG_SERIAL_RICCATI)) {
     g_create_error = "HSQP_FLAG_PARALLEL_RICCATI excludes HSQP_FLAG_SERIAL_RICCATI";
+    return HSQP_ERR_BAD_ARG;
+  }
+  if ((settings->flags & HSQP_FLAG_SEGMENTED_RICCATI) && (settings->flags & (HSQP_FLAG_PARALLEL_RICCATI | HSQP_FLAG_SERIAL_RICCATI))) {
+    g_create_error = "HSQP_FLAG_SEGMENTED_RICCATI excludes HSQP_FLAG_PARALLEL_RICCATI and HSQP_FLAG_SERIAL_RICCATI";
     return HSQP_ERR_BAD_ARG;
   }
   int ndev = 0;
@@ -650,6 +819,11 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_combine<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanCombWS<NX>));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_gains<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_forward<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  for (const void* f : {(const void*)k_seg_elem_ric<NX>, (const void*)k_seg_elem_ric<CNX>, (const void*)k_seg_riccati<NX>, (const void*)k_seg_riccati<CNX>,
+                        (const void*)k_ric_forward<NX>, (const void*)k_ric_forward<CNX>})
+    if (a5 == hipSuccess) a5 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  for (const void* f : {(const void*)k_seg_accumulate<NX>, (const void*)k_seg_accumulate<CNX>})
+    if (a5 == hipSuccess) a5 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SegAccWS));
   if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess || a5 != hipSuccess) return fail(HSQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   *out = h;
   g_create_error.clear();
@@ -834,10 +1008,18 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // feasible line-search iterate it can lose five digits.  Its result is therefore GATED: the KKT residual of the QP is evaluated
     // (k_kkt, one small kernel + one 3 B-double read-back) and, if a residual exceeds the gate (scan_gate_accepts, hsqp_scan.h), the
     // iteration is redone with the serial recursion (hsqp_scan_fallbacks counts these).
-    const bool scan = !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    // > 0: the two-level sweep with segP segments per instance (hsqp_segment.h; opt-in).  A problem class whose sweeps keep failing the gate
+    // (badly scaled QPs: |S| ~ 1e6 on perturbed centroidal batches) would pay sweep + fallback every iteration: after a rejection the handle
+    // backs off to the serial recursion for 1, 3, 7, .. 63 iterations before it tries again
+    int segP = segment_count(h, B, N);
+    if (segP > 0 && h->seg_backoff > 0) { --h->seg_backoff; segP = 0; }
+    const bool pscan = segP == 0 && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) &&
+                       ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    const bool scan = pscan || segP > 0;        // either way a KKT-gated sweep with the serial recursion as fallback
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
     auto launch_sweep = [&](bool use_scan, bool need_vf) -> int {
+      if (use_scan && segP > 0) return cent ? launch_segmented<CNX>(h, B, N, segP, want_kkt != 0) : launch_segmented<NX>(h, B, N, segP, want_kkt != 0);
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
         hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
@@ -865,7 +1047,10 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (last) HCHECK(hipEventRecord(h->ev[3], h->stream));   // kernel_ms buckets: {lq, project, riccati (backward + forward sweep), step + value pass + reductions}
     launch_step();
     if (scan) {   // the gate's inputs: KKT residuals, |g|_inf and the scan kernels' flags travel to pinned host memory while the kernels below run
-      { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
+      // (two-level sweep: the gate block holds its boundary-consistency numbers instead — no KKT kernel; the KKT report, if asked for, follows the verdict)
+      if (segP == 0) { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
+      else hipLaunchKernelGGL(k_kkt_boundaries, dim3(B * (segP - 1)), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_vf2, h->d_dx, h->d_ut, N, segP,
+                              h->d_kkt, h->d_ginf);
       HCHECK(hipMemcpyAsync(h->h_gate, h->d_kkt, gate_bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (want_kkt) {
       const int rc = launch_kkt(false);
@@ -892,6 +1077,19 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       for (int b = 0; b < B; ++b) {
         // (a flag = a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported in d_status)
         if (!scan_gate_accepts(hk[2 * b], hk[2 * b + 1], hk[2 * Bm + b], flags[b])) accept = false;
+      }
+      if (getenv("HSQP_SEG_DEBUG") && segP > 0) {
+        double m0 = 0, m1 = 0, m2 = 0; int fl = 0;
+        for (int b = 0; b < B; ++b) { m0 = fmax(m0, hk[2 * b]); m1 = fmax(m1, hk[2 * b + 1]); m2 = fmax(m2, hk[2 * Bm + b]); fl |= flags[b]; }
+        fprintf(stderr, "[hsqp seg gate] P=%d boundary-stage KKT stat %.3e prim %.3e |g| %.3e flags %d accept %d\n", segP, m0, m1, m2, fl, (int)accept);
+      }
+      if (accept && segP > 0 && want_kkt) {   // the KKT report of an accepted two-level sweep (the gate block is reused: zero it first)
+        HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));
+        hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf2, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+      }
+      if (segP > 0) {
+        if (accept) h->seg_backoff_len = 0;
+        else { h->seg_backoff_len = std::min(2 * h->seg_backoff_len + 1, 63); h->seg_backoff = h->seg_backoff_len; }
       }
       if (!accept) {
         ++h->scan_fallbacks;

@@ -80,7 +80,10 @@ constexpr int VF_SIZE = NX * NX + NX;
 template <int NXE = NX>
 HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const double* xN, const double* parN, const double* qp,
                               double* ric, int N, double* vf = nullptr, const double* termS = nullptr, const double* terms = nullptr,
-                              bool vf_terminal = true, double terms_sign = 1.0, int term_ld = NXE) {
+                              bool vf_terminal = true, double terms_sign = 1.0, int term_ld = NXE,
+                              double* linv_out = nullptr /* optional [N][LDB * LDB]: (L^-1)^T of every stage (segmented sweep, hsqp_segment.h) */,
+                              int vf_mode = 0 /* which nodes vf receives: 0 every node k (vf[k]); 1 node 0 only; 2 node 0 and the last stage's node N - 1
+                                                 (the two-level sweep's gate evaluates the KKT residual of the stages at the segment boundaries only) */) {
   WG_FOR(ctx, i, NX * NX + NX + 1) {
     if (i < NX * NX) {
       const int r = i / NX, c = i % NX;
@@ -267,6 +270,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           for (int l = 0; l < NUT; ++l) s += w.fac.Ef[r][EF_MI + l] * ((w.Em[l][EM_GVP] + w.Em[l][EM_GVP + 1]) + (w.Em[l][EM_GVP + 2] + w.Em[l][EM_GVP + 3]));
           w.zv[r] = s;
         }
+        if (linv_out) WG_FOR(hc, i, LDB * LDB) linv_out[(size_t)k * LDB * LDB + i] = w.fac.LinvT[i / LDB][i % LDB];
       }
     }
     WG_SYNC(ctx);
@@ -333,7 +337,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     PH_TICK(ctx, 5);
     // (no P6: the symmetric tile job writes the diagonal tiles of S symmetric itself — upper triangle computed, mirrored —, s stays
     //  in its four partial sums until the next stage's P2 adds them, b~ is double-buffered)
-    if (vf) {
+    if (vf && (vf_mode == 0 || k == 0 || (vf_mode == 2 && k == N - 1))) {
       WG_FOR(ctx, i, VF_SIZE) {
         const double* sp = &w.part[4 * (i >= NX * NX ? i - NX * NX : 0)];
         vf[(size_t)k * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : (sp[0] + sp[1]) + (sp[2] + sp[3]);

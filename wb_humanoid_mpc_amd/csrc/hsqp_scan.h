@@ -285,21 +285,25 @@ struct ScanInitWS {
   GjWS gj;
 };
 
-// q: QP record of the stage (hsqp_project.h), el: element out.  terminal: the element of the terminal cost 1/2 x'diag(Qf)x + qN'x.
+// the element of the terminal cost 1/2 x'diag(Qf)x + qN'x
+template <int n>
+HSQP_HD void scan_terminal_element(const Ctx& ctx, double* el, const double* Qf, const double* xN, const double* parN) {
+  using E = ScanEl<n>;
+  WG_FOR(ctx, i, E::SIZE) {
+    double v = 0.0;
+    if (i >= E::J && i < E::J + n * n) { const int r = (i - E::J) / n, c = (i - E::J) % n; v = r == c ? Qf[r] : 0.0; }
+    else if (i >= E::ETA && i < E::ETA + n) { const int r = i - E::ETA; v = -Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]); }
+    el[i] = v;
+  }
+  WG_SYNC(ctx);
+}
+
+// q: QP record of the stage (hsqp_project.h), el: element out.  terminal: the element of the terminal cost instead.
 template <int n>
 HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, double* el, bool terminal, const double* Qf, const double* xN,
                             const double* parN) {
   using E = ScanEl<n>;
-  if (terminal) {
-    WG_FOR(ctx, i, E::SIZE) {
-      double v = 0.0;
-      if (i >= E::J && i < E::J + n * n) { const int r = (i - E::J) / n, c = (i - E::J) % n; v = r == c ? Qf[r] : 0.0; }
-      else if (i >= E::ETA && i < E::ETA + n) { const int r = i - E::ETA; v = -Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]); }
-      el[i] = v;
-    }
-    WG_SYNC(ctx);
-    return;
-  }
+  if (terminal) { scan_terminal_element<n>(ctx, el, Qf, xN, parN); return; }
   constexpr int LG = 2 * NUT + 2;
   WG_FOR(ctx, i, NUT * LG + 2 * NUT * (n + 1) + NUT) {
     if (i < NUT * LG) {

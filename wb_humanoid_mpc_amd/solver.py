@@ -74,11 +74,12 @@ def _c(a):
 class HipSqpSolver:
     def __init__(self, model, max_nodes, max_batch=1, device=0, linesearch=False, riccati="auto"):
         """linesearch=True: run() uses the filter line search (ocs2 SqpSolver behaviour) instead of the full step.
-        riccati: "auto" (serial recursion; KKT-gated parallel-in-time scan for <= 2 instances on >= 48 nodes),
-        "serial", "parallel"."""
+        riccati: "auto" (serial recursion; KKT-gated parallel-in-time scan for <= 2 instances on >= 48 nodes), "serial", "parallel" (the scan
+        for every size), "segmented" (the KKT-gated two-level sweep of hsqp_segment.h for mid-sized batches: faster, but a declared
+        relaxation — its step is up to 4e-10 of the step's scale from the serial recursion's)."""
         self.lib = load_library()
         self.model = model
-        flags = (_abi.FLAG_LINESEARCH if linesearch else 0) | {"auto": 0, "serial": _abi.FLAG_SERIAL_RICCATI, "parallel": _abi.FLAG_PARALLEL_RICCATI}[riccati]
+        flags = (_abi.FLAG_LINESEARCH if linesearch else 0) | {"auto": 0, "serial": _abi.FLAG_SERIAL_RICCATI, "parallel": _abi.FLAG_PARALLEL_RICCATI, "segmented": _abi.FLAG_SEGMENTED_RICCATI}[riccati]
         st = _abi.Settings(max_nodes=max_nodes, max_batch=max_batch, device=device, flags=flags)
         h = C.c_void_p()
         rc = self.lib.hsqp_create(C.byref(model.desc), C.byref(st), C.byref(h))
