@@ -34,8 +34,8 @@ for k in range(4):
     for i in range(126):
         if t[k, i]:
             print(f"   phase {i:3d}: {t[k, i] / iters:12.0f} ticks  {100.0 * t[k, i] / tot:5.1f}%")
-    if k == 2 and t[k, 40:112].any():   # k_riccati: per-wave arrival at the barriers ending P2, P3, P5 (ticks per launch)
-        for slot, name in enumerate(("P2", "P3", "P5")):
+    if k == 2 and t[k, 40:112].any():   # k_riccati: per-wave arrival at the barriers ending Ph1, Ph2, Ph4, Ph3 (ticks per launch)
+        for slot, name in enumerate(("Ph1", "Ph2", "Ph4", "Ph3")):
             print(f"   {name} arrival per wave:", [int(v / iters) for v in t[k, 40 + 8 * slot:48 + 8 * slot]])
     if t[k, 93]:   # wave 0: tile-job calls split into prologue / matrix loop / epilogue
         n, nm = t[k, 93] / iters, t[k, 94] / iters

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(SCAN_FWD_THREADS) void k_scan_forward(const double*
 constexpr int SEG_ACC_THREADS = 512;
 // 1a: Riccati recursion over the segment from J = 0, eta = 0 (zero: n x n + n zeros): gains and (L^-1)^T of every stage, (J, s) at its first node
 template <int n>
-__global__ __launch_bounds__(RIC_THREADS) void k_seg_elem_ric(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+__global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_elem_ric(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
                                                               const double* __restrict__ qp, const double* __restrict__ zero, double* __restrict__ ric_tmp,
                                                               double* __restrict__ linv, double* __restrict__ vf0, int N, int P, int* __restrict__ status) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_seg_terminal(const DevModel* __restrict
 }
 // 3: the gains of the segment's stages from the value function at its end (suffix element p + 1 of the scanned array)
 template <int n>
-__global__ __launch_bounds__(RIC_THREADS) void k_seg_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+__global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
                                                              const double* __restrict__ qp, const double* __restrict__ el, double* __restrict__ ric, int N, int P,
                                                              int* __restrict__ status, double* __restrict__ vf, int vf_mode) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);

@@ -148,6 +148,7 @@ struct XtyJob {
   double* C; int ldc;             // destination (LDS or global)
   int sx1, sx2;                   // element stride of X along the output-row index (1 = row-major X[l][r]; ld = 1, sx = ld' reads X'[r][l])
   int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
+  double* C2; int ldc2;           // optional second destination in GLOBAL memory (device tile path; the host build copies it from C)
 };
 
 HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, double* C, int ldc,
@@ -155,9 +156,12 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0;
   return j;
 }
+
+HSQP_HD XtyJob xty_sym(XtyJob j) { j.sym = 1; return j; }
+HSQP_HD XtyJob xty_also_to(XtyJob j, double* C2, int ldc2) { j.C2 = C2; j.ldc2 = ldc2; return j; }
 
 #if defined(HSQP_PHASE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define XTY_PROF_T(name) const long long name = clock64()
@@ -188,7 +192,7 @@ typedef double __attribute__((address_space(1))) * hsqp_gptr;
 // GLOBAL memory -> address-space-qualified accesses.  A generic pointer compiles to FLAT instructions, whose loads also
 // count on lgkmcnt and make the LDS operand waits of the MFMA loop wait for the L2/HBM round trip.
 template <int NT, int SPACES>
-HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long long* prof = nullptr) {
+__attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long long* prof = nullptr) {
   XTY_PROF_T(t_begin);
   const int tn = (j.N + 15) >> 4;
   const int i = lane & 15, kk = lane >> 4;
@@ -273,6 +277,7 @@ HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long
           j.C[o1 + 4 * r * j.ldc] = v[r];
           if (mirror || diag) j.C[o2 + 4 * r] = v[r];
         }
+        if (j.C2) ((hsqp_gptr)j.C2)[(rb + 4 * r) * j.ldc2 + c] = v[r];
       };
       if (r0[t] + 16 <= j.M) {
 #pragma unroll
@@ -319,20 +324,23 @@ HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane
 // take part); a wave takes its tiles of a job two at a time.  Lets a phase spread its matrix work over all the waves that have
 // nothing else on its critical path (k_riccati: the helper waves take tiles after their copies, seven waves form S A~ while the
 // eighth eliminates).
+// one job of a dealt list: g0 = number of tiles of the jobs before it; returns its own tile count
+template <int SPACES = 0>
+__attribute__((always_inline)) HSQP_D int xty_deal_one(const XtyJob& j, int g0, int rank, int W, int lane, long long* prof = nullptr) {
+  const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
+  const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
+  if (rank < 0) return nt;
+  int t = rank - g0 % W;
+  if (t < 0) t += W;
+  for (; t + W < nt; t += 2 * W) { const int pair[2] = {xty_tile_id(j.sym, tn, t), xty_tile_id(j.sym, tn, t + W)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane, prof); }
+  if (t < nt) { const int one = xty_tile_id(j.sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane, prof); }
+  return nt;
+}
 template <int SPACES = 0>
 HSQP_D void xty_deal(const XtyJob* jobs, int njobs, int rank, int W, int lane) {
   if (rank < 0) return;
   int g0 = 0;
-  for (int jn = 0; jn < njobs; ++jn) {
-    const XtyJob& j = jobs[jn];
-    const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
-    const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
-    int t = rank - g0 % W;
-    if (t < 0) t += W;
-    for (; t + W < nt; t += 2 * W) { const int pair[2] = {xty_tile_id(j.sym, tn, t), xty_tile_id(j.sym, tn, t + W)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane); }
-    if (t < nt) { const int one = xty_tile_id(j.sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane); }
-    g0 += nt;
-  }
+  for (int jn = 0; jn < njobs; ++jn) g0 += xty_deal_one<SPACES>(jobs[jn], g0, rank, W, lane);
 }
 #endif
 
@@ -387,6 +395,7 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
         if (j.Add) v += j.Add[r * j.ldadd + c];
         j.C[r * j.ldc + c] = v;
         if (j.sym && c != r) j.C[c * j.ldc + r] = v;
+        if (j.C2) j.C2[r * j.ldc2 + c] = v;
       }
   }
 #endif

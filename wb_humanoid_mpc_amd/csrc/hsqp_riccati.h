@@ -1,14 +1,18 @@
 // Riccati recursion of the projected, equality-free stage QP (the reference solves
 // the same QP with HPIPM through ocs2's HpipmInterface — the minimiser is unique, A.1).
 //
-// Backward sweep, one workgroup per MPC instance, stage matrices in LDS:
-//   SB = S+ B~, sb = s+ + S+ b~
-//   [Lam | G | g] = [R~ + B~^T SB | P~ + SB^T A~ | r~ + B~^T sb]                                (G from SB: S+ is symmetric)
-//   SA = S+ A~ is only needed by the update of S, so it is formed by the otherwise idle waves WHILE one wave eliminates [Lam | I]
-//   Gauss-Jordan elimination of [Lam | I] on unscaled rows (one wave, in registers) -> L^-1, L^-T by row scaling;  Z = L^-1 G, z = L^-1 g
-//   S = Q~ + A~^T SA - Z^T Z,  s = q~ + A~^T sb - Z^T z          (= Q + A^T S A - G^T Lam^-1 G)
-//   K = -Lam^-1 G,  k = -Lam^-1 g
-// so no triangular back-substitution sits on the serial critical path.  The forward sweep is the mat-vec chain
+// Backward sweep, one workgroup (eight waves, FOUR matrix pipes) per MPC instance, stage matrices in LDS, four phases per stage:
+//   Ph1  [SB | S b~] = S+ [B~ | b~]                                      (8 tiles over the eight waves; b~ rides as the 24th column of B~)
+//   Ph2  G = P~ + SB^T A~,  Lam = R~ + B~^T SB,  sb = s+ + S+ b~,  g = r~ + B~^T sb                                    (12 tiles)
+//   Ph3  Gauss-Jordan elimination of [Lam | I | G | g] on unscaled rows in registers, lane = column, by TWO waves (Lam duplicated in
+//        both): with the Cholesky scaling D^-1/2 applied on the way out it leaves L^-1, Z = L^-1 G and z = L^-1 g at once.  The matrix
+//        pipes are idle during it, so the other six waves form what the S-update needs but the factorisation does not:
+//        SA = S+ A~ (16 tiles), one barrier in the middle of the elimination, W = Q~ + A~^T SA (10 symmetric tiles, into S)
+//   Ph4  S = W - Z^T Z,  s = q~ + A~^T sb - Z^T z,  K = -L^-T Z,  k = -L^-T z          (= Q + A^T S A - G^T Lam^-1 G; 18 short tiles)
+// so the serial critical path of a stage is 300 matrix instructions of 58-deep tiles, the elimination and 108 of 23-deep tiles; no
+// triangular back-substitution and no product with L^-1 sits on it, and 390 of the stage's 846 matrix instructions run under the
+// elimination (round 2's form had seven phases: SB | G, Lam | elimination of [Lam | I]
+// under S A~ | scaling | Z = L^-1 G | K | S-update with both contractions).  The forward sweep is the mat-vec chain
 //   dx+ = A~ dx + B~ (K dx + k) + b~   (A~ dx and K dx in one phase, then the 23-term B~ ut rows);
 // the closed-loop matrix A~ + B~ K is never formed: it is not needed by the backward recursion, and forming it there put
 // 96 matrix instructions and four tile calls per stage on the serial path.  The feed-forward/feedback inputs
@@ -24,48 +28,168 @@ namespace hsqp {
 constexpr int RIC_K = 0;                       // [23][58] feedback gain  K = -Lam^-1 G
 constexpr int RIC_KV = RIC_K + NUT * NX;       // [23]     feed-forward   k = -Lam^-1 g
 constexpr int RIC_SIZE = ((RIC_KV + NUT + 7) / 8) * 8;
-constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices
+constexpr int LDB = 24;                        // leading dimension of the 23-wide LDS matrices; column 23 of B carries b~ (and of SB: S b~)
+static_assert(LDB == NUT + 1, "b~ is the 24th column of the B~ workspace");
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
-constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: partial sums of g
+constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: g (host build: four partial sums, device: the sum in column 0)
 
 constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
-  double S[NX][NX];                            // alive through the whole stage: S A~ is formed during the factorisation
+  double S[NX][NX];                            // value function; Ph2 overwrites it with W = Q~ + A~^T S A~ (S is dead after Ph1)
   struct {                                     // scratch of the factorisation
-    double Ef[LDB][LDF];                       // [Lam | 0 | I] -> [U-ish | . | unit-lower inverse] -> columns 24.. scaled to L^-1
+    double Ef[LDB][LDF];                       // [Lam | . | L^-1]  (host build: [Lam | 0 | I] -> ... -> columns 24.. scaled to L^-1)
     double LinvT[LDB][LDB];                    // (L^-1)^T
   } fac;
   double A2[2][NX][NX], SA[NX][NX];            // A2: double-buffered A~ (stage k uses A2[k & 1])
-  double B[NX][LDB];
+  double B[NX][LDB];                           // [B~ | b~]
   union {
-    double SB[NX][LDB];
-    double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam is formed)
+    double SB[NX][LDB];                        // [S B~ | S b~]
+    double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam, G and sb are formed)
   };
-  double Em[NUT][LDE];                         // [g partials (4) . | G -> K | .]
-  double sv[NX], sb[NX], bt2[2][NX], dx[NX], zv[LDB], kv[LDB];   // bt2: b~ of stage k in bt2[k & 1] (the next stage's is prefetched into the other)
+  double Em[NUT][LDE];                         // [g . | G -> K | .]
+  double sv[NX], sb[NX], dx[NX], zv[LDB], kv[LDB];
   double part[NX * 4];                         // four partial sums per row: of the new s (backward sweep), of A~ dx (forward sweep)
   int ok;
 };
 
 static_assert(sizeof(RicWS) <= 163400, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) accepts 163 400 bytes on gfx950 and rejects 163 592");
 
-// The matrix products of one phase of the sweep.  In the 512-thread kernels every wave from `first_wave` on takes tiles (dealt
-// round-robin; a wave with copies / vector work in the same phase calls this AFTER that work); any other context (host build,
-// smaller workgroups) runs them on its matrix half as before.
-// waves [first_wave, first_wave + n_waves) take the tiles; n_waves = 0: the matrix half as before
+// The matrix products of one phase of the sweep.  In the 512-thread kernels the waves [first_wave, first_wave + n_waves) take the tiles
+// (dealt round-robin; a wave with copies / vector work in the same phase calls this AFTER that work); any other context (host build,
+// smaller workgroups) runs them on its matrix half.
 // SPACES = XTY_ADD_GLOBAL: the additive terms of the jobs are in global memory (the QP record) -> global instead of flat loads, which
 // would also count on lgkmcnt and hold up the LDS operand waits of the matrix loop
+// (the jobs are separate by-value arguments, not an array or pointers: a descriptor whose address is taken lives in scratch memory on the
+//  device and its tile loops stay generic)
+HSQP_HD XtyJob xty_no_job() { XtyJob j = xty_job(0, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0); return j; }
+#ifndef PROF_WAVE
+#define PROF_WAVE 2     // -DHSQP_PHASE_PROFILE builds: the wave whose tile calls are split into prologue / matrix loop / epilogue ticks
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// the tiles of one job over `W` waves chosen by the caller (rank < 0: this wave takes none)
 template <int SPACES = 0>
-HSQP_HD void ric_products(const Ctx& ctx, const XtyJob* jobs, int njobs, int first_wave = 0, int n_waves = 0) {
+HSQP_D void ric_products_ranked(const Ctx& ctx, int rank, int W, const XtyJob j0) {
+  if (rank < 0) return;
+#if defined(HSQP_PHASE_PROFILE)
+  long long* prof = (ctx.tid >> 6) == PROF_WAVE ? ctx.prof : nullptr;
+#else
+  long long* prof = nullptr;
+#endif
+  xty_deal_one<SPACES>(j0, 0, rank, W, ctx.tid & 63, prof);
+}
+#endif
+template <int SPACES = 0, int NJ = 1>
+HSQP_HD void ric_products(const Ctx& ctx, int first_wave, int n_waves, const XtyJob j0, const XtyJob j1 = xty_no_job(), const XtyJob j2 = xty_no_job()) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads == 512 && n_waves > 0) {
-    const int r = (ctx.tid >> 6) - first_wave;
-    xty_deal<SPACES>(jobs, njobs, r < n_waves ? r : -1, n_waves, ctx.tid & 63);
+    const int r0 = (ctx.tid >> 6) - first_wave, r = r0 < n_waves ? r0 : -1, lane = ctx.tid & 63;
+    if (r < 0) return;
+#if defined(HSQP_PHASE_PROFILE)
+    long long* prof = (ctx.tid >> 6) == PROF_WAVE ? ctx.prof : nullptr;
+#else
+    long long* prof = nullptr;
+#endif
+    int g0 = xty_deal_one<SPACES>(j0, 0, r, n_waves, lane, prof);
+    if constexpr (NJ > 1) g0 += xty_deal_one<SPACES>(j1, g0, r, n_waves, lane, prof);
+    if constexpr (NJ > 2) xty_deal_one<SPACES>(j2, g0, r, n_waves, lane, prof);
     return;
   }
 #endif
-  if (is_mfma_half(ctx)) wg_xty_jobs<false, SPACES>(mfma_ctx(ctx), jobs, njobs);
+  if (is_mfma_half(ctx)) {
+    const Ctx mc = mfma_ctx(ctx);
+    wg_xty_jobs<false, SPACES>(mc, &j0, 1);
+    if constexpr (NJ > 1) wg_xty_jobs<false, SPACES>(mc, &j1, 1);
+    if constexpr (NJ > 2) wg_xty_jobs<false, SPACES>(mc, &j2, 1);
+  }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void* hsqp_ldsptr;
+// Ph3 on the device: the whole elimination of [Lam | I | G | g] inside two waves, no barrier and no LDS traffic per step.  A lane holds one
+// column (23 registers).  Both waves carry the 23 columns of Lam in their lanes 0 .. 22 (the multipliers of a step come from them: row j
+// of the symmetric upper part, lane i = the multiplier of row i), so the waves never talk to each other.  Wave 0: lanes 23 .. 45 the
+// columns of I, 46 .. 63 the columns 0 .. 17 of G; wave 1: lanes 23 .. 23 + NXE - 19 the columns 18 .. NXE - 1 of G, lane 63 g.  The pivot
+// of step j and the multipliers come through v_readlane with compile-time lane numbers.  On the way out every row i is scaled with
+// d_i^-1/2 (Cholesky scaling of the unit-lower inverse), which turns the eliminated blocks into L^-1, Z = L^-1 G and z = L^-1 g.
+constexpr int ELIM_G0 = 64 - 2 * NUT;          // columns of G in wave 0 (18)
+constexpr int ELIM_SPLIT = 8;                  // steps before the mid-phase barrier (58 % of the row updates: S A~ finishes about then)
+struct ElimLane { bool isLam, isI, isG, isg; int gcol; };
+template <int NXE>
+HSQP_D ElimLane elim_lane(int wave, int lane) {
+  static_assert(NXE - ELIM_G0 <= 64 - NUT - 1, "the remaining columns of G and g fit the second wave");
+  ElimLane l;
+  l.isLam = lane < NUT;
+  l.isI = wave == 0 && lane >= NUT && lane < 2 * NUT;
+  l.gcol = wave == 0 ? lane - 2 * NUT : ELIM_G0 + lane - NUT;
+  l.isG = !l.isLam && !l.isI && (wave == 0 ? true : (l.gcol < NXE));
+  l.isg = wave == 1 && lane == 63;
+  return l;
+}
+// first part: the lane's column -> registers, steps [0, ELIM_SPLIT)
+// a_next / a_dst (a_next != nullptr): the eliminating waves also start the copy of the next stage's A~ into the other LDS buffer —
+// asynchronous 16-byte copies straight into LDS (no staging registers, no store pass): the LDS image of A~ is the record's [58][58]
+// block byte for byte; a wave instruction moves 64 x 16 B to (wave-uniform base) + lane x 16.  The compiler makes a wave wait for its
+// copies before that wave's next LDS access; these two waves have none until the mid-phase barrier (every other wave reads LDS all the time).
+template <int NXE>
+HSQP_D void eliminate_begin(const RicWS& w, int wave, int lane, double (&e)[NUT], const double* a_next, double* a_dst) {
+  const ElimLane l = elim_lane<NXE>(wave, lane);
+  const double* src = l.isLam ? &w.fac.Ef[0][lane] : (l.isg ? &w.Em[0][EM_GVP] : (l.isG ? &w.Em[0][EM_G + l.gcol] : &w.fac.Ef[0][0]));
+  const int stride = (l.isLam || !(l.isG || l.isg)) ? LDF : LDE;
+#pragma unroll
+  for (int i = 0; i < NUT; ++i) {
+    const double v = src[i * stride];
+    e[i] = l.isI ? (i == lane - NUT ? 1.0 : 0.0) : v;
+  }
+  if (a_next) {
+    constexpr int NCH = NX * NX / 2;                         // 16-byte chunks
+    static_assert((NX * NX) % 2 == 0 && QP_A % 2 == 0 && QP_SIZE % 2 == 0, "16-byte alignment of A~ in the record");
+#pragma unroll
+    for (int t = 0; t < (NCH + 127) / 128; ++t) {
+      const int c0 = (t * 2 + wave) * 64;                    // first chunk of this wave instruction
+      if (c0 + lane < NCH) __builtin_amdgcn_global_load_lds((hsqp_gcptr)a_next + 2 * (c0 + lane), (hsqp_ldsptr)(a_dst + 2 * c0), 16, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ELIM_SPLIT; ++j) {
+    const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));   // lane i: the multiplier of row i (one multiply per step, not per row)
+#pragma unroll
+    for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
+  }
+}
+// second part: the remaining steps, then every row i scaled with d_i^-1/2 on its way to LDS
+template <int NXE>
+HSQP_D void eliminate_end(RicWS& w, int wave, int lane, double (&e)[NUT]) {
+  const ElimLane l = elim_lane<NXE>(wave, lane);
+#pragma unroll
+  for (int j = ELIM_SPLIT; j < NUT - 1; ++j) {
+    const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));
+#pragma unroll
+    for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
+  }
+  // pivots: d_i sits in lane i (row i of column i is final after step i - 1)
+  double dv = 1.0;
+#pragma unroll
+  for (int i = 0; i < NUT; ++i) dv = lane == i ? e[i] : dv;
+  const bool bad = l.isLam && !(dv > 0.0);
+  if (bad) dv = 1.0;
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && wave == 0 && lane == 0) w.ok = 0;
+  const double rs = inv_sqrt(dv);
+  const int ic = lane - NUT;
+#pragma unroll
+  for (int i = 0; i < NUT; ++i) {
+    const double v = e[i] * readlane_f64(rs, i);
+    if (l.isI) {
+      const double vv = ic <= i ? v : 0.0;
+      w.fac.Ef[i][EF_MI + ic] = vv;
+      w.fac.LinvT[ic][i] = vv;
+    } else if (l.isg) {
+      w.zv[i] = v;
+    } else if (l.isG) {
+      w.Zs[i][l.gcol] = v;
+    }
+  }
+}
+#endif
 
 // qp: [N][QP_SIZE] of this instance, ric: [N][RIC_SIZE].  w.ok reports whether every Lam was positive definite.
 // vf (optional, [N+1][VF_SIZE]): the value function S_k, s_k of every node, for the KKT check (lam_k = S_k dx_k + s_k).
@@ -84,7 +208,12 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
                               double* linv_out = nullptr /* optional [N][LDB * LDB]: (L^-1)^T of every stage (segmented sweep, hsqp_segment.h) */,
                               int vf_mode = 0 /* which nodes vf receives: 0 every node k (vf[k]); 1 node 0 only; 2 node 0 and the last stage's node N - 1
                                                  (the two-level sweep's gate evaluates the KKT residual of the stages at the segment boundaries only) */) {
-  WG_FOR(ctx, i, NX * NX + NX + 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool dev512 = ctx.nthreads == 512;     // the kernels' shape: tiles over all eight waves, two-wave elimination, direct global -> LDS copies
+#else
+  const bool dev512 = false;
+#endif
+  WG_FOR(ctx, i, NX * NX + NX + 1 + LDB * LDB) {
     if (i < NX * NX) {
       const int r = i / NX, c = i % NX;
       w.S[r][c] = termS ? ((r < NXE && c < NXE) ? termS[r * term_ld + c] : 0.0) : (r == c ? Qf[r] : 0.0);
@@ -92,9 +221,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const int r = i - NX * NX;
       const double sr = termS ? (r < NXE ? terms_sign * terms[r] : 0.0) : Qf[r] * (xN[r] - parN[HSQP_P_XDES + r]);
       w.sv[r] = sr;
-      w.part[4 * r] = sr; w.part[4 * r + 1] = 0.0; w.part[4 * r + 2] = 0.0; w.part[4 * r + 3] = 0.0;   // s travels as four partial sums (P5 -> P2)
+      w.part[4 * r] = sr; w.part[4 * r + 1] = 0.0; w.part[4 * r + 2] = 0.0; w.part[4 * r + 3] = 0.0;   // s travels as four partial sums (Ph4 -> Ph1)
     }
-    else w.ok = 1;
+    else if (i == NX * NX + NX) w.ok = 1;
+    else { const int t = i - NX * NX - NX - 1; w.fac.LinvT[t / LDB][t % LDB] = 0.0; }   // (its padding row / column is never written)
   }
   WG_SYNC(ctx);
   if (vf && vf_terminal) {
@@ -105,204 +235,181 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     const double* q = qp + (size_t)(N - 1) * QP_SIZE;
     double(*An)[NX] = w.A2[(N - 1) & 1];
     constexpr int na = nbatches(NX * NX, 8);
-    WG_FOR(ctx, it, na + NX * LDB + NX) {
+    WG_FOR(ctx, it, na + NX * LDB) {
       if (it < na) copy_batch<8>(it, NX * NX, q + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
-      else if (it < na + NX * LDB) { const int i = it - na, r = i / LDB, c = i % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : 0.0; }
-      else w.bt2[(N - 1) & 1][it - na - NX * LDB] = q[QP_BV + it - na - NX * LDB];
+      else { const int i = it - na, r = i / LDB, c = i % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : q[QP_BV + r]; }
     }
   }
   WG_SYNC(ctx);
+  const Ctx& ctx_outer = ctx;
   for (int k = N - 1; k >= 0; --k) {
+    // The thread index is made opaque once per stage: everything a lane derives from it (tile coordinates, LDS offsets of its operand
+    // rows, the column it holds in the elimination) is loop-invariant, and hoisted out of the stage loop those values — well over a
+    // hundred registers — are spilled to scratch and re-loaded inside the serial chain.  Recomputing them costs a few hundred integer
+    // instructions per stage.
+    Ctx ctx = ctx_outer;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(ctx.tid));
+#endif
     const double* q = qp + (size_t)k * QP_SIZE;
     const double* qn = qp + (size_t)(k > 0 ? k - 1 : 0) * QP_SIZE;   // next stage to be processed
     double* rk = ric + (size_t)k * RIC_SIZE;
     double(*A)[NX] = w.A2[k & 1];
     double(*An)[NX] = w.A2[(k + 1) & 1];
-    const double* btc = w.bt2[k & 1];     // b~ of this stage
-    double* btn = w.bt2[(k + 1) & 1];      // ... of the next one to be processed (k - 1)
     PH_TICK(ctx, 1);
     PH_MARK(ctx);
-    // ---- P2: SB = S B (S symmetric => X = S) on the matrix cores, sb = s + S b
-    const XtyJob job_sa = xty_job(NXE, NXE, NXE, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX);   // runs under the elimination (P4a)
+    // ---- Ph1: [SB | S b~] = S [B~ | b~] (S symmetric => X = S); s of this stage from its partial sums
     {
-      const XtyJob job_sb = xty_job(NXE, NUT, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB);
+      const XtyJob jsb = xty_job(NXE, NUT + 1, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        // first half of the next stage's A~ into the other buffer (second half in P3).  One item = one batch of global loads,
-        // issued FIRST; the item's LDS-only work (a row of sb) runs under their L2/HBM round trip; the stores come last.
-        constexpr int nh = (NX * NX) / 2, na = nbatches(nh, 7);
-        static_assert(na <= RIC_HELPERS && NX <= RIC_HELPERS, "one pass");
-        WG_FOR(hc, it, RIC_HELPERS) {
-          double t[7];
-          if (k > 0) load_batch<7>(it, nh, qn + QP_A, t);
-          if (it < NX) {   // s of this stage = the four partial sums the previous stage's P5 left (no roll-up phase in between)
-            const double* sp = &w.part[4 * it];
-            const double svi = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-            w.sv[it] = svi;
-            if (it < NXE) w.sb[it] = svi + dot_strided<NXE>(&w.S[0][it], NX, btc);
-          }
-          if (k > 0) store_batch<7>(it, nh, t, [&](int i, double v) { An[i / NX][i % NX] = v; });
+        WG_FOR(hc, it, NX) {   // s of this stage = the four partial sums the previous stage's Ph4 left (no roll-up phase in between)
+          const double* sp = &w.part[4 * it];
+          w.sv[it] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        }
+        if (!dev512 && k > 0) {
+          constexpr int na = nbatches(NX * NX, 8);
+          WG_FOR(hc, it, na) copy_batch<8>(it, NX * NX, qn + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
         }
       }
-      ric_products(ctx, &job_sb, 1);
+      ric_products(ctx, 0, 8, jsb);
     }
     PH_ARRIVE(ctx, 0);
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
     PH_MARK(ctx);
-    // ---- P3: augmented matrix [Lam | G | g | B^T]; prefetch of the next stage's A~ into the other buffer
+    // ---- Ph2: G = P~ + SB^T A~, Lam = R~ + B~^T SB;  sb = s + S b~;  g = r~ + B~^T sb in four partial sums per row
     {
-      const XtyJob jobs[2] = {xty_job(NUT, NXE, NXE, &w.SB[0][0], LDB, &A[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX),
-                              xty_job(NUT, NUT, NXE, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT)};
-      constexpr int nh = (NX * NX) / 2, na = nbatches(NX * NX - nh, 7);
+      const XtyJob jg = xty_job(NUT, NXE, NXE, &w.SB[0][0], LDB, &A[0][0], NX, &w.Em[0][EM_G], LDE, q + QP_P, NX);
+      const XtyJob jl = xty_job(NUT, NUT, NXE, &w.B[0][0], LDB, &w.SB[0][0], LDB, &w.fac.Ef[0][0], LDF, q + QP_R, NUT);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        // same structure as in P2: global loads (second half of the next A~, r~) first, then the LDS-only work of the item
-        // (row of g, a slice of B^T and of the identity block of [Lam | I]), then the stores of the loaded values
-        static_assert(na <= RIC_HELPERS && 4 * NUT <= RIC_HELPERS, "one pass");
-        WG_FOR(hc, it, RIC_HELPERS) {
-          double t[7];
-          if (k > 0) load_batch<7>(it, NX * NX - nh, qn + QP_A + nh, t);
-          const double rv = (it < 4 * NUT && (it & 3) == 0) ? q[QP_RV + (it >> 2)] : 0.0;
-          for (int j = it; j < NUT * (LDF - NUT); j += RIC_HELPERS) { const int r = j / (LDF - NUT), c = NUT + j % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
-          if (it < 4 * NUT) {   // g = r~ + B^T sb in four partial sums per row (columns 0..3 of Em, added where g is used)
+        static_assert(128 + 4 * NUT <= RIC_HELPERS && NX <= 128, "one pass; the g items sit on the helper waves with the fewest tiles");
+        WG_FOR(hc, it0, RIC_HELPERS) {
+          const int it = it0 - 128;
+          if (it0 < NX) w.sb[it0] = it0 < NXE ? w.sv[it0] + w.SB[it0][NUT] : 0.0;
+          if (it >= 0 && it < 4 * NUT) {
             const int r = it >> 2, p = it & 3;
             constexpr int LA = (NXE + 3) / 4;
-            double sg = rv;
+            double sg = p == 0 ? q[QP_RV + r] : 0.0;
 #pragma unroll
-            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = w.B[lc][r], b = w.sb[lc]; sg += ll < NXE ? a * b : 0.0; }
+            for (int l = 0; l < LA; ++l) {
+              const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1;
+              const double a = w.B[lc][r], b = w.sv[lc] + w.SB[lc][NUT];
+              sg += ll < NXE ? a * b : 0.0;
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (dev512) {   // the four partial sums of a row sit in adjacent lanes: two DPP quad permutes leave the row's sum in column 0
+              sg += quad_perm_f64<0xB1>(sg);
+              sg += quad_perm_f64<0x4E>(sg);
+              if (p == 0) w.Em[r][EM_GVP] = sg;
+            } else
+#endif
             w.Em[r][EM_GVP + p] = sg;
           }
-          if (k > 0) store_batch<7>(it, NX * NX - nh, t, [&](int i, double v) { An[(i + nh) / NX][(i + nh) % NX] = v; });
         }
       }
-      // (dealing these tiles to the helper waves as well was measured: 1.87 -> 2.3 ms.  The additive terms stay generic pointers here:
-      //  as a two-job call with address-space-qualified terms the gfx950 backend of ROCm 7.2's clang crashes, as two calls it spills)
-      ric_products(ctx, jobs, 2);
+      ric_products<XTY_ADD_GLOBAL, 2>(ctx, 0, 8, jg, jl);
     }
     PH_ARRIVE(ctx, 1);
     WG_SYNC(ctx);
     PH_TICK(ctx, 3);
-    bool prefetched_b = false;
-    // ---- P4a: Gaussian elimination of [Lam | I] on full rows (rows stay unscaled, so a step needs no pivot broadcast
-    //      phase: one barrier per column).  Fixed (row, 3 strided columns) grid; every load is unconditional, so the
-    //      step is one LDS round trip + the reciprocal chain.  The multiplier is read from the (symmetric) upper part.
+    PH_MARK(ctx);
+    // ---- Ph3: factorisation.  Leaves L^-1 (Ef columns 24.., LinvT), Z = L^-1 G (Zs), z = L^-1 g (zv).  Under it: SA = S A~ (needed by the
+    //      S-update only), the next stage's A~ and [B~ | b~] -> LDS (B is dead since Ph2)
+    const XtyJob jsa = xty_job(NXE, NXE, NXE, &w.S[0][0], NX, &A[0][0], NX, &w.SA[0][0], NX);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (ctx.nthreads >= NUT * 16) {
-      // the two waves without elimination work fetch the next stage's B~, b~ meanwhile (B is dead since P3): the loads are
-      // issued here, travel while the elimination goes by, and land in LDS after the sweep
-      constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
-      const int pt = ctx.tid - 384;
-      double pb[NPB];
-      if (pt >= 0 && k > 0) {
-#pragma unroll
-        for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
-      }
-      // The whole sweep inside ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of [Lam | 0 | I]
-      // (23 registers); the pivot of step j and the multipliers Ef[j][i] (row j, read from the symmetric upper part: lane i) come
-      // through v_readlane with compile-time lane numbers; the arithmetic per element is that of the phase-per-column form below.
-      if (ctx.tid < 64) {
-        const int c = ctx.tid < LDF ? ctx.tid : LDF - 1;
+    if (dev512) {
+      // wave w sits on SIMD w % 4, and FP64 matrix and vector instructions of one SIMD do not overlap (measured: the elimination took
+      // 18 k cycles next to a wave with 75 matrix instructions, 12 k alone): SIMDs 0, 1 eliminate (waves 0, 1; waves 4, 5 only move the
+      // next stage's [B~ | b~]), SIMDs 2, 3 carry the tiles of S A~ (waves 2, 3, 6, 7)
+      const int wv = ctx.tid >> 6;
+      const int trank = (wv & 3) >= 2 ? (wv & 1) + (wv >> 2) * 2 : -1;
+      if (wv < 2) {
         double e[NUT];
+        eliminate_begin<NXE>(w, wv, ctx.tid & 63, e, k > 0 ? qn + QP_A : nullptr, &An[0][0]);
+        eliminate_end<NXE>(w, wv, ctx.tid & 63, e);
+      } else if (trank < 0) {
+        if (k > 0) {
+          constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
+          const int pt = ctx.tid - 256;
+          double pb[NPB];
 #pragma unroll
-        for (int i = 0; i < NUT; ++i) e[i] = w.fac.Ef[i][c];
+          for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
 #pragma unroll
-        for (int j = 0; j < NUT - 1; ++j) {
-          const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));   // lane i: the multiplier of row i (one multiply per step, not per row)
-#pragma unroll
-          for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
+          for (int t = 0; t < NPB; ++t) {
+            const int idx = pt + 128 * t;
+            if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
+            else if (idx < NX * NUT + NX) w.B[idx - NX * NUT][NUT] = pb[t];
+          }
         }
-        if (ctx.tid < LDF) {
-#pragma unroll
-          for (int i = 1; i < NUT; ++i) w.fac.Ef[i][c] = e[i];
-        }
-      }
-      // meanwhile the other seven waves form SA = S A~ on the matrix cores (16 tiles): it is not needed before P5
-      ric_products(ctx, &job_sa, 1, 1, 7);
-      WG_SYNC(ctx);
-      if (pt >= 0 && k > 0) {
-#pragma unroll
-        for (int t = 0; t < NPB; ++t) {
-          const int idx = pt + 128 * t;
-          if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
-          else if (idx < NX * NUT + NX) btn[idx - NX * NUT] = pb[t];
-        }
-      }
-      prefetched_b = true;
+      } else ric_products_ranked(ctx, trank, 4, jsa);
     } else
 #endif
     {
-    wg_xty_jobs(ctx, &job_sa, 1);
-    for (int j = 0; j < NUT - 1; ++j) {
-      WG_FOR(ctx, it, NUT * 16) {
-        const int i = it >> 4, c0 = it & 15;
-        if (i <= j) continue;
-        const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
-        const double ej0 = w.fac.Ef[j][c0], ej1 = w.fac.Ef[j][c0 + 16], ej2 = w.fac.Ef[j][c0 + 32];
-        const double ei0 = w.fac.Ef[i][c0], ei1 = w.fac.Ef[i][c0 + 16], ei2 = w.fac.Ef[i][c0 + 32];
-        const double f = fji * fast_rcp(pj);
-        w.fac.Ef[i][c0] = ei0 - f * ej0;
-        w.fac.Ef[i][c0 + 16] = ei1 - f * ej1;
-        w.fac.Ef[i][c0 + 32] = ei2 - f * ej2;
+      // generic form (host build): elimination of [Lam | I] on full rows in LDS (rows stay unscaled, so a step needs no pivot broadcast
+      // phase: one barrier per column; the multiplier is read from the symmetric upper part), the Cholesky scaling, then Z, z as products
+      WG_FOR(ctx, j, NUT * (LDF - NUT)) { const int r = j / (LDF - NUT), c = NUT + j % (LDF - NUT); w.fac.Ef[r][c] = (c - EF_MI == r) ? 1.0 : 0.0; }
+      ric_products(ctx, 0, 0, jsa);
+      WG_SYNC(ctx);
+      for (int j = 0; j < NUT - 1; ++j) {
+        WG_FOR(ctx, it, NUT * 16) {
+          const int i = it >> 4, c0 = it & 15;
+          if (i <= j) continue;
+          const double pj = w.fac.Ef[j][j], fji = w.fac.Ef[j][i];
+          const double ej0 = w.fac.Ef[j][c0], ej1 = w.fac.Ef[j][c0 + 16], ej2 = w.fac.Ef[j][c0 + 32];
+          const double ei0 = w.fac.Ef[i][c0], ei1 = w.fac.Ef[i][c0 + 16], ei2 = w.fac.Ef[i][c0 + 32];
+          const double f = fji * fast_rcp(pj);
+          w.fac.Ef[i][c0] = ei0 - f * ej0;
+          w.fac.Ef[i][c0 + 16] = ei1 - f * ej1;
+          w.fac.Ef[i][c0 + 32] = ei2 - f * ej2;
+        }
+        WG_SYNC(ctx);
+      }
+      WG_FOR(ctx, it, NUT * LDB) {   // L^-1 = D^-1/2 Mi (in place) and its transpose
+        const int r = it / LDB, c = it % LDB;
+        double dj = w.fac.Ef[r][r];
+        if (!(dj > 0.0)) { dj = 1.0; if (c == 0) w.ok = 0; }
+        const double v = c <= r ? w.fac.Ef[r][EF_MI + c] * inv_sqrt(dj) : 0.0;
+        w.fac.Ef[r][EF_MI + c] = v;
+        if (c < NUT) w.fac.LinvT[c][r] = v;
       }
       WG_SYNC(ctx);
-    }
-    }
-    // ---- P4b: Cholesky scaling: L^-1 = D^-1/2 Mi (in place) and its transpose
-    WG_FOR(ctx, it, NUT * LDB) {
-      const int r = it / LDB, c = it % LDB;
-      double dj = w.fac.Ef[r][r];
-      if (!(dj > 0.0)) { dj = 1.0; if (c == 0) w.ok = 0; }
-      const double v = c <= r ? w.fac.Ef[r][EF_MI + c] * inv_sqrt(dj) : 0.0;
-      w.fac.Ef[r][EF_MI + c] = v;
-      w.fac.LinvT[c][r] = v;
-    }
-    WG_SYNC(ctx);
-    // ---- P4c: Z = L^-1 G (matrix cores), z = L^-1 g
-    {
-      const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
-      if (is_helper_half(ctx)) {
-        const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, r, NUT) {
-          double s = 0.0;
-#pragma unroll
-          for (int l = 0; l < NUT; ++l) s += w.fac.Ef[r][EF_MI + l] * ((w.Em[l][EM_GVP] + w.Em[l][EM_GVP + 1]) + (w.Em[l][EM_GVP + 2] + w.Em[l][EM_GVP + 3]));
-          w.zv[r] = s;
-        }
-        if (linv_out) WG_FOR(hc, i, LDB * LDB) linv_out[(size_t)k * LDB * LDB + i] = w.fac.LinvT[i / LDB][i % LDB];
-      }
-    }
-    WG_SYNC(ctx);
-    // ---- P4d: K = -L^-T Z (matrix cores, over the G block), k = -L^-T z; both also to the record
-    {
-      const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0);
-      if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
-      if (is_helper_half(ctx)) {
-        const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, r, NUT) {
-          double s = 0.0;
-#pragma unroll
-          for (int l = 0; l < NUT; ++l) s += w.fac.LinvT[r][l] * w.zv[l];
-          w.kv[r] = -s;
-          rk[RIC_KV + r] = -s;
+      {
+        const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
+        if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
+        if (is_helper_half(ctx)) {
+          const Ctx hc = helper_ctx(ctx);
+          WG_FOR(hc, it, NUT + NX * LDB) {
+            if (it < NUT) {
+              double s = 0.0;
+              for (int l = 0; l < NUT; ++l) s += w.fac.Ef[it][EF_MI + l] * ((w.Em[l][EM_GVP] + w.Em[l][EM_GVP + 1]) + (w.Em[l][EM_GVP + 2] + w.Em[l][EM_GVP + 3]));
+              w.zv[it] = s;
+            } else if (k > 0) {
+              const int i = it - NUT, r = i / LDB, c = i % LDB;
+              w.B[r][c] = c < NUT ? qn[QP_B + r * NUT + c] : qn[QP_BV + r];
+            }
+          }
         }
       }
     }
+    PH_ARRIVE(ctx, 3);
     WG_SYNC(ctx);
     PH_TICK(ctx, 4);
     PH_MARK(ctx);
-    // ---- P5: S <- Q + A^T SA - Z^T Z, s <- q + A^T sb - Z^T z (left as four partial sums) ; K -> record;
-    //          prefetch of the next stage's B~, b~ (B is dead since P3)
+    // ---- Ph4: S = Q~ + A~^T SA - Z^T Z, K = -L^-T Z (into the G block and the record), s <- q~ + A~^T sb - Z^T z (left as four partial
+    //      sums), k = -L^-T z
     {
-      XtyJob js = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
-      js.L2 = NUT; js.X2 = &w.Zs[0][0]; js.ldx2 = NX; js.Y2 = &w.Zs[0][0]; js.ldy2 = NX; js.sign2 = -1.0;
-      js.sym = 1;   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
-      constexpr int nbb = nbatches(NX * LDB, 8);
+      XtyJob js0 = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
+      js0.L2 = NUT; js0.X2 = &w.Zs[0][0]; js0.ldx2 = NX; js0.Y2 = &w.Zs[0][0]; js0.ldy2 = NX; js0.sign2 = -1.0;
+      const XtyJob js = xty_sym(js0);   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
+      // (K goes to the G block — closed_loop_record reads it there — and straight to the record)
+      const XtyJob jk = xty_also_to(xty_job(NUT, NXE, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0), rk + RIC_K, NX);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, 4 * NX + NUT * NX) {
-          if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in P6): short chains, 232 lanes
+        static_assert(4 * NX + NUT <= RIC_HELPERS, "one pass");
+        WG_FOR(hc, it, RIC_HELPERS) {
+          if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in the next stage's Ph1): short chains, 232 lanes
             const int r = it >> 2, p = it & 3;
             constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
             double s = p == 0 ? q[QP_QV + r] : 0.0;
@@ -311,32 +418,30 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 #pragma unroll
             for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
             w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
-          } else {
-            const int j = it - 4 * NX;
-            rk[RIC_K + j] = (NXE == NX || j % NX < NXE) ? w.Em[j / NX][EM_G + j % NX] : 0.0;
+          } else if (it < 4 * NX + NUT) {
+            const int r = it - 4 * NX;
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < NUT; ++l) s += w.fac.LinvT[r][l] * w.zv[l];
+            w.kv[r] = -s;
+            rk[RIC_KV + r] = -s;
           }
         }
-        WG_FOR(hc, bb, nbb + NX) {   // prefetch B~, b~ of the next stage (unless the elimination phase already did)
-          if (k > 0 && !prefetched_b) {
-            if (bb < nbb) {
-              double t[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb, r = i / LDB, c = i % LDB; t[j] = (i < NX * LDB && c < NUT) ? qn[QP_B + r * NUT + c] : 0.0; }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) { const int i = bb + j * nbb; if (i < NX * LDB) w.B[i / LDB][i % LDB] = t[j]; }
-            } else {
-              btn[bb - nbb] = qn[QP_BV + bb - nbb];
-            }
-          }
-        }
+        if (linv_out) WG_FOR(hc, i, LDB * LDB) linv_out[(size_t)k * LDB * LDB + i] = w.fac.LinvT[i / LDB][i % LDB];
+        if (NXE < NX) WG_FOR(hc, i, NUT * (NX - NXE)) rk[RIC_K + (i / (NX - NXE)) * NX + NXE + i % (NX - NXE)] = 0.0;   // K vanishes on the padding states
       }
-      ric_products<XTY_ADD_GLOBAL>(ctx, &js, 1);    // (same: 1.87 -> 2.1 ms with waves 4-5 taking the two spare tiles)
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (dev512) {
+        ric_products<XTY_ADD_GLOBAL, 2>(ctx, 0, 8, js, jk);
+      } else
+#endif
+        ric_products<0, 2>(ctx, 0, 0, js, jk);
     }
     PH_ARRIVE(ctx, 2);
     WG_SYNC(ctx);
     PH_TICK(ctx, 5);
-    // (no P6: the symmetric tile job writes the diagonal tiles of S symmetric itself — upper triangle computed, mirrored —, s stays
-    //  in its four partial sums until the next stage's P2 adds them, b~ is double-buffered)
+    // (the symmetric tile jobs write the diagonal tiles of S symmetric themselves — upper triangle computed, mirrored —, s stays
+    //  in its four partial sums until the next stage's Ph1 adds them)
     if (vf && (vf_mode == 0 || k == 0 || (vf_mode == 2 && k == N - 1))) {
       WG_FOR(ctx, i, VF_SIZE) {
         const double* sp = &w.part[4 * (i >= NX * NX ? i - NX * NX : 0)];
@@ -345,6 +450,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     PH_TICK(ctx, 6);
   }
+  WG_SYNC(ctx);
 }
 
 // Forward sweep dx+ = A~ dx + B~ (K dx + k) + b~ (serial over stages); writes dx [N+1][58].  qp: the stage QP records, ric: the gains.
@@ -477,7 +583,7 @@ HSQP_HD void closed_loop_record(const Ctx& ctx, const RicWS& w, double* acl) {
       acl[it] = s;
     } else {
       const int i = it - NXE * NXE;
-      double s = w.bt2[0][i];
+      double s = w.B[i][NUT];
 #pragma unroll
       for (int m = 0; m < NUT; ++m) s += w.B[i][m] * w.kv[m];
       acl[it] = s;
