@@ -148,7 +148,7 @@ struct XtyJob {
   double* C; int ldc;             // destination (LDS or global)
   int sx1, sx2;                   // element stride of X along the output-row index (1 = row-major X[l][r]; ld = 1, sx = ld' reads X'[r][l])
   int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
-  double* C2; int ldc2;           // optional second destination in GLOBAL memory (device tile path; the host build copies it from C)
+  double* C2; int ldc2, nc2;      // optional second destination in GLOBAL memory for the columns < nc2 (device tile path; the host build copies it from C)
 };
 
 HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, double* C, int ldc,
@@ -156,12 +156,12 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0; j.nc2 = 0;
   return j;
 }
 
 HSQP_HD XtyJob xty_sym(XtyJob j) { j.sym = 1; return j; }
-HSQP_HD XtyJob xty_also_to(XtyJob j, double* C2, int ldc2) { j.C2 = C2; j.ldc2 = ldc2; return j; }
+HSQP_HD XtyJob xty_also_to(XtyJob j, double* C2, int ldc2, int nc2) { j.C2 = C2; j.ldc2 = ldc2; j.nc2 = nc2; return j; }
 
 #if defined(HSQP_PHASE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define XTY_PROF_T(name) const long long name = clock64()
@@ -277,7 +277,7 @@ __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, c
           j.C[o1 + 4 * r * j.ldc] = v[r];
           if (mirror || diag) j.C[o2 + 4 * r] = v[r];
         }
-        if (j.C2) ((hsqp_gptr)j.C2)[(rb + 4 * r) * j.ldc2 + c] = v[r];
+        if (j.C2 && c < j.nc2) ((hsqp_gptr)j.C2)[(rb + 4 * r) * j.ldc2 + c] = v[r];
       };
       if (r0[t] + 16 <= j.M) {
 #pragma unroll
@@ -395,7 +395,7 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
         if (j.Add) v += j.Add[r * j.ldadd + c];
         j.C[r * j.ldc + c] = v;
         if (j.sym && c != r) j.C[c * j.ldc + r] = v;
-        if (j.C2) j.C2[r * j.ldc2 + c] = v;
+        if (j.C2 && c < j.nc2) j.C2[r * j.ldc2 + c] = v;
       }
   }
 #endif

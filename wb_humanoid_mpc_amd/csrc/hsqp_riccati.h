@@ -33,6 +33,7 @@ static_assert(LDB == NUT + 1, "b~ is the 24th column of the B~ workspace");
 constexpr int LDF = 48, EF_MI = LDB;           // elimination matrix [Lam (23) | 0 | I (23) | 0]
 constexpr int EM_GVP = 0, EM_G = NUT, LDE = NUT + NX + 1;   // 82 columns; 0..3: g (host build: four partial sums, device: the sum in column 0)
 
+constexpr int LDZ = NX + 2;                     // Z carries z as one more column: K = -L^-T [Z | z] then yields k in the same tile job
 constexpr int RIC_HELPERS = 256;                // helper half of the 512-thread workgroup: item count of the fused helper passes
 struct RicWS {
   double S[NX][NX];                            // value function; Ph2 overwrites it with W = Q~ + A~^T S A~ (S is dead after Ph1)
@@ -44,7 +45,7 @@ struct RicWS {
   double B[NX][LDB];                           // [B~ | b~]
   union {
     double SB[NX][LDB];                        // [S B~ | S b~]
-    double Zs[NUT][NX];                        // L^-1 G (SB is dead once Lam, G and sb are formed)
+    double Zs[NUT][LDZ];                       // [L^-1 G | z = L^-1 g in column NXE] (SB is dead once Lam, G and sb are formed)
   };
   double Em[NUT][LDE];                         // [g . | G -> K | .]
   double sv[NX], sb[NX], dx[NX], zv[LDB], kv[LDB];
@@ -184,6 +185,7 @@ HSQP_D void eliminate_end(RicWS& w, int wave, int lane, double (&e)[NUT]) {
       w.fac.LinvT[ic][i] = vv;
     } else if (l.isg) {
       w.zv[i] = v;
+      w.Zs[i][NXE] = v;
     } else if (l.isG) {
       w.Zs[i][l.gcol] = v;
     }
@@ -263,9 +265,11 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const XtyJob jsb = xty_job(NXE, NUT + 1, NXE, &w.S[0][0], NX, &w.B[0][0], LDB, &w.SB[0][0], LDB);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        WG_FOR(hc, it, NX) {   // s of this stage = the four partial sums the previous stage's Ph4 left (no roll-up phase in between)
-          const double* sp = &w.part[4 * it];
-          w.sv[it] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        WG_FOR(hc, it, NX + NUT) {
+          if (it < NX) {   // s of this stage = the four partial sums the previous stage's Ph4 left (no roll-up phase in between)
+            const double* sp = &w.part[4 * it];
+            w.sv[it] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+          } else if (k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + it - NX] = w.Em[it - NX][EM_G + NXE];   // k of the previous stage
         }
         if (!dev512 && k > 0) {
           constexpr int na = nbatches(NX * NX, 8);
@@ -343,6 +347,15 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
             else if (idx < NX * NUT + NX) w.B[idx - NX * NUT][NUT] = pb[t];
           }
         }
+        // the part of the new s that does not wait for the factorisation: q~ + A~^T sb in four partial sums per row (Ph4 subtracts Z^T z)
+        for (int it = ctx.tid - 256; it < 4 * NX; it += 128) {
+          const int r = it >> 2, p = it & 3;
+          constexpr int LA = (NXE + 3) / 4;
+          double s = p == 0 ? q[QP_QV + r] : 0.0;
+#pragma unroll
+          for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
+          w.part[it] = s;
+        }
       } else ric_products_ranked(ctx, trank, 4, jsa);
     } else
 #endif
@@ -376,7 +389,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       }
       WG_SYNC(ctx);
       {
-        const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], NX);
+        const XtyJob job = xty_job(NUT, NXE, NUT, &w.fac.LinvT[0][0], LDB, &w.Em[0][EM_G], LDE, &w.Zs[0][0], LDZ);
         if (is_mfma_half(ctx)) wg_xty_jobs(mfma_ctx(ctx), &job, 1);
         if (is_helper_half(ctx)) {
           const Ctx hc = helper_ctx(ctx);
@@ -385,6 +398,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
               double s = 0.0;
               for (int l = 0; l < NUT; ++l) s += w.fac.Ef[it][EF_MI + l] * ((w.Em[l][EM_GVP] + w.Em[l][EM_GVP + 1]) + (w.Em[l][EM_GVP + 2] + w.Em[l][EM_GVP + 3]));
               w.zv[it] = s;
+              w.Zs[it][NXE] = s;
             } else if (k > 0) {
               const int i = it - NUT, r = i / LDB, c = i % LDB;
               w.B[r][c] = c < NUT ? qn[QP_B + r * NUT + c] : qn[QP_BV + r];
@@ -401,38 +415,38 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     //      sums), k = -L^-T z
     {
       XtyJob js0 = xty_job(NXE, NXE, NXE, &A[0][0], NX, &w.SA[0][0], NX, &w.S[0][0], NX, q + QP_Q, NX);
-      js0.L2 = NUT; js0.X2 = &w.Zs[0][0]; js0.ldx2 = NX; js0.Y2 = &w.Zs[0][0]; js0.ldy2 = NX; js0.sign2 = -1.0;
+      js0.L2 = NUT; js0.X2 = &w.Zs[0][0]; js0.ldx2 = LDZ; js0.Y2 = &w.Zs[0][0]; js0.ldy2 = LDZ; js0.sign2 = -1.0;
       const XtyJob js = xty_sym(js0);   // S is symmetric: tiles on/above the diagonal, mirrored into the LDS copy
-      // (K goes to the G block — closed_loop_record reads it there — and straight to the record)
-      const XtyJob jk = xty_also_to(xty_job(NUT, NXE, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], NX, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0), rk + RIC_K, NX);
+      // ([K | k] = -L^-T [Z | z] goes to the G block — closed_loop_record reads K there, k is picked up from its column NXE in the next
+      //  stage's Ph1 — and K straight to the record)
+      const XtyJob jk = xty_also_to(xty_job(NUT, NXE + 1, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], LDZ, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0), rk + RIC_K, NX, NXE);
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
-        static_assert(4 * NX + NUT <= RIC_HELPERS, "one pass");
-        WG_FOR(hc, it, RIC_HELPERS) {
-          if (it < 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in the next stage's Ph1): short chains, 232 lanes
-            const int r = it >> 2, p = it & 3;
-            constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
-            double s = p == 0 ? q[QP_QV + r] : 0.0;
+        static_assert(4 * NX <= RIC_HELPERS, "one pass");
+        WG_FOR(hc, it, 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in the next stage's Ph1): short chains, 232 lanes
+          const int r = it >> 2, p = it & 3;
+          constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
+          double s;
+          if (dev512) s = w.part[it];   // q~ + A^T sb: formed under the elimination (Ph3) by the waves that only moved B~
+          else {
+            s = p == 0 ? q[QP_QV + r] : 0.0;
 #pragma unroll
             for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
-#pragma unroll
-            for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
-            w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
-          } else if (it < 4 * NX + NUT) {
-            const int r = it - 4 * NX;
-            double s = 0.0;
-#pragma unroll
-            for (int l = 0; l < NUT; ++l) s += w.fac.LinvT[r][l] * w.zv[l];
-            w.kv[r] = -s;
-            rk[RIC_KV + r] = -s;
           }
+#pragma unroll
+          for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
+          w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
         }
         if (linv_out) WG_FOR(hc, i, LDB * LDB) linv_out[(size_t)k * LDB * LDB + i] = w.fac.LinvT[i / LDB][i % LDB];
         if (NXE < NX) WG_FOR(hc, i, NUT * (NX - NXE)) rk[RIC_K + (i / (NX - NXE)) * NX + NXE + i % (NX - NXE)] = 0.0;   // K vanishes on the padding states
       }
 #if defined(__HIP_DEVICE_COMPILE__)
       if (dev512) {
-        ric_products<XTY_ADD_GLOBAL, 2>(ctx, 0, 8, js, jk);
+        // per SIMD (waves w, w + 4) about the same number of matrix instructions, fewer on the waves with the vector items:
+        // S: waves 0-3 two tiles, 4-5 one; [K | k]: waves 6-7 two tiles, 2-5 one
+        const int wv = ctx.tid >> 6;
+        ric_products_ranked<XTY_ADD_GLOBAL>(ctx, wv < 6 ? wv : -1, 6, js);
+        ric_products_ranked(ctx, wv >= 6 ? wv - 6 : (wv >= 4 ? wv - 2 : (wv >= 2 ? wv + 2 : -1)), 6, jk);
       } else
 #endif
         ric_products<0, 2>(ctx, 0, 0, js, jk);
@@ -450,6 +464,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
     }
     PH_TICK(ctx, 6);
   }
+  WG_FOR(ctx, r, NUT) { const double kr = w.Em[r][EM_G + NXE]; w.kv[r] = kr; ric[RIC_KV + r] = kr; }   // k of stage 0
   WG_SYNC(ctx);
 }
 
