@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out
 rm -rf "$OUT/prof_seg"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_seg" -o seg -- python "$OUT/../bench.py" --no-cpu-baseline --batch ${SEGB:-32} --steps 5 --warmup 1 > "$OUT/prof_seg.log" 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_seg" -o seg -- python "$OUT/../bench.py" --no-cpu-baseline --batch ${SEGB:-32} --riccati ${SEGR:-segmented} --steps 5 --warmup 1 > "$OUT/prof_seg.log" 2>&1
 find "$OUT/prof_seg" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/seg_kernel_stats.csv"
 python - <<'PY'
 import csv, re

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 }
 // 1b: the (A, b, C) part of the segment's element by prepending its stages; el: [B][P + 1][ScanEl<n>::SIZE]
 template <int n>
-__global__ __launch_bounds__(SEG_ACC_THREADS) void k_seg_accumulate(const double* __restrict__ qp, const double* __restrict__ ric_tmp, const double* __restrict__ linv,
+__global__ __launch_bounds__(SEG_ACC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_accumulate(const double* __restrict__ qp, const double* __restrict__ ric_tmp, const double* __restrict__ linv,
                                                                    const double* __restrict__ vf0, int N, int P, double* __restrict__ el) {
   SegAccWS& w = *reinterpret_cast<SegAccWS*>(hsqp_smem);
   const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;

@@ -485,13 +485,16 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
   double* part2 = w.SA[0] + NR1;
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads >= NR1 + NUT) {
-    // device path: the row slices of stage k + 1 are fetched into registers while stage k is being combined, so the chain only waits
-    // on LDS and the three barriers.  Item it < NR1 owns row it >> 2 of [A~; K] (columns p + 4c) and, if it < 4 NX, row it >> 2 of
+    // device path: the row slices of a stage are fetched into registers PF stages ahead.  A stage takes ~0.4 us, its A~, B~, K come from
+    // HBM (the records of an iteration are far larger than the caches): with the loads only one stage ahead every stage waited out the
+    // HBM round trip (2.3 us per stage measured), so the slices travel in a ring of PF register sets (the loop is unrolled by PF so that
+    // every set has fixed registers).  Item it < NR1 owns row it >> 2 of [A~; K] (columns p + 4c) and, if it < 4 NX, row it >> 2 of
     // B~ as well; items NR1 .. NR1 + NUT - 1 carry k.
+    constexpr int PF = 3;    // (4 sets spill: 22 doubles per set)
     const int it = ctx.tid, row = it >> 2, p = it & 3;
     const bool rowA = it < 4 * NX, rowK = it >= 4 * NX && it < NR1, isk = it >= NR1 && it < NR1 + NUT;
     const bool liveA = rowA && (NXE == NX || row < NXE);
-    double a[NC], an[NC], bq[NCB], bqn[NCB], sc = 0.0, scn = 0.0;   // sc: b~ of the row (p == 0 items of A~ rows) or k (isk items)
+    double a[PF][NC], bq[PF][NCB], sc[PF];   // sc: b~ of the row (p == 0 items of A~ rows) or k (isk items)
     auto fetch = [&](int k, double* av, double* bv, double& s1) {
       const double* q = qp + (size_t)k * QP_SIZE;
       const double* rk = ric + (size_t)k * RIC_SIZE;
@@ -504,47 +507,49 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
       for (int c = 0; c < NCB; ++c) { const int cc = p + 4 * c; bv[c] = (liveA && cc < NUT) ? q[QP_B + row * NUT + cc] : 0.0; }
       s1 = (liveA && p == 0) ? q[QP_BV + row] : (isk ? rk[RIC_KV + it - NR1] : 0.0);
     };
-    fetch(0, an, bqn, scn);
-    for (int k = 0; k < N; ++k) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) a[c] = an[c];
+    for (int u = 0; u < PF; ++u) { if (u < N) fetch(u, a[u], bq[u], sc[u]); }
+    for (int k0 = 0; k0 < N; k0 += PF) {
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) bq[c] = bqn[c];
-      sc = scn;
-      if (k + 1 < N) fetch(k + 1, an, bqn, scn);
-      // TWO barriers per stage: the four partial sums of a row sit in four adjacent lanes and are added by DPP quad permutes (no LDS
-      // round trip for them); only ut = k + K dx (23 numbers every row needs) and the new dx go through LDS; dx is double-buffered
-      // (dx / sv) so that the next stage's reads do not race this stage's writes
-      const double* dcur = (k & 1) ? w.sv : w.dx;
-      double* dnxt = (k & 1) ? w.dx : w.sv;
-      double s1 = 0.0;
+      for (int u = 0; u < PF; ++u) {
+        const int k = k0 + u;
+        if (k < N) {
+          // TWO barriers per stage: the four partial sums of a row sit in four adjacent lanes and are added by DPP quad permutes (no LDS
+          // round trip for them); only ut = k + K dx (23 numbers every row needs) and the new dx go through LDS; dx is double-buffered
+          // (dx / sv) so that the next stage's reads do not race this stage's writes
+          const double* dcur = (k & 1) ? w.sv : w.dx;
+          double* dnxt = (k & 1) ? w.dx : w.sv;
+          double s1 = 0.0;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s1 += a[c] * dcur[cc]; }
-      if (rowK) {          // row of K: ut_j = k_j + K_j dx
-        double s = s1;
-        s += quad_perm_f64<0xB1>(s);
-        s += quad_perm_f64<0x4E>(s);
-        if (p == 0) w.zv[row - NX] = s;
-      } else if (isk) w.kv[it - NR1] = sc;
-      WG_SYNC(ctx);
-      {
-        double s = rowA ? s1 + (p == 0 ? sc : 0.0) : 0.0;      // A~ dx slice (+ b~ on the first lane of the quad)
+          for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NXE) s1 += a[u][c] * dcur[cc]; }
+          if (rowK) {          // row of K: ut_j = k_j + K_j dx
+            double s = s1;
+            s += quad_perm_f64<0xB1>(s);
+            s += quad_perm_f64<0x4E>(s);
+            if (p == 0) w.zv[row - NX] = s;
+          } else if (isk) w.kv[it - NR1] = sc[u];
+          WG_SYNC(ctx);
+          {
+            double s = rowA ? s1 + (p == 0 ? sc[u] : 0.0) : 0.0;      // A~ dx slice (+ b~ on the first lane of the quad)
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-          const int j = p + 4 * c, jc = j < NUT ? j : NUT - 1;
-          const double utj = w.kv[jc] + w.zv[jc];
-          s += (rowA && j < NUT) ? bq[c] * utj : 0.0;
-        }
-        s += quad_perm_f64<0xB1>(s);
-        s += quad_perm_f64<0x4E>(s);
-        if (rowA && p == 0) {
-          // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
-          const double v = (NXE == NX || row < NXE) ? s : dcur[row];
-          dnxt[row] = v;
-          dx_out[(size_t)(k + 1) * NX + row] = v;
+            for (int c = 0; c < NCB; ++c) {
+              const int j = p + 4 * c, jc = j < NUT ? j : NUT - 1;
+              const double utj = w.kv[jc] + w.zv[jc];
+              s += (rowA && j < NUT) ? bq[u][c] * utj : 0.0;
+            }
+            s += quad_perm_f64<0xB1>(s);
+            s += quad_perm_f64<0x4E>(s);
+            if (rowA && p == 0) {
+              // padding states (NXE < NX): dx+ = dx (A~ = I there), which is zero when the caller keeps them zero
+              const double v = (NXE == NX || row < NXE) ? s : dcur[row];
+              dnxt[row] = v;
+              dx_out[(size_t)(k + 1) * NX + row] = v;
+            }
+          }
+          if (k + PF < N) fetch(k + PF, a[u], bq[u], sc[u]);
+          WG_SYNC(ctx);
         }
       }
-      WG_SYNC(ctx);
     }
     return;
   }

@@ -79,7 +79,7 @@ HSQP_HD void seg_accumulate(const Ctx& ctx, SegAccWS& w, const double* qp, const
     // ---- U = B' T (nu x n); bcl = b + B k
     {
       const XtyJob job = xty_job(NUT, n, n, &w.B[0][0], LDB, &T[0][0], NX, &w.U[0][0], NX);
-      wg_xty_jobs(ctx, &job, 1);
+      wg_xty_jobs<true>(ctx, &job, 1);
       WG_FOR(ctx, i, n) {
         double s = w.bt[i];
 #pragma unroll
@@ -93,7 +93,7 @@ HSQP_HD void seg_accumulate(const Ctx& ctx, SegAccWS& w, const double* qp, const
       XtyJob jt = xty_job(n, n, n, &w.A[0][0], NX, &T[0][0], NX, &Tn[0][0], NX);
       jt.L2 = NUT; jt.X2 = &w.K[0][0]; jt.ldx2 = NX; jt.Y2 = &w.U[0][0]; jt.ldy2 = NX; jt.sign2 = 1.0;
       const XtyJob jobs[2] = {jt, xty_job(NUT, n, NUT, &w.LinvT[0][0], LDB, &w.U[0][0], NX, &w.Wt[0][0], NX)};
-      wg_xty_jobs(ctx, jobs, 2);
+      wg_xty_jobs<true>(ctx, jobs, 2);
       WG_FOR(ctx, i, n) {
         double s = w.bseg[cur][i];
         for (int l = 0; l < n; ++l) s += T[l][i] * w.bcl[l];
@@ -105,7 +105,7 @@ HSQP_HD void seg_accumulate(const Ctx& ctx, SegAccWS& w, const double* qp, const
     {
       XtyJob jc = xty_job(n, n, NUT, &w.Wt[0][0], NX, &w.Wt[0][0], NX, &w.C[0][0], NX, &w.C[0][0], NX);
       jc.sym = 1;
-      wg_xty_jobs(ctx, &jc, 1);
+      wg_xty_jobs<true>(ctx, &jc, 1);
     }
     WG_SYNC(ctx);
     cur = 1 - cur;
