@@ -91,3 +91,12 @@ class RefTerms:
         rc = self.lib.ref_foot_weights(task_file.encode(), prefix.encode(), w.ctypes.data_as(_dp))
         assert rc == 0, rc
         return w
+
+    def velocity_targets(self, reference_info, horizon, cmd, t0, x0, calls=200):
+        """WBMpcTargetTrajectoriesCalculator::commandedVelocityToTargetTrajectories called `calls` times with the same arguments (its command
+        filter is a function-local static: 0.8^200 ~ 4e-20 leaves the steady state) -> (times[3], states[3, nx])."""
+        t, s = np.zeros(3), np.zeros((3, self.nx))
+        rc = self.lib.ref_wb_velocity_targets(self.nj, reference_info.encode(), C.c_double(horizon), _d(cmd).ctypes.data_as(_dp), C.c_double(t0), _d(x0).ctypes.data_as(_dp),
+                                              int(calls), t.ctypes.data_as(_dp), s.ctypes.data_as(_dp))
+        assert rc == 0, rc
+        return t, s

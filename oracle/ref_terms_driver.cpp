@@ -9,12 +9,15 @@
 //   a12  humanoid_common_mpc/src/constraint/FrictionForceConeConstraint.cpp:78-224          value, dfdu, dfduu, dfdxx (diagonal shift)
 //   a7   humanoid_wb_mpc/src/cost/EndEffectorDynamicsCostHelpers.cpp:41-108                 EndEffectorDynamicsWeights::getWeights (the weight
 //        overwrite quirk) + toVector, read from the reference's own task.info through the stand-in INFO parser
+//   target generator (feeds a5)  humanoid_wb_mpc/src/command/WBMpcTargetTrajectoriesCalculator.cpp:80-136 + humanoid_common_mpc/src/command/
+//        TargetTrajectoriesCalculatorBase.cpp:41-160: commandedVelocityToTargetTrajectories on the reference's own reference.info
 // =====================================================================================
 #include <cstring>
 
 #include "humanoid_common_mpc/constraint/FrictionForceConeConstraint.h"
 #include "humanoid_common_mpc/constraint/ZeroWrenchConstraint.h"
 #include "humanoid_common_mpc/reference_manager/SwitchedModelReferenceManager.h"
+#include "humanoid_wb_mpc/command/WBMpcTargetTrajectoriesCalculator.h"
 #include "humanoid_wb_mpc/common/WBAccelMpcRobotModel.h"
 #include "humanoid_wb_mpc/cost/EndEffectorDynamicsCostHelpers.h"
 
@@ -164,6 +167,33 @@ int ref_foot_weights(const char* task_file, const char* prefix, double* w18) {
     for (int i = 0; i < 18; ++i) w18[i] = v(i);
     return 0;
   } catch (const std::exception& e) { std::cerr << "ref_foot_weights: " << e.what() << "\n"; return 1; }
+}
+
+// WBMpcTargetTrajectoriesCalculator(reference.info, model, horizon).commandedVelocityToTargetTrajectories(cmd, t0, x0), called `calls`
+// times with the same arguments: the command passes through a first-order filter whose state is a function-local STATIC of the
+// reference (TargetTrajectoriesCalculatorBase.cpp:117: it survives across calls and calculators), so the caller chooses how far it
+// has converged.  Out: the 3 knot times and 3 x nx knot states of the last call.
+int ref_wb_velocity_targets(int nj, const char* reference_info, double horizon, const double cmd[4], double t0, const double* x0, int calls, double* times3,
+                            double* states) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    WBMpcTargetTrajectoriesCalculator calc(reference_info, w.model, horizon);
+    const int nx = (int)w.model.getStateDim();
+    const vector_t xs = to_vec(x0, nx);
+    Eigen::Matrix<scalar_t, 4, 1> c;
+    for (int i = 0; i < 4; ++i) c(i) = cmd[i];
+    TargetTrajectories t;
+    for (int k = 0; k < calls; ++k) t = calc.commandedVelocityToTargetTrajectories(c, t0, xs);
+    if (t.timeTrajectory.size() != 3 || t.stateTrajectory.size() != 3 || t.inputTrajectory.size() != 3) return 2;
+    for (int k = 0; k < 3; ++k) {
+      times3[k] = t.timeTrajectory[k];
+      if ((int)t.stateTrajectory[k].size() != nx || (int)t.inputTrajectory[k].size() != (int)w.model.getInputDim()) return 2;
+      for (int i = 0; i < nx; ++i) states[(size_t)k * nx + i] = t.stateTrajectory[k](i);
+      for (int i = 0; i < (int)t.inputTrajectory[k].size(); ++i) if (t.inputTrajectory[k](i) != 0.0) return 3;
+    }
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_wb_velocity_targets: " << e.what() << "\n"; return 1; }
 }
 
 }  // extern "C"

@@ -6,7 +6,8 @@
 Contents: the whole-body robot model's layout and accessors on a random (x, u); FrictionForceConeConstraint (value, dfdu, dfduu, dfdxx
 diagonal, isActive) and ZeroWrenchConstraint (value, dfdu, isActive) of both contacts on random inputs at times inside stance / single
 support / flight phases of a run-gait schedule; SwitchedModelReferenceManager::getDesiredState (arm-swing reference on the current yaw),
-getPhaseVariable and getContactFlags on a walk schedule; EndEffectorDynamicsWeights::getWeights(task.info).toVector()."""
+getPhaseVariable and getContactFlags on a walk schedule; EndEffectorDynamicsWeights::getWeights(task.info).toVector();
+WBMpcTargetTrajectoriesCalculator::commandedVelocityToTargetTrajectories on reference.info (filter at steady state + one first call)."""
 import os
 import sys
 
@@ -22,6 +23,7 @@ from wb_humanoid_mpc_amd import load_model  # noqa: E402
 from wb_humanoid_mpc_amd.reference import tile_gait, velocity_command_targets  # noqa: E402
 
 TASK = "/root/reference/robot_models/unitree_g1/g1_wb_mpc/config/mpc/task.info"
+REFERENCE_INFO = "/root/reference/robot_models/unitree_g1/g1_wb_mpc/config/command/reference.info"
 
 
 def main():
@@ -76,6 +78,19 @@ def main():
         xn_off.append(ref.desired_state(arm, ev, seq, tt, ts, False, 0.0, 2.0, s, t)[0])
     out["des.xnom"], out["des.phase"], out["des.flags"], out["des.xnom_no_arm_swing"] = np.array(xn), np.array(ph), np.array(fl), np.array(xn_off)
     out["foot_weights"] = ref.foot_weights(TASK, "task_space_foot_cost_weights.")
+    # velocity-command target generator on the reference's own reference.info: random initial states (yaw, base velocity), commands and
+    # horizons; 200 identical calls each (the command filter is a function-local static of the reference)
+    cmds = np.column_stack([rng.uniform(-0.8, 0.8, 6), rng.uniform(-0.4, 0.4, 6), rng.uniform(0.6, 0.85, 6), rng.uniform(-0.6, 0.6, 6)])
+    x0s = np.tile(m.initial_state, (6, 1)) + 0.2 * rng.standard_normal((6, m.nx))
+    hor, t0s = rng.uniform(0.5, 3.0, 6), rng.uniform(0.0, 5.0, 6)
+    tt, ts = [], []
+    for c, xx, h, t0 in zip(cmds, x0s, hor, t0s):
+        a, b = ref.velocity_targets(REFERENCE_INFO, h, c, t0, xx)
+        tt.append(a); ts.append(b)
+    out["tgt.cmd"], out["tgt.x0"], out["tgt.horizon"], out["tgt.t0"], out["tgt.times"], out["tgt.states"] = cmds, x0s, hor, t0s, np.array(tt), np.array(ts)
+    # the first call after a fresh command: the filter's transient (documented, not reproduced by the host mirror)
+    a, b = ref.velocity_targets(REFERENCE_INFO, 2.0, np.array([5.0, 0.0, 0.7925, 0.0]), 0.0, m.initial_state, calls=1)
+    out["tgt.first_call_states"] = b
     path = os.path.join(ROOT, "tests", "golden", "ref_terms.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: np.shape(v) for k, v in out.items()})

@@ -130,6 +130,25 @@ def test_foot_cost_weights_carry_the_reference_loaders_quirk(model):
     assert np.array_equal(w[6:12], [5.0, 5.0, 0.0, 2.0, 2.0, 2.0]) and np.array_equal(w[12:], [0.01] * 6)
 
 
+def test_velocity_command_targets_equal_the_reference_compiled_generator(model):
+    """WBMpcTargetTrajectoriesCalculator::commandedVelocityToTargetTrajectories (WBMpcTargetTrajectoriesCalculator.cpp:80-136 with the base
+    class's filter / integration helpers), compiled from the reference and run on its own reference.info for random initial states,
+    commands, horizons and start times with the command filter converged: knot times and the three knot states equal the host mirror that
+    feeds every benchmark problem (reference.velocity_command_targets -> node parameters -> k_lq / the oracle).  The joint targets are the
+    `defaultJointState` of reference.info read by the reference's loader, so the exported model's default joint state is pinned too."""
+    from wb_humanoid_mpc_amd.reference import velocity_command_targets
+    for c, x0, h, t0, tt, ts in zip(G["tgt.cmd"], G["tgt.x0"], G["tgt.horizon"], G["tgt.t0"], G["tgt.times"], G["tgt.states"]):
+        got = velocity_command_targets(model, tuple(c), t0, x0, h)
+        np.testing.assert_allclose(np.asarray(got.times), tt, rtol=1e-15, atol=0)
+        np.testing.assert_allclose(np.asarray(got.states), ts, rtol=0, atol=1e-14)
+        assert np.array_equal(ts[0][6:6 + NJ], np.asarray(model.default_joint_state))
+    # what the mirror deliberately leaves out: the reference's filter state is a function-local STATIC (TargetTrajectoriesCalculatorBase.cpp:
+    # 117-119) — one call after a new command (vx = 5) it has moved 20 % of the way from wherever the PREVIOUS calculator left it (here the
+    # converged last command of the loop above; the initial state's yaw is zero), so the first targets of a command lag it
+    first = G["tgt.first_call_states"]
+    assert abs(first[0][6 + NJ] - (0.8 * G["tgt.cmd"][-1][0] + 0.2 * 5.0)) < 1e-12
+
+
 @pytest.mark.skipif(not ref_terms.available(), reason="oracle/_ref/libref_terms.so needs /root/reference (build container) or the prebuilt library")
 def test_fixture_is_what_the_library_returns_now(model):
     ref = ref_terms.RefTerms(NJ)
