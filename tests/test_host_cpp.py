@@ -99,3 +99,81 @@ def test_cpp_model_loader_builds_the_same_model_description_as_python(tmp_path, 
     bad.write_text(open(path).read().replace('"gravity"', '"gravitas"'))
     r = subprocess.run([str(exe), str(bad), str(tmp_path / "out2.bin")], capture_output=True, text=True)
     assert r.returncode == 3 and "gravity" in r.stdout
+
+
+BUILDER_SRC = r'''
+#include <cstdio>
+#include "HipSqpModelBuilder.h"
+int main(int argc, char** argv) {
+  try {
+    const bool cent = argc > 5 && std::string(argv[5]) == "centroidal";
+    const hsqp_model_desc md = hsqp_host::buildModelDesc(argv[1], argv[2], argv[3], cent);
+    const hsqp_swing_config sw = hsqp_host::buildSwingConfig(argv[1], argv[2], argv[3], cent);
+    FILE* f = std::fopen(argv[4], "wb");
+    std::fwrite(&md, sizeof(md), 1, f);
+    std::fwrite(&sw, sizeof(sw), 1, f);
+    std::fclose(f);
+    const hsqp_host::JsonValue img = hsqp_host::buildProblemImage(argv[1], argv[2], argv[3], cent);
+    std::printf("total_mass %.17g\n", img.at("total_mass").number());
+    return 0;
+  } catch (const std::exception& e) {
+    std::printf("error: %s\n", e.what());
+    return 3;
+  }
+}
+'''
+REF_ROOT = "/root/reference"
+
+
+def _assert_struct_close(a, b, path="desc"):
+    import ctypes
+    if isinstance(a, ctypes.Structure):
+        for name, _ in a._fields_:
+            _assert_struct_close(getattr(a, name), getattr(b, name), f"{path}.{name}")
+    elif isinstance(a, ctypes.Array):
+        for i in range(len(a)):
+            _assert_struct_close(a[i], b[i], f"{path}[{i}]")
+    elif isinstance(a, float):
+        assert abs(a - b) <= 1e-14 * max(1.0, abs(b)), f"{path}: {a!r} != {b!r}"
+    else:
+        assert a == b, f"{path}: {a!r} != {b!r}"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ROOT), reason="needs the reference's URDF / task.info / reference.info (/root/reference: build container only)")
+@pytest.mark.parametrize("formulation", ["wb", "centroidal"])
+def test_cpp_model_builder_from_task_urdf_reference_files_equals_the_exported_model(tmp_path, formulation):
+    """host/HipSqpModelBuilder.h: hsqp_model_desc straight from (taskFile, urdfFile, referenceFile) — the arguments of the reference's
+    interface constructors (WBMpcInterface.h:73-75) — in C++17 with the standard library only (own INFO and URDF readers): every field of
+    the struct equals the one built from the exported image (tools/export_g1_model.py -> data/*.json -> model.py) to 1e-14, integers
+    exactly; so a drop-in main() needs no Python.  A URDF with a prismatic MPC joint or a task.info without a key fails loudly."""
+    import ctypes
+    from wb_humanoid_mpc_amd import _abi, load_model
+    from wb_humanoid_mpc_amd.reference import swing_config
+    m = load_model(formulation=formulation)
+    pkg = "g1_centroidal_mpc" if formulation == "centroidal" else "g1_wb_mpc"
+    task = f"{REF_ROOT}/robot_models/unitree_g1/{pkg}/config/mpc/task.info"
+    urdf = f"{REF_ROOT}/robot_models/unitree_g1/g1_description/urdf/g1_29dof.urdf"
+    refi = f"{REF_ROOT}/robot_models/unitree_g1/{pkg}/config/command/reference.info"
+    src = tmp_path / "b.cpp"
+    src.write_text(BUILDER_SRC)
+    exe = tmp_path / "b"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "wb_humanoid_mpc_amd", "host"), str(src), "-o", str(exe)])
+    r = subprocess.run([str(exe), task, urdf, refi, str(tmp_path / "out.bin"), formulation], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    blob = (tmp_path / "out.bin").read_bytes()
+    n = ctypes.sizeof(m.desc)
+    got = _abi.ModelDesc.from_buffer_copy(blob[:n])
+    _assert_struct_close(got, m.desc)
+    sw = swing_config(m)
+    got_sw = type(sw).from_buffer_copy(blob[n:])
+    _assert_struct_close(got_sw, sw, "swing")
+    assert abs(float(r.stdout.split()[1]) - m.total_mass) <= 1e-12
+    # loud failures: a missing key, an unsupported joint type
+    bad = tmp_path / "task.info"
+    bad.write_text(open(task).read().replace("terminalCostScaling", "terminalCostScalin"))
+    r = subprocess.run([str(exe), str(bad), urdf, refi, str(tmp_path / "o2.bin"), formulation], capture_output=True, text=True)
+    assert r.returncode == 3 and "terminalCostScaling" in r.stdout
+    badu = tmp_path / "bad.urdf"
+    badu.write_text(open(urdf).read().replace('name="left_knee_joint" type="revolute"', 'name="left_knee_joint" type="prismatic"'))
+    r = subprocess.run([str(exe), task, str(badu), refi, str(tmp_path / "o3.bin"), formulation], capture_output=True, text=True)
+    assert r.returncode == 3 and "prismatic" in r.stdout

@@ -103,8 +103,7 @@ inline void barrier(hsqp_barrier& b, const JsonValue& v) { b.mu = v.at("barrier_
 }  // namespace detail
 
 /** The problem image (JSON) -> hsqp_model_desc, field for field as wb_humanoid_mpc_amd/model.py builds it (tests/test_host_cpp.py: bit-identical). */
-inline hsqp_model_desc loadModelDesc(const std::string& jsonPath) {
-  const JsonValue d = loadJsonFile(jsonPath);
+inline hsqp_model_desc modelDescFromImage(const JsonValue& d) {
   hsqp_model_desc m;
   std::memset(&m, 0, sizeof(m));
   const bool cent = d.has("formulation") && d.at("formulation").str == "centroidal";
@@ -158,9 +157,11 @@ inline hsqp_model_desc loadModelDesc(const std::string& jsonPath) {
   return m;
 }
 
+inline hsqp_model_desc loadModelDesc(const std::string& jsonPath) { return modelDescFromImage(loadJsonFile(jsonPath)); }
+
 /** task.info swing_trajectory_config of the same image -> hsqp_swing_config (SwingTrajectoryPlanner::Config). */
-inline hsqp_swing_config loadSwingConfig(const std::string& jsonPath) {
-  const JsonValue s = loadJsonFile(jsonPath).at("swing");
+inline hsqp_swing_config swingConfigFromImage(const JsonValue& image) {
+  const JsonValue& s = image.at("swing");
   hsqp_swing_config c;
   c.lift_off_velocity = s.at("liftOffVelocity").number(); c.touch_down_velocity = s.at("touchDownVelocity").number(); c.swing_height = s.at("swingHeight").number();
   c.touch_down_height_offset = s.at("touchDownHeightOffset").number(); c.swing_time_scale = s.at("swingTimeScale").number();
@@ -168,5 +169,6 @@ inline hsqp_swing_config loadSwingConfig(const std::string& jsonPath) {
   c.impact_touch_velocity = s.at("impactProximityFactorTouchDownVelocity").number();
   return c;
 }
+inline hsqp_swing_config loadSwingConfig(const std::string& jsonPath) { return swingConfigFromImage(loadJsonFile(jsonPath)); }
 
 }  // namespace hsqp_host
