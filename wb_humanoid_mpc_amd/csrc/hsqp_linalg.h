@@ -191,7 +191,7 @@ typedef double __attribute__((address_space(1))) * hsqp_gptr;
 // SPACES (XTY_ADD_GLOBAL | XTY_C_GLOBAL): the additive term / the destination of every job of the call is known to be in
 // GLOBAL memory -> address-space-qualified accesses.  A generic pointer compiles to FLAT instructions, whose loads also
 // count on lgkmcnt and make the LDS operand waits of the MFMA loop wait for the L2/HBM round trip.
-template <int NT, int SPACES>
+template <int NT, int SPACES, int XTY_PF = 1>
 __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, const int* tiles, int lane, long long* prof = nullptr) {
   XTY_PROF_T(t_begin);
   const int tn = (j.N + 15) >> 4;
@@ -232,24 +232,47 @@ __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, c
       for (int r = 0; r < 4; ++r) addv[t][r] = 0.0;
   }
   XTY_PROF_T(t_loop);
-  for (int k0 = 0; k0 < j.L1; k0 += 4) {
-    const int k = k0 + kk;
-    const bool ok = k < j.L1;
+  // The contraction as ONE sequence of 4-row steps (n1 of the first product, then n2 of the second) with the operands travelling XTY_PF
+  // steps ahead in a ring of register sets (template parameter; 1 = the reads of step s + 1 are issued behind the matrix instructions of
+  // step s, which is what a plain loop compiles to as well).  An LDS round trip is ~200 cycles under the load of eight waves, a matrix
+  // instruction holds the pipe for 64: with one step in flight a one-tile call keeps its pipe a third busy — the serial Riccati stage,
+  // whose phases are one or two tile calls long, asks for 3 (1.73 -> 1.62 ms); the throughput kernels (k_project: 3+ workgroups per CU
+  // hide the latency with other waves, and the extra registers cost occupancy) stay at 1.  A step beyond the end of a product reads a
+  // clamped (valid) row and contributes a * 0.
+  const int n1 = (j.L1 + 3) >> 2, n2 = (j.L2 + 3) >> 2, ns = n1 + n2;
+  auto fetch = [&](int s, double* a, double* b) {
+    if (s < n1) {
+      const int k = 4 * s + kk, kc = k < j.L1 ? k : j.L1 - 1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const double a = ok ? j.X1[k * j.ldx1 + xr[t] * j.sx1] : 0.0;
-      const double b = ok ? j.Y1[k * j.ldy1 + yc[t]] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        const double av = j.X1[kc * j.ldx1 + xr[t] * j.sx1];
+        a[t] = k < j.L1 ? av : 0.0;
+        b[t] = j.Y1[kc * j.ldy1 + yc[t]];
+      }
+    } else {
+      const int k = 4 * (s - n1) + kk, kc = k < j.L2 ? k : j.L2 - 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double av = j.sign2 * j.X2[kc * j.ldx2 + xr[t] * j.sx2];
+        a[t] = k < j.L2 ? av : 0.0;
+        b[t] = j.Y2[kc * j.ldy2 + yc[t]];
+      }
     }
-  }
-  for (int k0 = 0; k0 < j.L2; k0 += 4) {
-    const int k = k0 + kk;
-    const bool ok = k < j.L2;
+  };
+  double pa[XTY_PF][NT], pb[XTY_PF][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const double a = ok ? j.sign2 * j.X2[k * j.ldx2 + xr[t] * j.sx2] : 0.0;
-      const double b = ok ? j.Y2[k * j.ldy2 + yc[t]] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+  for (int u = 0; u < XTY_PF; ++u) { if (u < ns) fetch(u, pa[u], pb[u]); }
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s0 = 0; s0 < ns; s0 += XTY_PF) {
+#pragma unroll
+    for (int u = 0; u < XTY_PF; ++u) {
+      const int s = s0 + u;
+      if (s < ns) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u][t], pb[u][t], acc[t], 0, 0, 0);
+        if (s + XTY_PF < ns) fetch(s + XTY_PF, pa[u], pb[u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   XTY_PROF_T(t_epi);
@@ -325,15 +348,15 @@ HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane
 // nothing else on its critical path (k_riccati: the helper waves take tiles after their copies, seven waves form S A~ while the
 // eighth eliminates).
 // one job of a dealt list: g0 = number of tiles of the jobs before it; returns its own tile count
-template <int SPACES = 0>
+template <int SPACES = 0, int PF = 1>
 __attribute__((always_inline)) HSQP_D int xty_deal_one(const XtyJob& j, int g0, int rank, int W, int lane, long long* prof = nullptr) {
   const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
   const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
   if (rank < 0) return nt;
   int t = rank - g0 % W;
   if (t < 0) t += W;
-  for (; t + W < nt; t += 2 * W) { const int pair[2] = {xty_tile_id(j.sym, tn, t), xty_tile_id(j.sym, tn, t + W)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane, prof); }
-  if (t < nt) { const int one = xty_tile_id(j.sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane, prof); }
+  for (; t + W < nt; t += 2 * W) { const int pair[2] = {xty_tile_id(j.sym, tn, t), xty_tile_id(j.sym, tn, t + W)}; xty_job_tiles_mfma<2, SPACES, PF>(j, pair, lane, prof); }
+  if (t < nt) { const int one = xty_tile_id(j.sym, tn, t); xty_job_tiles_mfma<1, SPACES, PF>(j, &one, lane, prof); }
   return nt;
 }
 template <int SPACES = 0>

@@ -63,6 +63,7 @@ static_assert(sizeof(RicWS) <= 163400, "hipFuncSetAttribute(MaxDynamicSharedMemo
 // (the jobs are separate by-value arguments, not an array or pointers: a descriptor whose address is taken lives in scratch memory on the
 //  device and its tile loops stay generic)
 HSQP_HD XtyJob xty_no_job() { XtyJob j = xty_job(0, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0); return j; }
+constexpr int RIC_PF = 3;   // operand prefetch depth of the stage's tile loops (hsqp_linalg.h)
 #ifndef PROF_WAVE
 #define PROF_WAVE 2     // -DHSQP_PHASE_PROFILE builds: the wave whose tile calls are split into prologue / matrix loop / epilogue ticks
 #endif
@@ -76,7 +77,7 @@ HSQP_D void ric_products_ranked(const Ctx& ctx, int rank, int W, const XtyJob j0
 #else
   long long* prof = nullptr;
 #endif
-  xty_deal_one<SPACES>(j0, 0, rank, W, ctx.tid & 63, prof);
+  xty_deal_one<SPACES, RIC_PF>(j0, 0, rank, W, ctx.tid & 63, prof);
 }
 #endif
 template <int SPACES = 0, int NJ = 1>
@@ -90,9 +91,9 @@ HSQP_HD void ric_products(const Ctx& ctx, int first_wave, int n_waves, const Xty
 #else
     long long* prof = nullptr;
 #endif
-    int g0 = xty_deal_one<SPACES>(j0, 0, r, n_waves, lane, prof);
-    if constexpr (NJ > 1) g0 += xty_deal_one<SPACES>(j1, g0, r, n_waves, lane, prof);
-    if constexpr (NJ > 2) xty_deal_one<SPACES>(j2, g0, r, n_waves, lane, prof);
+    int g0 = xty_deal_one<SPACES, RIC_PF>(j0, 0, r, n_waves, lane, prof);
+    if constexpr (NJ > 1) g0 += xty_deal_one<SPACES, RIC_PF>(j1, g0, r, n_waves, lane, prof);
+    if constexpr (NJ > 2) xty_deal_one<SPACES, RIC_PF>(j2, g0, r, n_waves, lane, prof);
     return;
   }
 #endif
