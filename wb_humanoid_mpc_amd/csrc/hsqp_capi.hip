@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_jump(const double* __restrict__ dts, co
 
 // ---- Riccati backward sweep + closed-loop forward sweep (dx): one workgroup per instance
 template <int NXE>
-__global__ __launch_bounds__(RIC_THREADS) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
+__global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
                                                          const double* __restrict__ x, const double* __restrict__ par,
                                                          const double* __restrict__ qp, double* __restrict__ ric, int N,
                                                          double* __restrict__ dx, int* __restrict__ status, long long* prof,
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double
 // or, in the refinement pass, the one the first pass computed (vf_in: [N + 1][VF_SIZE] per instance).  Applying the exact Riccati map
 // once more contracts the scan's rounding error (oracle-level experiment: 5e-8 -> 5e-9 on the worst whole-body case).
 template <int n>
-__global__ __launch_bounds__(RIC_THREADS) void k_scan_gains(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
+__global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_gains(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
                                                             const double* __restrict__ qp, const double* __restrict__ el, const double* __restrict__ vf_in,
                                                             double* __restrict__ ric, int N, int* __restrict__ status, double* __restrict__ vf, double* __restrict__ acl) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);

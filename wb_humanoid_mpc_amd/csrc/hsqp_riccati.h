@@ -332,8 +332,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const int trank = (wv & 3) >= 2 ? (wv & 1) + (wv >> 2) * 2 : -1;
       if (wv < 2) {
         double e[NUT];
+        __builtin_amdgcn_s_setprio(3);
         eliminate_begin<NXE>(w, wv, ctx.tid & 63, e, k > 0 ? qn + QP_A : nullptr, &An[0][0]);
         eliminate_end<NXE>(w, wv, ctx.tid & 63, e);
+        __builtin_amdgcn_s_setprio(0);
       } else if (trank < 0) {
         if (k > 0) {
           constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
