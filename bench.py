@@ -326,10 +326,27 @@ def main():
     kkt_norm = float(np.max(out["kkt"].max(1) / np.maximum(1.0, out["grad_inf"])))   # r <= 1e-9 max(1, |g|_inf), per instance
     g_inf_min, g_inf_max = float(out["grad_inf"].min()), float(out["grad_inf"].max())
     # outside the timed region: the same iteration through hsqp_solve with HOST buffers (upload + iterate + download over PCIe)
+    # (solution buffers allocated once and reused, as an MPC loop would; first from pageable memory, then with every buffer page-locked
+    #  through hsqp_host_register)
+    into = solver.alloc_solution(B, N)
+    xs = [np.ascontiguousarray(a) for a in (x0, x, u, par)]
+    solver.run(*xs, dt, into=into)
     t1 = time.perf_counter()
     for _ in range(2):
-        solver.run(x0, x, u, par, dt)
+        solver.run(*xs, dt, into=into)
     pcie_ms = 1e3 * (time.perf_counter() - t1) / 2
+    pinned = xs + [into[1][k] for k in ("x", "u", "dx", "du")]
+    pcie_pinned_ms = None
+    try:
+        solver.pin(*pinned)
+        solver.run(*xs, dt, into=into)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            solver.run(*xs, dt, into=into)
+        pcie_pinned_ms = 1e3 * (time.perf_counter() - t1) / 2
+        solver.unpin(*pinned)
+    except Exception:  # noqa: BLE001  (page-locking 75 MB can be refused by the container's memlock limit)
+        pcie_pinned_ms = None
 
     elapsed, kkt, kkt_norm = group.max([elapsed, kkt, kkt_norm])   # max over ranks
     strong = None
@@ -403,7 +420,9 @@ def main():
             "assumptions": "every number depends on the oracle-level assumptions A1 (PieceWisePolynomialBarrierPenalty), A2 (orientation error to plane)" +
                            (" and A7 (centroidal flow map)" if cent else "") + ": DESIGN.md §2",
             "pcie_inclusive": {"ms_per_step": pcie_ms, "value": B / (pcie_ms * 1e-3), "unit": "SQP iters/s per GPU",
-                               "note": "hsqp_solve with host buffers (upload 36 MB + iterate incl. KKT check + download 39 MB at B=256, N=100); never `value`"},
+                               "pinned_ms_per_step": pcie_pinned_ms, "pinned_value": None if not pcie_pinned_ms else B / (pcie_pinned_ms * 1e-3),
+                               "note": "hsqp_solve with host buffers reused every call (upload 36 MB + iterate incl. KKT check + download 39 MB at B=256, N=100), from pageable memory and "
+                                       "with the buffers page-locked through hsqp_host_register; never `value`"},
         }
         if world > 1:
             res["weak_scaling"] = {"scaling": "weak", "value": weak_value, "unit": "SQP iters/s", "ms_per_step": 1e3 * elapsed / args.steps, "batch_per_gpu": B,

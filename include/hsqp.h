@@ -24,6 +24,7 @@
 #ifndef HSQP_H
 #define HSQP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -278,6 +279,16 @@ int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf /*[B
  * receiver: humanoid_centroidal_mpc_ros2 GainsReceiver): diagonal Q[58], R[35], Qf[58] in the layout of hsqp_model_desc; NULL keeps
  * the current values.  Takes effect with the next iteration. */
 int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf);
+
+/* Page-lock a caller-owned host buffer (hipHostRegister / hipHostUnregister behind the C ABI, so that a caller need not link the HIP
+ * runtime): hsqp_solve / hsqp_upload / hsqp_download move 36 + 39 MB per iteration at 256 instances x 100 nodes; from pageable memory the
+ * runtime stages them through its own bounce buffers, from registered buffers they are one DMA each.  The library does not copy into a staging area of its own: that would add a host memcpy of the same size.  Register the
+ * trajectory / parameter / solution arrays once, reuse them every MPC cycle, unregister before freeing them.
+ * HSQP_OK, HSQP_ERR_NO_DEVICE, HSQP_ERR_BAD_ARG (null / zero bytes) or HSQP_ERR_HIP (the runtime refused, e.g. the memlock limit).
+ * Measured (bench.py `pcie_inclusive`, buffers reused every call): 9.1 ms per hsqp_solve from pageable memory, 8.9 ms page-locked, of which
+ * the iteration with its KKT report is 7.3 ms — the runtime's pageable path already reaches ~40 GB/s on this host. */
+int hsqp_host_register(void* buffer, size_t bytes);
+int hsqp_host_unregister(void* buffer);
 /* Line-search settings of the handle (defaults: task.info g_max 1e-2, g_min 1e-6, deltaTol 1e-4; upstream gamma_c 1e-6,
  * armijoFactor 1e-4, alpha_decay 0.5, alpha_min 1e-4). */
 void hsqp_linesearch_defaults(hsqp_linesearch_settings* s);

@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
         "hsqp_create", "hsqp_destroy", "hsqp_solve", "hsqp_upload", "hsqp_iterate_device", "hsqp_download",
         "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_scan_fallbacks", "hsqp_version", "hsqp_device_count",
         "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference", "hsqp_joint_torques", "hsqp_evaluate_policy",
-        "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights"])
+        "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights", "hsqp_host_register", "hsqp_host_unregister"])
 
 
 def test_library_exports_every_declared_symbol():

@@ -529,3 +529,26 @@ def test_two_level_sweep_gate_rejects_and_backs_off(cmodel):
             s.close()
     assert res["serial"][1] == 0 and 1 <= res["segmented"][1] <= 3            # rejected, then 1 + 3 iterations of back-off, rejected again, ...
     assert np.array_equal(res["segmented"][0]["dx"], res["serial"][0]["dx"]) and np.array_equal(res["segmented"][0]["du"], res["serial"][0]["du"])
+
+
+def test_page_locked_caller_buffers_give_the_same_solution(model):
+    """hsqp_host_register / hsqp_host_unregister (include/hsqp.h): hsqp_solve on page-locked caller buffers returns bit for bit what it returns
+    on pageable ones; an empty buffer is an error code, not a crash."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver, HsqpError
+    x0, x, u, par, dt = make_problem(model, n_nodes=12, batch=3, perturb=True)
+    s = HipSqpSolver(model, max_nodes=12, max_batch=3)
+    try:
+        want = s.run(x0, x, u, par, dt)
+        want = {k: np.array(want[k]) for k in ("x", "u", "dx", "du")}
+        arrs = [np.ascontiguousarray(a) for a in (x0, x, u, par)]
+        into = s.alloc_solution(3, 12)
+        bufs = arrs + [into[1][k] for k in ("x", "u", "dx", "du")]
+        s.pin(*bufs)
+        got = s.run(*arrs, dt, into=into)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        s.unpin(*bufs)
+        with pytest.raises(HsqpError):
+            s.pin(np.zeros(0))          # nothing to lock: BAD_ARG, not a crash
+    finally:
+        s.close()

@@ -1258,6 +1258,17 @@ static int download_impl(hsqp_handle* h, hsqp_solution* s, bool device_dst) {
 int hsqp_download(hsqp_handle* h, hsqp_solution* s) { return download_impl(h, s, false); }
 int hsqp_download_device(hsqp_handle* h, hsqp_solution* s) { return download_impl(h, s, true); }
 
+int hsqp_host_register(void* buffer, size_t bytes) {
+  if (!buffer || bytes == 0) return HSQP_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HSQP_ERR_NO_DEVICE;
+  return hipHostRegister(buffer, bytes, hipHostRegisterDefault) == hipSuccess ? HSQP_OK : ((void)hipGetLastError(), HSQP_ERR_HIP);
+}
+int hsqp_host_unregister(void* buffer) {
+  if (!buffer) return HSQP_ERR_BAD_ARG;
+  return hipHostUnregister(buffer) == hipSuccess ? HSQP_OK : ((void)hipGetLastError(), HSQP_ERR_HIP);
+}
+
 int hsqp_solve(hsqp_handle* h, const hsqp_problem* problem, hsqp_solution* solution) {
   int rc = hsqp_upload(h, problem);
   if (rc != HSQP_OK) return rc;

@@ -47,6 +47,8 @@ def load_library():
     lib.hsqp_last_iterations.argtypes = [C.c_void_p]
     lib.hsqp_iteration_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(_abi.Perf), _dp, C.POINTER(C.c_int32)]
     lib.hsqp_update_weights.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.hsqp_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.hsqp_host_unregister.argtypes = [C.c_void_p]
     lib.hsqp_download.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
     lib.hsqp_upload_device.argtypes = [C.c_void_p, C.POINTER(_abi.Problem)]
     lib.hsqp_download_device.argtypes = [C.c_void_p, C.POINTER(_abi.Solution)]
@@ -158,9 +160,22 @@ class HipSqpSolver:
         return out
 
     # ---- SolverBase::run (one SQP iteration, sqpIteration = 1 as in task.info:81)
-    def run(self, x_init, x_traj, u_traj, params, dt):
+    def pin(self, *arrays):
+        """hsqp_host_register on caller-owned numpy arrays (page-locked: one DMA per transfer); unpin() before they are freed."""
+        for a in arrays:
+            self._check(self.lib.hsqp_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def unpin(self, *arrays):
+        for a in arrays:
+            self._check(self.lib.hsqp_host_unregister(a.ctypes.data_as(C.c_void_p)))
+
+    def alloc_solution(self, B, N):
+        """Solution buffers for run(..., into=...): allocate (and pin) once, reuse every cycle."""
+        return self._alloc_solution(B, N)
+
+    def run(self, x_init, x_traj, u_traj, params, dt, into=None):
         p, keep, (B, N) = self._problem(x_init, x_traj, u_traj, params, dt)
-        s, out, pb, pa = self._alloc_solution(B, N)
+        s, out, pb, pa = into if into is not None else self._alloc_solution(B, N)
         self._check(self.lib.hsqp_solve(self.h, C.byref(p), C.byref(s)))
         self._shape = (B, N)
         return self._finish(s, out, pb, pa)
