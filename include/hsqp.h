@@ -141,6 +141,12 @@ typedef struct hsqp_model_desc {
  * counts those. */
 #define HSQP_FLAG_SERIAL_RICCATI 2     /* always the serial recursion                                              */
 #define HSQP_FLAG_PARALLEL_RICCATI 4   /* the scan for every batch size and horizon (still gated); excludes HSQP_FLAG_SERIAL_RICCATI */
+/* Cost of the gate: it is all-or-nothing per call — one rejected instance redoes the serial sweep, the step, the KKT report and the
+ * performance indices for the whole batch.  Up to 256 instances nothing would be saved by redoing only the rejected ones (the serial
+ * sweep is one workgroup per instance on 256 CUs: 1.6 ms for 1 or 256 of them); beyond that, and on far-from-feasible line-search
+ * iterates that fail the gate regularly, a forced scan roughly doubles the iteration time — and it holds two value-function buffers of
+ * max_batch * (max_nodes + 1) * 3 422 doubles (1.4 GB at 256 x 100).  The flag is for measurements; the automatic choice is
+ * max_batch <= HSQP_SCAN_AUTO_BATCH. */
 #define HSQP_SCAN_AUTO_BATCH 2
 #define HSQP_SCAN_AUTO_MIN_NODES 48
 /* Two-level (segmented) sweep for the batches in between (csrc/hsqp_segment.h) — OPT-IN.  One workgroup per instance leaves 256 - B CUs idle
