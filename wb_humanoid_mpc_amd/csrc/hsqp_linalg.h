@@ -330,14 +330,14 @@ HSQP_HD int xty_tile_id(int sym, int tn, int t) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // tiles are numbered globally (base + t) and dealt round-robin to the waves; a wave takes its tiles two at a time
-template <int SPACES>
+template <int SPACES, int PF = 1>
 HSQP_D int xty_run_job(const XtyJob& j, int base, int wave, int nwaves, int lane, long long* prof = nullptr) {
   const int tm = (j.M + 15) >> 4, tn = (j.N + 15) >> 4;
   const int nt = j.sym ? tn * (tn + 1) / 2 : tm * tn;
   const int sym = j.sym;
   int t = (wave - base) & (nwaves - 1);   // round-robin over the waves (their number is a power of two)
-  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES>(j, pair, lane, prof); }
-  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES>(j, &one, lane, prof); }
+  for (; t + nwaves < nt; t += 2 * nwaves) { const int pair[2] = {xty_tile_id(sym, tn, t), xty_tile_id(sym, tn, t + nwaves)}; xty_job_tiles_mfma<2, SPACES, PF>(j, pair, lane, prof); }
+  if (t < nt) { const int one = xty_tile_id(sym, tn, t); xty_job_tiles_mfma<1, SPACES, PF>(j, &one, lane, prof); }
   return nt;
 }
 #endif
@@ -370,7 +370,7 @@ HSQP_D void xty_deal(const XtyJob* jobs, int njobs, int rank, int W, int lane) {
 // Executes `njobs` independent products; must be called by every thread of the workgroup (no barrier inside).
 // UNROLL: the loop over the jobs is unrolled so that each job gets code specialised for its (constant) shape and the
 // descriptors stay in registers — pays off for long contractions in throughput kernels, not inside the Riccati stage loop.
-template <bool UNROLL = false, int SPACES = 0>
+template <bool UNROLL = false, int SPACES = 0, int PF = 1>
 HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wave = ctx.tid >> 6, nwaves = ctx.nthreads >> 6, lane = ctx.tid & 63;
@@ -382,9 +382,9 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
 #endif
   if constexpr (UNROLL) {
 #pragma unroll
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane, prof);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES, PF>(jobs[jn], base, wave, nwaves, lane, prof);
   } else {
-    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES>(jobs[jn], base, wave, nwaves, lane, prof);
+    for (int jn = 0; jn < njobs; ++jn) base += xty_run_job<SPACES, PF>(jobs[jn], base, wave, nwaves, lane, prof);
   }
 #else
   // host build (tests/hostemu, oracle/cpu_baseline.cpp): rank-1 updates over contiguous rows of Y so that the inner loop

@@ -29,6 +29,8 @@
 #include "hsqp_riccati.h"
 
 namespace hsqp {
+constexpr int SCAN_PF = 3;   // operand prefetch depth of the scan kernels' tile loops (hsqp_linalg.h): one workgroup per element, latency-bound like the Riccati stage
+
 
 // KKT gate of the parallel-in-time sweep: the stationarity / primal residuals of the QP must be below BOTH HSQP_SCAN_GATE_REL max(1, |g|_inf)
 // (BASELINE.md §6's criterion for a QP solution) and HSQP_SCAN_GATE_ABS.  The absolute bound is what separates the two populations seen on
@@ -334,7 +336,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
   {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
     const XtyJob jobs[2] = {xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1),
                             xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1)};
-    wg_xty_jobs<true>(ctx, jobs, 2);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, jobs, 2);
     WG_FOR(ctx, r, NUT) { double s = 0.0; for (int l = 0; l < NUT; ++l) s += w.Ri[r][l] * w.rv[l]; w.wr[r] = s; }
   }
   WG_SYNC(ctx);
@@ -342,7 +344,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     const XtyJob jobs[3] = {xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WP[0][0], n + 1, el + E::A, n, q + QP_A, NX, -1.0),
                             xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1, el + E::C, n),
                             xty_job(n, n, NUT, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1, el + E::J, n, q + QP_Q, NX, -1.0)};
-    wg_xty_jobs<true>(ctx, jobs, 3);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, jobs, 3);
     WG_FOR(ctx, i, 2 * n + (E::SIZE - E::ETA - n)) {
       if (i < n) { double s = q[QP_BV + i]; for (int l = 0; l < NUT; ++l) s -= w.BT[l][i] * w.wr[l]; el[E::B + i] = s; }
       else if (i < 2 * n) { const int r = i - n; double s = q[QP_QV + r]; for (int l = 0; l < NUT; ++l) s -= w.Pm[l][r] * w.wr[l]; el[E::ETA + r] = -s; }
@@ -409,7 +411,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   PH_TICK(ctx, 20);
   {  // M - I = C1 J2 (C1 symmetric: X = C1), right-hand side b1 + C1 eta2, y = eta2 - J2 b1
     const XtyJob job = xty_job(n, n, n, &w.C1[0][0], LD, &w.J2[0][0], LD, &w.Mb[0][0], LD);
-    wg_xty_jobs<true>(ctx, &job, 1);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, &job, 1);
     WG_FOR(ctx, i, 2 * n) {
       if (i < n) { double s = w.b1[i]; for (int l = 0; l < n; ++l) s += w.C1[i][l] * w.eta2[l]; w.rh[i] = s; }
       else { const int r = i - n; double s = w.eta2[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.b1[l]; w.y[r] = s; }
@@ -448,7 +450,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   {  // A = A2 XA (to the output), V = J2 XA (over M);  z = XC y, b = A2 xb + b2
     const XtyJob jobs[2] = {xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][0], LX, out + E::A, n),
                             xty_job(n, n, n, &w.J2[0][0], LD, &w.X[0][0], LX, &w.Mb[0][0], LD)};
-    wg_xty_jobs<true>(ctx, jobs, 2);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, jobs, 2);
     WG_FOR(ctx, i, 2 * n) {
       if (i < n) { double s = 0.0; for (int l = 0; l < n; ++l) s += w.X[i][n + l] * w.y[l]; w.z[i] = s; }
       else { const int r = i - n; double s = w.b2[r]; for (int l = 0; l < n; ++l) s += w.A2T[l][r] * w.X[l][2 * n]; out[E::B + r] = s; }
@@ -470,7 +472,7 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
 #endif
   {
     const XtyJob job = xty_job(n, n, n, &w.A2T[0][0], LD, &w.X[0][n], LX, &w.X[0][0], LX);
-    wg_xty_jobs<true>(ctx, &job, 1);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, &job, 1);
     WG_FOR(ctx, r, n) { double s = w.y[r]; for (int l = 0; l < n; ++l) s -= w.J2[r][l] * w.z[l]; w.t[r] = s; }
   }
   WG_SYNC(ctx);   // J2 is dead
@@ -491,13 +493,13 @@ HSQP_HD void scan_combine(const Ctx& ctx, ScanCombWS<n>& w, const double* e1, co
   {
     XtyJob jc = xty_job(n, n, n, &w.X[0][0], 1, &w.A2T[0][0], LD, &w.X[0][n], LX, e2 + E::C, n);
     jc.sx1 = LX;
-    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, &jc, 1);
+    wg_xty_jobs<true, XTY_ADD_GLOBAL, SCAN_PF>(ctx, &jc, 1);
     WG_FOR(ctx, i, n) { double s = w.eta1[i]; for (int l = 0; l < n; ++l) s += w.J2[l][i] * w.t[l]; out[E::ETA + i] = s; }
   }
   WG_SYNC(ctx);   // A2' is dead
   {
     const XtyJob jj = xty_job(n, n, n, &w.J2[0][0], LD, &w.Mb[0][0], LD, &w.A2T[0][0], LD, e1 + E::J, n);
-    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, &jj, 1);
+    wg_xty_jobs<true, XTY_ADD_GLOBAL, SCAN_PF>(ctx, &jj, 1);
     WG_FOR(ctx, i, n * n) { const int r = i / n, c = i % n; out[E::C + i] = 0.5 * (w.X[r][n + c] + w.X[c][n + r]); }
   }
   WG_SYNC(ctx);
