@@ -286,10 +286,15 @@ def main():
     from wb_humanoid_mpc_amd.solver import HipSqpSolver, load_library
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    # HSQP_DIST_BACKEND=gloo: dry run of the N-rank code path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device);
+    # ranks then share the devices round-robin and the collectives are staged through the host — a logic check, never a measurement
+    backend = os.environ.get("HSQP_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")  # initialise the HIP runtime through torch before the library touches it
     load_library()
-    group = Group(world, backend="nccl", device=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    group = Group(world, backend=backend, device=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     cent = args.formulation == "centroidal"
     model = load_model(formulation=args.formulation)
@@ -355,7 +360,7 @@ def main():
     # RCCL really spans `world` GPUs: an all-reduce of ones over the ranks' devices
     rccl_ranks = 1
     if world > 1:
-        ones = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        ones = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
         group.dist.all_reduce(ones)
         rccl_ranks = int(round(float(ones.item())))
 

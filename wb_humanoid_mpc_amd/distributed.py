@@ -36,6 +36,9 @@ class Group:
         self.world = world
         self.device = device
         self.dist = None
+        # gloo with tensors in HBM (HSQP_DIST_BACKEND=gloo: the data path of N ranks dry-run on ONE GPU, where RCCL refuses two ranks on
+        # a device): its scatter / gather / all_gather take CPU tensors only, so those collectives are staged through the host
+        self.stage = backend == "gloo" and device is not None and getattr(device, "type", "cpu") != "cpu"
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -54,7 +57,7 @@ class Group:
         if self.dist is None:
             return [float(v) for v in values]
         import torch
-        t = torch.tensor(list(values), dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device if self.device is not None and not self.stage else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return [float(v) for v in t.cpu()]
 
@@ -63,7 +66,7 @@ class Group:
         if self.dist is None:
             return np.asarray([list(values)], dtype=float)
         import torch
-        t = torch.tensor(list(values), dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device if self.device is not None and not self.stage else "cpu")
         out = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return np.stack([o.cpu().numpy() for o in out])
@@ -78,7 +81,7 @@ def broadcast_image(group, payload):
     if group.dist is None:
         return bytes(payload)
     import torch
-    dev = group.device if group.device is not None else "cpu"
+    dev = group.device if group.device is not None and not group.stage else "cpu"
     n = torch.tensor([len(payload) if payload is not None else 0], dtype=torch.int64, device=dev)
     group.dist.broadcast(n, src=0)
     buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev) if env_rank()[0] == 0 else torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
@@ -117,7 +120,12 @@ class BatchShards:
                 if hi - lo < self.per:
                     blk = torch.cat([blk, global_tensor[:1].expand(self.per - (hi - lo), *row_shape)], dim=0)
                 pieces.append(blk.contiguous())
-        self.group.dist.scatter(local, pieces, src=0)
+        if self.group.stage:
+            host = torch.empty((self.per, *row_shape), dtype=dtype)
+            self.group.dist.scatter(host, None if pieces is None else [p.cpu() for p in pieces], src=0)
+            local.copy_(host)
+        else:
+            self.group.dist.scatter(local, pieces, src=0)
         return local
 
     def gather(self, local):
@@ -125,8 +133,14 @@ class BatchShards:
         import torch
         if self.group.dist is None:
             return local[: self.B].clone()
-        out = [torch.empty_like(local) for _ in range(self.world)] if self.rank == 0 else None
-        self.group.dist.gather(local.contiguous(), out, dst=0)
+        if self.group.stage:
+            host = local.contiguous().cpu()
+            outh = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            self.group.dist.gather(host, outh, dst=0)
+            out = None if outh is None else [o.to(local.device) for o in outh]
+        else:
+            out = [torch.empty_like(local) for _ in range(self.world)] if self.rank == 0 else None
+            self.group.dist.gather(local.contiguous(), out, dst=0)
         if self.rank != 0:
             return None
         return torch.cat([out[r][: shard_range(self.B, self.world, r)[1] - shard_range(self.B, self.world, r)[0]] for r in range(self.world)], dim=0)
