@@ -146,7 +146,8 @@ typedef struct hsqp_model_desc {
  * sweep is one workgroup per instance on 256 CUs: 1.6 ms for 1 or 256 of them); beyond that, and on far-from-feasible line-search
  * iterates that fail the gate regularly, a forced scan roughly doubles the iteration time — and it holds two value-function buffers of
  * max_batch * (max_nodes + 1) * 3 422 doubles (1.4 GB at 256 x 100).  The flag is for measurements; the automatic choice is
- * max_batch <= HSQP_SCAN_AUTO_BATCH. */
+ * max_batch <= HSQP_SCAN_AUTO_BATCH.  After a rejection the handle backs off: the next 1, 3, 7, .. 63 iterations go straight through the
+ * serial recursion before the scan is tried again (an accepted scan resets the count) — the iterates that fail the gate come in runs. */
 #define HSQP_SCAN_AUTO_BATCH 2
 #define HSQP_SCAN_AUTO_MIN_NODES 48
 /* Two-level (segmented) sweep for the batches in between (csrc/hsqp_segment.h) — OPT-IN.  One workgroup per instance leaves 256 - B CUs idle

@@ -548,7 +548,7 @@ struct hsqp_handle {
   // segmented sweep (allocated when first used): gains of the J = 0 recursions, (L^-1)^T of every stage, (J, s) at the segment starts, zeros
   double *d_ric2 = nullptr, *d_linv = nullptr, *d_vf0 = nullptr, *d_zero = nullptr;
   size_t vf0_capacity = 0;
-  int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected two-level sweep the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64)
+  int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected gated sweep (scan or two-level) the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   int* d_scanst = nullptr;   // flags of the scan kernels (bad pivot, rank-deficient D, failed Lam) of the current attempt: part of the gate, behind d_ginf
@@ -1013,8 +1013,11 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // backs off to the serial recursion for 1, 3, 7, .. 63 iterations before it tries again
     int segP = segment_count(h, B, N);
     if (segP > 0 && h->seg_backoff > 0) { --h->seg_backoff; segP = 0; }
-    const bool pscan = segP == 0 && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) &&
-                       ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    bool pscan = segP == 0 && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && !(h->st.flags & HSQP_FLAG_SEGMENTED_RICCATI) &&
+                 ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
+    // the same back-off for the scan: a rejected scan costs scan + serial sweep (0.55 + 1.45 ms at one whole-body instance), and the
+    // iterates that fail the gate — far-from-feasible line-search iterates — come in runs
+    if (pscan && h->seg_backoff > 0) { --h->seg_backoff; pscan = false; }
     const bool scan = pscan || segP > 0;        // either way a KKT-gated sweep with the serial recursion as fallback
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
@@ -1087,10 +1090,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));
         hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf2, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       }
-      if (segP > 0) {
-        if (accept) h->seg_backoff_len = 0;
-        else { h->seg_backoff_len = std::min(2 * h->seg_backoff_len + 1, 63); h->seg_backoff = h->seg_backoff_len; }
-      }
+      if (accept) h->seg_backoff_len = 0;
+      else { h->seg_backoff_len = std::min(2 * h->seg_backoff_len + 1, 63); h->seg_backoff = h->seg_backoff_len; }
       if (!accept) {
         ++h->scan_fallbacks;
         if (want_kkt && !h->d_vf) { h->err = "internal: value-function buffer missing"; return HSQP_ERR_HIP; }
