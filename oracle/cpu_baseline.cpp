@@ -47,7 +47,7 @@ int iterate_instance(const DevModel& dm, int N, double dt, const double* x_init,
     Workspaces& w = ws[omp_get_thread_num()];
     Ctx ctx{0, 1, nullptr};
     double* r = &rec[(size_t)k * REC_SIZE];
-    if (cent) cent_lq_node(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r);
+    if (cent) cent_lq_node<false>(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r);
     else lq_node<true>(ctx, dm, *w.lq, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC);
     project_node(ctx, *w.proj, r, dt, &qp[(size_t)k * QP_SIZE], cent);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) {

@@ -250,7 +250,7 @@ void emu_project_node(const double* rec, double dt, double* qp) {
 void emu_cent_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
-  if (deriv) cent_lq_node(ctx, dm, x, u, xnext, par, dt, rec);
+  if (deriv) cent_lq_node<true>(ctx, dm, x, u, xnext, par, dt, rec);
   else { cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 0); cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 1); }
 }
 void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_AB(rec, dt, AB); }
@@ -270,7 +270,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   const double dt_uniform = dt;
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
-    if (cent) cent_lq_node(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);
+    if (cent) cent_lq_node<true>(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);
     else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);

@@ -71,12 +71,13 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
 
 // ---- centroidal LQ approximation (hsqp_cent.h): one 256-thread workgroup per (instance, node), lane = tangent direction, waves
 //      0-1 the RK4 half, waves 2-3 the terms half; no LDS
+template <bool SPLIT>
 __global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_lq_node(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
+  cent_lq_node<SPLIT>(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
 }
 // ---- centroidal value-only pass: two lanes per (instance, node) in different waves (wave 0: RK4 defect, wave 1: terms)
 __global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
@@ -989,8 +990,10 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // (until_converged: any iteration may turn out to be the last one, so each is bracketed by the timing events and its times are summed)
     const bool last = it == n_iterations - 1 || until_converged;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
-    if (cent)
-      hipLaunchKernelGGL(k_lq_cent, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+    if (cent) {   // up to two workgroups per CU in flight: the latency form (hsqp_cent.h, cent_lq_node)
+      if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent<true>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+      else hipLaunchKernelGGL(k_lq_cent<false>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+    }
     else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);

@@ -26,6 +26,7 @@
 //   and  d(h/m)/dt = [g + sum f / m ;  sum ((p_c - com) x f + tau) / m].
 // Body velocities of the velocity-level model follow from the same pass plus the rigid base motion.
 #pragma once
+#include <type_traits>
 #include "hsqp_lq.h"
 
 namespace hsqp {
@@ -57,8 +58,8 @@ HSQP_HD Dual1 operator-(Dual1 a, double b) { return mk(a.v - b, a.d); }
 HSQP_HD Dual1 operator/(Dual1 a, Dual1 b) { const double q = a.v / b.v; return mk(q, (a.d - q * b.d) / b.v); }
 HSQP_HD Dual1 dsqrt(Dual1 a) { const double s = sqrt(a.v); return mk(s, 0.5 * a.d / s); }
 HSQP_HD double dsqrt(double a) { return sqrt(a); }
-HSQP_HD void dsincos(Dual1 a, Dual1& s, Dual1& c) { const double sv = sin(a.v), cv = cos(a.v); s = mk(sv, cv * a.d); c = mk(cv, -sv * a.d); }
-HSQP_HD void dsincos(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+HSQP_HD void dsincos(Dual1 a, Dual1& s, Dual1& c) { double sv, cv; sincos(a.v, &sv, &cv); s = mk(sv, cv * a.d); c = mk(cv, -sv * a.d); }   // one range reduction
+HSQP_HD void dsincos(double a, double& s, double& c) { sincos(a, &s, &c); }
 HSQP_HD double val(Dual1 a) { return a.v; }
 HSQP_HD double val(double a) { return a; }
 HSQP_HD void set_tan(Dual1& a) { a.d = 1.0; }
@@ -178,15 +179,39 @@ HSQP_HD void cent_collect(const DevModel& dm, int i, const BodyRec<T>& b, const 
 
 // One pass over the kinematic tree at q = [p_b, euler, q_j] with joint rates qd, then the base velocity from the normalized
 // momentum h and the normalized momentum rate for the contact wrenches W.  xdot[0..11] = [d(h/m)/dt ; pdot ; euler rates].
-template <class T, bool TERMS>
+// WAVE_TRIG (device, the LQ kernel's tangent lanes only): the 26 angles of the pass (3 euler + 23 joints) have the SAME value in every lane
+// of a wave — the lanes differ in their tangents only —, and their sines / cosines are where the instructions of a pass went (52 double-
+// precision library calls per lane and pass, ~ 6 k instructions, four passes in the RK4 half).  Lane a < 26 of the wave evaluates angle a
+// once; every lane picks the pair up with v_readlane (uniform index) and attaches its own tangent.  Needs lanes 0 .. 25 of every wave
+// that runs the pass to be active: cent_lq_node's lane layout guarantees it.
+template <class T, bool TERMS, bool WAVE_TRIG = false>
 HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, const T* qd, CentKin<T>& k, T* xdot) {
   const T zero = cst<T>(0.0), one = cst<T>(1.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  double wt_s = 0.0, wt_c = 1.0;
+  if constexpr (WAVE_TRIG) {
+    const int wl = (int)(threadIdx.x & 63);
+    if (wl < 3 + NJ) sincos(val(q[3 + wl]), &wt_s, &wt_c);
+  }
+#endif
+  auto trig = [&](int a /* angle index: q[3 + a] */, T& sn, T& cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WAVE_TRIG) {
+      const double sv = readlane_f64(wt_s, a), cv = readlane_f64(wt_c, a);
+      const T ang = q[3 + a];
+      sn = ang * 0.0 + sv; cs = ang * 0.0 + cv;   // value parts
+      if constexpr (!std::is_same<T, double>::value) { sn = mk(sv, cv * ang.d); cs = mk(cv, -sv * ang.d); }
+      return;
+    }
+#endif
+    dsincos(q[3 + a], sn, cs);
+  };
   CentSums<T> sums;
   for (int r = 0; r < 3; ++r) { sums.mc[r] = zero; sums.lin[r] = zero; sums.angO[r] = zero; sums.IO[r] = zero; sums.IO[3 + r] = zero; }
   T pc[2][3];   // contact points
   {
     T sz, cz, sy, cy, sx, cx;
-    dsincos(q[3], sz, cz); dsincos(q[4], sy, cy); dsincos(q[5], sx, cx);
+    trig(0, sz, cz); trig(1, sy, cy); trig(2, sx, cx);
     BodyRec<T> b0;   // R_0 = Rz Ry Rx
     b0.R[0] = cz * cy; b0.R[1] = cz * sy * sx - sz * cx; b0.R[2] = cz * sy * cx + sz * sx;
     b0.R[3] = sz * cy; b0.R[4] = sz * sy * sx + cz * cx; b0.R[5] = sz * sy * cx - cz * sx;
@@ -211,7 +236,7 @@ HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, c
         for (int cc = 0; cc < 3; ++cc)
           Rj[3 * r + cc] = cur.R[3 * r] * dm.Rfix[i][cc] + cur.R[3 * r + 1] * dm.Rfix[i][3 + cc] + cur.R[3 * r + 2] * dm.Rfix[i][6 + cc];
       T sn, cs;
-      dsincos(q[5 + i], sn, cs);
+      trig(2 + i, sn, cs);
       const double* a = dm.axis[i];
       // Rodrigues: Rot = I + s K + (1 - c) K^2,  K = [a]x (unit axis)
       const T omc = one - cs;
@@ -448,12 +473,12 @@ HSQP_HD void cent_seed(const double* x, const double* u, int dir, T* xs, T* us) 
   else if (dir >= CNX && dir < CNZ) set_tan(us[dir - CNX]);
 }
 // RK4: x_next (35) and the flow (12 dense rows) at (x, u)
-template <class T>
+template <class T, bool WAVE_TRIG = false>
 HSQP_HD void cent_rk4(const DevModel& dm, const double* x, const double* u, double dt, int dir, CentKin<T>& k, T* xn /*[CNX]*/, T* flow /*[12]*/) {
   T xs[CNX], us[NU], x0[CNX], k1[12], ks[12], acc[12];
   cent_seed<T>(x, u, dir, xs, us);
   for (int i = 0; i < CNX; ++i) x0[i] = xs[i];
-  cent_pass<T, false>(dm, xs, xs + 6, us, us + 12, k, k1);
+  cent_pass<T, false, WAVE_TRIG>(dm, xs, xs + 6, us, us + 12, k, k1);
   for (int r = 0; r < 12; ++r) { flow[r] = k1[r]; acc[r] = k1[r]; }
   // stages 2..4: x_s = x + c k_{s-1}; the joint rows of every k are qd_j
   for (int s = 1; s < 4; ++s) {
@@ -462,7 +487,7 @@ HSQP_HD void cent_rk4(const DevModel& dm, const double* x, const double* u, doub
     for (int r = 0; r < 12; ++r) xs[r] = x0[r] + kp[r] * c;
     for (int j = 0; j < NJ; ++j) xs[12 + j] = x0[12 + j] + us[12 + j] * c;
     T kn[12];
-    cent_pass<T, false>(dm, xs, xs + 6, us, us + 12, k, kn);
+    cent_pass<T, false, WAVE_TRIG>(dm, xs, xs + 6, us, us + 12, k, kn);
     const double wgt = s == 3 ? 1.0 : 2.0;
     for (int r = 0; r < 12; ++r) { ks[r] = kn[r]; acc[r] = acc[r] + kn[r] * wgt; }
   }
@@ -470,11 +495,11 @@ HSQP_HD void cent_rk4(const DevModel& dm, const double* x, const double* u, doub
   for (int j = 0; j < NJ; ++j) xn[12 + j] = x0[12 + j] + us[12 + j] * dt;
 }
 // terms: one tree pass with the side tables, then every cost / constraint term
-template <class T>
+template <class T, bool WAVE_TRIG = false>
 HSQP_HD void cent_terms_program(const DevModel& dm, const double* x, const double* u, const double* par, int dir, CentKin<T>& k, CentOut<T>& o) {
   T xs[CNX], us[NU], k1[12];
   cent_seed<T>(x, u, dir, xs, us);
-  cent_pass<T, true>(dm, xs, xs + 6, us, us + 12, k, k1);
+  cent_pass<T, true, WAVE_TRIG>(dm, xs, xs + 6, us, us + 12, k, k1);
   cent_terms<T>(dm, k, xs, us, par, o);
 }
 
@@ -527,10 +552,19 @@ HSQP_HD void cent_write_terms(const DevModel& dm, const CentOut<T>& o, const dou
 // ---- the LQ kernel body: lane = tangent direction, two lane groups of 128 (group 0: RK4 -> [A|B], defect, flow; group 1: terms
 //      -> residual rows, equality rows, diagonals).  Workspace: none (private memory only).
 constexpr int CENT_GROUP = 128, CENT_THREADS = 2 * CENT_GROUP;
+// SPLIT (the latency form, chosen for launches of a few hundred nodes: BASELINE configs 1-2 are one instance): the computing lanes are
+// split evenly over the group's two waves so that both can share their sines / cosines (cent_pass<.., WAVE_TRIG>): config 1's kernel
+// 0.233 -> 0.209 ms.  With thousands of nodes in flight the packed form (64 + 7 computing lanes, every lane its own trigonometry)
+// touches fewer private-memory lines per wave and is 8 % faster (64 x 100 nodes: 7.0 against 7.6 ms).
+template <bool SPLIT>
 HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt,
                           double* rec) {
   WG_FOR(ctx, it, CENT_THREADS) {
-    const int grp = it / CENT_GROUP, lane = it % CENT_GROUP;
+    // SPLIT: the 71 computing lanes (70 tangents + the value lane) are split 36 + 35 over the group's two waves so that lanes
+    // 0 .. 25 of BOTH waves run the model passes (cent_pass<.., WAVE_TRIG>); the 26 zero-fill lanes sit behind the first 36
+    const int grp = it / CENT_GROUP, gl = it % CENT_GROUP;
+    constexpr int CL0 = 36;
+    const int lane = !SPLIT ? gl : (gl < CL0 ? gl : (gl < CL0 + (CENT_LANES - CNZ - 1) ? CNZ + 1 + (gl - CL0) : (gl >= 64 && gl < 64 + (CNZ + 1 - CL0) ? CL0 + (gl - 64) : CENT_LANES)));
     if (lane >= CENT_LANES) continue;
     if (lane > CNZ) {   // zero-fill lanes: padding columns 35..57 and 93..95 of the rows of this group
       const int col = lane - CNZ - 1 < NX - CNX ? CNX + (lane - CNZ - 1) : NZ + (lane - CNZ - 1 - (NX - CNX));
@@ -547,13 +581,13 @@ HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, c
     CentKin<Dual1> k;
     if (grp == 0) {
       Dual1 xn[CNX], flow[12];
-      cent_rk4<Dual1>(dm, x, u, dt, dir, k, xn, flow);
+      cent_rk4<Dual1, SPLIT>(dm, x, u, dt, dir, k, xn, flow);
       if (lane == CNZ) { cent_write_dynamics<Dual1>(xn, flow, u, xnext, dt, rec, rec + REC_MISC); continue; }
       // [A|B] - [I|0] on the 12 dense rows (the joint rows are q_j+ = q_j + dt qd_j: structure known to the projection)
       for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + col] = xn[r].d - (r == lane ? 1.0 : 0.0);
     } else {
       CentOut<Dual1> o;
-      cent_terms_program<Dual1>(dm, x, u, par, dir, k, o);
+      cent_terms_program<Dual1, SPLIT>(dm, x, u, par, dir, k, o);
       if (lane == CNZ) { cent_write_terms<Dual1>(dm, o, x, u, par, dt, rec, rec + REC_MISC); continue; }
       const double sdt = sqrt(dt);
       for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = sdt * o.sc[s] * o.row[s].d;
