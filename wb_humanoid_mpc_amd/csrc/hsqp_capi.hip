@@ -91,6 +91,20 @@ __global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restric
   cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], misc + (size_t)node * 8, part);
 }
 
+// the same pass for launches of a few hundred nodes (BASELINE configs 1-2): one workgroup per node, wave = part, the lanes 0 .. 25 of a wave
+// run the node redundantly so that each evaluates ONE of the 26 sines / cosines of a model pass for all of them (cent_pass<.., WAVE_TRIG>;
+// a lane on its own spends over half of the value pass in the 208 library calls of the four RK4 passes)
+__global__ __launch_bounds__(128) void k_lq_cent_value_wave(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes, double* __restrict__ misc,
+                                                           const LsState* __restrict__ ls) {
+  const int node = blockIdx.x, part = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) >= 3 + NJ) return;
+  const int b = node / N, k = node % N;
+  if (ls && !ls[b].active) return;
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  cent_value_node<true>(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], misc + (size_t)node * 8, part);
+}
+
 // ---- projection: one workgroup per (instance, node)
 __global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
@@ -1064,8 +1078,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     }
     auto launch_perf = [&]() {   // value pass of the centroidal trial, performance indices before / after, line-search state of the full-step trial
       if (cent)
-        hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
-                           (const LsState*)nullptr);
+      {
+        if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent_value_wave, dim3(nodes), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
+                                             (const LsState*)nullptr);
+        else hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
+                                (const LsState*)nullptr);
+      }
       hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
                          (const LsState*)nullptr);
       hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
@@ -1126,8 +1144,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
           hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
           if (cent)
-            hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
-                               h->d_misc, (const LsState*)h->d_ls);
+          {
+            if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent_value_wave, dim3(nodes), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
+                                                 h->d_misc, (const LsState*)h->d_ls);
+            else hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
+                                    h->d_misc, (const LsState*)h->d_ls);
+          }
           else
             hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);

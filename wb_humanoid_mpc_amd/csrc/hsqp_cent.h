@@ -198,9 +198,8 @@ HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, c
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (WAVE_TRIG) {
       const double sv = readlane_f64(wt_s, a), cv = readlane_f64(wt_c, a);
-      const T ang = q[3 + a];
-      sn = ang * 0.0 + sv; cs = ang * 0.0 + cv;   // value parts
-      if constexpr (!std::is_same<T, double>::value) { sn = mk(sv, cv * ang.d); cs = mk(cv, -sv * ang.d); }
+      if constexpr (std::is_same<T, double>::value) { sn = sv; cs = cv; }
+      else { const T ang = q[3 + a]; sn = mk(sv, cv * ang.d); cs = mk(cv, -sv * ang.d); }
       return;
     }
 #endif
@@ -598,15 +597,18 @@ HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, c
 }
 
 // value-only evaluation of one node (performance index / line search), in the same two halves: part 0 writes misc[3], part 1 the rest
+// WAVE_TRIG: the caller runs the node on the lanes 0 .. 3 + NJ - 1 of a wave, all with the same inputs: lane a evaluates sincos of angle a
+// for everybody (cent_pass); every lane writes the same results.
+template <bool WAVE_TRIG = false>
 HSQP_HD void cent_value_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc, int part) {
   CentKin<double> k;
   if (part == 0) {
     double xn[CNX], flow[12];
-    cent_rk4<double>(dm, x, u, dt, -1, k, xn, flow);
+    cent_rk4<double, WAVE_TRIG>(dm, x, u, dt, -1, k, xn, flow);
     cent_write_dynamics<double>(xn, flow, u, xnext, dt, nullptr, misc);
   } else {
     CentOut<double> o;
-    cent_terms_program<double>(dm, x, u, par, -1, k, o);
+    cent_terms_program<double, WAVE_TRIG>(dm, x, u, par, -1, k, o);
     cent_write_terms<double>(dm, o, x, u, par, dt, nullptr, misc);
   }
 }
