@@ -122,6 +122,32 @@ int emu_scan_combine58(const double* e1, const double* e2, double* out) {
   scan_combine<NX>(ctx, *cw, e1, e2, out, &ok);
   return ok;
 }
+// The blocked (matrix-core) factorisation of the Riccati stage (hsqp_elim.h) on the host's 64-lane wave emulation: both waves one after the
+// other on a workspace filled with Lam (23 x 23, symmetric positive definite), G (23 x nxe), g (23); returns L^-1 (23 x 23), Z (23 x nxe), z (23)
+int emu_eliminate_blocked(int nxe, const double* lam, const double* G, const double* g, double* linv, double* linvT, double* Z, double* z) {
+  auto rw = std::make_unique<RicWS>();
+  RicWS& w = *rw;
+  memset(&w, 0, sizeof(RicWS));
+  for (int r = 0; r < NUT; ++r) {
+    for (int c = 0; c < NUT; ++c) w.fac.Ef[r][c] = lam[r * NUT + c];
+    for (int c = 0; c < nxe; ++c) w.Em[r][EM_G + c] = G[r * nxe + c];
+    w.Em[r][EM_GVP] = g[r];
+  }
+  for (int r = 0; r < LDB; ++r) for (int c = 0; c < LDF; ++c) if (r >= NUT || c >= NUT) w.fac.Ef[r][c] = 1e300;   // padding must not be read as data
+  w.ok = 1;
+  const ElimIO io{&w.fac.Ef[0][0], LDF, &w.Em[0][EM_G], &w.Em[0][EM_GVP], LDE, &w.fac.Ef[0][EF_MI], LDF, &w.fac.LinvT[0][0], LDB, &w.Zs[0][0], LDZ, w.zv, &w.ok};
+  const HostWave hw;
+  if (nxe == NX) { eliminate_blocked<NX, 0>(hw, io); eliminate_blocked<NX, 1>(hw, io); }
+  else if (nxe == 35) { eliminate_blocked<35, 0>(hw, io); eliminate_blocked<35, 1>(hw, io); }
+  else return -1;
+  for (int r = 0; r < NUT; ++r) {
+    for (int c = 0; c < NUT; ++c) { linv[r * NUT + c] = w.fac.Ef[r][EF_MI + c]; linvT[r * NUT + c] = w.fac.LinvT[r][c]; }
+    for (int c = 0; c < nxe; ++c) Z[r * nxe + c] = w.Zs[r][c];
+    z[r] = w.zv[r];
+    if (w.Zs[r][nxe] != w.zv[r]) return -2;
+  }
+  return w.ok;
+}
 int emu_scan_gate_accepts(double r_stat, double r_prim, double g_inf, int flags) { return scan_gate_accepts(r_stat, r_prim, g_inf, flags) ? 1 : 0; }
 void emu_set_scan(int on) { g_scan = on; }
 void emu_set_scan_refinements(int r) { g_scan_refinements = r; }

@@ -185,3 +185,34 @@ def test_two_level_sweep_of_the_kernel_sources_equals_the_serial_recursion(model
         assert gait == "run"
     assert err <= 1e-8 * sc
     assert np.array_equal(seg[0], rev[0]) and np.array_equal(seg[1], rev[1])   # race check
+
+
+@pytest.mark.parametrize("nxe", [58, 35])
+def test_blocked_matrix_core_factorisation_on_the_wave_emulation(emu, nxe):
+    """hsqp_elim.h (six panels of four rows in the accumulator layout of v_mfma_f64_16x16x4; what k_riccati runs on the device)
+    executed lane by lane on the host's 64-lane wave emulation: L^-1, Z = L^-1 G, z = L^-1 g against numpy's Cholesky."""
+    lib, _ = emu
+    rng = np.random.default_rng(11 + nxe)
+    for trial in range(6):
+        Bm = rng.standard_normal((23, 40)) * 10.0 ** rng.uniform(-2, 2, size=(23, 1))   # badly scaled rows: cond up to ~1e8
+        lam = Bm @ Bm.T + np.diag(10.0 ** rng.uniform(-5, 0, 23))
+        lam = 0.5 * (lam + lam.T)
+        G = rng.standard_normal((23, nxe)) * 10.0 ** rng.uniform(-1, 3)
+        g = rng.standard_normal(23)
+        linv, linvT, Z, z = np.zeros((23, 23)), np.zeros((23, 23)), np.zeros((23, nxe)), np.zeros(23)
+        ok = lib.emu_eliminate_blocked(nxe, P(lam), P(G), P(g), P(linv), P(linvT), P(Z), P(z))
+        assert ok == 1
+        L = np.linalg.cholesky(lam)
+        want_inv = np.linalg.inv(L)
+        cond = np.linalg.cond(lam)
+        tol = 1e-15 * cond ** 0.5 * 50
+        assert np.array_equal(linv, linvT.T) and np.all(np.triu(linv, 1) == 0.0)
+        assert np.abs(linv - want_inv).max() <= tol * np.abs(want_inv).max()
+        assert np.abs(Z - want_inv @ G).max() <= tol * np.abs(want_inv @ G).max()
+        assert np.abs(z - want_inv @ g).max() <= tol * np.abs(want_inv @ g).max()
+        # what the stage uses them for: Z^T Z = G^T Lam^-1 G, K = -L^-T Z = -Lam^-1 G
+        K = -linv.T @ Z
+        assert np.abs(lam @ K + G).max() <= 1e-13 * cond ** 0.5 * np.abs(G).max()
+    # an indefinite matrix is reported, not silently factorised
+    lam = np.eye(23); lam[7, 7] = -1.0
+    assert lib.emu_eliminate_blocked(nxe, P(lam), P(G), P(g), P(linv), P(linvT), P(Z), P(z)) == 0

@@ -29,9 +29,10 @@ t = np.zeros((4, 128), dtype=np.int64)
 s.lib.hsqp_debug_read(s.h, 100, t.ctypes.data_as(C.c_void_p), t.nbytes)
 names = ["k_lq<true>", "k_project", "k_riccati", "k_lq<false>"]
 for k in range(4):
-    tot = t[k, :126].sum()
+    # slots 0..39: phase ticks (PH_TICK); 40..111: per-wave barrier arrivals (PH_ARRIVE); 90..94: tile-call split; 112..119: PH_MARK stamps
+    tot = t[k, :40].sum()
     print(f"== {names[k]}: {tot / iters:.0f} ticks per launch (workgroup 0)  [~{tot / iters / 2.4e3:.1f} us at 2.4 GHz]")
-    for i in range(126):
+    for i in range(40):
         if t[k, i]:
             print(f"   phase {i:3d}: {t[k, i] / iters:12.0f} ticks  {100.0 * t[k, i] / tot:5.1f}%")
     if k == 2 and t[k, 40:112].any():   # k_riccati: per-wave arrival at the barriers ending Ph1, Ph2, Ph4, Ph3 (ticks per launch)

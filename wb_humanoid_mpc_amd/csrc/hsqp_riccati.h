@@ -21,6 +21,7 @@
 // X^T Y contraction (hsqp_linalg.h).
 #pragma once
 #include "hsqp_linalg.h"
+#include "hsqp_elim.h"
 #include "hsqp_project.h"
 
 namespace hsqp {
@@ -132,6 +133,18 @@ HSQP_D ElimLane elim_lane(int wave, int lane) {
 // asynchronous 16-byte copies straight into LDS (no staging registers, no store pass): the LDS image of A~ is the record's [58][58]
 // block byte for byte; a wave instruction moves 64 x 16 B to (wave-uniform base) + lane x 16.  The compiler makes a wave wait for its
 // copies before that wave's next LDS access; these two waves have none until the mid-phase barrier (every other wave reads LDS all the time).
+// the copy of the next stage's A~ (see above), issued by the two eliminating waves
+HSQP_D void next_a_to_lds(const double* a_next, double* a_dst, int wave, int lane) {
+  if (a_next) {
+    constexpr int NCH = NX * NX / 2;                         // 16-byte chunks
+    static_assert((NX * NX) % 2 == 0 && QP_A % 2 == 0 && QP_SIZE % 2 == 0, "16-byte alignment of A~ in the record");
+#pragma unroll
+    for (int t = 0; t < (NCH + 127) / 128; ++t) {
+      const int c0 = (t * 2 + wave) * 64;                    // first chunk of this wave instruction
+      if (c0 + lane < NCH) __builtin_amdgcn_global_load_lds((hsqp_gcptr)a_next + 2 * (c0 + lane), (hsqp_ldsptr)(a_dst + 2 * c0), 16, 0, 0);
+    }
+  }
+}
 template <int NXE>
 HSQP_D void eliminate_begin(const RicWS& w, int wave, int lane, double (&e)[NUT], const double* a_next, double* a_dst) {
   const ElimLane l = elim_lane<NXE>(wave, lane);
@@ -142,15 +155,7 @@ HSQP_D void eliminate_begin(const RicWS& w, int wave, int lane, double (&e)[NUT]
     const double v = src[i * stride];
     e[i] = l.isI ? (i == lane - NUT ? 1.0 : 0.0) : v;
   }
-  if (a_next) {
-    constexpr int NCH = NX * NX / 2;                         // 16-byte chunks
-    static_assert((NX * NX) % 2 == 0 && QP_A % 2 == 0 && QP_SIZE % 2 == 0, "16-byte alignment of A~ in the record");
-#pragma unroll
-    for (int t = 0; t < (NCH + 127) / 128; ++t) {
-      const int c0 = (t * 2 + wave) * 64;                    // first chunk of this wave instruction
-      if (c0 + lane < NCH) __builtin_amdgcn_global_load_lds((hsqp_gcptr)a_next + 2 * (c0 + lane), (hsqp_ldsptr)(a_dst + 2 * c0), 16, 0, 0);
-    }
-  }
+  next_a_to_lds(a_next, a_dst, wave, lane);
 #pragma unroll
   for (int j = 0; j < ELIM_SPLIT; ++j) {
     const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));   // lane i: the multiplier of row i (one multiply per step, not per row)
@@ -242,6 +247,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (it < na) copy_batch<8>(it, NX * NX, q + QP_A, [&](int i, double v) { An[i / NX][i % NX] = v; });
       else { const int i = it - na, r = i / LDB, c = i % LDB; w.B[r][c] = c < NUT ? q[QP_B + r * NUT + c] : q[QP_BV + r]; }
     }
+    if (dev512) WG_FOR(ctx, r, NUT) w.kv[r] = q[QP_RV + r];   // r~ of the first stage (see Ph3)
   }
   WG_SYNC(ctx);
   const Ctx& ctx_outer = ctx;
@@ -296,7 +302,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (it >= 0 && it < 4 * NUT) {
             const int r = it >> 2, p = it & 3;
             constexpr int LA = (NXE + 3) / 4;
-            double sg = p == 0 ? q[QP_RV + r] : 0.0;
+            double sg = p == 0 ? (dev512 ? w.kv[r] : q[QP_RV + r]) : 0.0;   // (device kernels: r~ staged in kv by the memory waves a stage ahead)
 #pragma unroll
             for (int l = 0; l < LA; ++l) {
               const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1;
@@ -330,16 +336,50 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       // next stage's [B~ | b~]), SIMDs 2, 3 carry the tiles of S A~ (waves 2, 3, 6, 7)
       const int wv = ctx.tid >> 6;
       const int trank = (wv & 3) >= 2 ? (wv & 1) + (wv >> 2) * 2 : -1;
+      constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
+      const int pt = ctx.tid - 256;
       if (wv < 2) {
-        double e[NUT];
         __builtin_amdgcn_s_setprio(3);
+#if defined(HSQP_ELIM_COLUMNWISE)
+        double e[NUT];
         eliminate_begin<NXE>(w, wv, ctx.tid & 63, e, k > 0 ? qn + QP_A : nullptr, &An[0][0]);
         eliminate_end<NXE>(w, wv, ctx.tid & 63, e);
+#else
+        const int lane = ctx.tid & 63;
+        const DevWave dw{lane};
+        const ElimIO io{&w.fac.Ef[0][0], LDF, &w.Em[0][EM_G], &w.Em[0][EM_GVP], LDE, &w.fac.Ef[0][EF_MI], LDF, &w.fac.LinvT[0][0], LDB, &w.Zs[0][0], LDZ, w.zv, &w.ok};
+        const double* a_next = k > 0 ? qn + QP_A : nullptr;
+        double* a_dst = &An[0][0];
+        auto prefetch = [&]() { next_a_to_lds(a_next, a_dst, wv, lane); };
+        if (wv == 0) eliminate_blocked<NXE, 0>(dw, io, prefetch);
+        else eliminate_blocked<NXE, 1>(dw, io, prefetch);
+#endif
         __builtin_amdgcn_s_setprio(0);
       } else if (trank < 0) {
+#if !defined(HSQP_RIC_HELPERS_PH3)
+        // These two waves share their SIMDs with the eliminating waves, and a SIMD runs the FP64 vector and matrix instructions of its waves
+        // one after the other: arithmetic done here (round 3: q~ + A~^T sb, 232 fifteen-term sums) lengthens the phase by its own duration.
+        // They are the stage's MEMORY waves now: global -> LDS staging of everything the later phases would otherwise fetch from HBM inside
+        // the serial chain (a round trip is 3.5 - 5 k cycles in this kernel; waiting costs no issue slot): the next stage's [B~ | b~], and
+        // q~ of this stage for the partial sums of Ph4 (into dx, unused by the backward sweep).
+        {
+          double pb[NPB];
+          const double qv = pt < NX ? q[QP_QV + pt] : 0.0;
+          if (k > 0) {
+#pragma unroll
+            for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
+#pragma unroll
+            for (int t = 0; t < NPB; ++t) {
+              const int idx = pt + 128 * t;
+              if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
+              else if (idx < NX * NUT + NX) w.B[idx - NX * NUT][NUT] = pb[t];
+            }
+          }
+          if (pt < NX) w.dx[pt] = qv;
+          if (k > 0 && pt >= 64 && pt < 64 + NUT) w.kv[pt - 64] = qn[QP_RV + pt - 64];   // r~ of the next stage (Ph2's g sums)
+        }
+#else
         if (k > 0) {
-          constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
-          const int pt = ctx.tid - 256;
           double pb[NPB];
 #pragma unroll
           for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
@@ -359,6 +399,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
           w.part[it] = s;
         }
+#endif
       } else ric_products_ranked(ctx, trank, 4, jsa);
     } else
 #endif
@@ -423,23 +464,40 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       // ([K | k] = -L^-T [Z | z] goes to the G block — closed_loop_record reads K there, k is picked up from its column NXE in the next
       //  stage's Ph1 — and K straight to the record)
       const XtyJob jk = xty_also_to(xty_job(NUT, NXE + 1, NUT, &w.fac.Ef[0][EF_MI], LDF, &w.Zs[0][0], LDZ, &w.Em[0][EM_G], LDE, nullptr, 0, -1.0), rk + RIC_K, NX, NXE);
+      // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in the next stage's Ph1): short chains, 232 items
+      auto s_item = [&](int it) {
+        const int r = it >> 2, p = it & 3;
+        constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
+        double s;
+#if defined(HSQP_RIC_HELPERS_PH3)
+        if (dev512) s = w.part[it];   // q~ + A^T sb: formed under the elimination (Ph3) by the waves that only moved B~
+        else
+#endif
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+          s = p == 0 ? (dev512 ? w.dx[r] : q[QP_QV + r]) : 0.0;   // (staged by the memory waves in Ph3)
+#else
+          s = p == 0 ? q[QP_QV + r] : 0.0;
+#endif
+#pragma unroll
+          for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
+        }
+#pragma unroll
+        for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
+        w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
+      };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_RIC_HELPERS_PH3)
+      if (dev512) {   // waves 6, 7 (two short tiles in this phase), two passes; waves 4, 5 go straight to their tiles
+        if (ctx.tid >= 384) for (int it = ctx.tid - 384; it < 4 * NX; it += 128) s_item(it);
+      }
+#endif
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         static_assert(4 * NX <= RIC_HELPERS, "one pass");
-        WG_FOR(hc, it, 4 * NX) {   // s <- q~ + A^T sb - Z^T z in four partial sums per row (added in the next stage's Ph1): short chains, 232 lanes
-          const int r = it >> 2, p = it & 3;
-          constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
-          double s;
-          if (dev512) s = w.part[it];   // q~ + A^T sb: formed under the elimination (Ph3) by the waves that only moved B~
-          else {
-            s = p == 0 ? q[QP_QV + r] : 0.0;
-#pragma unroll
-            for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
-          }
-#pragma unroll
-          for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
-          w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
-        }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_RIC_HELPERS_PH3)
+        if (!dev512)
+#endif
+        WG_FOR(hc, it, 4 * NX) s_item(it);
         if (linv_out) WG_FOR(hc, i, LDB * LDB) linv_out[(size_t)k * LDB * LDB + i] = w.fac.LinvT[i / LDB][i % LDB];
         if (NXE < NX) WG_FOR(hc, i, NUT * (NX - NXE)) rk[RIC_K + (i / (NX - NXE)) * NX + NXE + i % (NX - NXE)] = 0.0;   // K vanishes on the padding states
       }
