@@ -17,7 +17,7 @@
 // wave 0 also [I | G columns 0 .. 15], wave 1 the other columns of G and g (g rides as column NXE of G).
 //
 // The code is written once over a wave abstraction W (device: a lane's own value; host: 64 lanes in an array, tests/hostemu), so the index
-// logic and the arithmetic are checked in the GPU-less container against the column-by-column form (tests/test_hostemu.py).
+// logic and the arithmetic are checked in the GPU-less container against the column-by-column form (tests/hostemu).
 #pragma once
 #include "hsqp_linalg.h"
 
