@@ -24,6 +24,13 @@ using matrix_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic>;
 using vector_array_t = std::vector<vector_t>;
 using matrix_array_t = std::vector<matrix_t>;
 // upstream ocs2_core/Types.h: value + first (+ second) derivatives of a vector-valued function of (x, u)
-struct VectorFunctionLinearApproximation { vector_t f; matrix_t dfdx, dfdu; };
+struct VectorFunctionLinearApproximation {
+  vector_t f; matrix_t dfdx, dfdu;
+  static VectorFunctionLinearApproximation Zero(size_t nv, size_t nx, size_t nu) {
+    VectorFunctionLinearApproximation a; a.f = vector_t::Zero((Eigen::Index)nv); a.dfdx = matrix_t::Zero((Eigen::Index)nv, (Eigen::Index)nx); a.dfdu = matrix_t::Zero((Eigen::Index)nv, (Eigen::Index)nu); return a;
+  }
+};
+// upstream: value, gradient and Hessian blocks of a scalar function of (x, u)
+struct ScalarFunctionQuadraticApproximation { scalar_t f = 0.0; vector_t dfdx, dfdu; matrix_t dfdxx, dfdux, dfduu; };
 struct VectorFunctionQuadraticApproximation { vector_t f; matrix_t dfdx, dfdu; matrix_array_t dfdxx, dfdux, dfduu; };
 }  // namespace ocs2

@@ -100,3 +100,51 @@ class RefTerms:
                                               int(calls), t.ctypes.data_as(_dp), s.ctypes.data_as(_dp))
         assert rc == 0, rc
         return t, s
+
+    # ---- round 4: the assembly files (ref_terms_driver.cpp, second half) -------------------------------------------------------------
+    GAIN_KEYS = ("gain_pos_z", "gain_ori", "gain_linvel_z", "gain_linvel_xy", "gain_angvel", "gain_linacc_z", "gain_linacc_xy", "gain_angacc")   # FootConstraintConfig order
+
+    def stance_foot_constraint(self, gains, contact, event_times, mode_sequence, time, kin18, jac):
+        """ZeroAccelerationConstraintCppAd / EndEffectorDynamicsAccelerationsConstraint over handed-in kinematics -> dict(value, f, dfdx, dfdu, active)."""
+        ev, seq = _d(event_times), _i(mode_sequence)
+        value, f, dfdx, dfdu = np.zeros(6), np.zeros(6), np.zeros((6, self.nx)), np.zeros((6, self.nu))
+        act = C.c_int(0)
+        rc = self.lib.ref_stance_foot_constraint(self.nj, _d(gains).ctypes.data_as(_dp), int(contact), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip), C.c_double(time),
+                                                 _d(kin18).ctypes.data_as(_dp), _d(jac).ctypes.data_as(_dp), value.ctypes.data_as(_dp), f.ctypes.data_as(_dp),
+                                                 dfdx.ctypes.data_as(_dp), dfdu.ctypes.data_as(_dp), C.byref(act))
+        assert rc == 0, rc
+        return dict(value=value, f=f, dfdx=dfdx, dfdu=dfdu, active=bool(act.value))
+
+    def swing_foot_constraint(self, gains, zref, kin18, jac):
+        """EndEffectorDynamicsLinearAccConstraint (one row) with WBMpcPreComputation's per-node configuration -> dict(value, f, dfdx, dfdu)."""
+        value, f, dfdx, dfdu = np.zeros(1), np.zeros(1), np.zeros((1, self.nx)), np.zeros((1, self.nu))
+        rc = self.lib.ref_swing_foot_constraint(self.nj, _d(gains).ctypes.data_as(_dp), _d(zref).ctypes.data_as(_dp), _d(kin18).ctypes.data_as(_dp), _d(jac).ctypes.data_as(_dp),
+                                                value.ctypes.data_as(_dp), f.ctypes.data_as(_dp), dfdx.ctypes.data_as(_dp), dfdu.ctypes.data_as(_dp))
+        assert rc == 0, rc
+        return dict(value=value, f=f, dfdx=dfdx, dfdu=dfdu)
+
+    def state_input_quadratic_cost(self, arm_joints, total_mass, event_times, mode_sequence, target_times, target_states, arm_swing, t0, tf, Q, R, state, input, time):
+        """StateInputQuadraticCost -> (dx, du, value): the deviation its quadratic form is taken of, and 1/2 dx'Q dx + 1/2 du'R du."""
+        ev, seq, tt, ts = _d(event_times), _i(mode_sequence), _d(target_times), _d(target_states)
+        dx, du, val = np.zeros(self.nx), np.zeros(self.nu), C.c_double(0.0)
+        rc = self.lib.ref_state_input_quadratic_cost(self.nj, _i(arm_joints).ctypes.data_as(_ip), C.c_double(total_mass), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip),
+                                                     len(tt), tt.ctypes.data_as(_dp), ts.ctypes.data_as(_dp), int(bool(arm_swing)), C.c_double(t0), C.c_double(tf),
+                                                     _d(Q).ctypes.data_as(_dp), _d(R).ctypes.data_as(_dp), _d(state).ctypes.data_as(_dp), _d(input).ctypes.data_as(_dp),
+                                                     C.c_double(time), dx.ctypes.data_as(_dp), du.ctypes.data_as(_dp), C.byref(val))
+        assert rc == 0, rc
+        return dx, du, val.value
+
+    def joint_limits(self, q_lo, q_hi, mu, delta, state):
+        f, dfdx, dxx = C.c_double(0.0), np.zeros(self.nx), np.zeros(self.nx)
+        rc = self.lib.ref_joint_limits(self.nj, _d(q_lo).ctypes.data_as(_dp), _d(q_hi).ctypes.data_as(_dp), C.c_double(mu), C.c_double(delta), _d(state).ctypes.data_as(_dp),
+                                       C.byref(f), dfdx.ctypes.data_as(_dp), dxx.ctypes.data_as(_dp))
+        assert rc == 0, rc
+        return f.value, dfdx, dxx
+
+    def weight_comp_initializer(self, total_mass, event_times, mode_sequence, time, next_time, state):
+        ev, seq = _d(event_times), _i(mode_sequence)
+        u, xn = np.zeros(self.nu), np.zeros(self.nx)
+        rc = self.lib.ref_weight_comp_initializer(self.nj, C.c_double(total_mass), len(ev), ev.ctypes.data_as(_dp), seq.ctypes.data_as(_ip), C.c_double(time), C.c_double(next_time),
+                                                  _d(state).ctypes.data_as(_dp), u.ctypes.data_as(_dp), xn.ctypes.data_as(_dp))
+        assert rc == 0, rc
+        return u, xn

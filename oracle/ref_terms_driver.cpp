@@ -11,8 +11,22 @@
 //        overwrite quirk) + toVector, read from the reference's own task.info through the stand-in INFO parser
 //   target generator (feeds a5)  humanoid_wb_mpc/src/command/WBMpcTargetTrajectoriesCalculator.cpp:80-136 + humanoid_common_mpc/src/command/
 //        TargetTrajectoriesCalculatorBase.cpp:41-160: commandedVelocityToTargetTrajectories on the reference's own reference.info
+//   ---- round 4: the ASSEMBLY files (how kinematics, gains and references are combined), over an EndEffectorDynamics whose kinematics the
+//        caller hands in (the reference's only implementation of that interface is CppAD-generated)
+//   a9   humanoid_wb_mpc/src/constraint/EndEffectorDynamicsAccelerationsConstraint.cpp:97-146 (getValue, getLinearApproximation) behind
+//        ZeroAccelerationConstraintCppAd.cpp:60-87 (isActive = contact flag), config as WBMpcInterface.cpp:204-229 builds it
+//   a10  humanoid_wb_mpc/src/constraint/EndEffectorDynamicsLinearAccConstraint.cpp:78-127, config as WBMpcPreComputation.cpp:91-104 builds it
+//   a5   humanoid_common_mpc/src/cost/StateInputQuadraticCost.cpp:67-78 (state - x_nom(t), input - weight compensation on the contact flags)
+//   a14  humanoid_common_mpc/src/constraint/JointLimitsSoftConstraint.cpp:64-100 with the stand-in penalty (everything but ASSUMPTION A1)
+//   a18  humanoid_common_mpc/src/initialization/WeightCompInitializer.cpp:66-70
 // =====================================================================================
 #include <cstring>
+
+#include "humanoid_common_mpc/constraint/JointLimitsSoftConstraint.h"
+#include "humanoid_common_mpc/cost/StateInputQuadraticCost.h"
+#include "humanoid_common_mpc/initialization/WeightCompInitializer.h"
+#include "humanoid_wb_mpc/constraint/EndEffectorDynamicsLinearAccConstraint.h"
+#include "humanoid_wb_mpc/constraint/ZeroAccelerationConstraintCppAd.h"
 
 #include "humanoid_common_mpc/constraint/FrictionForceConeConstraint.h"
 #include "humanoid_common_mpc/constraint/ZeroWrenchConstraint.h"
@@ -41,6 +55,10 @@ ModelSettings::ModelSettings(const std::string&, const std::string&, const std::
   phaseTransitionStanceTime = 0.4;
 }
 }  // namespace ocs2::humanoid
+
+namespace ocs2::humanoid {
+scalar_t& ref_stub_total_mass() { static scalar_t m = 0.0; return m; }   // (see ref_stubs/humanoid_common_mpc/pinocchio_model/DynamicsHelperFunctions.h)
+}
 
 namespace {
 struct World {
@@ -194,6 +212,213 @@ int ref_wb_velocity_targets(int nj, const char* reference_info, double horizon, 
     }
     return 0;
   } catch (const std::exception& e) { std::cerr << "ref_wb_velocity_targets: " << e.what() << "\n"; return 1; }
+}
+
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the assembly files.
+namespace {
+// EndEffectorDynamics over kinematics the caller hands in: kin[18] = {position, orientation error wrt the plane, linear velocity, angular
+// velocity, linear acceleration, angular acceleration} of ONE end effector, jac[18][nx + nu] their Jacobians wrt (x, u).  State and input
+// arguments are ignored: whatever the reference's assembly code returns is a function of these numbers and of its configuration only.
+class HandedInEeDynamics final : public EndEffectorDynamics<scalar_t> {
+ public:
+  HandedInEeDynamics(const double* kin, const double* jac, int nx, int nu) : kin_(kin, kin + 18), jac_(jac, jac + 18 * (nx + nu)), nx_(nx), nu_(nu), ids_{"foot"} {}
+  HandedInEeDynamics* clone() const override { return new HandedInEeDynamics(*this); }
+  const std::vector<std::string>& getIds() const override { return ids_; }
+  std::vector<vector3_t> getPosition(const vector_t&) const override { return {v3(0)}; }
+  std::vector<vector3_t> getVelocity(const vector_t&, const vector_t&) const override { return {v3(6)}; }
+  std::vector<vector3_t> getOrientationErrorWrtPlane(const vector_t&, const std::vector<vector3_t>& normals) const override { check_normal(normals); return {v3(3)}; }
+  std::vector<vector6_t> getTwist(const vector_t&, const vector_t&) const override { return {v6(6)}; }
+  std::vector<vector3_t> getLinearAcceleration(const vector_t&, const vector_t&) const override { return {v3(12)}; }
+  std::vector<vector3_t> getAngularAcceleration(const vector_t&, const vector_t&) const override { return {v3(15)}; }
+  std::vector<vector6_t> getAccelerations(const vector_t&, const vector_t&) const override { return {v6(12)}; }
+  std::vector<VectorFunctionLinearApproximation> getPositionLinearApproximation(const vector_t&) const override { return {lin(0, 3, false)}; }
+  std::vector<VectorFunctionLinearApproximation> getVelocityLinearApproximation(const vector_t&, const vector_t&) const override { return {lin(6, 3, true)}; }
+  std::vector<VectorFunctionLinearApproximation> getOrientationErrorWrtPlaneLinearApproximation(const vector_t&, const std::vector<vector3_t>& normals) const override {
+    check_normal(normals);
+    return {lin(3, 3, false)};
+  }
+  std::vector<VectorFunctionLinearApproximation> getTwistLinearApproximation(const vector_t&, const vector_t&) const override { return {lin(6, 6, true)}; }
+  std::vector<VectorFunctionLinearApproximation> getLinearAccelerationLinearApproximation(const vector_t&, const vector_t&) const override { return {lin(12, 3, true)}; }
+  std::vector<VectorFunctionLinearApproximation> getAngularAccelerationLinearApproximation(const vector_t&, const vector_t&) const override { return {lin(15, 3, true)}; }
+  std::vector<VectorFunctionLinearApproximation> getAccelerationsLinearApproximation(const vector_t&, const vector_t&) const override { return {lin(12, 6, true)}; }
+
+ private:
+  static void check_normal(const std::vector<vector3_t>& n) {
+    if (n.size() != 1 || n[0](0) != 0.0 || n[0](1) != 0.0 || n[0](2) != 1.0) throw std::runtime_error("the ground plane normal the reference passes is (0, 0, 1)");
+  }
+  vector3_t v3(int o) const { return vector3_t(kin_[o], kin_[o + 1], kin_[o + 2]); }
+  vector6_t v6(int o) const { vector6_t v; for (int i = 0; i < 6; ++i) v(i) = kin_[o + i]; return v; }
+  // state-only quantities (position, orientation error): dfdu stays EMPTY, as a kinematics-only approximation has no input Jacobian
+  VectorFunctionLinearApproximation lin(int o, int n, bool with_u) const {
+    VectorFunctionLinearApproximation a;
+    a.f = vector_t::Zero(n); a.dfdx = matrix_t::Zero(n, nx_);
+    if (with_u) a.dfdu = matrix_t::Zero(n, nu_);
+    for (int r = 0; r < n; ++r) {
+      a.f(r) = kin_[o + r];
+      for (int c = 0; c < nx_; ++c) a.dfdx(r, c) = jac_[(size_t)(o + r) * (nx_ + nu_) + c];
+      if (with_u) for (int c = 0; c < nu_; ++c) a.dfdu(r, c) = jac_[(size_t)(o + r) * (nx_ + nu_) + nx_ + c];
+    }
+    return a;
+  }
+  std::vector<double> kin_, jac_;
+  int nx_, nu_;
+  std::vector<std::string> ids_;
+};
+void put_lin(const VectorFunctionLinearApproximation& l, int rows, int nx, int nu, double* f, double* dfdx, double* dfdu) {
+  for (int r = 0; r < rows; ++r) {
+    f[r] = l.f(r);
+    for (int c = 0; c < nx; ++c) dfdx[r * nx + c] = l.dfdx(r, c);
+    for (int c = 0; c < nu; ++c) dfdu[r * nu + c] = l.dfdu(r, c);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// Stance foot: ZeroAccelerationConstraintCppAd over EndEffectorDynamicsAccelerationsConstraint with the configuration
+// WBMpcInterface::getStanceFootConstraint builds from ModelSettings::FootConstraintConfig (WBMpcInterface.cpp:204-229, restated here: that file
+// needs Pinocchio).  gains[8] = {positionErrorGain_z, orientationErrorGain, linearVelocityErrorGain_z, linearVelocityErrorGain_xy,
+// angularVelocityErrorGain, linearAccelerationErrorGain_z, linearAccelerationErrorGain_xy, angularAccelerationErrorGain} (the struct's order).
+// Out: value[6] = getValue, f[6] / dfdx[6 nx] / dfdu[6 nu] = getLinearApproximation, active = isActive(time) on the mode schedule.
+int ref_stance_foot_constraint(int nj, const double gains[8], int contact, int n_events, const double* event_times, const int* mode_sequence, double time,
+                               const double* kin18, const double* jac, double* value, double* f, double* dfdx, double* dfdu, int* active) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    mgr->setModeSchedule(ModeSchedule(std::vector<scalar_t>(event_times, event_times + n_events), std::vector<size_t>(mode_sequence, mode_sequence + n_events + 1)));
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    HandedInEeDynamics ee(kin18, jac, nx, nu);
+    EndEffectorDynamicsAccelerationsConstraint::Config config;
+    config.b.setZero(6);
+    config.Ax.setZero(6, 6);
+    config.Av = matrix_t::Identity(6, 6);
+    config.Aa = matrix_t::Identity(6, 6);
+    if (gains[0] != 0.0) config.Ax(2, 2) = gains[0];
+    if (gains[1] != 0.0) config.Ax.block(3, 3, 3, 3) = matrix_t(matrix_t::Identity(3, 3) * gains[1]);
+    config.Av.block(0, 0, 2, 2) = matrix_t(matrix_t::Identity(2, 2) * gains[3]);
+    config.Av(2, 2) = gains[2];
+    config.Av.block(3, 3, 3, 3) = matrix_t(matrix_t::Identity(3, 3) * gains[4]);
+    config.Aa.block(0, 0, 2, 2) = matrix_t(matrix_t::Identity(2, 2) * gains[6]);
+    config.Aa(2, 2) = gains[5];
+    config.Aa.block(3, 3, 3, 3) = matrix_t(matrix_t::Identity(3, 3) * gains[7]);
+    ZeroAccelerationConstraintCppAd con(*mgr, ee, contact, config);
+    const vector_t xs = vector_t::Zero(nx), us = vector_t::Zero(nu);
+    const vector_t v = con.getValue(time, xs, us, NoPreComp());
+    const auto l = con.getLinearApproximation(time, xs, us, NoPreComp());
+    if ((int)con.getNumConstraints(time) != 6 || v.size() != 6) return 2;
+    for (int r = 0; r < 6; ++r) value[r] = v(r);
+    put_lin(l, 6, nx, nu, f, dfdx, dfdu);
+    *active = con.isActive(time) ? 1 : 0;
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_stance_foot_constraint: " << e.what() << "\n"; return 1; }
+}
+
+// Swing foot: EndEffectorDynamicsLinearAccConstraint (one row) with the configuration WBMpcPreComputation::request builds per node
+// (WBMpcPreComputation.cpp:91-104, restated here: that file needs Pinocchio) from the planner's z position / velocity / acceleration
+// references zref[3] and the gains (same array as above).  Out: value[1], f[1], dfdx[nx], dfdu[nu].
+int ref_swing_foot_constraint(int nj, const double gains[8], const double zref[3], const double* kin18, const double* jac, double* value, double* f, double* dfdx,
+                              double* dfdu) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    HandedInEeDynamics ee(kin18, jac, nx, nu);
+    EndEffectorDynamicsLinearAccConstraint::Config config;
+    config.b = (vector_t(1) << -gains[2] * zref[1]).finished();
+    config.Av = matrix_t::Zero(1, 3); config.Av(0, 2) = gains[2];
+    config.b(0) -= gains[5] * zref[2];
+    config.Aa = matrix_t::Zero(1, 3); config.Aa(0, 2) = gains[5];
+    if (gains[0] != 0.0) {
+      config.b(0) -= gains[0] * zref[0];
+      config.Ax = matrix_t::Zero(1, 3); config.Ax(0, 2) = gains[0];
+    }
+    EndEffectorDynamicsLinearAccConstraint con(ee, 1);
+    con.configure(config);
+    const vector_t xs = vector_t::Zero(nx), us = vector_t::Zero(nu);
+    const vector_t v = con.getValue(0.0, xs, us, NoPreComp());
+    const auto l = con.getLinearApproximation(0.0, xs, us, NoPreComp());
+    if (v.size() != 1) return 2;
+    value[0] = v(0);
+    put_lin(l, 1, nx, nu, f, dfdx, dfdu);
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_swing_foot_constraint: " << e.what() << "\n"; return 1; }
+}
+
+// StateInputQuadraticCost (diagonal Q[nx], R[nu]) on the manager's references: dx[nx], du[nu] = the deviation its quadratic form is taken of —
+// the gradient of the stand-in QuadraticStateInputCost under unit weights —, value = 1/2 dx'Q dx + 1/2 du'R du.
+int ref_state_input_quadratic_cost(int nj, const int arm[4], double total_mass, int n_events, const double* event_times, const int* mode_sequence, int n_knots,
+                                   const double* tt, const double* ts, int arm_swing, double t0, double tf, const double* Q, const double* R, const double* state,
+                                   const double* input, double time, double* dx, double* du, double* value) {
+  try {
+    World w(nj, arm);
+    ref_stub_total_mass() = total_mass;
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    TargetTrajectories targets;
+    for (int k = 0; k < n_knots; ++k) { targets.timeTrajectory.push_back(tt[k]); targets.stateTrajectory.push_back(to_vec(ts + (size_t)k * nx, nx)); }
+    mgr->setTargetTrajectories(targets);
+    mgr->setArmSwingReferenceActive(arm_swing != 0);
+    const vector_t xs = to_vec(state, nx), us = to_vec(input, nu);
+    mgr->preSolverRun(t0, tf, xs);
+    matrix_t Qm = matrix_t::Zero(nx, nx), Rm = matrix_t::Zero(nu, nu);
+    for (int i = 0; i < nx; ++i) Qm(i, i) = Q[i];
+    for (int i = 0; i < nu; ++i) Rm(i, i) = R[i];
+    const PinocchioInterface pin;
+    // (the deviation through unit weights — task weights may be zero —, the value through the given ones)
+    StateInputQuadraticCost unit(matrix_t::Identity(nx, nx), matrix_t::Identity(nu, nu), *mgr, pin, w.model);
+    const auto L1 = unit.getQuadraticApproximation(time, xs, us, mgr->getTargetTrajectories(), NoPreComp());
+    for (int i = 0; i < nx; ++i) dx[i] = L1.dfdx(i);
+    for (int i = 0; i < nu; ++i) du[i] = L1.dfdu(i);
+    StateInputQuadraticCost cost(Qm, Rm, *mgr, pin, w.model);
+    *value = cost.getValue(time, xs, us, mgr->getTargetTrajectories(), NoPreComp());
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_state_input_quadratic_cost: " << e.what() << "\n"; return 1; }
+}
+
+// JointLimitsSoftConstraint with the stand-in penalty (mu, delta): f, dfdx[nx], the diagonal of dfdxx[nx] (off-diagonal entries must be zero)
+int ref_joint_limits(int nj, const double* q_lo, const double* q_hi, double mu, double delta, const double* state, double* f, double* dfdx, double* dfdxx_diag) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    const int nx = (int)w.model.getStateDim();
+    JointLimitsSoftConstraint con({to_vec(q_lo, nj), to_vec(q_hi, nj)}, PieceWisePolynomialBarrierPenalty::Config(mu, delta), w.model);
+    const vector_t xs = to_vec(state, nx);
+    const TargetTrajectories none;
+    const auto L = con.getQuadraticApproximation(0.0, xs, none, NoPreComp());
+    if (con.getValue(0.0, xs, none, NoPreComp()) != L.f) return 2;
+    *f = L.f;
+    for (int i = 0; i < nx; ++i) {
+      dfdx[i] = L.dfdx(i); dfdxx_diag[i] = L.dfdxx(i, i);
+      for (int j = 0; j < nx; ++j) if (i != j && L.dfdxx(i, j) != 0.0) return 3;
+    }
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_joint_limits: " << e.what() << "\n"; return 1; }
+}
+
+// WeightCompInitializer::compute(time, state, nextTime) on the mode schedule: input[nu], nextState[nx]
+int ref_weight_comp_initializer(int nj, double total_mass, int n_events, const double* event_times, const int* mode_sequence, double time, double next_time,
+                                const double* state, double* input, double* next_state) {
+  try {
+    const int arm[4] = {0, 0, 0, 0};
+    World w(nj, arm);
+    ref_stub_total_mass() = total_mass;
+    auto mgr = make_manager(w, n_events, event_times, mode_sequence);
+    mgr->setModeSchedule(ModeSchedule(std::vector<scalar_t>(event_times, event_times + n_events), std::vector<size_t>(mode_sequence, mode_sequence + n_events + 1)));
+    const int nx = (int)w.model.getStateDim(), nu = (int)w.model.getInputDim();
+    const PinocchioInterface pin;
+    WeightCompInitializer init(pin, *mgr, w.model);
+    vector_t u, xn;
+    init.compute(time, to_vec(state, nx), next_time, u, xn);
+    if ((int)u.size() != nu || (int)xn.size() != nx) return 2;
+    for (int i = 0; i < nu; ++i) input[i] = u(i);
+    for (int i = 0; i < nx; ++i) next_state[i] = xn(i);
+    return 0;
+  } catch (const std::exception& e) { std::cerr << "ref_weight_comp_initializer: " << e.what() << "\n"; return 1; }
 }
 
 }  // extern "C"
