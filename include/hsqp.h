@@ -225,6 +225,7 @@ typedef struct hsqp_linesearch_settings {
   double armijo_factor;         /* Armijo sufficient-decrease factor                                     */
   double alpha_decay, alpha_min;/* back-tracking factor and smallest step length tried                   */
   double delta_tol;             /* escape when alpha*|dx| and alpha*|du| fall below it                   */
+  double cost_tol;              /* HSQP_ITER_UNTIL_CONVERGED: |merit after - merit before| below it (with the violation below g_min) ends the loop (ocs2 costTol) */
 } hsqp_linesearch_settings;
 
 #define HSQP_STEP_COST 0        /* accepted by the Armijo condition on the cost                          */
@@ -272,8 +273,9 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* problem, const hsq
 #define HSQP_ITER_TAKE_STEP 1    /* after every iteration but the last: x <- x + dx, u <- u + du            */
 #define HSQP_ITER_KKT 2          /* also evaluate the KKT residual of the projected QP (not part of a step)  */
 #define HSQP_ITER_LINESEARCH 4   /* filter line search on the step length instead of the plain full step     */
-/* n_iterations is an upper bound: stop as soon as EVERY instance has converged the way ocs2's SqpSolver::checkConvergence does on the
- * step — alpha |dx| and alpha |du| below delta_tol (PRIMAL), or no step length accepted (STEPSIZE).  One small read-back per iteration
+/* n_iterations is an upper bound: stop as soon as EVERY instance has converged the way ocs2's SqpSolver::checkConvergence does, in its
+ * order — no step length accepted (STEPSIZE), |merit after - merit before| < cost_tol with the constraint violation below g_min (METRICS),
+ * alpha |dx| and alpha |du| below delta_tol (PRIMAL).  One small read-back per iteration
  * (the line-search state); the trajectories never leave the device.  hsqp_last_iterations() tells how many were run, hsqp_iteration_log()
  * returns the performance index / step length / step type each of them ended with (sqpIteration > 1 of the reference in ONE call). */
 #define HSQP_ITER_UNTIL_CONVERGED 8
@@ -286,6 +288,21 @@ int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf /*[B
  * receiver: humanoid_centroidal_mpc_ros2 GainsReceiver): diagonal Q[58], R[35], Qf[58] in the layout of hsqp_model_desc; NULL keeps
  * the current values.  Takes effect with the next iteration. */
 int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf);
+/* The weights and gains of the other task terms, as the reference's gains updaters retune them at run time
+ * (humanoid_centroidal_mpc_ros2/include/humanoid_centroidal_mpc_ros2/gains/: EndEffectorFootGainsUpdater — foot task-space cost weights —,
+ * StateInputConstraintGainsUpdater — stance / swing foot constraint gains —, StateInputSoftConstraintGainsUpdater, JointLimitsGainsUpdater,
+ * FootCollisionGainsUpdater — barrier (mu, delta) —, EndEffectorKinematicsGainsUpdater — torso cost of the centroidal task).  Same fields and
+ * meaning as in hsqp_model_desc.  hsqp_get_term_weights fills the struct with the handle's current values; hsqp_update_term_weights
+ * replaces ALL of them (get, change, update) after re-running the model validation of hsqp_create on the result (HSQP_ERR_BAD_ARG and no
+ * change if it fails).  Takes effect with the next iteration. */
+typedef struct hsqp_term_weights {
+  double foot_sqrt_w[18];
+  double gain_pos_z, gain_ori, gain_linvel_z, gain_linvel_xy, gain_angvel, gain_linacc_z, gain_linacc_xy, gain_angacc;
+  hsqp_barrier friction_barrier, moment_barrier, joint_limit_barrier, collision_barrier;
+  double torso_sqrt_w[12], cent_foot_sqrt_w[12], ext_torque_sqrt_w[2][6];   /* centroidal formulation only */
+} hsqp_term_weights;
+int hsqp_get_term_weights(const hsqp_handle* h, hsqp_term_weights* out);
+int hsqp_update_term_weights(hsqp_handle* h, const hsqp_term_weights* w);
 
 /* Page-lock a caller-owned host buffer (hipHostRegister / hipHostUnregister behind the C ABI, so that a caller need not link the HIP
  * runtime): hsqp_solve / hsqp_upload / hsqp_download move 36 + 39 MB per iteration at 256 instances x 100 nodes; from pageable memory the
@@ -345,6 +362,9 @@ int hsqp_evaluate_policy(hsqp_handle* h, const double* s /*[B]*/, double* x /*[B
 const char* hsqp_last_error(const hsqp_handle* h);   /* h may be NULL: last creation error */
 /* Iterations since hsqp_create whose parallel-in-time sweep failed the KKT gate and were redone with the serial recursion (-1: h is NULL). */
 long long hsqp_scan_fallbacks(const hsqp_handle* h);
+/* Iterations that ran the serial recursion because the AUTOMATIC sweep choice was backing off after a rejected gate (a sweep forced by
+ * HSQP_FLAG_PARALLEL_RICCATI / HSQP_FLAG_SEGMENTED_RICCATI is attempted every iteration; every upload resets the back-off). */
+long long hsqp_scan_backoffs(const hsqp_handle* h);
 const char* hsqp_version(void);
 int hsqp_device_count(void);
 

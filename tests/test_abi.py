@@ -23,7 +23,8 @@ def test_header_declares_the_expected_entry_points():
         "hsqp_create", "hsqp_destroy", "hsqp_solve", "hsqp_upload", "hsqp_iterate_device", "hsqp_download",
         "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_scan_fallbacks", "hsqp_version", "hsqp_device_count",
         "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference", "hsqp_joint_torques", "hsqp_evaluate_policy",
-        "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights", "hsqp_host_register", "hsqp_host_unregister"])
+        "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights", "hsqp_host_register", "hsqp_host_unregister",
+        "hsqp_scan_backoffs", "hsqp_get_term_weights", "hsqp_update_term_weights"])
 
 
 def test_library_exports_every_declared_symbol():
@@ -35,14 +36,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_c_compiler(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "hsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "hsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(hsqp_body),sizeof(hsqp_frame),sizeof(hsqp_model_desc),sizeof(hsqp_settings),sizeof(hsqp_problem),"
-                   "sizeof(hsqp_perf),sizeof(hsqp_timings),sizeof(hsqp_solution),sizeof(hsqp_linesearch_settings),sizeof(hsqp_swing_config),sizeof(hsqp_reference));return 0;}\n")
+                   "sizeof(hsqp_perf),sizeof(hsqp_timings),sizeof(hsqp_solution),sizeof(hsqp_linesearch_settings),sizeof(hsqp_swing_config),sizeof(hsqp_reference),sizeof(hsqp_term_weights));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(s) for s in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(t) for t in (_abi.Body, _abi.Frame, _abi.ModelDesc, _abi.Settings, _abi.Problem, _abi.Perf,
-                                           _abi.Timings, _abi.Solution, _abi.LinesearchSettings, _abi.SwingConfig, _abi.Reference)]
+                                           _abi.Timings, _abi.Solution, _abi.LinesearchSettings, _abi.SwingConfig, _abi.Reference, _abi.TermWeights)]
 
 
 def test_linesearch_defaults_follow_task_info():
@@ -51,7 +52,7 @@ def test_linesearch_defaults_follow_task_info():
     s = _abi.LinesearchSettings()
     lib.hsqp_linesearch_defaults(C.byref(s))
     assert (s.g_max, s.g_min, s.delta_tol) == (1e-2, 1e-6, 1e-4)
-    assert (s.gamma_c, s.armijo_factor, s.alpha_decay, s.alpha_min) == (1e-6, 1e-4, 0.5, 1e-4)
+    assert (s.gamma_c, s.armijo_factor, s.alpha_decay, s.alpha_min, s.cost_tol) == (1e-6, 1e-4, 0.5, 1e-4, 1e-4)
 
 
 def test_no_cpu_fallback(model):

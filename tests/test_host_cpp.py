@@ -177,3 +177,31 @@ def test_cpp_model_builder_from_task_urdf_reference_files_equals_the_exported_mo
     badu.write_text(open(urdf).read().replace('name="left_knee_joint" type="revolute"', 'name="left_knee_joint" type="prismatic"'))
     r = subprocess.run([str(exe), task, str(badu), refi, str(tmp_path / "o3.bin"), formulation], capture_output=True, text=True)
     assert r.returncode == 3 and "prismatic" in r.stdout
+
+
+INFO_SRC = r'''
+#include <cstdio>
+#include <fstream>
+#include "HipSqpModelBuilder.h"
+int main(int argc, char** argv) {
+  { std::ofstream f(argv[1]);
+    f << "urdf package://g1_description/urdf/g1.urdf  // a remark behind a pair\n"
+         "quoted \"a;b // c\" ; a real comment\n"
+         "path //abs/dir\n"
+         "block { k1 v1 ; c\n k2 \"v 2\" }\n"; }
+  for (const auto& t : hsqp_host::detail::infoTokens(argv[1])) std::printf("[%s]", t.c_str());
+  std::printf("\n");
+  return 0;
+}
+'''
+
+
+def test_info_reader_comment_rules(tmp_path):
+    """ADVICE r3: Boost INFO comments start with ';' OUTSIDE quotes only; "//" is data (package:// URIs, paths) — except as the start of a
+    token behind a complete key-value pair of the same line, the remark style of the reference's task files (task.info:3)."""
+    src = tmp_path / "i.cpp"
+    src.write_text(INFO_SRC)
+    exe = tmp_path / "i"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "wb_humanoid_mpc_amd", "host"), "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe), str(tmp_path / "t.info")], text=True).strip()
+    assert out == "[urdf][package://g1_description/urdf/g1.urdf][quoted][a;b // c][path][//abs/dir][block][{][k1][v1][k2][v 2][}]"

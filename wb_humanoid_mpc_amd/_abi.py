@@ -95,7 +95,14 @@ class Reference(C.Structure):
 
 class LinesearchSettings(C.Structure):
     _fields_ = [("g_max", C.c_double), ("g_min", C.c_double), ("gamma_c", C.c_double), ("armijo_factor", C.c_double),
-                ("alpha_decay", C.c_double), ("alpha_min", C.c_double), ("delta_tol", C.c_double)]
+                ("alpha_decay", C.c_double), ("alpha_min", C.c_double), ("delta_tol", C.c_double), ("cost_tol", C.c_double)]
+
+
+class TermWeights(C.Structure):
+    _fields_ = [("foot_sqrt_w", C.c_double * 18)] + [(k, C.c_double) for k in ("gain_pos_z", "gain_ori", "gain_linvel_z", "gain_linvel_xy", "gain_angvel", "gain_linacc_z",
+                                                                               "gain_linacc_xy", "gain_angacc")] + \
+               [(k, Barrier) for k in ("friction_barrier", "moment_barrier", "joint_limit_barrier", "collision_barrier")] + \
+               [("torso_sqrt_w", C.c_double * 12), ("cent_foot_sqrt_w", C.c_double * 12), ("ext_torque_sqrt_w", (C.c_double * 6) * 2)]
 
 
 STEP_COST, STEP_DUAL, STEP_CONSTRAINT, STEP_ZERO, STEP_FULL = 0, 1, 2, 3, 4

@@ -563,7 +563,10 @@ struct hsqp_handle {
   // segmented sweep (allocated when first used): gains of the J = 0 recursions, (L^-1)^T of every stage, (J, s) at the segment starts, zeros
   double *d_ric2 = nullptr, *d_linv = nullptr, *d_vf0 = nullptr, *d_zero = nullptr;
   size_t vf0_capacity = 0;
-  int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected gated sweep (scan or two-level) the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64)
+  int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected gated sweep (scan or two-level) the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64);
+                                              // state of the AUTOMATIC sweep choice only (a sweep forced by a flag is always attempted), reset by every upload
+  long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
+  bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   int* d_scanst = nullptr;   // flags of the scan kernels (bad pivot, rank-deficient D, failed Lam) of the current attempt: part of the gate, behind d_ginf
@@ -571,6 +574,8 @@ struct hsqp_handle {
   LsState* d_ls = nullptr;
   int* d_counts = nullptr;
   hsqp_linesearch_settings ls_settings;
+  std::vector<LsState> h_ls;                  // host copies for HSQP_ITER_UNTIL_CONVERGED (reused across iterations and calls)
+  std::vector<hsqp_perf> h_perf_before;
   double* d_el[2] = {nullptr, nullptr};   // scan elements (allocated when the parallel-in-time sweep is first used)
   size_t el_capacity = 0;                 // in doubles per buffer
   void* d_stage = nullptr;        // grow-only staging area for the small per-call inputs (reference, policy queries)
@@ -730,6 +735,7 @@ int hsqp_device_count(void) {
 }
 
 long long hsqp_scan_fallbacks(const hsqp_handle* h) { return h ? h->scan_fallbacks : -1; }
+long long hsqp_scan_backoffs(const hsqp_handle* h) { return h ? h->backoff_iterations : -1; }
 
 const char* hsqp_last_error(const hsqp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -753,6 +759,7 @@ void hsqp_linesearch_defaults(hsqp_linesearch_settings* s) {
   s->g_max = 1e-2; s->g_min = 1e-6;      // g1_wb_mpc/config/mpc/task.info:83-84
   s->gamma_c = 1e-6; s->armijo_factor = 1e-4; s->alpha_decay = 0.5; s->alpha_min = 1e-4;   // upstream ocs2 sqp::Settings defaults
   s->delta_tol = 1e-4;                   // task.info deltaTol
+  s->cost_tol = 1e-4;                    // upstream ocs2 sqp::Settings::costTol default (the task file does not set it)
 }
 
 // trials after which every instance has either accepted a step or fallen below alpha_min (zero step)
@@ -761,8 +768,8 @@ static int ls_max_trials(const hsqp_linesearch_settings& s) { return (int)ceil(l
 
 int hsqp_set_linesearch(hsqp_handle* h, const hsqp_linesearch_settings* s) {
   if (!h) return HSQP_ERR_BAD_ARG;
-  if (!s || !(s->alpha_decay > 0.0 && s->alpha_decay < 1.0) || !(s->alpha_min > 0.0) || !(s->g_max >= s->g_min)) {
-    h->err = "line-search settings: need 0 < alpha_decay < 1, alpha_min > 0, g_max >= g_min";
+  if (!s || !(s->alpha_decay > 0.0 && s->alpha_decay < 1.0) || !(s->alpha_min > 0.0) || !(s->g_max >= s->g_min) || !(s->cost_tol >= 0.0)) {
+    h->err = "line-search settings: need 0 < alpha_decay < 1, alpha_min > 0, g_max >= g_min, cost_tol >= 0";
     return HSQP_ERR_BAD_ARG;
   }
   if (s->alpha_min < 1.0 && ls_max_trials(*s) > HSQP_LS_MAX_TRIALS) {
@@ -789,6 +796,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device visible (this library has no CPU path)"; return HSQP_ERR_NO_DEVICE; }
   if (settings->device < 0 || settings->device >= ndev) { g_create_error = "device ordinal out of range"; return HSQP_ERR_BAD_ARG; }
   hsqp_handle* h = new hsqp_handle;
+  h->seg_debug = getenv("HSQP_SEG_DEBUG") != nullptr;
   h->md = *model;
   h->st = *settings;
   h->device = settings->device;
@@ -912,6 +920,7 @@ static int upload_impl(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
   HCHECK(hipStreamSynchronize(h->stream));
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
+  h->seg_backoff = 0; h->seg_backoff_len = 0;   // the gate's history belongs to the problem that produced it
   return HSQP_OK;
 }
 
@@ -983,6 +992,7 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   if (bad) { h->err = "a swing phase has no lift-off / touch-down inside the mode schedule"; return HSQP_ERR_BAD_ARG; }
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
+  h->seg_backoff = 0; h->seg_backoff_len = 0;
   return HSQP_OK;
 }
 
@@ -1029,12 +1039,15 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // (badly scaled QPs: |S| ~ 1e6 on perturbed centroidal batches) would pay sweep + fallback every iteration: after a rejection the handle
     // backs off to the serial recursion for 1, 3, 7, .. 63 iterations before it tries again
     int segP = segment_count(h, B, N);
-    if (segP > 0 && h->seg_backoff > 0) { --h->seg_backoff; segP = 0; }
+    // (a sweep the caller FORCED by a flag is attempted every iteration: the back-off is part of the automatic choice only, so forced
+    //  timings and the parity tests of the forced sweeps never silently measure the serial recursion)
+    const bool forced_seg = (h->st.flags & HSQP_FLAG_SEGMENTED_RICCATI) != 0, forced_scan = (h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) != 0;
+    if (segP > 0 && !forced_seg && h->seg_backoff > 0) { --h->seg_backoff; ++h->backoff_iterations; segP = 0; }
     bool pscan = segP == 0 && !(h->st.flags & HSQP_FLAG_SERIAL_RICCATI) && !(h->st.flags & HSQP_FLAG_SEGMENTED_RICCATI) &&
                  ((h->st.flags & HSQP_FLAG_PARALLEL_RICCATI) || (B <= HSQP_SCAN_AUTO_BATCH && N >= HSQP_SCAN_AUTO_MIN_NODES));
     // the same back-off for the scan: a rejected scan costs scan + serial sweep (0.55 + 1.45 ms at one whole-body instance), and the
     // iterates that fail the gate — far-from-feasible line-search iterates — come in runs
-    if (pscan && h->seg_backoff > 0) { --h->seg_backoff; pscan = false; }
+    if (pscan && !forced_scan && h->seg_backoff > 0) { --h->seg_backoff; ++h->backoff_iterations; pscan = false; }
     const bool scan = pscan || segP > 0;        // either way a KKT-gated sweep with the serial recursion as fallback
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
@@ -1102,7 +1115,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         // (a flag = a bad pivot / failed factorisation inside the scan: the serial recursion decides what is reported in d_status)
         if (!scan_gate_accepts(hk[2 * b], hk[2 * b + 1], hk[2 * Bm + b], flags[b])) accept = false;
       }
-      if (getenv("HSQP_SEG_DEBUG") && segP > 0) {
+      if (h->seg_debug && segP > 0) {
         double m0 = 0, m1 = 0, m2 = 0; int fl = 0;
         for (int b = 0; b < B; ++b) { m0 = fmax(m0, hk[2 * b]); m1 = fmax(m1, hk[2 * b + 1]); m2 = fmax(m2, hk[2 * Bm + b]); fl |= flags[b]; }
         fprintf(stderr, "[hsqp seg gate] P=%d boundary-stage KKT stat %.3e prim %.3e |g| %.3e flags %d accept %d\n", segP, m0, m1, m2, fl, (int)accept);
@@ -1167,21 +1180,28 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (last && !ev4_early) HCHECK(hipEventRecord(h->ev[4], h->stream));
     h->last_iterations = it + 1;
     if (until_converged) {
-      // SqpSolver::checkConvergence on the step (upstream ocs2_sqp): STEPSIZE (no step length accepted) or PRIMAL (alpha |dx| and
-      // alpha |du| below deltaTol) for EVERY instance ends the loop; the record of the iteration goes to the log
+      // SqpSolver::checkConvergence (upstream ocs2_sqp, restated from the published source; the fork's copy is absent): after ITERATIONS
+      // (the loop bound) STEPSIZE (no step length accepted), then METRICS (|merit after - merit before| < costTol and the constraint
+      // violation after the step below g_min), then PRIMAL (alpha |dx| and alpha |du| below deltaTol); the loop ends when EVERY instance
+      // meets one of them.  The record of the iteration goes to the log.  The read-back lands in the handle's host buffers (no
+      // allocation per iteration); with n_iterations == 1 the loop ends regardless of the verdict, but the log is still filled (the
+      // adaptor reads step length and type from it).
       hsqp_handle::IterLog rec;
       rec.perf.resize(B); rec.alpha.resize(B); rec.type.resize(B);
-      std::vector<LsState> ls(B);
-      HCHECK(hipMemcpyAsync(ls.data(), h->d_ls, (size_t)B * sizeof(LsState), hipMemcpyDeviceToHost, h->stream));
+      h->h_ls.resize(B); h->h_perf_before.resize(B);
+      HCHECK(hipMemcpyAsync(h->h_ls.data(), h->d_ls, (size_t)B * sizeof(LsState), hipMemcpyDeviceToHost, h->stream));
       HCHECK(hipMemcpyAsync(rec.perf.data(), h->d_perf_after, (size_t)B * sizeof(hsqp_perf), hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipMemcpyAsync(h->h_perf_before.data(), h->d_perf_before, (size_t)B * sizeof(hsqp_perf), hipMemcpyDeviceToHost, h->stream));
       HCHECK(hipStreamSynchronize(h->stream));
+      const std::vector<LsState>& ls = h->h_ls;
       converged = true;
       for (int b = 0; b < B; ++b) {
         rec.alpha[b] = linesearch ? ls[b].alpha : 1.0;
         rec.type[b] = linesearch ? ls[b].step_type : HSQP_STEP_FULL;
         const bool zero_step = linesearch && ls[b].step_type == HSQP_STEP_ZERO;
+        const bool metrics = fabs(rec.perf[b].merit - h->h_perf_before[b].merit) < h->ls_settings.cost_tol && ls_violation(rec.perf[b]) < h->ls_settings.g_min;
         const bool primal = rec.alpha[b] * ls[b].dxnorm < h->ls_settings.delta_tol && rec.alpha[b] * ls[b].dunorm < h->ls_settings.delta_tol;
-        if (!zero_step && !primal) converged = false;
+        if (!zero_step && !metrics && !primal) converged = false;
       }
       h->iter_log.push_back(std::move(rec));
       float msi[4];
@@ -1222,11 +1242,19 @@ int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf, dou
 
 int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf) {
   if (!h) return HSQP_ERR_BAD_ARG;
-  for (const double* w : {Q, R, Qf}) {
-    if (!w) continue;
-    const int n = w == R ? NU : NX;
-    for (int i = 0; i < n; ++i)
-      if (!(w[i] >= 0.0) || !std::isfinite(w[i])) { h->err = "hsqp_update_weights: weights must be finite and >= 0"; return HSQP_ERR_BAD_ARG; }
+  // explicit lengths (Q: 58, R: 35, Qf: 58; the same buffer may be passed twice) and the conditions the model validation at hsqp_create
+  // applies: state weights finite and >= 0, input weights finite and > 0 (the reduced Hessian
+  // Lam = R~ + B~^T S B~ of every stage has to stay positive definite)
+  const struct { const double* w; int n; bool positive; const char* name; } sets[3] = {{Q, NX, false, "Q"}, {R, NU, true, "R"}, {Qf, NX, false, "Qf"}};
+  for (const auto& st : sets) {
+    if (!st.w) continue;
+    for (int i = 0; i < st.n; ++i) {
+      const bool must_be_positive = st.positive;   // (both formulations use all 35 inputs)
+      if (!std::isfinite(st.w[i]) || st.w[i] < 0.0 || (must_be_positive && !(st.w[i] > 0.0))) {
+        h->err = std::string("hsqp_update_weights: ") + st.name + " must be finite and " + (st.positive ? "> 0" : ">= 0");
+        return HSQP_ERR_BAD_ARG;
+      }
+    }
   }
   if (h->hdm.formulation == HSQP_FORM_CENTROIDAL)
     for (const double* w : {Q, Qf})
@@ -1237,6 +1265,47 @@ int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const 
   if (R) { memcpy(h->hdm.R, R, NU * 8); memcpy(h->md.R, R, NU * 8); }
   if (Qf) { memcpy(h->hdm.Qf, Qf, NX * 8); memcpy(h->md.Qf, Qf, NX * 8); }
   HCHECK(hipStreamSynchronize(h->stream));   // no kernel of an earlier call may still be reading the image
+  HCHECK(hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice));
+  return HSQP_OK;
+}
+
+int hsqp_get_term_weights(const hsqp_handle* h, hsqp_term_weights* out) {
+  if (!h || !out) return HSQP_ERR_BAD_ARG;
+  const hsqp_model_desc& m = h->md;
+  memcpy(out->foot_sqrt_w, m.foot_sqrt_w, sizeof(out->foot_sqrt_w));
+  out->gain_pos_z = m.gain_pos_z; out->gain_ori = m.gain_ori; out->gain_linvel_z = m.gain_linvel_z; out->gain_linvel_xy = m.gain_linvel_xy;
+  out->gain_angvel = m.gain_angvel; out->gain_linacc_z = m.gain_linacc_z; out->gain_linacc_xy = m.gain_linacc_xy; out->gain_angacc = m.gain_angacc;
+  out->friction_barrier = m.friction_barrier; out->moment_barrier = m.moment_barrier; out->joint_limit_barrier = m.joint_limit_barrier;
+  out->collision_barrier = m.collision_barrier;
+  memcpy(out->torso_sqrt_w, m.torso_sqrt_w, sizeof(out->torso_sqrt_w));
+  memcpy(out->cent_foot_sqrt_w, m.cent_foot_sqrt_w, sizeof(out->cent_foot_sqrt_w));
+  memcpy(out->ext_torque_sqrt_w, m.ext_torque_sqrt_w, sizeof(out->ext_torque_sqrt_w));
+  return HSQP_OK;
+}
+
+int hsqp_update_term_weights(hsqp_handle* h, const hsqp_term_weights* w) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  if (!w) { h->err = "hsqp_update_term_weights: null argument"; return HSQP_ERR_BAD_ARG; }
+  const double* all = reinterpret_cast<const double*>(w);
+  for (size_t i = 0; i < sizeof(hsqp_term_weights) / sizeof(double); ++i)
+    if (!std::isfinite(all[i])) { h->err = "hsqp_update_term_weights: every entry must be finite"; return HSQP_ERR_BAD_ARG; }
+  for (const hsqp_barrier* b : {&w->friction_barrier, &w->moment_barrier, &w->joint_limit_barrier, &w->collision_barrier})
+    if (!(b->mu > 0.0) || !(b->delta > 0.0)) { h->err = "hsqp_update_term_weights: barrier mu and delta must be > 0"; return HSQP_ERR_BAD_ARG; }
+  hsqp_model_desc m = h->md;
+  memcpy(m.foot_sqrt_w, w->foot_sqrt_w, sizeof(m.foot_sqrt_w));
+  m.gain_pos_z = w->gain_pos_z; m.gain_ori = w->gain_ori; m.gain_linvel_z = w->gain_linvel_z; m.gain_linvel_xy = w->gain_linvel_xy;
+  m.gain_angvel = w->gain_angvel; m.gain_linacc_z = w->gain_linacc_z; m.gain_linacc_xy = w->gain_linacc_xy; m.gain_angacc = w->gain_angacc;
+  m.friction_barrier = w->friction_barrier; m.moment_barrier = w->moment_barrier; m.joint_limit_barrier = w->joint_limit_barrier;
+  m.collision_barrier = w->collision_barrier;
+  memcpy(m.torso_sqrt_w, w->torso_sqrt_w, sizeof(m.torso_sqrt_w));
+  memcpy(m.cent_foot_sqrt_w, w->cent_foot_sqrt_w, sizeof(m.cent_foot_sqrt_w));
+  memcpy(m.ext_torque_sqrt_w, w->ext_torque_sqrt_w, sizeof(m.ext_torque_sqrt_w));
+  DevModel dm;
+  const std::string e = build_dev_model(m, dm);       // the validation of hsqp_create on the updated description
+  if (!e.empty()) { h->err = "hsqp_update_term_weights: " + e; return HSQP_ERR_BAD_ARG; }
+  HCHECK(hipSetDevice(h->device));
+  HCHECK(hipStreamSynchronize(h->stream));   // no kernel of an earlier call may still be reading the image
+  h->md = m; h->hdm = dm;
   HCHECK(hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice));
   return HSQP_OK;
 }

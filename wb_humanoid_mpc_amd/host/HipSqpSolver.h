@@ -59,7 +59,7 @@ class HipSqpSolver {
     hsqp_solution s{};
     s.alpha = stepSize_.data(); s.step_type = stepType_.data();
     s.x = solution_.stateTrajectory.data(); s.u = solution_.inputTrajectory.data();
-    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = kkt_.data();
+    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = reportKkt_ ? kkt_.data() : nullptr;
     const int rc = hsqp_solve(h_, &p, &s);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_solve failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
     bench_.linearQuadraticApproximationTime = s.timings.lq_approximation;
@@ -82,7 +82,7 @@ class HipSqpSolver {
     int rc = hsqp_upload_reference(h_, &p, &ref);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_upload_reference failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
     rc = hsqp_iterate_device(h_, maxIterations < 1 ? 1 : maxIterations,
-                             HSQP_ITER_TAKE_STEP | HSQP_ITER_KKT | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0) | HSQP_ITER_UNTIL_CONVERGED);
+                             HSQP_ITER_TAKE_STEP | (reportKkt_ ? HSQP_ITER_KKT : 0) | (takeStepWithLinesearch ? HSQP_ITER_LINESEARCH : 0) | HSQP_ITER_UNTIL_CONVERGED);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_iterate_device failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
     iterations_ = hsqp_last_iterations(h_);
     solution_.batch = batch; solution_.nodes = nodes;
@@ -92,7 +92,7 @@ class HipSqpSolver {
     kkt_.assign((size_t)batch * 2, 0.0); stepSize_.assign(batch, 0.0); stepType_.assign(batch, HSQP_STEP_FULL);
     hsqp_solution s{};
     s.x = solution_.stateTrajectory.data(); s.u = solution_.inputTrajectory.data();
-    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = kkt_.data();
+    s.perf_before = perfBefore_.data(); s.perf_after = perf_.data(); s.kkt = reportKkt_ ? kkt_.data() : nullptr;
     s.alpha = stepSize_.data(); s.step_type = stepType_.data();
     rc = hsqp_download(h_, &s);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_download failed (" + std::to_string(rc) + "): " + hsqp_last_error(h_));
@@ -114,7 +114,10 @@ class HipSqpSolver {
   const PrimalSolution& getPrimalSolution() const { return solution_; }
   const std::vector<hsqp_perf>& getPerformanceIndeces() const { return perf_; }
   const std::vector<hsqp_perf>& getPerformanceIndecesBeforeStep() const { return perfBefore_; }
+  /** KKT residuals {stationarity, primal} of the projected QP per instance — a DIAGNOSTIC that costs a kernel and, at 256 instances, 4.5 GB
+   *  of reads per call: evaluated only after setReportKkt(true) (zeros otherwise); getBenchmarks() does not depend on it. */
   const std::vector<double>& getKktResiduals() const { return kkt_; }
+  void setReportKkt(bool on) { reportKkt_ = on; }
   /** Step length and FilterLinesearch::StepType (HSQP_STEP_*) per instance of the last run. */
   const std::vector<double>& getStepSizes() const { return stepSize_; }
   const std::vector<int32_t>& getStepTypes() const { return stepType_; }
@@ -142,6 +145,7 @@ class HipSqpSolver {
   std::vector<int32_t> stepType_;
   Benchmarks bench_;
   int iterations_ = 0;
+  bool reportKkt_ = false;
 };
 
 }  // namespace hsqp_host

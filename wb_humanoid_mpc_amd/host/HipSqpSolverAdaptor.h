@@ -78,7 +78,7 @@ class HipSqpSolverAdaptor final : public SolverBase {
     hsqp_linesearch_settings ls;
     hsqp_linesearch_defaults(&ls);
     ls.g_max = settings_.g_max; ls.g_min = settings_.g_min; ls.gamma_c = settings_.gamma_c; ls.armijo_factor = settings_.armijoFactor;
-    ls.alpha_decay = settings_.alpha_decay; ls.alpha_min = settings_.alpha_min; ls.delta_tol = settings_.deltaTol;
+    ls.alpha_decay = settings_.alpha_decay; ls.alpha_min = settings_.alpha_min; ls.delta_tol = settings_.deltaTol; ls.cost_tol = settings_.costTol;
     impl_.setLinesearchSettings(ls);
   }
 

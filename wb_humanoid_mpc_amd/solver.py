@@ -59,6 +59,10 @@ def load_library():
     lib.hsqp_last_error.restype = C.c_char_p
     lib.hsqp_scan_fallbacks.argtypes = [C.c_void_p]
     lib.hsqp_scan_fallbacks.restype = C.c_longlong
+    lib.hsqp_get_term_weights.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hsqp_update_term_weights.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hsqp_scan_backoffs.argtypes = [C.c_void_p]
+    lib.hsqp_scan_backoffs.restype = C.c_longlong
     lib.hsqp_version.restype = C.c_char_p
     lib.hsqp_joint_torques.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.hsqp_evaluate_policy.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
@@ -240,6 +244,16 @@ class HipSqpSolver:
         arrs = [None if a is None else _c(a) for a in (Q, R, Qf)]
         self._check(self.lib.hsqp_update_weights(self.h, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]))
 
+    def term_weights(self):
+        """hsqp_get_term_weights: the handle's current foot-cost weights, foot-constraint gains, barrier parameters (an _abi.TermWeights)."""
+        w = _abi.TermWeights()
+        self._check(self.lib.hsqp_get_term_weights(self.h, C.byref(w)))
+        return w
+
+    def update_term_weights(self, w):
+        """hsqp_update_term_weights: replace them (what the reference's gains updaters retune at run time)."""
+        self._check(self.lib.hsqp_update_term_weights(self.h, C.byref(w)))
+
     # ---- sqp::Settings of the line search (task.info sqp block + upstream defaults)
     def linesearch_settings(self):
         s = _abi.LinesearchSettings()
@@ -280,6 +294,10 @@ class HipSqpSolver:
         ms = np.zeros(5)
         self._check(self.lib.hsqp_last_kernel_ms(self.h, ms.ctypes.data_as(_dp)))
         return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
+
+    def scan_backoffs(self):
+        """Iterations that ran the serial recursion because the automatic sweep choice was backing off (hsqp_scan_backoffs)."""
+        return int(self.lib.hsqp_scan_backoffs(self.h))
 
     def scan_fallbacks(self):
         """Iterations whose parallel-in-time sweep failed the KKT gate and were redone with the serial recursion (hsqp_scan_fallbacks)."""
