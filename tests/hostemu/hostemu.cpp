@@ -10,6 +10,7 @@
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_host.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent_lq.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_scan.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_segment.h"
 
@@ -276,7 +277,8 @@ void emu_project_node(const double* rec, double dt, double* qp) {
 void emu_cent_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
-  if (deriv) cent_lq_node<true>(ctx, dm, x, u, xnext, par, dt, rec);
+  if (deriv == 2) cent_lq_node<true>(ctx, dm, x, u, xnext, par, dt, rec);     // the first form (one tangent direction per lane on a tree pass)
+  else if (deriv) { auto ws = std::make_unique<CentWST<true>>(); cent_lq_node2<true>(ctx, dm, *ws, x, u, xnext, par, dt, rec, rec + REC_MISC); }
   else { cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 0); cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 1); }
 }
 void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_AB(rec, dt, AB); }

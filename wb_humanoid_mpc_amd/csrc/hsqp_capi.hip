@@ -16,6 +16,7 @@
 #include "hsqp_params.h"
 #include "hsqp_policy.h"
 #include "hsqp_cent.h"
+#include "hsqp_cent_lq.h"
 #include "hsqp_scan.h"
 #include "hsqp_segment.h"
 
@@ -78,6 +79,18 @@ __global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __rest
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   cent_lq_node<SPLIT>(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
+}
+// ---- centroidal LQ approximation, second form (hsqp_cent_lq.h): one 128-thread workgroup per (instance, node), values once per node in an LDS
+//      workspace, tangent lanes on closed-form seeds; four workgroups per CU
+static_assert(sizeof(CentWST<true>) <= 163840 / 4, "centroidal LQ workspace: four workgroups per CU");
+__global__ __launch_bounds__(CLQ_THREADS, 2) void k_lq_cent2(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                             const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  CentWST<true>& w = *reinterpret_cast<CentWST<true>*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  double* r = rec + (size_t)node * REC_SIZE;
+  cent_lq_node2<true>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], r, r + REC_MISC);
 }
 // ---- centroidal value-only pass: two lanes per (instance, node) in different waves (wave 0: RK4 defect, wave 1: terms)
 __global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
@@ -831,6 +844,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_step_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
+  if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_lq_cent2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CentWST<true>));
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
   hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   hipError_t a5 = hipFuncSetAttribute((const void*)k_riccati<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
@@ -1014,9 +1028,13 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // (until_converged: any iteration may turn out to be the last one, so each is bracketed by the timing events and its times are summed)
     const bool last = it == n_iterations - 1 || until_converged;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
-    if (cent) {   // up to two workgroups per CU in flight: the latency form (hsqp_cent.h, cent_lq_node)
+    if (cent) {
+#if defined(HSQP_CENT_LQ_V1)
       if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent<true>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
       else hipLaunchKernelGGL(k_lq_cent<false>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+#else
+      hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+#endif
     }
     else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,

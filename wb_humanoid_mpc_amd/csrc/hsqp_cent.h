@@ -62,6 +62,8 @@ HSQP_HD void dsincos(Dual1 a, Dual1& s, Dual1& c) { double sv, cv; sincos(a.v, &
 HSQP_HD void dsincos(double a, double& s, double& c) { sincos(a, &s, &c); }
 HSQP_HD double val(Dual1 a) { return a.v; }
 HSQP_HD double val(double a) { return a; }
+HSQP_HD double tan_of(Dual1 a) { return a.d; }
+HSQP_HD double tan_of(double) { return 0.0; }
 HSQP_HD void set_tan(Dual1& a) { a.d = 1.0; }
 HSQP_HD void set_tan(double&) {}
 template <class T> HSQP_HD T cst(double v);
@@ -177,6 +179,49 @@ HSQP_HD void cent_collect(const DevModel& dm, int i, const BodyRec<T>& b, const 
       }
 }
 
+// The closing solve of a model pass: from the momentum sums of the joint motion (cent_accumulate; positions relative to p0, or absolute with
+// p0 given), the euler-rate axes E, the contact points pc (same origin as the sums), the normalized momentum h and the wrenches W:
+//   com, the base velocity vb = [pdot; euler rates], its angular velocity wb, and xdot[0..11] = [d(h/m)/dt ; pdot ; euler rates].
+template <class T>
+HSQP_HD void cent_finish(const DevModel& dm, const CentSums<T>& sums, const T* E, const T (*pc)[3], const T* h, const T* W, T* xdot, T* vb, T* wb, T* com,
+                         const T* p0 = nullptr) {
+  const T zero = cst<T>(0.0);
+  const double M = dm.total_mass, iM = 1.0 / M;
+  for (int r = 0; r < 3; ++r) com[r] = sums.mc[r] * iM;
+  const T* cm = com;
+  const T* IO = sums.IO;
+  const T cm2 = t_dot(cm, cm);
+  T Ic[9];
+  Ic[0] = IO[0] - (cm2 - cm[0] * cm[0]) * M; Ic[1] = IO[1] + (cm[0] * cm[1]) * M; Ic[2] = IO[2] + (cm[0] * cm[2]) * M;
+  Ic[4] = IO[3] - (cm2 - cm[1] * cm[1]) * M; Ic[5] = IO[4] + (cm[1] * cm[2]) * M; Ic[8] = IO[5] - (cm2 - cm[2] * cm[2]) * M;
+  Ic[3] = Ic[1]; Ic[6] = Ic[2]; Ic[7] = Ic[5];
+  T angJ[3], t[3];
+  t_cross(cm, sums.lin, t);
+  for (int r = 0; r < 3; ++r) angJ[r] = sums.angO[r] - t[r];
+  // euler rates = (Ic E)^-1 (M h_ang - angJ)
+  T A22[9], A22i[9], rhs[3];
+  for (int r = 0; r < 3; ++r)
+    for (int e = 0; e < 3; ++e) A22[3 * r + e] = Ic[3 * r] * E[e] + Ic[3 * r + 1] * E[3 + e] + Ic[3 * r + 2] * E[6 + e];
+  t_inverse3(A22, A22i);
+  for (int r = 0; r < 3; ++r) rhs[r] = h[3 + r] * M - angJ[r];
+  t_mulv(A22i, rhs, vb + 3);
+  t_mulv(E, vb + 3, wb);
+  T d[3];
+  for (int r = 0; r < 3; ++r) d[r] = p0 ? cm[r] - p0[r] : cm[r];
+  t_cross(wb, d, t);
+  for (int r = 0; r < 3; ++r) vb[r] = h[r] - sums.lin[r] * iM - t[r];
+  // normalized momentum rate (getNormalizedCentroidalMomentumRate; gravity 9.81 hard-coded as upstream does)
+  T fs[3] = {zero, zero, cst<T>(-9.81 * M)}, ns[3] = {zero, zero, zero};
+  for (int f = 0; f < 2; ++f) {
+    T arm[3];
+    for (int r = 0; r < 3; ++r) arm[r] = pc[f][r] - cm[r];
+    t_cross(arm, W + 6 * f, t);
+    for (int r = 0; r < 3; ++r) { fs[r] = fs[r] + W[6 * f + r]; ns[r] = ns[r] + t[r] + W[6 * f + 3 + r]; }
+  }
+  for (int r = 0; r < 3; ++r) { xdot[r] = fs[r] * iM; xdot[3 + r] = ns[r] * iM; }
+  for (int r = 0; r < 6; ++r) xdot[6 + r] = vb[r];
+}
+
 // One pass over the kinematic tree at q = [p_b, euler, q_j] with joint rates qd, then the base velocity from the normalized
 // momentum h and the normalized momentum rate for the contact wrenches W.  xdot[0..11] = [d(h/m)/dt ; pdot ; euler rates].
 // WAVE_TRIG (device, the LQ kernel's tangent lanes only): the 26 angles of the pass (3 euler + 23 joints) have the SAME value in every lane
@@ -262,52 +307,34 @@ HSQP_HD void cent_pass(const DevModel& dm, const T* h, const T* q, const T* W, c
     }
     k.ends[1 + c] = cur;
   }
-  const double M = dm.total_mass, iM = 1.0 / M;
-  for (int r = 0; r < 3; ++r) k.com[r] = sums.mc[r] * iM;
-  const T* cm = k.com;
-  const T* IO = sums.IO;
-  const T cm2 = t_dot(cm, cm);
-  T Ic[9];
-  Ic[0] = IO[0] - (cm2 - cm[0] * cm[0]) * M; Ic[1] = IO[1] + (cm[0] * cm[1]) * M; Ic[2] = IO[2] + (cm[0] * cm[2]) * M;
-  Ic[4] = IO[3] - (cm2 - cm[1] * cm[1]) * M; Ic[5] = IO[4] + (cm[1] * cm[2]) * M; Ic[8] = IO[5] - (cm2 - cm[2] * cm[2]) * M;
-  Ic[3] = Ic[1]; Ic[6] = Ic[2]; Ic[7] = Ic[5];
-  T angJ[3], t[3];
-  t_cross(cm, sums.lin, t);
-  for (int r = 0; r < 3; ++r) angJ[r] = sums.angO[r] - t[r];
-  // euler rates = (Ic E)^-1 (M h_ang - angJ)
-  T A22[9], A22i[9], rhs[3];
-  for (int r = 0; r < 3; ++r)
-    for (int e = 0; e < 3; ++e) A22[3 * r + e] = Ic[3 * r] * k.E[e] + Ic[3 * r + 1] * k.E[3 + e] + Ic[3 * r + 2] * k.E[6 + e];
-  t_inverse3(A22, A22i);
-  for (int r = 0; r < 3; ++r) rhs[r] = h[3 + r] * M - angJ[r];
-  t_mulv(A22i, rhs, k.vb + 3);
-  t_mulv(k.E, k.vb + 3, k.wb);
-  T d[3];
-  for (int r = 0; r < 3; ++r) d[r] = cm[r] - k.p0[r];
-  t_cross(k.wb, d, t);
-  for (int r = 0; r < 3; ++r) k.vb[r] = h[r] - sums.lin[r] * iM - t[r];
-  // normalized momentum rate (getNormalizedCentroidalMomentumRate; gravity 9.81 hard-coded as upstream does)
-  T fs[3] = {zero, zero, cst<T>(-9.81 * M)}, ns[3] = {zero, zero, zero};
-  for (int f = 0; f < 2; ++f) {
-    T arm[3];
-    for (int r = 0; r < 3; ++r) arm[r] = pc[f][r] - cm[r];
-    t_cross(arm, W + 6 * f, t);
-    for (int r = 0; r < 3; ++r) { fs[r] = fs[r] + W[6 * f + r]; ns[r] = ns[r] + t[r] + W[6 * f + 3 + r]; }
-  }
-  for (int r = 0; r < 3; ++r) { xdot[r] = fs[r] * iM; xdot[3 + r] = ns[r] * iM; }
-  for (int r = 0; r < 6; ++r) xdot[6 + r] = k.vb[r];
+  cent_finish<T>(dm, sums, k.E, pc, h, W, xdot, k.vb, k.wb, k.com, k.p0);
 }
 
 // world position and LOCAL_WORLD_ALIGNED velocity of a point fixed to a body (velocity-level model: base motion + joint motion)
 template <class T>
-HSQP_HD void cent_point(const CentKin<T>& k, const BodyRec<T>& b, const double* pl, T* pos, T* vlin, T* vang) {
+HSQP_HD void cent_point(const T* p0, const T* vb, const T* wb, const BodyRec<T>& b, const double* pl, T* pos, T* vlin, T* vang) {
   T rp[3], d[3], t1[3], t2[3];
   t_mulc(b.R, pl, rp);
-  for (int r = 0; r < 3; ++r) { pos[r] = b.p[r] + rp[r]; d[r] = pos[r] - k.p0[r]; vang[r] = k.wb[r] + b.om[r]; }
-  t_cross(k.wb, d, t1);          // rigid base motion of the point
+  for (int r = 0; r < 3; ++r) { pos[r] = b.p[r] + rp[r]; d[r] = pos[r] - p0[r]; vang[r] = wb[r] + b.om[r]; }
+  t_cross(wb, d, t1);            // rigid base motion of the point
   t_cross(b.om, rp, t2);         // joint motion relative to the base
-  for (int r = 0; r < 3; ++r) vlin[r] = k.vb[r] + t1[r] + b.v[r] + t2[r];
+  for (int r = 0; r < 3; ++r) vlin[r] = vb[r] + t1[r] + b.v[r] + t2[r];
 }
+template <class T>
+HSQP_HD void cent_point(const CentKin<T>& k, const BodyRec<T>& b, const double* pl, T* pos, T* vlin, T* vang) { cent_point(k.p0, k.vb, k.wb, b, pl, pos, vlin, vang); }
+// what cent_terms asks of the kinematics, answered from the side tables of a tree pass (cent_pass<T, true>); the LQ kernel answers the same
+// questions from its LDS workspace (hsqp_cent_lq.h: CentLaneKin)
+template <class T>
+struct CentPassKin {
+  const CentKin<T>& k;
+  HSQP_HD const T* p0() const { return k.p0; }
+  HSQP_HD const T* vb() const { return k.vb; }
+  HSQP_HD const T* wb() const { return k.wb; }
+  HSQP_HD const BodyRec<T>& foot(int f) const { return k.side.foot[f]; }
+  HSQP_HD const BodyRec<T>& torso() const { return k.side.torso; }
+  HSQP_HD void point(int p, T* out) const { for (int r = 0; r < 3; ++r) out[r] = k.side.pts[p][r]; }
+  HSQP_HD void ext_arm(int f, int a, T* ea) const { for (int r = 0; r < 4; ++r) ea[r] = k.side.ea[f][a][r]; }
+};
 
 // quaternion (x, y, z, w) of a rotation matrix, branch chosen on the values (oracle ASSUMPTION A8)
 template <class T>
@@ -329,117 +356,127 @@ HSQP_HD void cent_quat(const T* R, T* q) {
   }
 }
 
-// Everything one lane produces for its node.
+// Everything one lane produces for its node, kept in arrays (the single-lane value kernels and the tree-pass form; the LQ kernel's lanes
+// write their rows straight to the record through sinks of their own, hsqp_cent_lq.h).  A SINK of cent_terms has: header, fric_d1, gn
+// (Gauss-Newton row: value r, weight sqrt(w)), pen (penalty row: constraint value h, penalty p), raw (a row with an explicit scale and no
+// gradient / cost contribution: the friction cone's curvature rows), eq (equality row).
 template <class T>
 struct CentOut {
   T row[NRS];            // residual rows (unscaled: the quantity whose square / penalty is the cost term)
   double sc[NRS];        // row scale: sqrt(w) (Gauss-Newton) or sqrt(p'') (penalty); 0 = inactive
   double rho[NRS];       // sc * value (Gauss-Newton) or p' / sqrt(p'') (penalty)
-  double pen[NRS];       // cost contribution of the row: 0.5 rho^2 (Gauss-Newton) or the penalty value
-  T eq[NE_MAX];
+  double pen_[NRS];      // cost contribution of the row: 0.5 rho^2 (Gauss-Newton) or the penalty value
+  T eq_[NE_MAX];
   int ne, contact[2], eq_off[2];
   double hfric_d1[2];    // p' of the friction barrier per foot (0 if not in contact): Hessian diagonal shift
+  HSQP_HD void header(int ne_, int c0, int c1, int o0, int o1) {
+    ne = ne_; contact[0] = c0; contact[1] = c1; eq_off[0] = o0; eq_off[1] = o1; hfric_d1[0] = hfric_d1[1] = 0.0;
+    for (int s = 0; s < NRS; ++s) { row[s] = cst<T>(0.0); sc[s] = 0.0; rho[s] = 0.0; pen_[s] = 0.0; }
+    for (int r = 0; r < NE_MAX; ++r) eq_[r] = cst<T>(0.0);
+  }
+  HSQP_HD void fric_d1(int f, double d1) { hfric_d1[f] = d1; }
+  HSQP_HD void gn(int s, const T& r, double w) { row[s] = r; sc[s] = w; rho[s] = w * val(r); pen_[s] = 0.5 * rho[s] * rho[s]; }
+  HSQP_HD void pen(int s, const T& hh, const Pen3& p) {
+    row[s] = hh; pen_[s] = p.p;
+    if (p.d2 > 0.0) { sc[s] = sqrt(p.d2); rho[s] = p.d1 / sc[s]; }
+  }
+  HSQP_HD void raw(int s, const T& r, double scale) { row[s] = r; sc[s] = scale; }
+  HSQP_HD void eq(int r, const T& v) { eq_[r] = v; }
 };
 
-// Cost / constraint terms of the node from the stage-1 kinematics k at (x, u); order and sources as oracle/centroidal.hpp.
-template <class T>
-HSQP_HD void cent_terms(const DevModel& dm, const CentKin<T>& k, const T* x, const T* u, const double* par, CentOut<T>& o) {
+// Cost / constraint terms of the node from the stage-1 kinematics `kin` at (x, u) (W = the twelve wrench entries of u); order and sources as
+// oracle/centroidal.hpp.
+template <class T, class Kin, class Sink>
+HSQP_HD void cent_terms(const DevModel& dm, const Kin& kin, const T* W, const double* par, Sink& o) {
   const T zero = cst<T>(0.0);
   const int c0 = par[HSQP_P_CONTACT] > 0.5, c1 = par[HSQP_P_CONTACT + 1] > 0.5;
   const bool both = c0 && c1;
-  o.contact[0] = c0; o.contact[1] = c1;
-  o.eq_off[0] = 0; o.eq_off[1] = c0 ? 6 : 7;
-  o.ne = o.eq_off[1] + (c1 ? 6 : 7);
-  for (int s = 0; s < NRS; ++s) { o.row[s] = zero; o.sc[s] = 0.0; o.rho[s] = 0.0; o.pen[s] = 0.0; }
-  for (int r = 0; r < NE_MAX; ++r) o.eq[r] = zero;
-  auto gn = [&](int s, const T& r, double w) { o.row[s] = r; o.sc[s] = w; o.rho[s] = w * val(r); o.pen[s] = 0.5 * o.rho[s] * o.rho[s]; };
-  auto pen = [&](int s, const T& hh, const Pen3& p) {
-    o.row[s] = hh; o.pen[s] = p.p;
-    if (p.d2 > 0.0) { o.sc[s] = sqrt(p.d2); o.rho[s] = p.d1 / o.sc[s]; }
-  };
+  const int contact[2] = {c0, c1}, eq_off[2] = {0, c0 ? 6 : 7};
+  o.header(eq_off[1] + (c1 ? 6 : 7), c0, c1, eq_off[0], eq_off[1]);
   // ---- torso task-space cost: EndEffectorKinematicsQuadraticCost.cpp:110-138 (quaternionDistance, velocity differences)
   {
-    const BodyRec<T>& tb = k.side.torso;
+    const BodyRec<T> tb = kin.torso();
     T Rt[9], qc[4], pos[3], vl[3], va[3];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) Rt[3 * r + c] = tb.R[3 * r] * dm.torso_R[c] + tb.R[3 * r + 1] * dm.torso_R[3 + c] + tb.R[3 * r + 2] * dm.torso_R[6 + c];
     cent_quat(Rt, qc);
-    cent_point(k, tb, dm.torso_p, pos, vl, va);
+    cent_point(kin.p0(), kin.vb(), kin.wb(), tb, dm.torso_p, pos, vl, va);
     const double* ref = par + HSQP_PC_TORSO;
     const T rv[3] = {cst<T>(ref[3]), cst<T>(ref[4]), cst<T>(ref[5])};
     T cr[3];
     t_cross(qc, rv, cr);
     for (int c = 0; c < 3; ++c) {
-      gn(CROW_TORSO + c, rv[c] * qc[3] - qc[c] * ref[6] + cr[c], dm.torso_sqrt_w[3 + c]);
-      gn(CROW_TORSO + 3 + c, vl[c] - ref[7 + c], dm.torso_sqrt_w[6 + c]);
-      gn(CROW_TORSO + 6 + c, va[c] - ref[10 + c], dm.torso_sqrt_w[9 + c]);
+      o.gn(CROW_TORSO + c, rv[c] * qc[3] - qc[c] * ref[6] + cr[c], dm.torso_sqrt_w[3 + c]);
+      o.gn(CROW_TORSO + 3 + c, vl[c] - ref[7 + c], dm.torso_sqrt_w[6 + c]);
+      o.gn(CROW_TORSO + 6 + c, va[c] - ref[10 + c], dm.torso_sqrt_w[9 + c]);
     }
   }
   // ---- foot collision (FootCollisionConstraint.cpp:92-144), inactive in double support
   if (!both) {
-    const T (*pts)[3] = k.side.pts;
     for (int r = 0; r < 16; ++r) {
       int a, b;
       coll_pair(r, a, b);
-      T dd[3];
-      for (int c = 0; c < 3; ++c) dd[c] = pts[a][c] - pts[b][c];
+      T pa[3], pb[3], dd[3];
+      kin.point(a, pa);
+      kin.point(b, pb);
+      for (int c = 0; c < 3; ++c) dd[c] = pa[c] - pb[c];
       const T hh = dsqrt(t_dot(dd, dd)) - 2.0 * (r == 9 ? dm.r_knee : dm.r_foot);
-      pen(CROW_COLL + r, hh, pwp_barrier(dm.coll_bmu, dm.coll_bdelta, val(hh)));
+      o.pen(CROW_COLL + r, hh, pwp_barrier(dm.coll_bmu, dm.coll_bdelta, val(hh)));
     }
   }
   // ---- per foot
-  o.hfric_d1[0] = o.hfric_d1[1] = 0.0;
   for (int f = 0; f < 2; ++f) {
-    const int ct = o.contact[f];
-    const BodyRec<T>& fb = k.side.foot[f];
+    const int ct = contact[f];
+    const BodyRec<T> fb = kin.foot(f);
     T pos[3], vl[3], va[3], ori[3];
-    cent_point(k, fb, dm.contact_p[f], pos, vl, va);
+    cent_point(kin.p0(), kin.vb(), kin.wb(), fb, dm.contact_p[f], pos, vl, va);
     {  // orientation error to the ground plane (oracle ASSUMPTION A2): (n x a) / sqrt(2 (1 + a.n)), a = R e_z, n = e_z
       const T s = dsqrt((fb.R[8] + 1.0) * 2.0);
       ori[0] = -fb.R[5] / s; ori[1] = fb.R[2] / s; ori[2] = zero;
     }
-    const T* Wf = u + 6 * f;
+    const T* Wf = W + 6 * f;
     if (ct) {
       // friction cone (FrictionForceConeConstraint.cpp:78-224): relaxed barrier of h; its second-order term p' d2h as three rows
       const T T2 = Wf[0] * Wf[0] + Wf[1] * Wf[1] + dm.friction_reg;
       const T hh = (Wf[2] + dm.friction_grip) * dm.friction_mu - dsqrt(T2);
       const Pen3 p = relaxed_barrier(dm.friction_bmu, dm.friction_bdelta, val(hh));
-      pen(CROW_FRIC + 4 * f, hh, p);
-      o.hfric_d1[f] = p.d1;
+      o.pen(CROW_FRIC + 4 * f, hh, p);
+      o.fric_d1(f, p.d1);
       const double T3 = val(T2) * sqrt(val(T2));
-      o.row[CROW_FRIC + 4 * f + 1] = Wf[0]; o.sc[CROW_FRIC + 4 * f + 1] = sqrt(-p.d1 * dm.friction_reg / T3);
-      o.row[CROW_FRIC + 4 * f + 2] = Wf[1]; o.sc[CROW_FRIC + 4 * f + 2] = sqrt(-p.d1 * dm.friction_reg / T3);
-      o.row[CROW_FRIC + 4 * f + 3] = Wf[0] * val(Wf[1]) - Wf[1] * val(Wf[0]); o.sc[CROW_FRIC + 4 * f + 3] = sqrt(-p.d1 / T3);
+      o.raw(CROW_FRIC + 4 * f + 1, Wf[0], sqrt(-p.d1 * dm.friction_reg / T3));
+      o.raw(CROW_FRIC + 4 * f + 2, Wf[1], sqrt(-p.d1 * dm.friction_reg / T3));
+      o.raw(CROW_FRIC + 4 * f + 3, Wf[0] * val(Wf[1]) - Wf[1] * val(Wf[0]), sqrt(-p.d1 / T3));
       // contact moment XY (ContactMomentXYConstraintCppAd.cpp:77-104): wrench in the contact frame
       T lf[3], lm[3];
       t_tmulv(fb.R, Wf, lf);
       t_tmulv(fb.R, Wf + 3, lm);
       const T hm[4] = {lm[0] - lf[2] * dm.rect_y_min, lf[2] * dm.rect_y_max - lm[0], -lm[1] - lf[2] * dm.rect_x_min, lm[1] + lf[2] * dm.rect_x_max};
-      for (int r = 0; r < 4; ++r) pen(CROW_MXY + 4 * f + r, hm[r], relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, val(hm[r])));
+      for (int r = 0; r < 4; ++r) o.pen(CROW_MXY + 4 * f + r, hm[r], relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, val(hm[r])));
       // external torque cost (ExternalTorqueQuadraticCostAD.cpp:110-135): (J_ee^T W)[6 + j] .* sqrtW * (1 - impactProximity of the other foot)
       const double mid = 1.0 - par[HSQP_P_IMPACT + (1 - f)];
       for (int a = 0; a < 6; ++a) {
-        const T* ea = k.side.ea[f][a];
+        T ea[4];
+        kin.ext_arm(f, a, ea);
         const T tau = pos[0] * ea[0] + pos[1] * ea[1] + pos[2] * ea[2] + ea[3];
-        gn(crow_ext(f, both, a), tau, dm.ext_sqrt_w[f][a] * mid);
+        o.gn(crow_ext(f, both, a), tau, dm.ext_sqrt_w[f][a] * mid);
       }
     }
     // equalities: zeroWrench (swing), zeroVelocity (stance), normalVelocity (swing) — CentroidalMpcInterface.cpp:203-207,232-257
-    const int r0 = o.eq_off[f];
+    const int r0 = eq_off[f];
     const double zp = par[HSQP_P_SWING + 3 * f], zv = par[HSQP_P_SWING + 3 * f + 1];
     if (ct) {
-      for (int i = 0; i < 3; ++i) o.eq[r0 + i] = i == 2 ? vl[2] + (pos[2] - zp) * dm.gain_pos_z : vl[i];
-      for (int i = 0; i < 3; ++i) o.eq[r0 + 3 + i] = va[i] + ori[i] * dm.gain_ori;
+      for (int i = 0; i < 3; ++i) o.eq(r0 + i, i == 2 ? vl[2] + (pos[2] - zp) * dm.gain_pos_z : vl[i]);
+      for (int i = 0; i < 3; ++i) o.eq(r0 + 3 + i, va[i] + ori[i] * dm.gain_ori);
     } else {
-      for (int i = 0; i < 6; ++i) o.eq[r0 + i] = Wf[i];
-      o.eq[r0 + 6] = vl[2] - zv + (pos[2] - zp) * dm.gain_pos_z;
+      for (int i = 0; i < 6; ++i) o.eq(r0 + i, Wf[i]);
+      o.eq(r0 + 6, vl[2] - zv + (pos[2] - zp) * dm.gain_pos_z);
     }
     // foot task-space cost (CentroidalMpcEndEffectorFootCost.cpp:90-152): [oriErr, v * impactProximity, w] .* sqrtW
     const double ip = par[HSQP_P_IMPACT + f];
     for (int c = 0; c < 3; ++c) {
-      gn(CROW_FOOT + 9 * f + c, ori[c], dm.cent_foot_sqrt_w[3 + c]);
-      gn(CROW_FOOT + 9 * f + 3 + c, vl[c], dm.cent_foot_sqrt_w[6 + c] * ip);
-      gn(CROW_FOOT + 9 * f + 6 + c, va[c], dm.cent_foot_sqrt_w[9 + c]);
+      o.gn(CROW_FOOT + 9 * f + c, ori[c], dm.cent_foot_sqrt_w[3 + c]);
+      o.gn(CROW_FOOT + 9 * f + 3 + c, vl[c], dm.cent_foot_sqrt_w[6 + c] * ip);
+      o.gn(CROW_FOOT + 9 * f + 6 + c, va[c], dm.cent_foot_sqrt_w[9 + c]);
     }
   }
 }
@@ -499,7 +536,7 @@ HSQP_HD void cent_terms_program(const DevModel& dm, const double* x, const doubl
   T xs[CNX], us[NU], k1[12];
   cent_seed<T>(x, u, dir, xs, us);
   cent_pass<T, true, WAVE_TRIG>(dm, xs, xs + 6, us, us + 12, k, k1);
-  cent_terms<T>(dm, k, xs, us, par, o);
+  cent_terms<T>(dm, CentPassKin<T>{k}, us, par, o);
 }
 
 // value lane of the RK4 half: defect, flow; misc[3] = dt |b|^2
@@ -522,11 +559,11 @@ HSQP_HD void cent_write_terms(const DevModel& dm, const CentOut<T>& o, const dou
   double cost = 0.0;
   for (int i = 0; i < CNX; ++i) { const double d = x[i] - xnom[i]; cost += 0.5 * dm.Q[i] * d * d; }
   for (int i = 0; i < NU; ++i) { const double d = u[i] - unom[i]; cost += 0.5 * dm.R[i] * d * d; }
-  for (int s = 0; s < NRS; ++s) cost += o.pen[s];
+  for (int s = 0; s < NRS; ++s) cost += o.pen_[s];
   for (int j = 0; j < NJ; ++j)   // JointLimitsSoftConstraint.cpp:64-100
     cost += pwp_barrier(dm.jl_bmu, dm.jl_bdelta, x[12 + j] - dm.q_lo[j]).p + pwp_barrier(dm.jl_bmu, dm.jl_bdelta, dm.q_hi[j] - x[12 + j]).p;
   double eq = 0.0;
-  for (int r = 0; r < o.ne; ++r) eq += val(o.eq[r]) * val(o.eq[r]);
+  for (int r = 0; r < o.ne; ++r) eq += val(o.eq_[r]) * val(o.eq_[r]);
   misc[0] = (double)o.ne; misc[1] = dt * cost; misc[2] = dt * eq;
   misc[4] = (double)o.contact[0]; misc[5] = (double)o.contact[1]; misc[6] = (double)o.eq_off[0]; misc[7] = (double)o.eq_off[1];
   if (!rec) return;
@@ -545,7 +582,7 @@ HSQP_HD void cent_write_terms(const DevModel& dm, const CentOut<T>& o, const dou
     rec[REC_D + i] = dt * d;
     rec[REC_GD + i] = dt * g;
   }
-  for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + NZ] = r < o.ne ? val(o.eq[r]) : 0.0;
+  for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + NZ] = r < o.ne ? val(o.eq_[r]) : 0.0;
 }
 
 // ---- the LQ kernel body: lane = tangent direction, two lane groups of 128 (group 0: RK4 -> [A|B], defect, flow; group 1: terms
@@ -590,7 +627,7 @@ HSQP_HD void cent_lq_node(const Ctx& ctx, const DevModel& dm, const double* x, c
       if (lane == CNZ) { cent_write_terms<Dual1>(dm, o, x, u, par, dt, rec, rec + REC_MISC); continue; }
       const double sdt = sqrt(dt);
       for (int s = 0; s < NRS; ++s) rec[REC_J + s * LDJ + col] = sdt * o.sc[s] * o.row[s].d;
-      for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = r < o.ne ? o.eq[r].d : 0.0;
+      for (int r = 0; r < NE_MAX; ++r) rec[REC_CDE + r * LDJ + col] = r < o.ne ? o.eq_[r].d : 0.0;
     }
   }
   WG_SYNC(ctx);
