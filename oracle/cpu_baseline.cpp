@@ -22,6 +22,7 @@
 #include "../wb_humanoid_mpc_amd/csrc/hsqp_host.h"
 #include "../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
 #include "../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
+#include "../wb_humanoid_mpc_amd/csrc/hsqp_cent_lq.h"
 
 using namespace hsqp;
 
@@ -32,6 +33,8 @@ struct Workspaces {   // one per inner thread
   std::unique_ptr<LqWST<false>> lqv{new LqWST<false>};
   std::unique_ptr<ProjWS> proj{new ProjWS};
   std::unique_ptr<StepWS> step{new StepWS};
+  std::unique_ptr<CentWST<true>> clq{new CentWST<true>};
+  std::unique_ptr<CentWST<false>> clqv{new CentWST<false>};
 };
 
 // one SQP iteration of one instance on `inner` threads; returns 0 or HSQP_ERR_NUMERIC.  perf = {cost, dyn, eq} before / after
@@ -47,7 +50,7 @@ int iterate_instance(const DevModel& dm, int N, double dt, const double* x_init,
     Workspaces& w = ws[omp_get_thread_num()];
     Ctx ctx{0, 1, nullptr};
     double* r = &rec[(size_t)k * REC_SIZE];
-    if (cent) cent_lq_node<false>(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r);
+    if (cent) cent_lq_node2<true>(ctx, dm, *w.clq, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC);
     else lq_node<true>(ctx, dm, *w.lq, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC);
     project_node(ctx, *w.proj, r, dt, &qp[(size_t)k * QP_SIZE], cent);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) {
@@ -82,7 +85,7 @@ int iterate_instance(const DevModel& dm, int N, double dt, const double* x_init,
     Workspaces& w = ws[omp_get_thread_num()];
     Ctx c2{0, 1, nullptr};
     double misc[8];
-    if (cent) { for (int part = 0; part < 2; ++part) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, misc, part); }
+    if (cent) cent_lq_node2<false>(c2, dm, *w.clqv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, misc);
     else lq_node<false>(c2, dm, *w.lqv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, misc);
     pa0 += misc[1]; pa1 += misc[3]; pa2 += misc[2];
   }

@@ -245,7 +245,7 @@ int emu_cent_node_params(void* h, const hsqp_swing_config* cfg, double terrain, 
   int bad = 0;
   for (int k = 0; k <= N; ++k) {
     if (!node_params_eval(*cfg, terrain, arm_swing, n_ev, ev, seq, n_knots, tt, ts, t0 + k * dt, par + (size_t)k * NP)) bad = 1;
-    cent_params_finish(dm, par + (size_t)k * NP);
+    { Ctx ctx{0, 1, nullptr}; auto ws = std::make_unique<CentWST<false>>(); cent_params_torso(ctx, dm, *ws, par + (size_t)k * NP); }
   }
   return bad;
 }
@@ -277,9 +277,8 @@ void emu_project_node(const double* rec, double dt, double* qp) {
 void emu_cent_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
-  if (deriv == 2) cent_lq_node<true>(ctx, dm, x, u, xnext, par, dt, rec);     // the first form (one tangent direction per lane on a tree pass)
-  else if (deriv) { auto ws = std::make_unique<CentWST<true>>(); cent_lq_node2<true>(ctx, dm, *ws, x, u, xnext, par, dt, rec, rec + REC_MISC); }
-  else { cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 0); cent_value_node(dm, x, u, xnext, par, dt, rec + REC_MISC, 1); }
+  if (deriv) { auto ws = std::make_unique<CentWST<true>>(); cent_lq_node2<true>(ctx, dm, *ws, x, u, xnext, par, dt, rec, rec + REC_MISC); }
+  else { auto ws = std::make_unique<CentWST<false>>(); cent_lq_node2<false>(ctx, dm, *ws, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
 }
 void emu_cent_expand_AB(const double* rec, double dt, double* AB) { cent_expand_AB(rec, dt, AB); }
 // one full SQP iteration of one instance through the kernel sources; returns 0 or HSQP_ERR_NUMERIC
@@ -298,7 +297,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   const double dt_uniform = dt;
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
-    if (cent) cent_lq_node<true>(ctx, dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);
+    if (cent) { auto cw = std::make_unique<CentWST<true>>(); double* r = &rec[(size_t)k * REC_SIZE]; cent_lq_node2<true>(ctx, dm, *cw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC); }
     else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
@@ -345,7 +344,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   std::vector<double> r2(REC_SIZE);
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
-    if (cent) { for (int part = 0; part < 2; ++part) cent_value_node(dm, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, r2.data() + REC_MISC, part); }
+    if (cent) { auto cw = std::make_unique<CentWST<false>>(); cent_lq_node2<false>(ctx, dm, *cw, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC); }
     else lq_node<false>(ctx, dm, *lwv, x_new + k * NX, u_new + k * NU, x_new + (k + 1) * NX, par + k * NP, dt, nullptr, r2.data() + REC_MISC);
     pa[0] += r2[REC_MISC + 1]; pa[1] += r2[REC_MISC + 3]; pa[2] += r2[REC_MISC + 2];
   }

@@ -70,16 +70,6 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
                  DERIV ? rec + (size_t)node * REC_SIZE + REC_MISC : misc + (size_t)node * 8);
 }
 
-// ---- centroidal LQ approximation (hsqp_cent.h): one 256-thread workgroup per (instance, node), lane = tangent direction, waves
-//      0-1 the RK4 half, waves 2-3 the terms half; no LDS
-template <bool SPLIT>
-__global__ __launch_bounds__(CENT_THREADS) void k_lq_cent(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                          const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
-  const int node = blockIdx.x, b = node / N, k = node % N;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
-  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_lq_node<SPLIT>(ctx, *dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
-}
 // ---- centroidal LQ approximation, second form (hsqp_cent_lq.h): one 128-thread workgroup per (instance, node), values once per node in an LDS
 //      workspace, tangent lanes on closed-form seeds; four workgroups per CU
 static_assert(sizeof(CentWST<true>) <= 163840 / 4, "centroidal LQ workspace: four workgroups per CU");
@@ -92,30 +82,24 @@ __global__ __launch_bounds__(CLQ_THREADS, 2) void k_lq_cent2(const DevModel* __r
   double* r = rec + (size_t)node * REC_SIZE;
   cent_lq_node2<true>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], r, r + REC_MISC);
 }
-// ---- centroidal value-only pass: two lanes per (instance, node) in different waves (wave 0: RK4 defect, wave 1: terms)
-__global__ __launch_bounds__(128) void k_lq_cent_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                      const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes, double* __restrict__ misc,
-                                                      const LsState* __restrict__ ls) {
-  const int node = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  if (node >= nodes) return;
-  const int b = node / N, k = node % N;
+// ---- centroidal value-only pass (performance index, line-search trials): the same node function without derivative storage, one wave per
+//      (instance, node), 13 KB of LDS
+static_assert(sizeof(CentWST<false>) <= 163840 / 8, "centroidal value-only workspace: eight workgroups per CU");
+__global__ __launch_bounds__(64) void k_lq_cent2_value(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                       const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ misc,
+                                                       const LsState* __restrict__ ls) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
   if (ls && !ls[b].active) return;
+  CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_value_node(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], misc + (size_t)node * 8, part);
+  cent_lq_node2<false>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], nullptr, misc + (size_t)node * 8);
 }
-
-// the same pass for launches of a few hundred nodes (BASELINE configs 1-2): one workgroup per node, wave = part, the lanes 0 .. 25 of a wave
-// run the node redundantly so that each evaluates ONE of the 26 sines / cosines of a model pass for all of them (cent_pass<.., WAVE_TRIG>;
-// a lane on its own spends over half of the value pass in the 208 library calls of the four RK4 passes)
-__global__ __launch_bounds__(128) void k_lq_cent_value_wave(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes, double* __restrict__ misc,
-                                                           const LsState* __restrict__ ls) {
-  const int node = blockIdx.x, part = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) >= 3 + NJ) return;
-  const int b = node / N, k = node % N;
-  if (ls && !ls[b].active) return;
-  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  cent_value_node<true>(*dm, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], misc + (size_t)node * 8, part);
+// ---- torso task-space reference of the node parameters of a centroidal handle (behind k_params): one wave per (instance, node)
+__global__ __launch_bounds__(64) void k_params_cent_torso(const DevModel* __restrict__ dm, double* __restrict__ par) {
+  CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  cent_params_torso(ctx, *dm, w, par + (size_t)blockIdx.x * NP);
 }
 
 // ---- projection: one workgroup per (instance, node)
@@ -466,14 +450,13 @@ __global__ __launch_bounds__(64) void k_params(const DevModel* __restrict__ dm, 
   const int b = id / (N + 1), k = id % (N + 1);
   const bool ok = node_params_eval(cfg, terrain, arm_swing, n_events[b], ev + (size_t)b * max_events, seq + (size_t)b * (max_events + 1), n_knots,
                                    tt + (size_t)b * n_knots, ts + (size_t)b * n_knots * NX, times ? times[id] : t0 + k * dt, par + (size_t)id * NP);
-  if (dm->formulation == HSQP_FORM_CENTROIDAL) cent_params_finish(*dm, par + (size_t)id * NP);   // torso task-space reference
   if (!ok) atomicExch(bad, 1);
 }
 
 // ---- policy evaluation / joint torques in three small kernels.
 //  k_policy_inputs: one workgroup per pair — xt != null: interpolate the trajectories of instance blockIdx.x at s[blockIdx.x]
 //                   (uniform grid, or dts != null: the instance's interval lengths); otherwise take the pair from xin / uin.
-//  k_cent_policy_map (centroidal handles): one thread per pair — the whole-body (x, u) computeJointTorques needs
+//  k_cent_policy_map (centroidal handles): one wave per pair — the whole-body (x, u) computeJointTorques needs
 //                   (CentroidalMpcMrtJointController::computeJointControlAction, humanoid_centroidal_mpc/src/mrt/
 //                   CentroidalMpcMrtJointController.cpp:155-175): q = getGeneralizedCoordinates(x), qd = getGeneralizedVelocities(x, u)
 //                   with the base velocity from the centroidal momentum, v_b = A_b^-1 (m h - A_j qd_j) = rows 6..11 of the flow map,
@@ -491,29 +474,22 @@ __global__ __launch_bounds__(64) void k_policy_inputs(const double* __restrict__
     for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) xout[(size_t)b * NX + i] = xin[(size_t)b * NX + i]; else uout[(size_t)b * NU + i - NX] = uin[(size_t)b * NU + i - NX]; }
   }
 }
-// (kept out of line: inlined into the kernel below, this pass crashes the gfx950 backend of ROCm 7.2's clang)
-__device__ __attribute__((noinline)) void cent_base_velocity(const DevModel& dm, const double* hq, const double* W, const double* qd, double* xdot) {
-  CentKin<double> kin;
-  cent_pass<double, true>(dm, hq, hq + 6, W, qd, kin, xdot);
-}
 __global__ __launch_bounds__(64) void k_cent_policy_map(const DevModel* __restrict__ dm, int n, const double* __restrict__ xc, const double* __restrict__ uc,
                                                         double* __restrict__ xwb, double* __restrict__ uwb) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
+  const int b = blockIdx.x;
+  CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* x = xc + (size_t)b * NX;
   const double* u = uc + (size_t)b * NU;
-  double xdot[12];
-  double hq[HSQP_CNX], W[12], qd[NJ];   // local copies, as cent_params_finish does (the <double, false> instantiation on global pointers crashes this compiler)
-  for (int i = 0; i < HSQP_CNX; ++i) hq[i] = x[i];
-  for (int i = 0; i < 12; ++i) W[i] = u[i];
-  for (int i = 0; i < NJ; ++i) qd[i] = u[12 + i];
-  cent_base_velocity(*dm, hq, W, qd, xdot);
   double* xo = xwb + (size_t)b * NX;
   double* uo = uwb + (size_t)b * NU;
-  for (int i = 0; i < NV; ++i) xo[i] = x[6 + i];
-  for (int i = 0; i < 6; ++i) xo[NV + i] = xdot[6 + i];
-  for (int j = 0; j < NJ; ++j) { xo[NV + 6 + j] = u[12 + j]; uo[12 + j] = x[HSQP_CNX + j]; }
-  for (int i = 0; i < 12; ++i) uo[i] = u[i];
+  cent_base_velocity(ctx, *dm, w, x, u, xo + NV);     // [pdot; euler rates] -> the base velocities of the whole-body state
+  for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) {
+    if (i < NV) xo[i] = x[6 + i];
+    else if (i >= NV + 6 && i < NX) { const int j = i - NV - 6; xo[i] = u[12 + j]; }
+    else if (i >= NX && i < NX + 12) uo[i - NX] = u[i - NX];
+    else if (i >= NX + 12) { const int j = i - NX - 12; uo[12 + j] = x[HSQP_CNX + j]; }
+  }
 }
 struct PolicyWS { StageWST<false> st; double x[NX], u[NU]; };
 __global__ __launch_bounds__(128) void k_policy_torques(const DevModel* __restrict__ dm, const double* __restrict__ xwb, const double* __restrict__ uwb,
@@ -996,6 +972,8 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
     const int total = (int)(B * (N + 1));
     hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->d_dm, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
                        (int)K, d_tt, d_ts, r->t0, r->dt, (const double*)d_nt, (int)N, (int)B, h->d_par, d_bad);
+    if (h->hdm.formulation == HSQP_FORM_CENTROIDAL)   // torso task-space reference of every row
+      hipLaunchKernelGGL(k_params_cent_torso, dim3(total), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_par);
     step(hipGetLastError(), "k_params");
   }
   int bad = 0;
@@ -1029,12 +1007,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool last = it == n_iterations - 1 || until_converged;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     if (cent) {
-#if defined(HSQP_CENT_LQ_V1)
-      if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent<true>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
-      else hipLaunchKernelGGL(k_lq_cent<false>, dim3(nodes), dim3(CENT_THREADS), 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
-#else
       hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
-#endif
     }
     else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
@@ -1109,12 +1082,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     }
     auto launch_perf = [&]() {   // value pass of the centroidal trial, performance indices before / after, line-search state of the full-step trial
       if (cent)
-      {
-        if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent_value_wave, dim3(nodes), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
-                                             (const LsState*)nullptr);
-        else hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes, h->d_misc,
-                                (const LsState*)nullptr);
-      }
+        hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
+                           (const LsState*)nullptr);
       hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
                          (const LsState*)nullptr);
       hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
@@ -1175,12 +1144,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
           hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
           if (cent)
-          {
-            if (nodes <= 512) hipLaunchKernelGGL(k_lq_cent_value_wave, dim3(nodes), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
-                                                 h->d_misc, (const LsState*)h->d_ls);
-            else hipLaunchKernelGGL(k_lq_cent_value, dim3((nodes + 63) / 64), dim3(128), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, nodes,
-                                    h->d_misc, (const LsState*)h->d_ls);
-          }
+            hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
+                               (const LsState*)h->d_ls);
           else
             hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
@@ -1423,7 +1388,7 @@ static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s
       hipLaunchKernelGGL(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)nullptr, (const double*)nullptr, 0, 0.0, (const double*)nullptr,
                          (const double*)nullptr, (const double*)d_in, (const double*)(d_in + (size_t)n * NX), d_x, d_u);
     if (cent) {
-      hipLaunchKernelGGL(k_cent_policy_map, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_dm, n, (const double*)d_x, (const double*)d_u, d_xw, d_uw);
+      hipLaunchKernelGGL(k_cent_policy_map, dim3(n), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, n, (const double*)d_x, (const double*)d_u, d_xw, d_uw);
       hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_xw, (const double*)d_uw, d_tau);
     } else {
       hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_x, (const double*)d_u, d_tau);

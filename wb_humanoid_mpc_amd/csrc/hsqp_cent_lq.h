@@ -1,7 +1,7 @@
 // Centroidal LQ approximation, second form (round 4): values ONCE per node in an LDS workspace, tangents in closed form.
 //
-// The first form (hsqp_cent.h: cent_pass on dual numbers, one tangent direction per lane) made every lane walk the whole kinematic tree
-// with its own copy of every body record: 9 KB of private memory per lane, one wave per SIMD, ~160 k wave instructions per node.  Here
+// The first form (rounds 1-3: a scalar program on dual numbers, one tangent direction per lane) made every lane walk the whole kinematic
+// tree with its own copy of every body record: 9 KB of private memory per lane, one wave per SIMD, ~160 k wave instructions per node.  Here
 //   * the model pass of a stage runs once per node, cooperatively, in workgroup phases over an LDS workspace (the whole-body kernel's
 //     scheme, hsqp_model.h): one sincos per angle, the placement walk per (chain, row), joint-rate velocities per body, per-body momentum
 //     sums, a 15-entry reduction;
@@ -9,10 +9,10 @@
 //         dR_i = [w_c]x R_i,  dr_i = w_c x (r_i - r_c),  d om_i = w_c x (om_i - om_c),  d v_i = w_c x (v_i - v_c) + (om_c x w_c) x (r_i - r_c)
 //     for the bodies i of the subtree (a contiguous range of the depth-first order), nothing else; a joint rate qd_c adds w_c to their
 //     angular and w_c x (r_i - r_c) to their origin velocities; an euler angle rotates the whole robot about the base origin, so the
-//     momentum sums themselves rotate (no loop); h, W and the base position enter the closing 3 x 3 solve only.  The lane feeds these
-//     seeds to the SAME per-body accumulation and the same closing solve as the value pass (hsqp_cent.h: cent_accumulate, cent_finish on
-//     Dual1), so the arithmetic that was verified against the oracle is reused, on 1 .. 11 bodies instead of 24 and without any per-lane
-//     array: no private memory;
+//     momentum sums themselves rotate (no loop); h, W and the base position enter the closing 3 x 3 solve only.  The lane turns these
+//     seeds into the tangents of the momentum sums by the product rule on the per-body values of the stage (1 .. 11 bodies instead of 24),
+//     then runs the closing solve (hsqp_cent.h: cent_finish) and the terms (cent_terms) on one-tangent dual numbers — the arithmetic that
+//     was verified against the oracle — without any per-lane array;
 //   * the four stage Jacobians (12 x 70 each) stay in LDS and are chained per column at the end (12 x 12 blocks), as the whole-body kernel
 //     chains its 6 x 6 blocks;
 //   * the cost / constraint rows are produced by the same lanes right behind their stage-1 column (the closing solve's base velocity
@@ -155,7 +155,7 @@ HSQP_HD void cent_lane_sums(const DevModel& dm, const WS& ws, CentCol col, CentS
       d[9] = 2.0 * WI[0]; d[10] = WI[1] + WI[3]; d[11] = WI[2] + WI[6]; d[12] = 2.0 * WI[4]; d[13] = WI[5] + WI[7]; d[14] = 2.0 * WI[8];
     } else if (col.kind == CK_Q || col.kind == CK_QD) {
       const int c = col.idx + 1, n = ws.sub[c];
-      // the tangents of the per-body sums (cent_accumulate) under the lane's rigid motion of the subtree, from the per-body values of the
+      // the tangents of the per-body sums under the lane's rigid motion of the subtree, from the per-body values of the
       // stage (product rule by hand: a quarter of the instructions of the generic dual-number accumulation, and no value is recomputed)
       const double* wa = ws.w[c];
       const double* a0 = ws.r[c];
@@ -266,7 +266,8 @@ struct CentLaneKin {
   HSQP_HD BodyRec<T> foot(int f) const { return cent_seed_body<T>(ws, dm.contact_body[f], col, ws.x + 6); }
   HSQP_HD BodyRec<T> torso() const { return cent_seed_body<T>(ws, dm.torso_body, col, ws.x + 6); }
   HSQP_HD void point(int p, T* out) const { cent_seed_point<T>(ws, dm.coll_body[p], dm.coll_p[p], col, ws.x + 6, out); }
-  // external-torque joint a of foot f: tau = pos_foot . ea[0..2] + ea[3]  (hsqp_cent.h: cent_collect)
+  // external-torque joint a of foot f: tau = w_j . (m + (pos - p_j) x f) = pos . (f x w_j) + (w_j . m - p_j . (f x w_j)) = pos . ea[0..2] + ea[3];
+  // zero unless joint j carries the foot
   HSQP_HD void ext_arm(int f, int a, T* ea) const {
     const int i = 1 + dm.ext_joint[f][a], cb = dm.contact_body[f];
     const bool carries = cb >= i && cb < i + ws.sub[i];
@@ -440,7 +441,7 @@ HSQP_HD void cent_stage_values(const Ctx& ctx, const DevModel& dm, W& ws, int s,
   WG_SYNC(ctx);
   // ---- per-body momentum sums, then their totals
   WG_FOR(ctx, i, NB) {
-    // (the arithmetic of cent_accumulate, with the per-body values kept for the tangent lanes)
+    // centre of mass, its velocity, rotational inertia in world axes (kept for the tangent lanes), and the body's share of the sums
     const double m = dm.mass[i];
     const double* Rb = ws.R[i];
     double rc[3], c[3], t[3], vc[3];
@@ -599,6 +600,51 @@ HSQP_HD void cent_lq_node2(const Ctx& ctx, const DevModel& dm, CentWST<DERIV>& w
       }
       for (int r = 0; r < 12; ++r) rec[REC_PV + r * LDJ + rcol] = dt / 6.0 * acc[r];
     }
+  }
+  WG_SYNC(ctx);
+}
+
+// ---- the two other users of the model pass, on the same workspace (one workgroup — one wave is enough — per evaluation)
+// [pdot; euler rates] of the base at a centroidal (x, u): the generalized velocities CentroidalMpcMrtJointController::computeJointControlAction
+// needs (humanoid_centroidal_mpc/src/mrt/CentroidalMpcMrtJointController.cpp:155-175) -> vb6
+template <class W>
+HSQP_HD void cent_base_velocity(const Ctx& ctx, const DevModel& dm, W& ws, const double* x, const double* u, double* vb6) {
+  cent_ws_topology(ctx, dm, ws);
+  WG_FOR(ctx, i, CNX + NU) { if (i < CNX) ws.x[i] = x[i]; else ws.u[i - CNX] = u[i - CNX]; }
+  WG_SYNC(ctx);
+  cent_stage_values(ctx, dm, ws, 0, 0.0);
+  WG_FOR(ctx, it, 1) {
+    CentBase<double> base;
+    double xdot[12];
+    cent_lane_flow<double>(dm, ws, CentCol{CK_NONE, 0}, xdot, base);
+    for (int k = 0; k < 6; ++k) vb6[k] = base.vb[k];
+  }
+  WG_SYNC(ctx);
+}
+// Torso task-space reference of a node-parameter row (after node_params_eval has filled the desired state): kinematics of the torso link at
+// (xRef, uRef = 0) — EndEffectorKinematicsQuadraticCost::getParameters / getReferenceCostElement
+// (humanoid_common_mpc/src/cost/EndEffectorKinematicsQuadraticCost.cpp:80-104)
+template <class W>
+HSQP_HD void cent_params_torso(const Ctx& ctx, const DevModel& dm, W& ws, double* par) {
+  cent_ws_topology(ctx, dm, ws);
+  WG_FOR(ctx, i, CNX + NU) { if (i < CNX) ws.x[i] = par[HSQP_P_XDES + i]; else ws.u[i - CNX] = 0.0; }
+  WG_SYNC(ctx);
+  cent_stage_values(ctx, dm, ws, 0, 0.0);
+  WG_FOR(ctx, it, 1) {
+    CentLaneKin<double, W> kin{dm, ws, CentCol{CK_NONE, 0}, {}, {}};
+    double xdot[12];
+    cent_lane_flow<double>(dm, ws, kin.col, xdot, kin.base);
+    for (int k = 0; k < 3; ++k) kin.base.p0[k] = ws.x[6 + k];
+    const BodyRec<double> tb = kin.torso();
+    double Rt[9], pos[3], vl[3], va[3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rt[3 * r + c] = tb.R[3 * r] * dm.torso_R[c] + tb.R[3 * r + 1] * dm.torso_R[3 + c] + tb.R[3 * r + 2] * dm.torso_R[6 + c];
+    cent_point(kin.p0(), kin.vb(), kin.wb(), tb, dm.torso_p, pos, vl, va);
+    double* ref = par + HSQP_PC_TORSO;
+    cent_quat(Rt, ref + 3);
+    for (int r = 0; r < 3; ++r) { ref[r] = pos[r]; ref[7 + r] = vl[r]; ref[10 + r] = va[r]; }
+    for (int i = HSQP_PC_TORSO + 13; i < NX; ++i) par[HSQP_P_XDES + i] = 0.0;
+    par[HSQP_P_SWING + 2] = 0.0; par[HSQP_P_SWING + 5] = 0.0;   // the velocity-level constraints have no acceleration reference
   }
   WG_SYNC(ctx);
 }
