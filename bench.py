@@ -52,24 +52,50 @@ PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
 
 
+PROFILE_ROUND = "r04"            # which committed PMC passes the per-kernel HBM bytes / matrix-pipe shares are read from (profiles/<round>_pmc_*)
+
+
 def pmc_kernel_info():
-    """Per kernel: HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) and the matrix-pipe busy share from the committed rocprofv3 --pmc
-    passes of this same command (tools/gpu_profiles_r03.sh -> profiles/r03_pmc_summary.json, profiles/r03_pmc_sq_summary.json).
-    Empty if absent."""
-    out = {}
+    """Per kernel: HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) and the matrix-pipe busy share from the COMMITTED rocprofv3 --pmc
+    passes of this same command (tools/gpu_profiles.sh -> profiles/<round>_pmc_summary.json, <round>_pmc_sq_summary.json): read, not
+    measured in this run — the returned provenance says so.  A summary whose kernel names are not all present in the library this run
+    loads (a profile of another build) is dropped.  -> (info per kernel, provenance)"""
+    from wb_humanoid_mpc_amd import build as _build
+    out, prov = {}, {"source": [], "measured_in_this_run": False, "round": PROFILE_ROUND}
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as fh:
-            for k, v in json.load(fh)["kernels"].items():
+        lib_bytes = open(os.environ.get("HSQP_LIB", _build.LIB), "rb").read()
+    except Exception:
+        lib_bytes = b""
+
+    def names_match(keys):
+        ours = [k for k in keys if k.startswith("k_")]
+        missing = [k for k in ours if k.split("<")[0].encode() not in lib_bytes]
+        if missing or not ours:
+            prov.setdefault("dropped", []).append({"missing_in_library": missing})
+            return False
+        return True
+
+    try:
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")
+        with open(path) as fh:
+            kernels = json.load(fh)["kernels"]
+        if names_match(kernels):
+            for k, v in kernels.items():
                 out.setdefault(k, {})["hbm_bytes"] = v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]
+            prov["source"].append(os.path.relpath(path, ROOT))
     except Exception:
         pass
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.json")) as fh:
-            for k, v in json.load(fh).items():
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_sq_summary.json")
+        with open(path) as fh:
+            kernels = json.load(fh)
+        if names_match(kernels):
+            for k, v in kernels.items():
                 out.setdefault(k, {})["mfma_busy"] = v.get("mfma_busy")
+            prov["source"].append(os.path.relpath(path, ROOT))
     except Exception:
         pass
-    return out
+    return out, prov
 
 
 def cpu_baseline(model, n_nodes, seed, cent=False):
@@ -378,8 +404,8 @@ def main():
         # Gauss-Newton contraction J^T J (F_gn) runs in k_project (hsqp_project.h), not in the LQ kernel; the LQ kernel's dense count is
         # the RK4 sensitivity product only — its real work (four analytic rigid-body model evaluations per node) is vector FP64 and is
         # not part of SURVEY's count, so its fraction is reported against the same FP64 peak but its bound is VALU issue, not the matrix pipe.
-        pmc = pmc_kernel_info()
-        kern = {"k_lq_cent" if cent else "k_lq<true>": (kms[0], f_rk4, "valu-issue"),
+        pmc, pmc_prov = pmc_kernel_info()
+        kern = {"k_lq_cent2" if cent else "k_lq<true>": (kms[0], f_rk4, "valu-issue"),
                 "k_project": (kms[1], f_proj + f_gn, "mfma"),
                 ("k_scan_*" if scan_used else ("k_seg_*" if seg_used else "k_riccati")): (kms[2], f_ric, "latency (serial stage chain; matrix pipe)" if not scan_used else "mfma"),
                 "k_step_value (+ reductions)": (kms[3], 0.0, "valu-issue / hbm")}
@@ -413,7 +439,8 @@ def main():
                          "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": per_kernel[dom]["hbm_bytes"],
                          "peak_note": "FP64 vector = FP64 matrix peak (78.6 TFLOP/s; tools/microbench/f64_rates.hip measured 77.4 / 73)",
                          "traffic_note": "HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE) from the committed rocprofv3 --pmc "
-                                         "passes of this command (profiles/r03_pmc_summary.json); null for other shapes or when the passes are absent",
+                                         "passes of this command (see counters_provenance); null for other shapes or when the passes are absent",
+                         "counters_provenance": pmc_prov,
                          "note": "achieved = ALGORITHMIC (dense-count, SURVEY §8d) flops of the dominant kernel / its HIP-event duration; the kernels exploit "
                                  "the flow map's structure and execute fewer flops than the dense count (DESIGN.md); the N = 1 measurement of this rank",
                          "per_kernel": per_kernel,

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 evidence (GPU box, via gpurun): rocprofv3 kernel stats of the bench command, HBM traffic counters (separate --pmc passes, one
-# counter each, kernel trace only), SQ counters, instruction mix; summaries under gpurun_out/ — tools/collect_profiles_r03.sh copies them
-# to profiles/r03_*.
+# evidence of a round (GPU box, via gpurun): rocprofv3 kernel stats of the bench command, HBM traffic counters (separate --pmc passes, one
+# counter each, kernel trace only), SQ counters, instruction mix; summaries under gpurun_out/ — tools/collect_profiles.sh copies them
+# to profiles/<round>_*.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 evidence in one GPU call: the bench lines of every BASELINE config on one GPU, the data-path leg at 32 / 64 instances (what one
-# GPU of an 8- / 4-GPU run of config 4 holds), the parity report, the phase profile, then tools/gpu_profiles_r03.sh (rocprofv3 kernel
-# stats + the PMC passes).  tools/collect_profiles_r03.sh copies the results to profiles/r03_*.
+# a round's evidence in one GPU call: the bench lines of every BASELINE config on one GPU, the data-path leg at 32 / 64 instances (what one
+# GPU of an 8- / 4-GPU run of config 4 holds), the parity report, the phase profile, then tools/gpu_profiles.sh (rocprofv3 kernel
+# stats + the PMC passes).  tools/collect_profiles.sh <round> copies the results to profiles/<round>_*.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
@@ -25,4 +25,4 @@ run bench_strong32 --steps 10 --warmup 3 --no-cpu-baseline --force-strong --glob
 run bench_strong64 --steps 10 --warmup 3 --no-cpu-baseline --force-strong --global-batch 64 --batch 64
 timeout 900 python tools/parity_report.py > "$OUT/parity_report.log" 2>&1; echo "parity rc=$?"; tail -12 "$OUT/parity_report.log"
 timeout 300 python tools/phase_profile.py > "$OUT/phase.log" 2>&1; echo "phase rc=$?"
-bash tools/gpu_profiles_r03.sh > "$OUT/profiles_r03.log" 2>&1; echo "profiles rc=$?"; tail -40 "$OUT/profiles_r03.log"
+bash tools/gpu_profiles.sh > "$OUT/profiles.log" 2>&1; echo "profiles rc=$?"; tail -40 "$OUT/profiles.log"

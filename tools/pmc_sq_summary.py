@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SQ counters of the bench kernels (tools/gpu_profiles_r03.sh): per-launch means, the matrix-pipe busy share
+"""SQ counters of the bench kernels (tools/gpu_profiles.sh): per-launch means, the matrix-pipe busy share
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz) with the duration from the rocprofv3 kernel stats of the same
 command, the issue share ACTIVE_INST_ANY / WAVE_CYCLES, and the dynamic instruction mix per wave.  SQ_INSTS_VALU_MFMA_MOPS_F64 counts
 in units of 512 flop: a v_mfma_f64_16x16x4 (2048 flop) is 4 of them."""
@@ -35,7 +35,7 @@ except Exception as e:  # noqa: BLE001
 sq, insts = per_kernel("pmc_sq"), per_kernel("pmc_insts")
 summary = {}
 with open(os.path.join(out, "pmc_sq_summary.txt"), "w") as fh:
-    fh.write("# tools/gpu_profiles_r03.sh: SQ counters per launch (M), bench.py --steps 2 --warmup 1, config 4\n")
+    fh.write("# tools/gpu_profiles.sh: SQ counters per launch (M), bench.py --steps 2 --warmup 1, config 4\n")
     for k, v in sq.items():
         e = {"counters_M_per_launch": {c: round(x / 1e6, 2) for c, x in v.items()}}
         if k in dur and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
