@@ -11,6 +11,7 @@
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent_lq.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_lqv.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_scan.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_segment.h"
 
@@ -210,6 +211,13 @@ void emu_lq_node(void* h, const double* x, const double* u, const double* xnext,
   Ctx ctx{0, 1, nullptr};
   if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
   else { auto w = std::make_unique<LqWST<false>>(); lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
+}
+// the value pass on a quad of lanes (hsqp_lqv.h), lane by lane: misc[8]; returns the number of limbs (0: the model does not fit the form)
+int emu_value_quad(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  if (dm.n_limbs == 0) return 0;
+  qv_node_host(dm, x, u, xnext, par, dt, misc);
+  return dm.n_limbs;
 }
 // dense blocks from a record: AB[58*93], H[93*93], g[93], CDe[14*94]
 void emu_expand(const double* rec, double dt, double* AB, double* H, double* g, double* CDe) {

@@ -632,3 +632,32 @@ def test_scan_back_off_is_per_problem_and_only_for_the_automatic_choice(model, o
     assert a1 == a2 and p1 == p2, counts                       # per problem, not per handle history
     assert a1[0] >= 1 and a1[1] >= 1 and a1[0] + a1[1] <= 3, counts   # rejected, then backed off
     assert p1[1] == 0 and p1[0] >= a1[0], counts               # forced: attempted every time
+
+
+def test_value_pass_on_quads_of_lanes_equals_the_phase_form(model):
+    """The whole-body value pass (performance index of the stepped trajectory, line-search trials) runs on quads of lanes — a lane per limb,
+    16 nodes per wave (hsqp_lqv.h); HSQP_VALUE_PHASE_FORM at hsqp_create selects its phase form (one wave per node, fused with the step).  Same
+    numbers up to the order of the sums over bodies and cost terms; the step itself is bit-identical.  A batch whose node count is not a multiple
+    of 16 (padding quads) and a line-search run (masked instances) are part of the case."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    res = {"quad": [], "phase": []}
+    x0, x, u, par, dt = make_problem(model, n_nodes=37, batch=5, perturb=True, seed=21)
+    for form in ("quad", "phase"):
+        for linesearch in (False, True):
+            if form == "phase":
+                os.environ["HSQP_VALUE_PHASE_FORM"] = "1"
+            try:
+                s = HipSqpSolver(model, max_nodes=37, max_batch=5, linesearch=linesearch)
+            finally:
+                os.environ.pop("HSQP_VALUE_PHASE_FORM", None)
+            try:
+                res[form].append(s.run(x0, x, u, par, dt))
+            finally:
+                s.close()
+    for a, b in zip(res["quad"], res["phase"]):
+        assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["du"], b["du"])
+        assert np.array_equal(a["alpha"], b["alpha"]) and np.array_equal(a["step_type"], b["step_type"])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["u"], b["u"])
+        for pa, pb in zip(a["perf_after"], b["perf_after"]):
+            for key in ("cost", "dynamics_sse", "equality_sse"):
+                assert abs(pa[key] - pb[key]) <= 1e-12 * max(1.0, abs(pb[key])), (key, pa, pb)

@@ -57,6 +57,23 @@ def test_lq_record_expands_to_the_oracle_blocks(model, oracle, emu, gait, n):
             assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 10), ("run", 14)])
+def test_value_pass_on_a_quad_of_lanes_equals_the_phase_form(model, emu, gait, n):
+    """hsqp_lqv.h (one lane per limb, four lanes per node) against lq_node<false> (one wave per node, phases over an LDS workspace): the same
+    numbers with the sums over bodies / cost terms taken in another order."""
+    lib, h = emu
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=11)
+    off = lib.emu_rec_misc_offset()
+    for k in range(n):
+        for dtk in (dt, 0.0) if k == 1 else (dt,):
+            rec, misc = np.zeros(lib.emu_rec_size()), np.zeros(8)
+            lib.emu_lq_node(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dtk), 0, P(rec))
+            assert lib.emu_value_quad(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dtk), P(misc)) == 4
+            want = rec[off:off + 8]
+            assert np.array_equal(misc[[0, 4, 5, 6, 7]], want[[0, 4, 5, 6, 7]])
+            assert np.allclose(misc[1:4], want[1:4], rtol=1e-12, atol=1e-13 * max(1.0, np.abs(want[1:4]).max())), (k, misc, want)
+
+
 @pytest.mark.parametrize("gait,n", [("stance", 4), ("walk", 8), ("run", 14)])
 def test_full_iteration_matches_oracle(model, oracle, emu, gait, n):
     lib, h = emu

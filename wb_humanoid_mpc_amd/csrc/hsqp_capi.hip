@@ -19,6 +19,7 @@
 #include "hsqp_cent_lq.h"
 #include "hsqp_scan.h"
 #include "hsqp_segment.h"
+#include "hsqp_lqv.h"
 
 using namespace hsqp;
 
@@ -321,6 +322,54 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
   lq_node<false, true>(ctx, *dm, w, nullptr, nullptr, nullptr, par + ((size_t)b * (N + 1) + k) * NP, dts[node], nullptr, misc + (size_t)node * 8);
 }
 
+// ---- whole-body value pass on quads of lanes (hsqp_lqv.h): a wave evaluates QV_NODES nodes, one lane per limb; misc as k_lq<false> writes it.
+//      Nodes of instances whose line search is over (ls) are evaluated with the rest of their wave but not written.
+__global__ __launch_bounds__(QV_THREADS) void k_value_quad(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                          const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes,
+                                                          double* __restrict__ misc, const LsState* __restrict__ ls) {
+  __shared__ QvWS w;
+  const int lane = threadIdx.x, nn = lane >> 2, L = lane & 3;
+  const int node0 = blockIdx.x * QV_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
+  const int b = node / N, k = node % N;
+  const bool live = node0 + nn < nodes && (!ls || ls[b].active);
+  if (__ballot(live) == 0ull) return;
+  const Ctx ctx{lane, QV_THREADS, nullptr};
+  qv_load_const(ctx, *dm, w.k, [] {});
+  for (int idx = lane; idx < QV_NODES * NZ; idx += QV_THREADS) {
+    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
+    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
+    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
+  }
+  __syncthreads();
+  const double* xs = w.x[nn];
+  const double* us = w.u[nn];
+  const double* pn = par + ((size_t)b * (N + 1) + k) * NP;
+  const double dt = dts[node];
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto quad_sum = [](double v) { v += quad_perm_f64<0xB1>(v); v += quad_perm_f64<0x4E>(v); return v; };   // the sum over the node's four lanes, in all of them
+#else
+  auto quad_sum = [](double v) { return v; };
+#endif
+  QvCarry c;
+  qv_carry_init(c);
+  double cost = 0.0, eq = 0.0;
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    double part[16];
+    qv_limb_stage(*dm, w.k, xs, us, L, s, dt, c, part, w.cp[nn]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[e] = quad_sum(part[e]);
+    qv_base_solve(part, s, c);
+    if (s == 0) {
+      __syncthreads();   // (one wave: orders the collision points of the four lanes before their readers)
+      qv_node_terms(*dm, xs, us, pn, L, c, w.cp[nn], cost, eq);
+    }
+  }
+  double dyn = qv_defect(xs, us, x + ((size_t)b * (N + 1) + k + 1) * NX, L, dt, c);
+  cost = quad_sum(cost); eq = quad_sum(eq); dyn = quad_sum(dyn);
+  if (live && L == 0) qv_write_misc(pn, dt, cost, eq, dyn, misc + (size_t)node * 8);
+}
+
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
 __global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
                                                 const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
@@ -556,6 +605,7 @@ struct hsqp_handle {
                                               // state of the AUTOMATIC sweep choice only (a sweep forced by a flag is always attempted), reset by every upload
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
+  bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
   int* d_scanst = nullptr;   // flags of the scan kernels (bad pivot, rank-deficient D, failed Lam) of the current attempt: part of the gate, behind d_ginf
@@ -792,6 +842,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   hsqp_linesearch_defaults(&h->ls_settings);
   const std::string e = build_dev_model(*model, h->hdm);
   if (!e.empty()) { g_create_error = e; delete h; return HSQP_ERR_BAD_ARG; }
+  h->value_quad = h->hdm.formulation == HSQP_FORM_WB && h->hdm.n_limbs > 0 && getenv("HSQP_VALUE_PHASE_FORM") == nullptr;
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return fail(HSQP_ERR_HIP, "hipSetDevice failed");
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
@@ -1057,7 +1108,12 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       if (cent)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                            h->d_xnew, h->d_unew, h->d_stepinfo);
-      else   // whole-body: the step and its value pass are one kernel (k_step_value)
+      else if (h->value_quad) {   // whole-body: the step (HBM-bound), then the value pass on quads of lanes (hsqp_lqv.h)
+        hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+                           h->d_xnew, h->d_unew, h->d_stepinfo);
+        hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES - 1) / QV_NODES), dim3(QV_THREADS), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+                           N, nodes, h->d_misc, (const LsState*)nullptr);
+      } else   // a tree with more than four limbs: the phase form of the value pass, fused with the step (k_step_value)
         hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
                            h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384);
     };
@@ -1146,6 +1202,9 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
           if (cent)
             hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
                                (const LsState*)h->d_ls);
+          else if (h->value_quad)
+            hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES - 1) / QV_NODES), dim3(QV_THREADS), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+                               N, nodes, h->d_misc, (const LsState*)h->d_ls);
           else
             hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);

@@ -38,6 +38,7 @@ constexpr int LDJ = 96;        // leading dimension of Jacobian rows over z = [x
 constexpr int MAXCHAIN = 6;    // longest chain (maximal single-child path) of the kinematic tree
 constexpr int NANC = 8;        // longest path of moving bodies from the base to a leaf
 constexpr int NLEVELS = 8;     // depth of the body tree incl. the base
+constexpr int QV_LIMBS = 4;    // root-to-leaf paths of the kinematic tree the quad value pass walks, one per lane (hsqp_lqv.h)
 
 struct Ctx {
   int tid;
@@ -149,6 +150,14 @@ struct DevModel {
   int ext_joint[2][6];
   int chain_par_slot[NB];        // per chain: where its first body's parent record sits (0 = base, 1 + c = last body of chain c)
   double torso_p[3], torso_R[9], torso_sqrt_w[12], cent_foot_sqrt_w[12], ext_sqrt_w[2][6];
+  // limbs (hsqp_lqv.h): the root-to-leaf paths of moving bodies, root first, eight body indices packed into a word; bit k of limb_own: the limb adds
+  // body k of its path to the sums over bodies (a shared ancestor is owned by the first limb that passes it; limb 0 owns the base).  n_limbs = 0: the
+  // tree has more than QV_LIMBS leaves (or both feet on one limb) and the value pass runs in its phase form
+  unsigned long long limb_path[QV_LIMBS];
+  int limb_len[QV_LIMBS];
+  unsigned limb_own[QV_LIMBS];
+  int limb_max_len, n_limbs;
+  int foot_limb[2];
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -85,6 +85,38 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
       for (int r = 0; r < 3; ++r) dm.axis_p[i][r] = b.R[3 * r] * b.axis[0] + b.R[3 * r + 1] * b.axis[1] + b.R[3 * r + 2] * b.axis[2];
     }
   }
+  // limbs of the quad value pass (hsqp_lqv.h): one per leaf of the tree
+  {
+    int nchild[NB] = {0};
+    for (int i = 1; i < NB; ++i) nchild[dm.parent[i]]++;
+    bool owned[NB] = {false};
+    int nl = 0;
+    bool fits = true;
+    for (int i = 1; i < NB && fits; ++i) {
+      if (nchild[i] != 0) continue;
+      if (nl == QV_LIMBS) { fits = false; break; }
+      unsigned long long path = 0;
+      unsigned own = 0;
+      for (int k = 0; k < dm.n_anc[i]; ++k) {
+        const int b = dm.anc[i][k];
+        path |= (unsigned long long)b << (8 * k);
+        if (!owned[b]) { own |= 1u << k; owned[b] = true; }
+      }
+      dm.limb_path[nl] = path; dm.limb_len[nl] = dm.n_anc[i]; dm.limb_own[nl] = own;
+      if (dm.n_anc[i] > dm.limb_max_len) dm.limb_max_len = dm.n_anc[i];
+      ++nl;
+    }
+    for (int f = 0; f < 2 && fits; ++f) {
+      const int cb = md.contact[f].body;
+      dm.foot_limb[f] = -1;
+      for (int l = 0; l < nl && dm.foot_limb[f] < 0; ++l)
+        for (int k = 0; k < dm.limb_len[l]; ++k)
+          if ((int)((dm.limb_path[l] >> (8 * k)) & 0xffull) == cb) { dm.foot_limb[f] = l; break; }
+      if (dm.foot_limb[f] < 0) fits = false;   // (a contact frame on the base itself)
+    }
+    if (fits && dm.foot_limb[0] == dm.foot_limb[1]) fits = false;
+    dm.n_limbs = fits ? nl : 0;
+  }
   dm.gravity = md.gravity;
   for (int f = 0; f < 2; ++f) {
     dm.contact_body[f] = md.contact[f].body;
