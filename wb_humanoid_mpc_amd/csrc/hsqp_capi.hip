@@ -324,17 +324,18 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
 
 // ---- whole-body value pass on quads of lanes (hsqp_lqv.h): a wave evaluates QV_NODES nodes, one lane per limb; misc as k_lq<false> writes it.
 //      Nodes of instances whose line search is over (ls) are evaluated with the rest of their wave but not written.
-__global__ __launch_bounds__(QV_THREADS) void k_value_quad(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                          const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes,
+__global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_value_quad(const DevModel* __restrict__ dm, const double* __restrict__ x,
+                                                          const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts, int N, int nodes,
                                                           double* __restrict__ misc, const LsState* __restrict__ ls) {
-  __shared__ QvWS w;
-  const int lane = threadIdx.x, nn = lane >> 2, L = lane & 3;
-  const int node0 = blockIdx.x * QV_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
+  __shared__ QvWS ws;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
+  auto& w = ws.wv[wave];
+  const int node0 = (blockIdx.x * QV_WAVES + wave) * QV_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
   const int b = node / N, k = node % N;
   const bool live = node0 + nn < nodes && (!ls || ls[b].active);
-  if (__ballot(live) == 0ull) return;
-  const Ctx ctx{lane, QV_THREADS, nullptr};
-  qv_load_const(ctx, *dm, w.k, [] {});
+  if (__syncthreads_or(live) == 0) return;
+  const Ctx ctx{(int)threadIdx.x, QV_THREADS * QV_WAVES, nullptr};
+  qv_load_const(ctx, *dm, ws.k, [] {});
   for (int idx = lane; idx < QV_NODES * NZ; idx += QV_THREADS) {
     const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
     if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
@@ -353,18 +354,19 @@ __global__ __launch_bounds__(QV_THREADS) void k_value_quad(const DevModel* __res
   QvCarry c;
   qv_carry_init(c);
   double cost = 0.0, eq = 0.0;
-#pragma unroll 1
-  for (int s = 0; s < 4; ++s) {
+  auto stage = [&](int s) {
     double part[16];
-    qv_limb_stage(*dm, w.k, xs, us, L, s, dt, c, part, w.cp[nn]);
+    qv_limb_stage(*dm, ws.k, xs, us, L, s, dt, c, part, w.cp[nn]);
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[e] = quad_sum(part[e]);
-    qv_base_solve(part, s, c);
-    if (s == 0) {
-      __syncthreads();   // (one wave: orders the collision points of the four lanes before their readers)
-      qv_node_terms(*dm, xs, us, pn, L, c, w.cp[nn], cost, eq);
-    }
-  }
+    qv_base_solve(part, xs, s, dt, c);
+  };
+  // the first stage apart from the loop: what it captures for the node terms (the foot frame, 33 doubles per lane) is dead before the second
+  stage(0);
+  __syncthreads();   // orders the collision points of a node's four lanes before their readers
+  qv_node_terms(*dm, xs, us, pn, L, c, w.cp[nn], cost, eq);
+#pragma unroll 1
+  for (int s = 1; s < 4; ++s) stage(s);
   double dyn = qv_defect(xs, us, x + ((size_t)b * (N + 1) + k + 1) * NX, L, dt, c);
   cost = quad_sum(cost); eq = quad_sum(eq); dyn = quad_sum(dyn);
   if (live && L == 0) qv_write_misc(pn, dt, cost, eq, dyn, misc + (size_t)node * 8);
@@ -1111,7 +1113,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       else if (h->value_quad) {   // whole-body: the step (HBM-bound), then the value pass on quads of lanes (hsqp_lqv.h)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                            h->d_xnew, h->d_unew, h->d_stepinfo);
-        hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES - 1) / QV_NODES), dim3(QV_THREADS), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+        hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                            N, nodes, h->d_misc, (const LsState*)nullptr);
       } else   // a tree with more than four limbs: the phase form of the value pass, fused with the step (k_step_value)
         hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
@@ -1203,7 +1205,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
             hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
                                (const LsState*)h->d_ls);
           else if (h->value_quad)
-            hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES - 1) / QV_NODES), dim3(QV_THREADS), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+            hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, nodes, h->d_misc, (const LsState*)h->d_ls);
           else
             hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,

@@ -16,17 +16,27 @@
 
 namespace hsqp {
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keeps the ILP scheduler from hoisting a later block's operand loads over this point (register pressure) */
+#else
+#define QV_SCHED_FENCE() ((void)0)
+#endif
+
 constexpr int QV_NODES = 16, QV_THREADS = 64;   // a wave evaluates 16 nodes, four lanes each
 static_assert(QV_NODES * QV_LIMBS == QV_THREADS && QV_LIMBS == 4, "a node is a DPP quad");
 
 struct QvConst {   // body constants (one copy per workgroup: lanes index them by the body of their step)
   double Rfix[NB][9], pfix[NB][3], axis[NB][3], axis_p[NB][3], com[NB][3], inertia[NB][9], mass[NB];
 };
+constexpr int QV_WAVES = 2;         // waves per workgroup: they share the body constants (37 KB per workgroup: eight waves per CU)
 struct QvWS {
   QvConst k;
-  double x[QV_NODES][NX], u[QV_NODES][NU];
-  double cp[QV_NODES][10][3];      // collision points relative to the base origin (stage 1), written by the lanes that own their bodies
+  struct {
+    double x[QV_NODES][NX], u[QV_NODES][NU];
+    double cp[QV_NODES][10][3];    // collision points relative to the base origin (stage 1), written by the lanes that own their bodies
+  } wv[QV_WAVES];
 };
+static_assert(sizeof(QvWS) * 4 <= 163840, "four workgroups per CU");
 
 template <class F>
 HSQP_HD void qv_load_const(const Ctx& ctx, const DevModel& dm, QvConst& k, F&& sync) {
@@ -46,16 +56,16 @@ HSQP_HD void qv_load_const(const Ctx& ctx, const DevModel& dm, QvConst& k, F&& s
 // what a lane carries from one RK4 stage to the next and to the node terms (registers on the device)
 struct QvCarry {
   double vb[6], ap[6];       // base part of the previous stage's velocity, base acceleration of the previous stage
-  double vcur[6];            // base velocity of the stage being evaluated
   double sv[6], sa[6];       // RK4 sums v1 + 2 v2 + 2 v3 + v4, a1 + 2 a2 + 2 a3 + a4 of the base rows
-  double Einv[9];            // euler-rate map of the stage being evaluated
+  double ecs[4];             // cos, sin of the euler angles z, y of the stage being evaluated (the euler-rate map of its base solve)
   double fR[9], fr[3], fv[6], fa[6];   // stage 1: placement, velocity and (gravity-trick) acceleration of the lane's foot body
   double y0[3], ab0[6];      // stage 1: E a_ang, base acceleration
 };
 HSQP_HD void qv_carry_init(QvCarry& c) {
-  for (int k = 0; k < 6; ++k) { c.vb[k] = 0.0; c.ap[k] = 0.0; c.vcur[k] = 0.0; c.sv[k] = 0.0; c.sa[k] = 0.0; c.fv[k] = 0.0; c.fa[k] = 0.0; c.ab0[k] = 0.0; }
-  for (int k = 0; k < 9; ++k) { c.Einv[k] = 0.0; c.fR[k] = 0.0; }
+  for (int k = 0; k < 6; ++k) { c.vb[k] = 0.0; c.ap[k] = 0.0; c.sv[k] = 0.0; c.sa[k] = 0.0; c.fv[k] = 0.0; c.fa[k] = 0.0; c.ab0[k] = 0.0; }
+  for (int k = 0; k < 9; ++k) c.fR[k] = 0.0;
   for (int k = 0; k < 3; ++k) { c.fr[k] = 0.0; c.y0[k] = 0.0; }
+  for (int k = 0; k < 4; ++k) c.ecs[k] = 0.0;
 }
 
 // One RK4 stage s (0..3) of limb L: part[0..5] = this lane's share of F_ext - F {moment, force} about the base origin, part[6..15] of the
@@ -67,7 +77,7 @@ HSQP_HD void qv_limb_stage(const DevModel& dm, const QvConst& kc, const double* 
   const double cprev = s <= 1 ? 0.0 : 0.5 * dt;   // the factor of the stage before (whose velocity moves this stage's q)
   double qe[3], vb[6];
   for (int k = 0; k < 3; ++k) qe[k] = x[3 + k] + (s == 0 ? 0.0 : cs * c.vb[3 + k]);
-  for (int k = 0; k < 6; ++k) { vb[k] = x[NV + k] + cs * (s == 0 ? 0.0 : c.ap[k]); c.vcur[k] = vb[k]; }
+  for (int k = 0; k < 6; ++k) vb[k] = x[NV + k] + cs * (s == 0 ? 0.0 : c.ap[k]);
   for (int e = 0; e < 16; ++e) part[e] = 0.0;
   // ---- the base: euler chain z -> y' -> x'' (F0 - F4 of stage_eval for the three euler links)
   double sz, cz, sy, cy, sx, cx;
@@ -75,11 +85,7 @@ HSQP_HD void qv_limb_stage(const DevModel& dm, const QvConst& kc, const double* 
   sincos(qe[1], &sy, &cy);
   sincos(qe[2], &sx, &cx);
   const double wz[3] = {0.0, 0.0, 1.0}, wy[3] = {-sz, cz, 0.0}, wx[3] = {cz * cy, sz * cy, -sy};
-  {
-    double E[9];
-    for (int r = 0; r < 3; ++r) { E[3 * r] = wz[r]; E[3 * r + 1] = wy[r]; E[3 * r + 2] = wx[r]; }
-    m3_inverse(E, c.Einv);
-  }
+  c.ecs[0] = cz; c.ecs[1] = sz; c.ecs[2] = cy; c.ecs[3] = sy;
   double R[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};
   double r[3] = {0.0, 0.0, 0.0};
   double vl[6], al[6];
@@ -108,6 +114,7 @@ HSQP_HD void qv_limb_stage(const DevModel& dm, const QvConst& kc, const double* 
     In[0] = m; In[1] = m * cc3[0]; In[2] = m * cc3[1]; In[3] = m * cc3[2];
     In[4] = Iw[0] + m * (cc - cc3[0] * cc3[0]); In[5] = Iw[1] - m * cc3[0] * cc3[1]; In[6] = Iw[2] - m * cc3[0] * cc3[2];
     In[7] = Iw[4] + m * (cc - cc3[1] * cc3[1]); In[8] = Iw[5] - m * cc3[1] * cc3[2]; In[9] = Iw[8] + m * (cc - cc3[2] * cc3[2]);
+    QV_SCHED_FENCE();
     double h[6], fa[6], fv[6];
     inertia_apply(In, vl, h);
     inertia_apply(In, al, fa);
@@ -115,6 +122,7 @@ HSQP_HD void qv_limb_stage(const DevModel& dm, const QvConst& kc, const double* 
     const double mk = own ? 1.0 : 0.0;
     for (int k = 0; k < 6; ++k) part[k] -= mk * (fa[k] + fv[k]);
     for (int e = 0; e < 10; ++e) part[6 + e] += mk * In[e];
+    QV_SCHED_FENCE();
     for (int f = 0; f < 2; ++f) {
       if (dm.contact_body[f] != i || dm.foot_limb[f] != L) continue;
       // contact point of foot f relative to O and its wrench about O {moment, force}
@@ -165,12 +173,21 @@ HSQP_HD void qv_limb_stage(const DevModel& dm, const QvConst& kc, const double* 
     for (int k = 0; k < 6; ++k) al[k] += S[k] * qdd + Sd[k] * qd;
     for (int k = 0; k < 9; ++k) R[k] = Rn[k];
     for (int k = 0; k < 3; ++k) r[k] = rn[k];
+    QV_SCHED_FENCE();
     body(i, ((own >> st) & 1u) != 0);
   }
 }
 
 // totals of a stage -> base acceleration (stage_eval: "totals and the block-diagonal base solve"); moves the carry on to the next stage
-HSQP_HD void qv_base_solve(const double* tot, int s, QvCarry& c) {
+HSQP_HD void qv_base_solve(const double* tot, const double* x, int s, double dt, QvCarry& c) {
+  const double cs = s == 0 ? 0.0 : (s == 3 ? dt : 0.5 * dt);
+  double Einv[9], vcur[6];
+  {
+    const double cz = c.ecs[0], sz = c.ecs[1], cy = c.ecs[2], sy = c.ecs[3];
+    const double E[9] = {0.0, -sz, cz * cy, 0.0, cz, sz * cy, 1.0, 0.0, -sy};   // columns: the world axes of the euler rates z, y, x (stage_eval F1)
+    m3_inverse(E, Einv);
+  }
+  for (int k = 0; k < 6; ++k) vcur[k] = x[NV + k] + cs * (s == 0 ? 0.0 : c.ap[k]);   // the stage's base velocity (as qv_limb_stage formed it)
   const double* I6 = tot + 10;
   const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
   double Iinv[9], y[3], ab[6];
@@ -178,12 +195,12 @@ HSQP_HD void qv_base_solve(const double* tot, int s, QvCarry& c) {
   m3_mulv(Iinv, tot, y);
   const double minv = 1.0 / tot[6];
   for (int k = 0; k < 3; ++k) ab[k] = tot[3 + k] * minv;
-  m3_mulv(c.Einv, y, ab + 3);
+  m3_mulv(Einv, y, ab + 3);
   const double wg = (s == 0 || s == 3) ? 1.0 : 2.0;
   for (int k = 0; k < 6; ++k) {
-    c.sv[k] += wg * c.vcur[k];
+    c.sv[k] += wg * vcur[k];
     c.sa[k] += wg * ab[k];
-    c.vb[k] = c.vcur[k];
+    c.vb[k] = vcur[k];
     c.ap[k] = ab[k];
   }
   if (s == 0) {
@@ -334,7 +351,7 @@ inline void qv_node_host(const DevModel& dm, const double* x, const double* u, c
     double part[QV_LIMBS][16], tot[16];
     for (int L = 0; L < QV_LIMBS; ++L) qv_limb_stage(dm, *kc, x, u, L, s, dt, c[L], part[L], cp);
     for (int e = 0; e < 16; ++e) tot[e] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    for (int L = 0; L < QV_LIMBS; ++L) qv_base_solve(tot, s, c[L]);
+    for (int L = 0; L < QV_LIMBS; ++L) qv_base_solve(tot, x, s, dt, c[L]);
   }
   double cost[QV_LIMBS], eq[QV_LIMBS], dyn[QV_LIMBS];
   for (int L = 0; L < QV_LIMBS; ++L) {
