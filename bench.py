@@ -408,10 +408,12 @@ def main():
         kern = {"k_lq_cent2" if cent else "k_lq<true>": (kms[0], f_rk4, "valu-issue"),
                 "k_project": (kms[1], f_proj + f_gn, "mfma"),
                 ("k_scan_*" if scan_used else ("k_seg_*" if seg_used else "k_riccati")): (kms[2], f_ric, "latency (serial stage chain; matrix pipe)" if not scan_used else "mfma"),
-                "k_step_value (+ reductions)": (kms[3], 0.0, "valu-issue / hbm")}
+                ("k_step + k_lq_cent2_value (+ reductions)" if cent else "k_step + k_value_quad (+ reductions)"): (kms[3], 0.0, "hbm (step) / valu-issue (value pass)")}
         per_kernel = {}
         for name, (ms, fl, bound) in kern.items():
             info = pmc.get(name.split(" ")[0].replace("k_scan_*", "k_scan_combine").replace("k_riccati", "k_riccati<58>"), {}) if (B, N) == (256, 100) and not cent else {}
+            if name.startswith("k_step + k_value_quad") and info:   # two kernels in this bucket: their HBM bytes add up
+                info = {"hbm_bytes": info.get("hbm_bytes", 0.0) + pmc.get("k_value_quad", {}).get("hbm_bytes", 0.0), "mfma_busy": 0.0}
             per_kernel[name] = {"ms": ms, "bound": bound, "algorithmic_TFLOPs": nodes * fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
                                 "frac_fp64": nodes * fl / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS if ms > 0 else None,
                                 "mfma_busy": info.get("mfma_busy"), "hbm_bytes": info.get("hbm_bytes")}

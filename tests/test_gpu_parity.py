@@ -636,7 +636,8 @@ def test_scan_back_off_is_per_problem_and_only_for_the_automatic_choice(model, o
 
 def test_value_pass_on_quads_of_lanes_equals_the_phase_form(model):
     """The whole-body value pass (performance index of the stepped trajectory, line-search trials) runs on quads of lanes — a lane per limb,
-    16 nodes per wave (hsqp_lqv.h); HSQP_VALUE_PHASE_FORM at hsqp_create selects its phase form (one wave per node, fused with the step).  Same
+    16 nodes per wave (hsqp_lqv.h) — for handles sized to fill the GPU; HSQP_VALUE_PHASE_FORM / HSQP_VALUE_QUAD_FORM at hsqp_create force its phase form (one wave per
+    node, fused with the step) / the quad form.  Same
     numbers up to the order of the sums over bodies and cost terms; the step itself is bit-identical.  A batch whose node count is not a multiple
     of 16 (padding quads) and a line-search run (masked instances) are part of the case."""
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
@@ -644,12 +645,12 @@ def test_value_pass_on_quads_of_lanes_equals_the_phase_form(model):
     x0, x, u, par, dt = make_problem(model, n_nodes=37, batch=5, perturb=True, seed=21)
     for form in ("quad", "phase"):
         for linesearch in (False, True):
-            if form == "phase":
-                os.environ["HSQP_VALUE_PHASE_FORM"] = "1"
+            key = "HSQP_VALUE_PHASE_FORM" if form == "phase" else "HSQP_VALUE_QUAD_FORM"   # (a handle this small would take the phase form by itself)
+            os.environ[key] = "1"
             try:
                 s = HipSqpSolver(model, max_nodes=37, max_batch=5, linesearch=linesearch)
             finally:
-                os.environ.pop("HSQP_VALUE_PHASE_FORM", None)
+                os.environ.pop(key, None)
             try:
                 res[form].append(s.run(x0, x, u, par, dt))
             finally:

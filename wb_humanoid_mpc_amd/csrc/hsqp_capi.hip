@@ -40,6 +40,9 @@ namespace {
 #endif
 constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 
+#ifndef HSQP_VALUE_QUAD_MIN_NODES
+#define HSQP_VALUE_QUAD_MIN_NODES 2048   /* handles sized below this keep the phase form of the whole-body value pass (hsqp_create) */
+#endif
 #ifndef HSQP_PROJ_THREADS
 #define HSQP_PROJ_THREADS 256
 #endif
@@ -844,7 +847,11 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   hsqp_linesearch_defaults(&h->ls_settings);
   const std::string e = build_dev_model(*model, h->hdm);
   if (!e.empty()) { g_create_error = e; delete h; return HSQP_ERR_BAD_ARG; }
-  h->value_quad = h->hdm.formulation == HSQP_FORM_WB && h->hdm.n_limbs > 0 && getenv("HSQP_VALUE_PHASE_FORM") == nullptr;
+  // the value pass on quads of lanes (hsqp_lqv.h) is a throughput form: a wave evaluates 16 nodes in ~100 us whatever their number, the phase form one node
+  // in ~40 us — so a handle sized for fewer nodes than fill the GPU once (config 3: one instance, 100 nodes) keeps the phase form.  Decided per HANDLE, not
+  // per call: every solve of a handle runs the same arithmetic (an instance of a batch equals its solo solve bit for bit)
+  h->value_quad = h->hdm.formulation == HSQP_FORM_WB && h->hdm.n_limbs > 0 && getenv("HSQP_VALUE_PHASE_FORM") == nullptr &&
+                  (getenv("HSQP_VALUE_QUAD_FORM") != nullptr || (size_t)settings->max_batch * settings->max_nodes >= HSQP_VALUE_QUAD_MIN_NODES);
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return fail(HSQP_ERR_HIP, "hipSetDevice failed");
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
