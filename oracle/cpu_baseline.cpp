@@ -68,15 +68,15 @@ int iterate_instance(const DevModel& dm, int N, double dt, const double* x_init,
   else riccati_backward(ctx, rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, nullptr);
   if (!rw.ok) return HSQP_ERR_NUMERIC;
   double t2 = omp_get_wtime();
-  if (cent) riccati_forward<CNX>(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx);
-  else riccati_forward(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx);
+  if (cent) riccati_forward<CNX>(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
+  else riccati_forward(ctx, rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
   double pa0 = 0, pa1 = 0, pa2 = 0;
 #pragma omp parallel for num_threads(inner) schedule(static) if (inner > 1)
   for (int k = 0; k < N; ++k) {
     Workspaces& w = ws[omp_get_thread_num()];
     Ctx c2{0, 1, nullptr};
     step_node(c2, *w.step, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],
-              du + k * NU, x_new + k * NX, u_new + k * NU);
+              du + k * NU, x_new + k * NX, u_new + k * NU, nullptr, &ut[(size_t)k * NUT]);
   }
   for (int i = 0; i < NX; ++i) x_new[N * NX + i] = x[N * NX + i] + dx[N * NX + i];
   double t3 = omp_get_wtime();

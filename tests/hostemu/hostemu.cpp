@@ -331,12 +331,13 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   if (!rw->ok) return HSQP_ERR_NUMERIC;
   if (cent && g_scan && !g_segments) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
   else if (g_scan && !g_segments) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
-  else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
-  else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx);
+  else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
+  else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
+  const bool ut_given = !(g_scan && !g_segments);   // the serial roll-out leaves ut = k + K dx of every node (as k_riccati / k_ric_forward do)
   auto sw = std::make_unique<StepWS>();
   for (int k = 0; k < N; ++k)
     step_node(ctx, *sw, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],
-              du + k * NU, x_new + k * NX, u_new + k * NU);
+              du + k * NU, x_new + k * NX, u_new + k * NU, nullptr, ut_given ? &ut[(size_t)k * NUT] : nullptr);
   for (int i = 0; i < NX; ++i) x_new[N * NX + i] = x[N * NX + i] + dx[N * NX + i];
   auto kw = std::make_unique<KktWS>();
   kkt[0] = kkt[1] = 0.0;

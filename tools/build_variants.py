@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tuning builds of the HIP library (launch shapes etc.) -> wb_humanoid_mpc_amd/variants/libhsqp_<name>.so.
-Run on the build host; tools/gpu_variants.sh benches every variant found on the GPU box."""
+Run on the build host; tools/gpu_ab_quick.sh benches every variant found on the GPU box."""
 import os
 import sys
 

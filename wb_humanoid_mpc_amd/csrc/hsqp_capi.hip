@@ -128,7 +128,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                          const double* __restrict__ x, const double* __restrict__ par,
                                                          const double* __restrict__ qp, double* __restrict__ ric, int N,
                                                          double* __restrict__ dx, int* __restrict__ status, long long* prof,
-                                                         double* __restrict__ vf) {
+                                                         double* __restrict__ vf, double* __restrict__ ut) {
   const int b = blockIdx.x;
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
   const int bad = __syncthreads_or(mybad);
   riccati_backward<NXE>(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
   PH_TICK(ctx, 0);
-  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, qpb, ricb, N, dx + (size_t)b * (N + 1) * NX);
+  riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, xb, qpb, ricb, N, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT);
   PH_TICK(ctx, 10);
   // OR-accumulated over the iterations of one hsqp_iterate_device call (the host clears it once per call): a numeric failure
   // in an early iteration must not be masked by a later clean one
@@ -268,25 +268,26 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 // 4: the roll-out alone (k_riccati runs it behind its backward sweep)
 template <int NXE>
 __global__ __launch_bounds__(RIC_THREADS) void k_ric_forward(const double* __restrict__ x_init, const double* __restrict__ x, const double* __restrict__ qp,
-                                                             const double* __restrict__ ric, int N, double* __restrict__ dx) {
+                                                             const double* __restrict__ ric, int N, double* __restrict__ dx, double* __restrict__ ut) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, qp + (size_t)b * N * QP_SIZE, ric + (size_t)b * N * RIC_SIZE, N,
-                       dx + (size_t)b * (N + 1) * NX);
+                       dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT);
 }
 
-// ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N
+// ---- input recovery + step: one 64-thread workgroup per (instance, node); the last node of an instance also steps x_N.
+//      ut_given: ut holds ut = k + K dx of every node already (the serial roll-out writes it as it goes) and the gains are not read
 __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, const double* __restrict__ ric, const double* __restrict__ dx,
                                              const double* __restrict__ x, const double* __restrict__ u, int N, double alpha,
-                                             double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
-                                             double* __restrict__ u_new, double* __restrict__ info) {
+                                             double* ut, double* __restrict__ du, double* __restrict__ x_new,
+                                             double* __restrict__ u_new, double* __restrict__ info, int ut_given) {
   __shared__ StepWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, w, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
-            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4);
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr);
   if (k == N - 1)
     for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
 }
@@ -299,8 +300,9 @@ __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, cons
 __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const DevModel* __restrict__ dm, const double* __restrict__ qp, const double* __restrict__ ric,
                                                                           const double* __restrict__ dx, const double* __restrict__ x, const double* __restrict__ u,
                                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, double alpha,
-                                                                          double* __restrict__ ut, double* __restrict__ du, double* __restrict__ x_new,
-                                                                          double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc, long long* prof) {
+                                                                          double* ut, double* __restrict__ du, double* __restrict__ x_new,
+                                                                          double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc, long long* prof,
+                                                                          int ut_given) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   LqWST<false>& w = *reinterpret_cast<LqWST<false>*>(hsqp_smem);
   static_assert(sizeof(StepWS) <= sizeof(w.st), "the step scratch aliases the stage workspace");
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
   PH_TICK(ctx, 126);
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, sw, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
-            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4);
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr);
   WG_SYNC(ctx);
   WG_FOR(ctx, i, NX + NU + NX) {
     if (i < NX) w.nw.x[i] = x[xo + i] + alpha * sw.dx[i];
@@ -764,7 +766,7 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
   }
   hipLaunchKernelGGL(k_seg_riccati<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_el[cur], h->d_ric, N, P,
                      h->d_scanst, h->d_vf2, want_vf ? 0 : 2);
-  hipLaunchKernelGGL(k_ric_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_ric, N, h->d_dx);
+  hipLaunchKernelGGL(k_ric_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_ric, N, h->d_dx, h->d_ut);
   return HSQP_OK;
 }
 
@@ -1102,29 +1104,31 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool scan = pscan || segP > 0;        // either way a KKT-gated sweep with the serial recursion as fallback
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
+    int ut_given = 0;   // the last sweep's roll-out left ut = k + K dx of every node in d_ut (the serial roll-out does, the scan's closed-loop roll-out does not)
     auto launch_sweep = [&](bool use_scan, bool need_vf) -> int {
+      ut_given = (use_scan && segP == 0) ? 0 : 1;
       if (use_scan && segP > 0) return cent ? launch_segmented<CNX>(h, B, N, segP, want_kkt != 0) : launch_segmented<NX>(h, B, N, segP, want_kkt != 0);
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
         hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr);
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       else
         hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
-                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr);
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       return HSQP_OK;
     };
     auto launch_step = [&]() {
       if (cent)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                           h->d_xnew, h->d_unew, h->d_stepinfo);
+                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given);
       else if (h->value_quad) {   // whole-body: the step (HBM-bound), then the value pass on quads of lanes (hsqp_lqv.h)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                           h->d_xnew, h->d_unew, h->d_stepinfo);
+                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given);
         hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                            N, nodes, h->d_misc, (const LsState*)nullptr);
       } else   // a tree with more than four limbs: the phase form of the value pass, fused with the step (k_step_value)
         hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
-                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384);
+                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384, ut_given);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
       if (!from_scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // kkt, |g|_inf (and the scan flags) are one block; the scan path has zeroed it before its kernels

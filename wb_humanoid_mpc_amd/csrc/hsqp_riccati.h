@@ -532,8 +532,11 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
 // Forward sweep dx+ = A~ dx + B~ (K dx + k) + b~ (serial over stages); writes dx [N+1][58].  qp: the stage QP records, ric: the gains.
 // Three phases per stage: (1) the partial sums of A~ dx (58 rows) and K dx (23 rows), four per row; (2) the partial sums of B~ ut with
 // ut = k + K dx taken from the partial sums of (1) by every item itself (no separate phase for 23 numbers); (3) dx+.
+// ut_out (optional, [N][NUT]): ut = k + K dx of every stage as the sweep forms it (the device path: bit for bit what step_node would compute from the same
+// dx — the same partial sums in the same order), so that the step kernel need not read the gains again (10.7 of its 33 KB per node)
 template <int NXE = NX>
-HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* qp, const double* ric, int N, double* dx_out) {
+HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, const double* x, const double* qp, const double* ric, int N, double* dx_out,
+                             double* ut_out = nullptr) {
   WG_FOR(ctx, i, NX) {
     const double d = x_init[i] - x[i];
     w.dx[i] = d;
@@ -590,6 +593,7 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
             if (p == 0) w.zv[row - NX] = s;
           } else if (isk) w.kv[it - NR1] = sc[u];
           WG_SYNC(ctx);
+          if (ut_out && it < NUT) ut_out[(size_t)k * NUT + it] = w.kv[it] + w.zv[it];
           {
             double s = rowA ? s1 + (p == 0 ? sc[u] : 0.0) : 0.0;      // A~ dx slice (+ b~ on the first lane of the quad)
 #pragma unroll
@@ -624,6 +628,7 @@ HSQP_HD void riccati_forward(const Ctx& ctx, RicWS& w, const double* x_init, con
       else w.kv[it - NR1] = rk[RIC_KV + it - NR1];
     }
     WG_SYNC(ctx);
+    if (ut_out) WG_FOR(ctx, j, NUT) { const double* pj = &part1[4 * (NX + j)]; ut_out[(size_t)k * NUT + j] = w.kv[j] + ((pj[0] + pj[1]) + (pj[2] + pj[3])); }
     WG_FOR(ctx, it, 4 * NX) {
       const int row = it >> 2, p = it & 3;
       double s = 0.0;
@@ -756,8 +761,9 @@ struct StepWS {
 };
 // info (optional, 3 doubles): {q~.dx + r~.ut (Armijo descent metric of the projected QP, ocs2 multiple_shooting::
 // armijoDescentMetric on the projected cost), |dx|^2, |du|^2} of this node.
+// ut_in (optional): ut of this node as the serial roll-out left it (riccati_forward's ut_out); the gains are then not read.
 HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double* rk, const double* dx, const double* x, const double* u,
-                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr) {
+                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr, const double* ut_in = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads == 64) {
     // One-wave kernels (k_step, k_step_value): the phase-by-phase form below exposes four dependent HBM round trips (dx; the rows of K;
@@ -767,14 +773,14 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
     const int l = ctx.tid;
     constexpr int NCX = (NX + 3) / 4, NCU = (NUT + 3) / 4;
     const double dxl = l < NX ? dx[l] : 0.0, xl = l < NX ? x[l] : 0.0;
-    const double ul = l < NU ? u[l] : 0.0, pel = l < NU ? q[QP_PE + l] : 0.0, kvl = l < NUT ? rk[RIC_KV + l] : 0.0;
+    const double ul = l < NU ? u[l] : 0.0, pel = l < NU ? q[QP_PE + l] : 0.0, kvl = l < NUT ? (ut_in ? ut_in[l] : rk[RIC_KV + l]) : 0.0;
     const double qvl = (info && l < NX) ? q[QP_QV + l] : 0.0, rvl = (info && l < NUT) ? q[QP_RV + l] : 0.0;
     double kk[2][NCX], px[3][NCX], pu[3][NCU];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int it = l + 64 * j, r = it >> 2, pp = it & 3;
 #pragma unroll
-      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; kk[j][c] = (it < NUT * 4 && cc < NX) ? rk[RIC_K + r * NX + cc] : 0.0; }
+      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; kk[j][c] = (!ut_in && it < NUT * 4 && cc < NX) ? rk[RIC_K + r * NX + cc] : 0.0; }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -786,18 +792,22 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
     }
     if (l < NX) { w.dx[l] = dxl; x_new[l] = xl + alpha * dxl; }
     WG_SYNC(ctx);
+    if (ut_in) {   // (wave-uniform)
+      if (l < NUT) { w.ut[l] = kvl; if (ut_out != ut_in) ut_out[l] = kvl; }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int it = l + 64 * j, pp = it & 3;
-      if (it < NUT * 4) {
-        double sacc = 0.0;
+      for (int j = 0; j < 2; ++j) {
+        const int it = l + 64 * j, pp = it & 3;
+        if (it < NUT * 4) {
+          double sacc = 0.0;
 #pragma unroll
-        for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; if (cc < NX) sacc += kk[j][c] * w.dx[cc]; }
-        w.part[it] = sacc;
+          for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; if (cc < NX) sacc += kk[j][c] * w.dx[cc]; }
+          w.part[it] = sacc;
+        }
       }
+      WG_SYNC(ctx);
+      if (l < NUT) { const double v = kvl + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3])); w.ut[l] = v; ut_out[l] = v; }
     }
-    WG_SYNC(ctx);
-    if (l < NUT) { const double v = kvl + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3])); w.ut[l] = v; ut_out[l] = v; }
     WG_SYNC(ctx);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -835,9 +845,13 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
 #endif
   WG_FOR(ctx, i, NX) { w.dx[i] = dx[i]; x_new[i] = x[i] + alpha * dx[i]; }
   WG_SYNC(ctx);
-  WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_K + (it >> 2) * NX, w.dx, it & 3);
-  WG_SYNC(ctx);
-  WG_FOR(ctx, i, NUT) w.ut[i] = rk[RIC_KV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
+  if (ut_in) {
+    WG_FOR(ctx, i, NUT) w.ut[i] = ut_in[i];
+  } else {
+    WG_FOR(ctx, it, NUT * 4) w.part[it] = matvec_part<NX>(rk + RIC_K + (it >> 2) * NX, w.dx, it & 3);
+    WG_SYNC(ctx);
+    WG_FOR(ctx, i, NUT) w.ut[i] = rk[RIC_KV + i] + ((w.part[4 * i] + w.part[4 * i + 1]) + (w.part[4 * i + 2] + w.part[4 * i + 3]));
+  }
   WG_SYNC(ctx);
   WG_FOR(ctx, it, NU * 4 + NUT) {
     if (it < NU * 4) {
