@@ -6,12 +6,16 @@
     a feasible trajectory);
   * KKT residuals of the projected QP: r_stat, r_prim <= 1e-9 * max(1, |g|_inf), g = the stage-cost gradients of the instance.
 
-Measured on MI355X (tools/parity_report.py -> profiles/r02_parity_report.json): worst trajectory error 4.4e-9 (du, config 3),
-worst performance-index error 4.4e-11, worst normalised stationarity 3e-11 on the serial sweeps and on config 2's parallel-in-time
-sweep, worst primal residual 7e-14 — over BASELINE configs 1, 2, 3, 4 (instances 0, 37, 128, 255 of the 256) and a config-5 slice
-(N = 200, slow_walk, 8 instances).  Config 3 takes the parallel-in-time sweep by default: its stationarity is 1.07e-9 absolute, judged
-against the gradient of the projected QP (38) in tests/test_gpu_parity.py::test_config3_exactly_against_the_oracle[auto]; the serial
-path of the same config is held to the unprojected stage gradients as before ([serial])."""
+Measured on MI355X (tools/parity_report.py -> profiles/r04_parity_report.txt, round 4): worst trajectory error 6.1e-9 (du of config 3
+through the parallel-in-time sweep: 2.0e-11 of the step's scale; 3.2e-9 / 4.4e-9 on configs 4 / 5 with the serial sweep), worst
+performance-index error 5.3e-11, worst normalised stationarity 6.3e-13 on the serial sweeps, 3.0e-11 on config 2's and 9.2e-10 on config
+3's parallel-in-time sweep (both against the unprojected stage gradients: tests/test_gpu_parity.py::
+test_config3_exactly_against_the_oracle[auto] and [serial] use the same yardstick), worst primal residual 4.4e-14 — over BASELINE configs 1,
+2, 3, 4 (instances 0, 37, 128, 255 of the 256) and a config-5 slice (N = 200, slow_walk, 8 instances).
+
+Kernel variants of ONE quantity are held to each other more tightly than to the oracle: the value pass on quads of lanes against its
+phase form 1e-12 relative (sums over bodies / cost terms in another order), the blocked matrix-core factorisation against numpy's
+Cholesky 50 eps sqrt(cond) (tests/test_hostemu.py), reference-compiled assembly rows against the oracle 1e-12 (tests/test_ref_assembly.py)."""
 import numpy as np
 
 TRAJ_ABS = 1e-8
