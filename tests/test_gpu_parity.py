@@ -213,8 +213,9 @@ def test_instances_of_a_large_batch_equal_their_solo_solves(model):
 
 
 def test_config4_instances_against_oracle_at_full_size(model, oracle):
-    """BASELINE config 4 at full size (N = 100, 256 perturbed instances, every CU busy): two instances of the batch against the
-    CPU oracle; step max-abs <= 1e-8 * scale."""
+    """BASELINE config 4 at full size (N = 100, 256 perturbed instances, every CU busy): four instances of the batch against the CPU oracle
+    (step max-abs <= 1e-8; performance index before / after the step — at this size the value pass runs on quads of lanes, 16 nodes per wave), and
+    EVERY instance through the size-independent property the device reports itself: the KKT residual of its QP within 1e-9 max(1, |g|_inf)."""
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
     B, N = 256, 100
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True)
@@ -223,9 +224,13 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
         out = s.run(x0, x, u, par, dt)
     finally:
         s.close()
-    for b in (37, 255):
-        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4, want_perf=False)
+    for b in (0, 37, 128, 255):
+        r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4)
         assert_step(out, r, b, "config 4")
+        assert_perf(out["perf_before"][b], r["perf_before"], f"config 4 instance {b} before")
+        assert_perf(out["perf_after"][b], r["perf_after"], f"config 4 instance {b} after")
+    for b in range(B):
+        assert_kkt(out["kkt"][b], out["grad_inf"][b], f"config 4 instance {b}")
 
 
 @pytest.mark.parametrize("riccati", ["serial", "auto"])
