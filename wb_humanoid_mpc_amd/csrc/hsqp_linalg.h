@@ -7,6 +7,7 @@
 // VALU implementation: one work item = one TM x TN output tile with TM*TN independent accumulators
 // (latency hiding without extra waves; 2 LDS reads per TM*TN/(TM+TN) FMAs).  Host-testable.
 #pragma once
+#include <utility>
 #include "hsqp_common.h"
 
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -175,6 +176,20 @@ __device__ inline double quad_perm_f64(double v) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// a loop whose index is a compile-time constant in the body (DPP controls are immediates): f(std::integral_constant<int, 0>{}), ..., <N - 1>
+template <class F, int... K>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// DPP row broadcast of a double: every lane of a 16-lane row receives the value of lane K of ITS row (row_newbcast:K, gfx90a and later)
+template <int K>
+__device__ inline double row_bcast_f64(double v) {
+  static_assert(K >= 0 && K < 16, "lane within the row");
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + K, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + K, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value

@@ -294,51 +294,65 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   WG_SYNC(ctx);
   PH_TICK(ctx, 8);
 #if defined(__HIP_DEVICE_COMPILE__)
-  // device: the whole factorisation in the registers of ONE wave, no barrier and no LDS traffic per step.  Lane c holds column c of the
-  // 36 x 16 matrix (36 registers); the pivot column comes through v_readlane with compile-time lane numbers (its elements are then
-  // wave-uniform), norm, dot product and update are lane-local.  Same arithmetic per element as the two-phase form below (which the host
-  // build runs), summation order aside.
+  // device: the whole factorisation in the registers of ONE wave, no barrier and no LDS traffic per step.  Lane (g << 4) | c holds the rows
+  // 4 t + g (t = 0 .. 8) of column c of the 36 x 16 matrix — four row groups, one per DPP row of 16 lanes (round 3 kept a whole column in a
+  // lane: 16 of 64 lanes busy, 36 registers walked per step, 3.5 k vector instructions = 28 % of the workgroup's).  The pivot column comes to
+  // every lane of a row through one DPP row broadcast per register (row_newbcast:k — lane k of the own row holds the same rows of column k), the
+  // norm, the dot product and the own column's row-k entry through one butterfly over the four row groups.  The partial sums are those of the
+  // round-3 form (rows i mod 4, ascending; ((0 + 1) + (2 + 3))).  Same arithmetic per element as the two-phase form below
+  // (which the host build runs), summation order aside.
   if (ctx.tid < 64) {
-    const int c = ctx.tid & (LDR - 1);
-    const bool owner = ctx.tid < LDR;
-    double e[NU + 1];
+    const int lane = ctx.tid, g = lane >> 4, c = lane & 15;
+    constexpr int NT9 = (NU + 1) / 4;
+    static_assert(NT9 * 4 == NU + 1 && LDR == 16, "four row groups of nine rows, one column per lane of a DPP row");
+    double e[NT9];
 #pragma unroll
-    for (int i = 0; i <= NU; ++i) e[i] = w.qr.Rm[i][c];
-#pragma unroll
-    for (int k = 0; k < NE_MAX; ++k) {
+    for (int t = 0; t < NT9; ++t) e[t] = w.qr.Rm[4 * t + g][c];
+    auto xsum = [](double v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };   // over the four row groups, in every lane
+    static_for<NE_MAX>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
       if (k < ned) {
-        double x[NU + 1];
+        double x[NT9];
+        double pn = 0.0, pd = 0.0;
 #pragma unroll
-        for (int i = k; i <= NU; ++i) x[i] = readlane_f64(e[i], k);
-        double n4[4] = {0.0, 0.0, 0.0, 0.0}, d4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = k; i <= NU; ++i) { n4[i & 3] += x[i] * x[i]; d4[i & 3] += x[i] * e[i]; }
-        const double nrm2 = (n4[0] + n4[1]) + (n4[2] + n4[3]), rkk = x[k];
+        for (int t = k >> 2; t < NT9; ++t) {
+          x[t] = row_bcast_f64<k>(e[t]);
+          const bool in = 4 * t + g >= k;
+          const double xm = in ? x[t] : 0.0;
+          pn += xm * xm;
+          pd += xm * e[t];
+        }
+        const double ekp = g == (k & 3) ? e[k >> 2] : 0.0;        // row k of the own column (one row group holds it)
+        const double nrm2 = xsum(pn), dot = xsum(pd), ek = xsum(ekp);
+        const double rkk = readlane_f64(e[k >> 2], ((k & 3) << 4) | k);
         const double rs = inv_sqrt(nrm2 > 1e-300 ? nrm2 : 1e-300);
         const double nrm = nrm2 * rs;
         const double alpha = rkk >= 0.0 ? -nrm : nrm;
         const double hv = nrm2 - alpha * rkk;      // = |v|^2 / 2
         const double beta = hv > 1e-300 ? fast_rcp(hv) : 0.0;
-        const double sdot = beta * (((d4[0] + d4[1]) + (d4[2] + d4[3])) - alpha * e[k]);
-        if (ctx.tid == 0) {
+        const double sdot = beta * (dot - alpha * ek);
+        if (lane == 0) {
           w.qr.beta[k] = beta;
           w.qr.Rdiag[k] = alpha;
           w.qr.rinv[k] = rkk >= 0.0 ? -rs : rs;
           if (!(nrm >= 1e-12)) w.ok = 0;
         }
-        if (owner && c == k) {
+        if (c == k) {
 #pragma unroll
-          for (int i = 0; i <= NU; ++i) w.qr.V[k][i] = i < k ? 0.0 : (i == k ? x[k] - alpha : x[i]);
+          for (int t = 0; t < NT9; ++t) { const int i = 4 * t + g; w.qr.V[k][i] = i < k ? 0.0 : (i == k ? rkk - alpha : (t >= (k >> 2) ? x[t] : 0.0)); }
         } else if (c > k) {
-          e[k] -= sdot * (x[k] - alpha);
 #pragma unroll
-          for (int i = k + 1; i <= NU; ++i) e[i] -= sdot * x[i];
+          for (int t = k >> 2; t < NT9; ++t) {
+            const int i = 4 * t + g;
+            if (i == k) e[t] -= sdot * (rkk - alpha);
+            else if (i > k) e[t] -= sdot * x[t];
+          }
         }
       }
-    }
-    if (owner) {   // R1 above the diagonal (the W phase reads Rm[j][i], j < i)
+    });
+    if (c < LDR) {   // R1 above the diagonal (the W phase reads Rm[j][i], j < i)
 #pragma unroll
-      for (int j = 0; j < NE_MAX; ++j) if (j < c) w.qr.Rm[j][c] = e[j];
+      for (int t = 0; t < NT9; ++t) { const int j = 4 * t + g; if (j < NE_MAX && j < c) w.qr.Rm[j][c] = e[t]; }
     }
   }
   WG_SYNC(ctx);
