@@ -138,7 +138,7 @@ constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nb
 //   A[i][k] = X[k0 + (lane >> 4)][r0 + (lane & 15)],  B[k][j] = Y[k0 + (lane >> 4)][c0 + (lane & 15)],
 //   D: lane holds rows (lane >> 4) + 4 reg, column lane & 15  (reg = 0..3).
 // A job list is executed cooperatively: 16x16 output tiles are dealt round-robin to the waves of the workgroup.
-constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2;
+constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2, XTY_ROW_JUMP = 4;   // (XTY_ROW_JUMP: the jobs of the call use XtyJob::rsplit / rjump)
 struct XtyJob {
   int M, N;                       // output size
   int L1; const double* X1; int ldx1; const double* Y1; int ldy1;
@@ -150,6 +150,8 @@ struct XtyJob {
   int sx1, sx2;                   // element stride of X along the output-row index (1 = row-major X[l][r]; ld = 1, sx = ld' reads X'[r][l])
   int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
   double* C2; int ldc2, nc2;      // optional second destination in GLOBAL memory for the columns < nc2 (device tile path; the host build copies it from C)
+  int rsplit, rjump;              // rsplit > 0: output rows >= rsplit land rjump rows further down in C (two row blocks of one product written to
+                                  // separate places: the dense rows of [A~ | B~]); device tile path only with XTY_ROW_JUMP
 };
 
 HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const double* Y, int ldy, double* C, int ldc,
@@ -157,7 +159,7 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0; j.nc2 = 0;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0; j.nc2 = 0; j.rsplit = 0; j.rjump = 0;
   return j;
 }
 
@@ -188,8 +190,9 @@ template <int K>
 __device__ inline double row_bcast_f64(double v) {
   static_assert(K >= 0 && K < 16, "lane within the row");
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + K, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + K, 0xf, 0xf, false);
+  const int l0 = (int)(b & 0xffffffffll), h0 = (int)(b >> 32);   // (every lane is written: the source doubles as the "old" value, no zero to set up)
+  const int lo = __builtin_amdgcn_update_dpp(l0, l0, 0x150 + K, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(h0, h0, 0x150 + K, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // a double of lane `lane` (compile-time constant after unrolling) as a wave-uniform value
@@ -308,6 +311,12 @@ __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, c
       for (int r = 0; r < 4; ++r) v[r] = j.Add ? j.scale * acc[t][r] + addv[t][r] : j.scale * acc[t][r];
       auto put = [&](int r) {
         if (diag && rb + 4 * r > c) return;
+        if constexpr ((SPACES & XTY_ROW_JUMP) != 0) {
+          const int row = rb + 4 * r + ((j.rsplit > 0 && rb + 4 * r >= j.rsplit) ? j.rjump : 0);
+          if (SPACES & XTY_C_GLOBAL) ((hsqp_gptr)j.C)[row * j.ldc + c] = v[r];
+          else j.C[row * j.ldc + c] = v[r];
+          return;
+        }
         if (SPACES & XTY_C_GLOBAL) {
           ((hsqp_gptr)j.C)[o1 + 4 * r * j.ldc] = v[r];
           if (mirror || diag) ((hsqp_gptr)j.C)[o2 + 4 * r] = v[r];
@@ -431,7 +440,7 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
       for (int c = j.sym ? r : 0; c < N; ++c) {   // symmetric jobs: elements on / above the diagonal, mirrored
         double v = j.scale * acc[(size_t)r * N + c];
         if (j.Add) v += j.Add[r * j.ldadd + c];
-        j.C[r * j.ldc + c] = v;
+        j.C[(r + ((j.rsplit > 0 && r >= j.rsplit) ? j.rjump : 0)) * j.ldc + c] = v;
         if (j.sym && c != r) j.C[c * j.ldc + r] = v;
         if (j.C2 && c < j.nc2) j.C2[r * j.ldc2 + c] = v;
       }

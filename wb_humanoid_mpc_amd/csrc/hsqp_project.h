@@ -317,8 +317,8 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
 #pragma unroll
         for (int t = k >> 2; t < NT9; ++t) {
           x[t] = row_bcast_f64<k>(e[t]);
-          const bool in = 4 * t + g >= k;
-          const double xm = in ? x[t] : 0.0;
+          // (only the register that holds row k mixes finished rows — i < k — with live ones; g < 4 is not known to the compiler)
+          const double xm = (t > (k >> 2) || g >= (k & 3)) ? x[t] : 0.0;
           pn += xm * xm;
           pd += xm * e[t];
         }
@@ -339,13 +339,18 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         }
         if (c == k) {
 #pragma unroll
-          for (int t = 0; t < NT9; ++t) { const int i = 4 * t + g; w.qr.V[k][i] = i < k ? 0.0 : (i == k ? rkk - alpha : (t >= (k >> 2) ? x[t] : 0.0)); }
+          for (int t = 0; t < NT9; ++t) {
+            double v = 0.0;
+            if (t > (k >> 2)) v = x[t];
+            else if (t == (k >> 2)) v = g == (k & 3) ? rkk - alpha : (g > (k & 3) ? x[t] : 0.0);
+            w.qr.V[k][4 * t + g] = v;
+          }
         } else if (c > k) {
 #pragma unroll
           for (int t = k >> 2; t < NT9; ++t) {
-            const int i = 4 * t + g;
-            if (i == k) e[t] -= sdot * (rkk - alpha);
-            else if (i > k) e[t] -= sdot * x[t];
+            if (t > (k >> 2)) e[t] -= sdot * x[t];
+            else if (g == (k & 3)) e[t] -= sdot * (rkk - alpha);
+            else if (g > (k & 3)) e[t] -= sdot * x[t];
           }
         }
       }
@@ -554,23 +559,28 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // scaled row of Tm: item = (column c of [Px | Pu | Pe], row group), which walks down its column with constant strides
   {
     const int r1 = cent ? 6 : NV;   // first row of the second dense block
-    XtyJob ja0 = xty_job(6, NX, NU, &w.PV[0][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A, NX, &w.PV[0][0][0], LDJ);
-    XtyJob ja1 = xty_job(6, NX, NU, &w.PV[1][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A + r1 * NX, NX, &w.PV[1][0][0], LDJ);
-    XtyJob jb0 = xty_job(6, NUT, NU, &w.PV[0][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B, NUT);
-    XtyJob jb1 = xty_job(6, NUT, NU, &w.PV[1][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B + r1 * NUT, NUT);
-    ja0.sx1 = LDJ; ja1.sx1 = LDJ; jb0.sx1 = LDJ; jb1.sx1 = LDJ;
-    const XtyJob jobs[4] = {ja0, ja1, jb0, jb1};
-    wg_xty_jobs<true, XTY_C_GLOBAL>(ctx, jobs, 4);
+    // both dense row blocks in ONE product each (twelve rows of a 16-row tile instead of twice six): the rows of the second block land r1 - 6
+    // rows further down in the record (XTY_ROW_JUMP)
+    XtyJob ja = xty_job(12, NX, NU, &w.PV[0][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A, NX, &w.PV[0][0][0], LDJ);
+    XtyJob jb = xty_job(12, NUT, NU, &w.PV[0][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B, NUT);
+    ja.sx1 = LDJ; jb.sx1 = LDJ;
+    ja.rsplit = 6; ja.rjump = r1 - 6; jb.rsplit = 6; jb.rjump = r1 - 6;
+    const XtyJob jobs[2] = {ja, jb};
+    wg_xty_jobs<true, XTY_C_GLOBAL | XTY_ROW_JUMP>(ctx, jobs, 2);
   }
   constexpr int NCG = 3;   // row groups per column
-  WG_FOR(ctx, it, NCG * (NTW + 1) + 12) {
-    if (it >= NCG * (NTW + 1)) {   // b~ of the dense rows
-      const int i = it - NCG * (NTW + 1), pw = i / 6, pr = i % 6, r = cent ? i : (pw == 0 ? pr : NV + pr);
-      const double* Brow = &w.PV[pw][pr][NX];
-      double s = w.bvec[r];
+  constexpr int NCI = NCG * (NTW + 1), NBI = 256 - NCI;   // column items; the items left of one 256-thread round share the twelve b~ rows
+  static_assert(NBI >= 1 && NBI <= 12, "one round of the 256-thread workgroup (a second round would be wave 0's alone)");
+  WG_FOR(ctx, it, 256) {
+    if (it >= NCI) {   // b~ of the dense rows
+      for (int i = it - NCI; i < 12; i += NBI) {
+        const int pw = i / 6, pr = i % 6, r = cent ? i : (pw == 0 ? pr : NV + pr);
+        const double* Brow = &w.PV[pw][pr][NX];
+        double s = w.bvec[r];
 #pragma unroll 5
-      for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][NTW];
-      qp[QP_BV + r] = s;
+        for (int k = 0; k < NU; ++k) s += Brow[k] * w.Tm[k][NTW];
+        qp[QP_BV + r] = s;
+      }
       continue;
     }
     const int c = it % (NTW + 1), g = it / (NTW + 1);
