@@ -56,11 +56,11 @@ struct ProjWS {
     double PV[2][6][LDJ];        // the non-trivial rows of [A|B]: stored while Tm is being formed, over Rm / V / the scalars (dead by then)
     struct {
       double Jt[NRP][LDTM];      // the projected residual rows of the current pass (column 81 = rho')
-      double JuT[NU][NRP];       // transposed input block of the residual rows of the current (next) pass; overlaps Wm
+      double JuT[NU + 1][NRP];   // transposed input block of the residual rows of the current (next) pass (row NU: their rho); overlaps Wm
     } ps;
   };
   union {
-    double Tm[NU][LDTM];         // [Px (58) | Pu (23) | Pe | 0 ...]
+    double Tm[NU + 1][LDTM];     // [Px (58) | Pu (23) | Pe | 0 ...]; row NU = e_NTW: with rho as row NU of JuT the product J_u [Pu | Pe] also adds rho to its last column
     double CDe[NE_MAX][LDJ];     // the equality rows, until W = R1^-T [C|e] is formed (Tm is written after that)
   };
   int ne, nut, ok;
@@ -245,6 +245,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     }
     // structure of the equality rows (closed forms, one item per input / row): a swing foot f contributes the unit rows
     // off[f] .. off[f]+5 on the inputs 6f .. 6f+5
+    WG_FOR(ctx, i, LDTM) w.Tm[NU][i] = i == NTW ? 1.0 : 0.0;   // (beyond the equality rows that share the block until Tm is formed)
     WG_FOR(ctx, i, NU + NE_MAX + 1) {
       const int ne_ = (int)rec[REC_MISC];
       const int sw0 = rec[REC_MISC + 4] == 0.0 ? 1 : 0, sw1 = rec[REC_MISC + 5] == 0.0 ? 1 : 0;
@@ -527,12 +528,12 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   };
   auto store_ju = [&](int r0, int nr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    (void)r0;
 #pragma unroll
     for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < nr * NU) w.ps.JuT[e % NU][e / NU] = tju[j]; }
 #else
     WG_FOR(ctx, e, nr * NU) w.ps.JuT[e % NU][e / NU] = rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU];
 #endif
+    WG_FOR(ctx, e, NRP) w.ps.JuT[NU][e] = e < nr ? w.rho[r0 + e] : 0.0;   // rho rides as one more row of the contraction (against e_NTW, row NU of Tm)
   };
   // ---- Tm = [Px | Pu | Pe | 0 ...]:  [Px | Pe] = -Q1 W  (X^T Y with X = Q1^T);  Pu is in place
   load_pv();
@@ -621,15 +622,11 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   GramAcc g;
   gram_init(ctx, g);
   auto project_rows = [&](int r0, int nr) {
+    // (the second product carries rho' = rho + J_u Pe as its 24th column: 36 = 9 x 4 contraction steps, as many as for 35 — round 3 formed it
+    //  as 24 serial 35-term sums on one wave behind the tiles)
     const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
-                            xty_job(nr, NUT, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
+                            xty_job(nr, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
     wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
-    WG_FOR(ctx, i, nr) {
-      double sdot = w.rho[r0 + i];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) sdot += w.ps.JuT[k][i] * w.Tm[k][NTW];
-      w.ps.Jt[i][NTW] = sdot;
-    }
   };
   project_rows(0, NRP);
   WG_SYNC(ctx);
