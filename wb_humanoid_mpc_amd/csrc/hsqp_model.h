@@ -319,6 +319,19 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 22);
+  // totals and the block-diagonal base solve (one item).  Itot / ftot: the sums over all bodies
+  auto totals = [&](const double* Itot, const double* ftot) {
+    double Fext[6];
+    for (int k = 0; k < 6; ++k) Fext[k] = ws.Fx[0][k] + ws.Fx[1][k];
+    for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ftot[k];
+    const double* I6 = Itot + 4;
+    const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
+    m3_inverse(Ib, ws.Iinv);
+    m3_mulv(ws.Iinv, ws.Ftil, ws.y);
+    const double minv = 1.0 / Itot[0];
+    for (int k = 0; k < 3; ++k) ws.ab[k] = ws.Ftil[3 + k] * minv;
+    m3_mulv(ws.Einv, ws.y, ws.ab + 3);
+  };
   if (DERIV) {
     WG_FOR(ctx, it, NB * 6) {
       const int i = it / 6, k = it % 6;
@@ -349,7 +362,10 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
     // differences: an item = (quantity, half of the bodies), fully unrolled over its 12 bodies so that all loads are in flight
     // together (a rolled item loop pays two dependent LDS round trips per body: 7 k cycles per stage)
     static_assert(NB == 24, "two groups of twelve bodies");
-    WG_FOR(ctx, it, 2 * 52) {
+    // (one more item, on the second wave beside its 40 difference items: the totals and the base solve — after the suffix sums row 0 of
+    //  In / f IS the sum over all bodies, bit for bit the composite of the base (x - 0) — instead of a one-item phase of its own)
+    WG_FOR(ctx, it, 2 * 52 + 1) {
+      if (it == 2 * 52) { totals(ws.In[0], ws.f[0]); continue; }
       const int e = it % 52, i0 = (it / 52) * 12;
       const double* own = e < 10 ? &ws.In[0][e] : (e < 16 ? &ws.f[0][e - 10] : &ws.BB[0][e - 16]);
       double* comp = e < 10 ? &ws.Ic[0][e] : (e < 16 ? &ws.fc[0][e - 10] : &ws.BBc[0][e - 16]);
@@ -377,22 +393,10 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
   }
   WG_SYNC(ctx);
   PH_TICK(ctx, 24);
-  // ---- totals and the block-diagonal base solve
-  WG_FOR(ctx, it, 1) {
-    double Fext[6];
-    for (int k = 0; k < 6; ++k) Fext[k] = ws.Fx[0][k] + ws.Fx[1][k];
-    const double* ftot = ws.fc[0];
-    const double* Itot = ws.Ic[0];
-    for (int k = 0; k < 6; ++k) ws.Ftil[k] = Fext[k] - ftot[k];
-    const double* I6 = Itot + 4;
-    const double Ib[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
-    m3_inverse(Ib, ws.Iinv);
-    m3_mulv(ws.Iinv, ws.Ftil, ws.y);
-    const double minv = 1.0 / Itot[0];
-    for (int k = 0; k < 3; ++k) ws.ab[k] = ws.Ftil[3 + k] * minv;
-    m3_mulv(ws.Einv, ws.y, ws.ab + 3);
+  if (!DERIV) {
+    WG_FOR(ctx, it, 1) totals(ws.Ic[0], ws.fc[0]);
+    WG_SYNC(ctx);
   }
-  WG_SYNC(ctx);
   PH_TICK(ctx, 25);
   if (!DERIV) return;
   // ---- Jacobian columns: items (jc, kind in {q, qd, qdd}) and the 12 wrench components
