@@ -231,6 +231,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     double* dst1 = &w.bvec[0];
     double* dst2 = &w.rho[0];
     double* dst3 = &w.CDe[0][0];
+    // the scalars of the record that steer the structure items below: fetched WITH the block loads (behind the stores of the load loop they were a
+    // second, dependent HBM round trip in front of the factorisation)
+    const double m_ne = rec[REC_MISC], m_c0 = rec[REC_MISC + 4], m_c1 = rec[REC_MISC + 5], m_o0 = rec[REC_MISC + 6], m_o1 = rec[REC_MISC + 7], m_nr = rec[REC_NROWS];
     WG_FOR(ctx, b, nb) {
       double t[8];
 #pragma unroll
@@ -247,9 +250,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     // off[f] .. off[f]+5 on the inputs 6f .. 6f+5
     WG_FOR(ctx, i, LDTM) w.Tm[NU][i] = i == NTW ? 1.0 : 0.0;   // (beyond the equality rows that share the block until Tm is formed)
     WG_FOR(ctx, i, NU + NE_MAX + 1) {
-      const int ne_ = (int)rec[REC_MISC];
-      const int sw0 = rec[REC_MISC + 4] == 0.0 ? 1 : 0, sw1 = rec[REC_MISC + 5] == 0.0 ? 1 : 0;
-      const int off0 = (int)rec[REC_MISC + 6], off1 = (int)rec[REC_MISC + 7];
+      const int ne_ = (int)m_ne;
+      const int sw0 = m_c0 == 0.0 ? 1 : 0, sw1 = m_c1 == 0.0 ? 1 : 0;
+      const int off0 = (int)m_o0, off1 = (int)m_o1;
       const int nel = 6 * (sw0 + sw1);
       auto clamp6 = [](int v) { return v < 0 ? 0 : (v > 6 ? 6 : v); };
       if (i < NU) {
@@ -270,7 +273,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         w.ok = 1;
         w.ned = ne_ - nel;
         w.nub = NU - nel;
-        w.nrows = (int)rec[REC_NROWS];
+        w.nrows = (int)m_nr;
       }
     }
   }
@@ -285,9 +288,12 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       // e' = e - D_a e_U: the eliminated inputs are fixed at -e_U (the unit rows have C = 0)
       double ep = 0.0;
       if (c < ned) {
+        // (only the twelve wrench inputs can be eliminated; a fixed loop over them in ascending order — the order of ub's tail — keeps its
+        //  loads independent: the walk over ub[nub ..] was twelve dependent LDS round trips on the phase's critical path)
         const int ri = w.rd[c];
         ep = w.CDe[ri][NZ];
-        for (int t = nub; t < NU; ++t) { const int ue = w.ub[t]; ep -= w.CDe[ri][NX + ue] * w.CDe[w.urow[ue]][NZ]; }
+#pragma unroll
+        for (int ue = 0; ue < 12; ++ue) { const int ur = w.urow[ue]; const double eu_ = w.CDe[ur >= 0 ? ur : 0][NZ]; if (ur >= 0) ep -= w.CDe[ri][NX + ue] * eu_; }
       }
       w.qr.ep[c] = ep;
     }
