@@ -443,17 +443,26 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     double col[NT4];
 #pragma unroll
     for (int t = 0; t < NT4; ++t) col[t] = (p + 4 * t == c && livec) ? 1.0 : 0.0;
-    for (int k = 0; k < ned; ++k) {
-      double vk[NT4], sdot = 0.0;
+    // (the next reflector is fetched while this one is applied: its loads do not depend on the column)
+    double vk[NT4], bk = 0.0;
+    auto fetch_v = [&](int k, double* v, double& b) {
 #pragma unroll
-      for (int t = 0; t < NT4; ++t) { const int i = p + 4 * t; vk[t] = i <= NU ? w.qr.V[k][i < NU + 1 ? i : NU] : 0.0; }
+      for (int t = 0; t < NT4; ++t) { const int i = p + 4 * t; v[t] = i <= NU ? w.qr.V[k][i < NU + 1 ? i : NU] : 0.0; }
+      b = w.qr.beta[k];
+    };
+    if (ned > 0) fetch_v(0, vk, bk);
+    for (int k = 0; k < ned; ++k) {
+      double vn[NT4], bn = 0.0;
+      fetch_v(k + 1 < ned ? k + 1 : k, vn, bn);
+      double sdot = 0.0;
 #pragma unroll
       for (int t = 0; t < NT4; ++t) sdot += vk[t] * col[t];
       sdot += quad_perm_f64<0xB1>(sdot);
       sdot += quad_perm_f64<0x4E>(sdot);
-      sdot *= w.qr.beta[k];
+      sdot *= bk;
 #pragma unroll
-      for (int t = 0; t < NT4; ++t) col[t] -= sdot * vk[t];
+      for (int t = 0; t < NT4; ++t) { col[t] -= sdot * vk[t]; vk[t] = vn[t]; }
+      bk = bn;
     }
     if (c < NU) {
       const int uc = w.ub[c];
@@ -551,7 +560,8 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       const int r = i / (LDTM - NTW), cc = i % (LDTM - NTW);
       if (cc == 0) {
         double sdot = 0.0;
-        for (int j = 0; j < ned; ++j) sdot += w.qr.Q1T[j][r] * w.qr.Wm[j][NX];
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) sdot += (j < ned ? w.qr.Q1T[j][r] : 0.0) * w.qr.Wm[j][NX];   // (fixed trip count: independent loads; rows >= ned of W are zero)
         w.Tm[r][NTW] = w.eu[r] - sdot;
       }
       else w.Tm[r][NTW + cc] = 0.0;
