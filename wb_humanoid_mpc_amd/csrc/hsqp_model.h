@@ -441,7 +441,7 @@ HSQP_HD void stage_eval(const Ctx& ctx, const DevModel& dm, StageWST<DERIV>& ws,
         double dext[3] = {0.0, 0.0, 0.0};
         for (int f = 0; f < 2; ++f) {
           const int cb = dm.contact_body[f];
-          if (jc < 3 || (cb >= bi && cb < bi + dm.subtree_size[bi])) {
+          if (jc < 3 || (cb >= bi && cb < bi + (int)ws.sub[bi])) {
             double d[3], dr[3], t[3];
             for (int k = 0; k < 3; ++k) d[k] = ws.rP[f][k] - (jc < 3 ? 0.0 : ws.r[bi][k]);
             v3_cross(Sx, d, dr);

@@ -60,11 +60,13 @@ HSQP_HD void ori_error_d(const double* R, const double* da, double* de) {  // di
   de[2] = 0.0;
 }
 
-// does revolute coordinate jc move body b?
-HSQP_HD bool supports(const DevModel& dm, int jc, int b) {
+// does revolute coordinate jc move body b?  (sub: the subtree sizes in the stage workspace — an LDS read in front of the item's LDS operands, not a
+// lane-indexed load from the model image in global memory)
+template <class SW>
+HSQP_HD bool supports(const SW& ws, int jc, int b) {
   if (jc < 3) return true;
   const int bi = jc - 2;
-  return b >= bi && b < bi + dm.subtree_size[bi];
+  return b >= bi && b < bi + (int)ws.sub[bi];
 }
 
 // pairs of collision points per constraint row (FootCollisionConstraint.cpp:118-141); point ids follow DevModel::coll_body:
@@ -289,7 +291,7 @@ HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw
     dpos_extra[col] = 1.0;
   } else if (col < NV) {
     const int jc = col - 3;
-    if (supports(dm, jc, b)) {
+    if (supports(ws, jc, b)) {
       const double* Sx = ws.S[jc];
       double dvv[6], daa[6], t[6], pc[3];
       for (int k = 0; k < 6; ++k) dvv[k] = vi[k] - ws.vl[jc][k];
@@ -317,7 +319,7 @@ HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw
       for (int k = 0; k < 6; ++k) da[k] = -t[k];
     } else {
       const int jc = c - 3;
-      if (supports(dm, jc, b)) {
+      if (supports(ws, jc, b)) {
         const double* Sx = ws.S[jc];
         double t[6];
         for (int k = 0; k < 6; ++k) dv[k] = Sx[k];
@@ -327,7 +329,7 @@ HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw
     }
   } else if (col >= NX + 12) {
     const int jc = 3 + (col - NX - 12);
-    if (supports(dm, jc, b))
+    if (supports(ws, jc, b))
       for (int k = 0; k < 6; ++k) da[k] = ws.S[jc][k];
   }
   // chain through the base acceleration a_b(z): d alpha += E G[3:6], d aO += G[0:3]  (S_e pass through O)
@@ -366,7 +368,7 @@ HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw
 HSQP_HD bool point_column(const DevModel& dm, const StageWS& ws, int body, const double* rpt, int c, double* d) {
   if (c < 3) { d[0] = d[1] = d[2] = 0.0; d[c] = 1.0; return true; }
   const int jc = c - 3;
-  if (!supports(dm, jc, body)) return false;
+  if (!supports(ws, jc, body)) return false;
   double pc[3];
   for (int k = 0; k < 3; ++k) pc[k] = rpt[k] - (jc < 3 ? 0.0 : ws.r[jc - 2][k]);
   v3_cross(ws.S[jc], pc, d);
@@ -435,7 +437,7 @@ HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS&
         double dlf[3] = {0, 0, 0}, dlm[3] = {0, 0, 0};
         if (col >= 3 && col < NV) {
           const int jc = col - 3;
-          if (supports(dm, jc, dm.contact_body[f])) {
+          if (supports(ws, jc, dm.contact_body[f])) {
             double t[3];
             v3_cross(nw.u + 6 * f, ws.S[jc], t);
             m3_tmulv(Rf, t, dlf);
