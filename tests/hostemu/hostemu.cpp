@@ -212,6 +212,16 @@ void emu_lq_node(void* h, const double* x, const double* u, const double* xnext,
   if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
   else { auto w = std::make_unique<LqWST<false>>(); lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
 }
+// the limb tables of the quad value pass (build_dev_model): out = {n_limbs, max_len, foot_limb[2], len[4], times every body 1 .. NB-1 is owned (NB - 1 entries)}
+void emu_limbs(void* h, int* out) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  out[0] = dm.n_limbs; out[1] = dm.limb_max_len; out[2] = dm.foot_limb[0]; out[3] = dm.foot_limb[1];
+  for (int l = 0; l < QV_LIMBS; ++l) out[4 + l] = dm.limb_len[l];
+  for (int b = 1; b < NB; ++b) out[8 + b - 1] = 0;
+  for (int l = 0; l < dm.n_limbs; ++l)
+    for (int k = 0; k < dm.limb_len[l]; ++k)
+      if ((dm.limb_own[l] >> k) & 1u) out[8 + (int)((dm.limb_path[l] >> (8 * k)) & 0xffull) - 1] += 1;
+}
 // the value pass on a quad of lanes (hsqp_lqv.h), lane by lane: misc[8]; returns the number of limbs (0: the model does not fit the form)
 int emu_value_quad(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, double* misc) {
   const DevModel& dm = *static_cast<DevModel*>(h);

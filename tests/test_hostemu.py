@@ -57,6 +57,17 @@ def test_lq_record_expands_to_the_oracle_blocks(model, oracle, emu, gait, n):
             assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
+def test_limb_tables_of_the_quad_value_pass(model, emu):
+    """build_dev_model's limbs (hsqp_host.h): the G1 tree has four root-to-leaf paths (two legs, waist + arm twice), the feet sit on different limbs,
+    and every moving body is owned — counted in the sums over bodies — by exactly one limb (the waist bodies, walked by both arm lanes, by the first)."""
+    lib, h = emu
+    out = np.zeros(8 + _abi.NB - 1, dtype=np.int32)
+    lib.emu_limbs(h, out.ctypes.data_as(C.POINTER(C.c_int)))
+    assert out[0] == 4 and out[2] != out[3] and min(out[2], out[3]) >= 0
+    assert sorted(out[4:8]) == [6, 6, 7, 7] and out[1] == 7
+    assert np.array_equal(out[8:], np.ones(_abi.NB - 1, dtype=np.int32))
+
+
 @pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 10), ("run", 14)])
 def test_value_pass_on_a_quad_of_lanes_equals_the_phase_form(model, emu, gait, n):
     """hsqp_lqv.h (one lane per limb, four lanes per node) against lq_node<false> (one wave per node, phases over an LDS workspace): the same
