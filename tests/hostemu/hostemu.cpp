@@ -12,12 +12,14 @@
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent_lq.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_lqv.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_lql.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_scan.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_segment.h"
 
 using namespace hsqp;
 
 static int g_scan_refinements = 0;   // whole-body scan: refinement passes (HSQP_SCAN_WB_REFINEMENTS in hsqp_capi.hip; emu_set_scan_refinements)
+static int g_lq_limb = 1;   // whole-body LQ approximation: limb-lane form (hsqp_lql.h) as the product runs it; 0: the phase form (lq_node<true>)
 static int g_scan = 0;   // centroidal formulation: backward sweep by the parallel scan (hsqp_scan.h) instead of the serial recursion
 
 // the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
@@ -202,14 +204,27 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 }
 
 
+// the limb-lane form of the model's derivative half (hsqp_lql.h): the four lanes of a node one after the other.  GT[4][96][6], as4[4][6], kin[emu_kin_size()]
+int emu_kin_size() { return KIN_SIZE; }
+void emu_set_lq_limb(int on) { g_lq_limb = on; }
+int emu_ql_ok(void* h) { return static_cast<DevModel*>(h)->ql_ok; }
+void emu_ql_node(void* h, const double* x, const double* u, double dt, double* GT, double* as4, double* kin) {
+  ql_node_host(*static_cast<DevModel*>(h), x, u, dt, GT, as4, reinterpret_cast<KinImg*>(kin));
+}
+
 // LQ record of one node (REC_SIZE doubles) + dense expansions for comparison with the oracle
 int emu_rec_size() { return REC_SIZE; }
 int emu_rec_misc_offset() { return REC_MISC; }
 int emu_rec_flow_offset() { return REC_FLOW; }
+int emu_rec_gs_offset() { return REC_GS; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
-  if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
+  if (deriv && g_lq_limb && dm.ql_ok) {   // the product's form: limb lanes for the model, then the node-term phases (hsqp_lql.h)
+    ql_node_host(dm, x, u, dt, rec + REC_GS, rec + REC_AS, reinterpret_cast<KinImg*>(rec + REC_KIN));
+    auto w = std::make_unique<LqbWS>();
+    lqb_node(ctx, dm, *w, x, u, xnext, par, dt, rec);
+  } else if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
   else { auto w = std::make_unique<LqWST<false>>(); lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
 }
 // the limb tables of the quad value pass (build_dev_model): out = {n_limbs, max_len, foot_limb[2], len[4], times every body 1 .. NB-1 is owned (NB - 1 entries)}
@@ -316,7 +331,12 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
     if (cent) { auto cw = std::make_unique<CentWST<true>>(); double* r = &rec[(size_t)k * REC_SIZE]; cent_lq_node2<true>(ctx, dm, *cw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC); }
-    else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
+    else if (g_lq_limb && dm.ql_ok) {
+      double* r = &rec[(size_t)k * REC_SIZE];
+      ql_node_host(dm, x + k * NX, u + k * NU, dt, r + REC_GS, r + REC_AS, reinterpret_cast<KinImg*>(r + REC_KIN));
+      auto bw = std::make_unique<LqbWS>();
+      lqb_node(ctx, dm, *bw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r);
+    } else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) return HSQP_ERR_NUMERIC;

@@ -20,6 +20,7 @@
 #include "hsqp_scan.h"
 #include "hsqp_segment.h"
 #include "hsqp_lqv.h"
+#include "hsqp_lql.h"
 
 using namespace hsqp;
 
@@ -42,6 +43,9 @@ constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 
 #ifndef HSQP_VALUE_QUAD_MIN_NODES
 #define HSQP_VALUE_QUAD_MIN_NODES 2048   /* handles sized below this keep the phase form of the whole-body value pass (hsqp_create) */
+#endif
+#ifndef HSQP_LQ_LIMB_MIN_NODES
+#define HSQP_LQ_LIMB_MIN_NODES 2048    /* handles sized below this keep the phase form of the whole-body LQ kernel (hsqp_create) */
 #endif
 #ifndef HSQP_PROJ_THREADS
 #define HSQP_PROJ_THREADS 256
@@ -377,6 +381,156 @@ __global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_
   if (live && L == 0) qv_write_misc(pn, dt, cost, eq, dyn, misc + (size_t)node * 8);
 }
 
+// ---- whole-body LQ approximation on limb lanes (hsqp_lql.h), part 1: the rigid-body model and its Jacobian at the four RK4 stages.  A wave
+//      evaluates QL_NODES nodes, one lane per limb; writes REC_GS (transposed), REC_AS, REC_KIN of the node's record.
+#ifndef HSQP_QL_WAVES
+#define HSQP_QL_WAVES 2          /* waves per workgroup: they share the body constants */
+#endif
+#ifndef HSQP_QL_WPE
+#define HSQP_QL_WPE 1            /* waves per SIMD the register budget is cut for (1: 512 registers per lane) */
+#endif
+constexpr int QL_WAVES = HSQP_QL_WAVES;
+struct QlWS {
+  QvConst k;
+  struct {
+    double x[QL_NODES][NX], u[QL_NODES][NU];
+    double csn[QL_MAXLEN][QL_THREADS][2];   // cos / sin of the joints a lane passed on its way to the leaf, for the way back
+  } wv[QL_WAVES];
+};
+__global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QL_WPE, HSQP_QL_WPE))) void k_lq_limb(
+    const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N, int nodes,
+    double* __restrict__ rec) {
+  __shared__ QlWS ws;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
+  auto& w = ws.wv[wave];
+  const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
+  const int b = node / N, k = node % N;
+  (void)b; (void)k;
+  const bool live = node0 + nn < nodes;
+  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, nullptr};
+  qv_load_const(ctx, *dm, ws.k, [] {});
+  for (int idx = lane; idx < QL_NODES * NZ; idx += QL_THREADS) {
+    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
+    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
+    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
+  }
+  __syncthreads();
+  const double* xs = w.x[nn];
+  const double* us = w.u[nn];
+  const double dt = dts[node];
+  double* grec = rec + (size_t)node * REC_SIZE;
+  KinImg* kin = reinterpret_cast<KinImg*>(grec + REC_KIN);
+  double* csn = &w.csn[0][lane][0];
+  constexpr int CSN_LD = QL_THREADS * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto quad_sum = [](double v) { v += quad_perm_f64<0xB1>(v); v += quad_perm_f64<0x4E>(v); return v; };   // the sum over the node's four lanes, in all of them
+  auto quad_x1 = [](double v) { return quad_perm_f64<0xB1>(v); };   // the value of lane L ^ 1 / L ^ 2 / L ^ 3 of the quad
+  auto quad_x2 = [](double v) { return quad_perm_f64<0x4E>(v); };
+  auto quad_x3 = [](double v) { return quad_perm_f64<0x1B>(v); };
+#else
+  auto quad_sum = [](double v) { return v; };
+  auto quad_x1 = quad_sum, quad_x2 = quad_sum, quad_x3 = quad_sum;
+#endif
+  const int foot_step = ql_foot_step(*dm, L);
+  const int max_len = dm->limb_max_len;
+  const bool own_root = (dm->limb_own[L] & 1u) != 0;
+  QlCarry c;
+  for (int i = 0; i < 6; ++i) { c.vb[i] = 0.0; c.ap[i] = 0.0; }
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    QlBaseKin bk;
+    QlState st;
+    QlShared sh;
+    double rP[3], Ff[3];
+    ql_base_kin(*dm, xs, s, dt, c, bk);
+    {
+      double part[16];
+      ql_forward(*dm, ws.k, xs, us, L, s, dt, bk, st, part, csn, CSN_LD, rP, Ff, (s == 0 && live) ? kin : nullptr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[e] = quad_sum(part[e]);
+      ql_base_solve(part, bk, sh);
+    }
+    if (live && L == 0) {
+      for (int i = 0; i < 6; ++i) grec[REC_AS + 6 * s + i] = sh.ab[i];
+      if (s == 0) {
+        for (int e = 0; e < 3; ++e) for (int i = 0; i < 3; ++i) kin->E[3 * i + e] = bk.w[e][i];
+        for (int i = 0; i < 3; ++i) kin->y[i] = sh.y[i];
+        for (int i = 0; i < 6; ++i) kin->ab[i] = sh.ab[i];
+      }
+    }
+    double* gs = grec + REC_GS + (size_t)s * LDJ * GT_LD;
+    auto emit = [&](int col, const double* g) {
+      if (!live) return;
+      double2* p = reinterpret_cast<double2*>(gs + col * GT_LD);
+      p[0] = make_double2(g[0], g[1]); p[1] = make_double2(g[2], g[3]); p[2] = make_double2(g[4], g[5]);
+    };
+    double cmp[NCMP];
+#pragma unroll
+    for (int e = 0; e < NCMP; ++e) cmp[e] = 0.0;
+#pragma unroll 1
+    for (int t = max_len - 1; t >= 0; --t) {
+      // limbs that join below this step hand over their composites (the G1 tree: the two arm lanes, once, at the torso)
+      const unsigned mg = dm->limb_merge[t][L];
+      const unsigned any = (unsigned)dm->limb_merge[t][0] | dm->limb_merge[t][1] | dm->limb_merge[t][2] | dm->limb_merge[t][3];
+      if (any & 2u) {
+        const double m = (mg & 2u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x1(cmp[e]);
+      }
+      if (any & 4u) {
+        const double m = (mg & 4u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x2(cmp[e]);
+      }
+      if (any & 8u) {
+        const double m = (mg & 8u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x3(cmp[e]);
+      }
+      ql_back_step(*dm, ws.k, xs, us, L, s, dt, t, st, cmp, sh, csn, CSN_LD, rP, Ff, foot_step, emit);
+    }
+    // ---- the base: composite of the whole robot = the limbs that own their root-side body + the base body; its columns
+    {
+      const double r0[3] = {0.0, 0.0, 0.0};
+      double In[10], own[NCMP];
+      ql_inertia(ws.k, 0, bk.R, r0, In);
+      ql_body_comp(In, bk.vl[2], bk.al[2], own);
+      const double mk = own_root ? 1.0 : 0.0;
+#pragma unroll
+      for (int e = 0; e < NCMP; ++e) cmp[e] = quad_sum(mk * cmp[e]) + own[e];
+    }
+    double dext_e[9];
+#pragma unroll
+    for (int jc = 0; jc < 3; ++jc) {
+      double dr[3], tt[3];
+      v3_cross(bk.w[jc], rP, dr);
+      v3_cross(dr, Ff, tt);   // (a lane without a foot carries rP = Ff = 0)
+      for (int i = 0; i < 3; ++i) dext_e[3 * jc + i] = quad_sum(tt[i]);
+    }
+    ql_base_columns(*dm, L, bk, cmp, sh, dext_e, rP, emit);
+    ql_carry_advance(xs, s, dt, sh, c);
+  }
+}
+
+// ---- ... part 2: node terms and the RK4 chain, one workgroup per (instance, node) in the phase form, fed by part 1's kinematics image
+#ifndef HSQP_LQB_THREADS
+#define HSQP_LQB_THREADS 128
+#endif
+#ifndef HSQP_LQB_WPE
+#define HSQP_LQB_WPE 3            /* 175 -> 168 registers: three waves per SIMD (A/B on config 4: k_lq_terms 1.04 -> 0.87 ms; 4: spills, 1.37 ms) */
+#endif
+constexpr int LQB_THREADS = HSQP_LQB_THREADS;
+__global__ __launch_bounds__(LQB_THREADS, HSQP_LQB_WPE) void k_lq_terms(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
+                                                                       const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec,
+                                                                       long long* prof) {
+  const int node = blockIdx.x, b = node / N, k = node % N;
+  LqbWS& w = *reinterpret_cast<LqbWS*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);
+  const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
+  lqb_node(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
+}
+
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
 __global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
                                                 const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
@@ -612,6 +766,7 @@ struct hsqp_handle {
                                               // state of the AUTOMATIC sweep choice only (a sweep forced by a flag is always attempted), reset by every upload
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
+  bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_terms) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
   bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
@@ -854,6 +1009,9 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   // per call: every solve of a handle runs the same arithmetic (an instance of a batch equals its solo solve bit for bit)
   h->value_quad = h->hdm.formulation == HSQP_FORM_WB && h->hdm.n_limbs > 0 && getenv("HSQP_VALUE_PHASE_FORM") == nullptr &&
                   (getenv("HSQP_VALUE_QUAD_FORM") != nullptr || (size_t)settings->max_batch * settings->max_nodes >= HSQP_VALUE_QUAD_MIN_NODES);
+  // the LQ approximation on limb lanes (hsqp_lql.h) is a throughput form like the quad value pass; same rule, same per-handle decision
+  h->lq_limb = h->hdm.formulation == HSQP_FORM_WB && h->hdm.ql_ok && getenv("HSQP_LQ_PHASE_FORM") == nullptr &&
+               (getenv("HSQP_LQ_LIMB_FORM") != nullptr || (size_t)settings->max_batch * settings->max_nodes >= HSQP_LQ_LIMB_MIN_NODES);
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return fail(HSQP_ERR_HIP, "hipSetDevice failed");
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
@@ -1071,7 +1229,11 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (cent) {
       hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
     }
-    else
+    else if (h->lq_limb) {   // limb lanes for the model (16 nodes per wave), then the node-term phases (hsqp_lql.h)
+      hipLaunchKernelGGL(k_lq_limb, dim3((nodes + QL_NODES * QL_WAVES - 1) / (QL_NODES * QL_WAVES)), dim3(QL_THREADS * QL_WAVES), 0, h->stream, h->d_dm, h->d_x, h->d_u,
+                         h->d_dt, N, nodes, h->d_rec);
+      hipLaunchKernelGGL(k_lq_terms, dim3(nodes), dim3(LQB_THREADS), sizeof(LqbWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec, h->d_prof);
+    } else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));

@@ -158,6 +158,11 @@ struct DevModel {
   unsigned limb_own[QV_LIMBS];
   int limb_max_len, n_limbs;
   int foot_limb[2];
+  // limb lanes of the LQ kernel (hsqp_lql.h): on the way back from the leaves, before step t lane L adds the composite of lane L ^ k for every set
+  // bit k (1..3) of limb_merge[t][L] — the limbs that hang off body path_L[t] below the part of the path the two lanes share.  ql_ok = 0: the tree
+  // does not fit that scheme (no limbs, or a foot's ancestors shared with another limb) and the LQ kernel keeps its phase form
+  unsigned char limb_merge[NANC][QV_LIMBS];
+  int ql_ok;
 };
 
 // ------------------------------------------------------------------------------------------------

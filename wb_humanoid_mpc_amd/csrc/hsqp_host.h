@@ -116,6 +116,51 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
     }
     if (fits && dm.foot_limb[0] == dm.foot_limb[1]) fits = false;
     dm.n_limbs = fits ? nl : 0;
+    // merge table of the LQ kernel's way back (hsqp_lql.h): simulate which bodies every lane's composite holds
+    dm.ql_ok = 0;
+    memset(dm.limb_merge, 0, sizeof(dm.limb_merge));
+    if (dm.n_limbs > 0) {
+      bool ok = true;
+      unsigned sets[QV_LIMBS] = {0, 0, 0, 0};
+      auto body_at = [&](int l, int t) { return (int)((dm.limb_path[l] >> (8 * t)) & 0xffull); };
+      for (int t = dm.limb_max_len - 1; t >= 0 && ok; --t) {
+        unsigned snap[QV_LIMBS];
+        for (int l = 0; l < QV_LIMBS; ++l) snap[l] = sets[l];
+        for (int l = 0; l < nl; ++l) {
+          if (t >= dm.limb_len[l]) continue;
+          const int i = body_at(l, t);
+          unsigned needed = 0;
+          for (int b = i + 1; b < i + dm.subtree_size[i]; ++b) needed |= 1u << b;
+          unsigned have = snap[l];
+          for (int k = 1; k < QV_LIMBS; ++k) {
+            const int p = l ^ k;
+            if (p >= nl || snap[p] == 0 || (snap[p] & ~needed) != 0 || (snap[p] & have) != 0) continue;
+            dm.limb_merge[t][l] |= (unsigned char)(1u << k);
+            have |= snap[p];
+          }
+          if (have != needed) ok = false;
+          sets[l] = have | (1u << i);
+        }
+      }
+      unsigned all = 0;
+      for (int l = 0; l < nl && ok; ++l) {
+        if (!(dm.limb_own[l] & 1u)) continue;
+        if (all & sets[l]) ok = false;
+        all |= sets[l];
+      }
+      if (all != ((1u << NB) - 2u)) ok = false;
+      // the ancestors of a foot may not be shared with another limb (the lane that forms their columns must hold the foot's contact point)
+      for (int f = 0; f < 2 && ok; ++f) {
+        const int l = dm.foot_limb[f];
+        for (int t = 0; t < dm.limb_len[l] && ok; ++t) {
+          const int b = body_at(l, t);
+          for (int l2 = 0; l2 < nl; ++l2)
+            if (l2 != l && t < dm.limb_len[l2] && body_at(l2, t) == b) ok = false;
+          if (b == md.contact[f].body) break;
+        }
+      }
+      dm.ql_ok = ok ? 1 : 0;
+    }
   }
   dm.gravity = md.gravity;
   for (int f = 0; f < 2; ++f) {

@@ -26,8 +26,12 @@ constexpr int REC_CDE = REC_GD + LDJ;             // [NE_MAX][LDJ] rows [C|D|e]
 constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [16] ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt), contact flags (2), first equality row of each foot (2), [8] = NROWS
 constexpr int REC_NROWS = REC_MISC + 8;           //      residual rows in use (compact layout, hsqp_node.h); the rows up to the end of their 24-row pass are zero
 constexpr int REC_FLOW = REC_MISC + 16;           // [64] xdot at (x,u)
-constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel)
-constexpr int REC_SIZE = REC_GS + 4 * 6 * LDJ;
+constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel; limb-lane form: transposed, [4][LDJ][6])
+constexpr int REC_AS = REC_GS + 4 * 6 * LDJ;      // [4][6]      base accelerations of the RK4 stages   } limb-lane form (hsqp_lql.h): from the model kernel
+constexpr int REC_KIN = REC_AS + 24;              // [KIN_DOUBLES] kinematics image of stage 1          } to the node-term kernel
+constexpr int KIN_DOUBLES = 4 * (NJC + 1) * 6 + (NB + 1) * 12 + 9 + 6 + 3 + 6;
+constexpr int REC_SIZE = REC_KIN + KIN_DOUBLES;
+static_assert(REC_GS % 2 == 0 && REC_KIN % 2 == 0 && REC_SIZE % 2 == 0, "16-byte aligned pieces");
 
 // Model constants: read from global memory through the vector L1 (every workgroup of a CU reads the same 9 KB), or,
 // with -DHSQP_DM_LDS=1, from a per-workgroup LDS copy (costs 9 KB of LDS = one workgroup of occupancy per CU).
@@ -87,7 +91,10 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
 // The RK4 sensitivity chain of ONE column of [A|B] (see lq_node): Ab_1 = G_1, Ab_s = direct(G_s) + c_s G_s[:, v_b] Ab_{s-1} + c_s c_{s-1} G_s[:, q_b] Ab_{s-2};
 // P6 = dt^2/6 (Ab_1 + Ab_2 + Ab_3), V6 = dt/6 (Ab_1 + 2 Ab_2 + 2 Ab_3 + Ab_4) -> rec[REC_PV].  gs = rec + REC_GS: the stage Jacobians as the
 // column phases wrote them; the own-column entries of a stage and its selection partners are fetched one stage ahead of their use.
+// GT: the stage Jacobians are stored transposed, [stage][column][6] (written by the limb lanes of hsqp_lql.h), else [stage][6][LDJ].
+template <bool GT = false>
 HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* rec) {
+  constexpr int RS = GT ? 1 : LDJ, CS = GT ? 6 : 1, SS = 6 * LDJ;   // strides of a row, a column, a stage
   const bool vcol = col >= NV && col < NX, acol = col >= NX + 12 && col < NZ;
   const int j = col - NX - 12;
   const int iA = col < NZ ? col : 0, iB = vcol ? col - NV : (acol ? NV + 6 + j : iA), iC = acol ? 6 + j : iA;
@@ -96,9 +103,9 @@ HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int
   double a2[6], a1[6], P[6], V[6];   // Ab_{s-2}, Ab_{s-1}
   double gA[6], gB[6], gC[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) { a1[r] = live * gs[r * LDJ + iA]; a2[r] = 0.0; P[r] = a1[r]; V[r] = a1[r]; }
+  for (int r = 0; r < 6; ++r) { a1[r] = live * gs[r * RS + iA * CS]; a2[r] = 0.0; P[r] = a1[r]; V[r] = a1[r]; }
 #pragma unroll
-  for (int r = 0; r < 6; ++r) { gA[r] = gs[(6 + r) * LDJ + iA]; gB[r] = gs[(6 + r) * LDJ + iB]; gC[r] = gs[(6 + r) * LDJ + iC]; }
+  for (int r = 0; r < 6; ++r) { gA[r] = gs[SS + r * RS + iA * CS]; gB[r] = gs[SS + r * RS + iB * CS]; gC[r] = gs[SS + r * RS + iC * CS]; }
 #pragma unroll
   for (int sg = 0; sg < 3; ++sg) {
     const double c = cs[sg], cprev = sg == 0 ? 0.0 : cs[sg - 1];
@@ -109,7 +116,7 @@ HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int
 #endif
     if (sg < 2) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) { nA[r] = gs[((sg + 2) * 6 + r) * LDJ + iA]; nB[r] = gs[((sg + 2) * 6 + r) * LDJ + iB]; nC[r] = gs[((sg + 2) * 6 + r) * LDJ + iC]; }
+      for (int r = 0; r < 6; ++r) { nA[r] = gs[(sg + 2) * SS + r * RS + iA * CS]; nB[r] = gs[(sg + 2) * SS + r * RS + iB * CS]; nC[r] = gs[(sg + 2) * SS + r * RS + iC * CS]; }
     }
 #pragma unroll 2
     for (int r = 0; r < 6; ++r) {   // (two rows at a time: fully unrolled, the scheduler fetches all 72 block entries first and spills)

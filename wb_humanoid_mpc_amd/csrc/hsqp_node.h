@@ -279,7 +279,8 @@ HSQP_HD double node_cost(const NW& nw) {
 
 // partial derivatives of one foot frame's kinematic quantities w.r.t. ONE column of z = [x;u]
 // out[18] = d{pos, ori, vlin, vang, alin, aang}/dz_col
-HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw, int f, int col, double* out) {
+template <class SW>
+HSQP_HD void foot_column(const DevModel& dm, const SW& ws, const NodeWS& nw, int f, int col, double* out) {
   const int b = dm.contact_body[f], jb = b + 2;
   const double* rP = ws.rP[f];
   const double* vi = ws.vl[jb];
@@ -365,7 +366,8 @@ HSQP_HD void foot_column(const DevModel& dm, const StageWS& ws, const NodeWS& nw
 }
 
 // derivative of a body-fixed point position w.r.t. generalized coordinate c (0..28); returns false if zero
-HSQP_HD bool point_column(const DevModel& dm, const StageWS& ws, int body, const double* rpt, int c, double* d) {
+template <class SW>
+HSQP_HD bool point_column(const DevModel& dm, const SW& ws, int body, const double* rpt, int c, double* d) {
   if (c < 3) { d[0] = d[1] = d[2] = 0.0; d[c] = 1.0; return true; }
   const int jc = c - 3;
   if (!supports(ws, jc, body)) return false;
@@ -378,7 +380,8 @@ HSQP_HD bool point_column(const DevModel& dm, const StageWS& ws, int body, const
 // First-order data: residual rows J (compact row layout of NodeWST, written to Jout[nrows_pad][LDJ], scaled by sqrt(dt)) and their
 // rho (rho_out[NRS]), d, gd (x dt), CDe.  After node_values() and node_scalars(); ws.G must hold the stage-1 Jacobian.
 // Everything here reads LDS and writes the record (and nw.d / nw.gd): one phase.
-HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const StageWS& ws, NodeWS& nw, double dt, double* Jout, double* CDe /*[NE_MAX][LDJ], global*/,
+template <class SW>
+HSQP_HD void node_derivatives(const Ctx& ctx, const DevModel& dm, const SW& ws, NodeWS& nw, double dt, double* Jout, double* CDe /*[NE_MAX][LDJ], global*/,
                               double* rho_out) {
   const double sdt = sqrt(dt);
   // ---- foot columns: task-space cost rows + stance / swing equality rows.  Items are grouped by the KIND of their column so that a
