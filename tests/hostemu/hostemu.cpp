@@ -204,12 +204,16 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 }
 
 
-// the limb-lane form of the model's derivative half (hsqp_lql.h): the four lanes of a node one after the other.  GT[4][96][6], as4[4][6], kin[emu_kin_size()]
-int emu_kin_size() { return KIN_SIZE; }
+// the limb-lane form of the whole-body LQ approximation (hsqp_lql.h): the four lanes of a node one after the other (k_lq_limb), then the chain /
+// defect pass (k_lq_chain); rec: REC_SIZE doubles, ZERO-FILLED by the caller (entries that are zero for every state are never written)
 void emu_set_lq_limb(int on) { g_lq_limb = on; }
 int emu_ql_ok(void* h) { return static_cast<DevModel*>(h)->ql_ok; }
-void emu_ql_node(void* h, const double* x, const double* u, double dt, double* GT, double* as4, double* kin) {
-  ql_node_host(*static_cast<DevModel*>(h), x, u, dt, GT, as4, reinterpret_cast<KinImg*>(kin));
+static void lq_limb_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* rec) {
+  Ctx ctx{0, 1, nullptr};
+  ql_node_host(dm, x, u, dt, rec);
+  ql_rows_host(dm, x, u, par, dt, rec);
+  auto cw = std::make_unique<LqChainWS>();
+  lq_chain_node(ctx, *cw, x, u, xnext, dt, rec);
 }
 
 // LQ record of one node (REC_SIZE doubles) + dense expansions for comparison with the oracle
@@ -220,10 +224,9 @@ int emu_rec_gs_offset() { return REC_GS; }
 void emu_lq_node(void* h, const double* x, const double* u, const double* xnext, const double* par, double dt, int deriv, double* rec) {
   const DevModel& dm = *static_cast<DevModel*>(h);
   Ctx ctx{0, 1, nullptr};
-  if (deriv && g_lq_limb && dm.ql_ok) {   // the product's form: limb lanes for the model, then the node-term phases (hsqp_lql.h)
-    ql_node_host(dm, x, u, dt, rec + REC_GS, rec + REC_AS, reinterpret_cast<KinImg*>(rec + REC_KIN));
-    auto w = std::make_unique<LqbWS>();
-    lqb_node(ctx, dm, *w, x, u, xnext, par, dt, rec);
+  if (deriv && g_lq_limb && dm.ql_ok) {   // the product's form for handles that fill the GPU
+    for (int i = 0; i < REC_SIZE; ++i) rec[i] = 0.0;
+    lq_limb_node(dm, x, u, xnext, par, dt, rec);
   } else if (deriv) { auto w = std::make_unique<LqWST<true>>(); lq_node<true>(ctx, dm, *w, x, u, xnext, par, dt, rec, rec + REC_MISC); }
   else { auto w = std::make_unique<LqWST<false>>(); lq_node<false>(ctx, dm, *w, x, u, xnext, par, dt, nullptr, rec + REC_MISC); }
 }
@@ -250,15 +253,15 @@ void emu_expand(const double* rec, double dt, double* AB, double* H, double* g, 
   const int nrows = (int)rec[REC_NROWS];   // compact residual rows (hsqp_node.h); rows beyond them are not part of the model
   for (int a = 0; a < NZ; ++a) {
     double ga = rec[REC_GD + a];
-    for (int r = 0; r < nrows; ++r) ga += rec[REC_J + r * LDJ + a] * rec[REC_RHO + r];
+    for (int r = 0; r < nrows; ++r) ga += rec_J_at(rec, r, a) * rec[REC_RHO + r];
     g[a] = ga;
     for (int b = 0; b < NZ; ++b) {
       double s = a == b ? rec[REC_D + a] : 0.0;
-      for (int r = 0; r < nrows; ++r) s += rec[REC_J + r * LDJ + a] * rec[REC_J + r * LDJ + b];
+      for (int r = 0; r < nrows; ++r) s += rec_J_at(rec, r, a) * rec_J_at(rec, r, b);
       H[a * NZ + b] = s;
     }
   }
-  for (int r = 0; r < NE_MAX; ++r) for (int c = 0; c <= NZ; ++c) CDe[r * (NZ + 1) + c] = rec[REC_CDE + r * LDJ + c];
+  for (int r = 0; r < NE_MAX; ++r) for (int c = 0; c <= NZ; ++c) CDe[r * (NZ + 1) + c] = rec_CDe_at(rec, r, c);
 }
 
 // per-node parameter table of one instance through the device-side generator (hsqp_params.h); returns 0 if every swing
@@ -332,10 +335,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
     const double dt = dts ? dts[k] : dt_uniform;
     if (cent) { auto cw = std::make_unique<CentWST<true>>(); double* r = &rec[(size_t)k * REC_SIZE]; cent_lq_node2<true>(ctx, dm, *cw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC); }
     else if (g_lq_limb && dm.ql_ok) {
-      double* r = &rec[(size_t)k * REC_SIZE];
-      ql_node_host(dm, x + k * NX, u + k * NU, dt, r + REC_GS, r + REC_AS, reinterpret_cast<KinImg*>(r + REC_KIN));
-      auto bw = std::make_unique<LqbWS>();
-      lqb_node(ctx, dm, *bw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r);
+      lq_limb_node(dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);   // (rec: zero-filled vector)
     } else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);

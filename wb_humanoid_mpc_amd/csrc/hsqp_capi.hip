@@ -381,13 +381,16 @@ __global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_
   if (live && L == 0) qv_write_misc(pn, dt, cost, eq, dyn, misc + (size_t)node * 8);
 }
 
-// ---- whole-body LQ approximation on limb lanes (hsqp_lql.h), part 1: the rigid-body model and its Jacobian at the four RK4 stages.  A wave
-//      evaluates QL_NODES nodes, one lane per limb; writes REC_GS (transposed), REC_AS, REC_KIN of the node's record.
+// ---- whole-body LQ approximation on limb lanes (hsqp_lql.h), kernel 1 of 3: the rigid-body model and its Jacobian at the four RK4 stages.  A wave
+//      evaluates QL_NODES nodes, one lane per limb; writes REC_GS (transposed) and REC_AS of the node's record.
 #ifndef HSQP_QL_WAVES
 #define HSQP_QL_WAVES 2          /* waves per workgroup: they share the body constants */
 #endif
 #ifndef HSQP_QL_WPE
 #define HSQP_QL_WPE 1            /* waves per SIMD the register budget is cut for (1: 512 registers per lane) */
+#endif
+#ifndef HSQP_QR_WPE
+#define HSQP_QR_WPE 1
 #endif
 constexpr int QL_WAVES = HSQP_QL_WAVES;
 struct QlWS {
@@ -397,17 +400,28 @@ struct QlWS {
     double csn[QL_MAXLEN][QL_THREADS][2];   // cos / sin of the joints a lane passed on its way to the leaf, for the way back
   } wv[QL_WAVES];
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QL_QUAD_OPS                                                                                                                                    \
+  auto quad_sum = [](double v) { v += quad_perm_f64<0xB1>(v); v += quad_perm_f64<0x4E>(v); return v; }; /* the sum over the node's four lanes, in all of them */ \
+  auto quad_x1 = [](double v) { return quad_perm_f64<0xB1>(v); }; /* the value of lane L ^ 1 / L ^ 2 / L ^ 3 of the quad */                       \
+  auto quad_x2 = [](double v) { return quad_perm_f64<0x4E>(v); };                                                                                 \
+  auto quad_x3 = [](double v) { return quad_perm_f64<0x1B>(v); };                                                                                 \
+  (void)quad_x1; (void)quad_x2; (void)quad_x3
+#else
+#define QL_QUAD_OPS                             \
+  auto quad_sum = [](double v) { return v; };  \
+  auto quad_x1 = quad_sum, quad_x2 = quad_sum, quad_x3 = quad_sum; (void)quad_x1; (void)quad_x2; (void)quad_x3
+#endif
 __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QL_WPE, HSQP_QL_WPE))) void k_lq_limb(
     const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N, int nodes,
-    double* __restrict__ rec) {
+    double* __restrict__ rec, long long* prof) {
   __shared__ QlWS ws;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
   auto& w = ws.wv[wave];
   const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
-  const int b = node / N, k = node % N;
-  (void)b; (void)k;
   const bool live = node0 + nn < nodes;
-  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, nullptr};
+  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);
   qv_load_const(ctx, *dm, ws.k, [] {});
   for (int idx = lane; idx < QL_NODES * NZ; idx += QL_THREADS) {
     const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
@@ -419,18 +433,9 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   const double* us = w.u[nn];
   const double dt = dts[node];
   double* grec = rec + (size_t)node * REC_SIZE;
-  KinImg* kin = reinterpret_cast<KinImg*>(grec + REC_KIN);
   double* csn = &w.csn[0][lane][0];
   constexpr int CSN_LD = QL_THREADS * 2;
-#if defined(__HIP_DEVICE_COMPILE__)
-  auto quad_sum = [](double v) { v += quad_perm_f64<0xB1>(v); v += quad_perm_f64<0x4E>(v); return v; };   // the sum over the node's four lanes, in all of them
-  auto quad_x1 = [](double v) { return quad_perm_f64<0xB1>(v); };   // the value of lane L ^ 1 / L ^ 2 / L ^ 3 of the quad
-  auto quad_x2 = [](double v) { return quad_perm_f64<0x4E>(v); };
-  auto quad_x3 = [](double v) { return quad_perm_f64<0x1B>(v); };
-#else
-  auto quad_sum = [](double v) { return v; };
-  auto quad_x1 = quad_sum, quad_x2 = quad_sum, quad_x3 = quad_sum;
-#endif
+  QL_QUAD_OPS;
   const int foot_step = ql_foot_step(*dm, L);
   const int max_len = dm->limb_max_len;
   const bool own_root = (dm->limb_own[L] & 1u) != 0;
@@ -442,27 +447,22 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
     QlState st;
     QlShared sh;
     double rP[3], Ff[3];
+    PH_TICK(ctx, 0);
     ql_base_kin(*dm, xs, s, dt, c, bk);
     {
       double part[16];
-      ql_forward(*dm, ws.k, xs, us, L, s, dt, bk, st, part, csn, CSN_LD, rP, Ff, (s == 0 && live) ? kin : nullptr);
+      ql_forward(*dm, ws.k, xs, us, L, s, dt, bk, st, part, csn, CSN_LD, rP, Ff);
 #pragma unroll
       for (int e = 0; e < 16; ++e) part[e] = quad_sum(part[e]);
       ql_base_solve(part, bk, sh);
     }
-    if (live && L == 0) {
+    PH_TICK(ctx, 1);
+    if (live && L == 0)
       for (int i = 0; i < 6; ++i) grec[REC_AS + 6 * s + i] = sh.ab[i];
-      if (s == 0) {
-        for (int e = 0; e < 3; ++e) for (int i = 0; i < 3; ++i) kin->E[3 * i + e] = bk.w[e][i];
-        for (int i = 0; i < 3; ++i) kin->y[i] = sh.y[i];
-        for (int i = 0; i < 6; ++i) kin->ab[i] = sh.ab[i];
-      }
-    }
     double* gs = grec + REC_GS + (size_t)s * LDJ * GT_LD;
-    auto emit = [&](int col, const double* g) {
+    auto putg = [&](int col, const double* g) {
       if (!live) return;
-      double2* p = reinterpret_cast<double2*>(gs + col * GT_LD);
-      p[0] = make_double2(g[0], g[1]); p[1] = make_double2(g[2], g[3]); p[2] = make_double2(g[4], g[5]);
+      ql_st2(gs + col * GT_LD, g[0], g[1]); ql_st2(gs + col * GT_LD + 2, g[2], g[3]); ql_st2(gs + col * GT_LD + 4, g[4], g[5]);
     };
     double cmp[NCMP];
 #pragma unroll
@@ -471,24 +471,25 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
     for (int t = max_len - 1; t >= 0; --t) {
       // limbs that join below this step hand over their composites (the G1 tree: the two arm lanes, once, at the torso)
       const unsigned mg = dm->limb_merge[t][L];
-      const unsigned any = (unsigned)dm->limb_merge[t][0] | dm->limb_merge[t][1] | dm->limb_merge[t][2] | dm->limb_merge[t][3];
-      if (any & 2u) {
+      const unsigned anym = (unsigned)dm->limb_merge[t][0] | dm->limb_merge[t][1] | dm->limb_merge[t][2] | dm->limb_merge[t][3];
+      if (anym & 2u) {
         const double m = (mg & 2u) ? 1.0 : 0.0;
 #pragma unroll
         for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x1(cmp[e]);
       }
-      if (any & 4u) {
+      if (anym & 4u) {
         const double m = (mg & 4u) ? 1.0 : 0.0;
 #pragma unroll
         for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x2(cmp[e]);
       }
-      if (any & 8u) {
+      if (anym & 8u) {
         const double m = (mg & 8u) ? 1.0 : 0.0;
 #pragma unroll
         for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x3(cmp[e]);
       }
-      ql_back_step(*dm, ws.k, xs, us, L, s, dt, t, st, cmp, sh, csn, CSN_LD, rP, Ff, foot_step, emit);
+      ql_back_step(*dm, ws.k, xs, us, L, s, dt, t, st, cmp, sh, csn, CSN_LD, rP, Ff, foot_step, putg);
     }
+    PH_TICK(ctx, 3);
     // ---- the base: composite of the whole robot = the limbs that own their root-side body + the base body; its columns
     {
       const double r0[3] = {0.0, 0.0, 0.0};
@@ -507,28 +508,91 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
       v3_cross(dr, Ff, tt);   // (a lane without a foot carries rP = Ff = 0)
       for (int i = 0; i < 3; ++i) dext_e[3 * jc + i] = quad_sum(tt[i]);
     }
-    ql_base_columns(*dm, L, bk, cmp, sh, dext_e, rP, emit);
+    ql_base_columns(*dm, L, bk, cmp, sh, dext_e, rP, putg);
     ql_carry_advance(xs, s, dt, sh, c);
+    PH_TICK(ctx, 4);
   }
 }
 
-// ---- ... part 2: node terms and the RK4 chain, one workgroup per (instance, node) in the phase form, fed by part 1's kinematics image
-#ifndef HSQP_LQB_THREADS
-#define HSQP_LQB_THREADS 128
-#endif
-#ifndef HSQP_LQB_WPE
-#define HSQP_LQB_WPE 3            /* 175 -> 168 registers: three waves per SIMD (A/B on config 4: k_lq_terms 1.04 -> 0.87 ms; 4: spills, 1.37 ms) */
-#endif
-constexpr int LQB_THREADS = HSQP_LQB_THREADS;
-__global__ __launch_bounds__(LQB_THREADS, HSQP_LQB_WPE) void k_lq_terms(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u,
-                                                                       const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec,
-                                                                       long long* prof) {
+// ---- ... kernel 2 of 3: the node terms of RK4 stage 1 — values, penalties, and the residual / equality rows of every column, formed by the lane
+//      that owns the column from the stage-1 Jacobian columns kernel 1 left in the record (a kinematics-only walk of the limb).  Writes REC_J,
+//      REC_CDE (transposed), REC_RHO, REC_D, REC_GD, REC_FLOW, REC_MISC.
+struct QrWS {
+  QvConst k;
+  struct {
+    double x[QL_NODES][NX], u[QL_NODES][NU];
+    double csn[QL_MAXLEN][QL_THREADS][2];
+    QlNodeLds nl[QL_NODES];                 // what the four lanes of a node share (foot frames, collision points, row scalings)
+  } wv[QL_WAVES];
+};
+static_assert(sizeof(QrWS) * (4 / QL_WAVES) <= 163840, "four waves per CU");
+__global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QR_WPE, HSQP_QR_WPE))) void k_lq_rows(
+    const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts,
+    int N, int nodes, double* __restrict__ rec) {
+  __shared__ QrWS ws;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
+  auto& w = ws.wv[wave];
+  const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;
+  const int b = node / N, k = node % N;
+  const bool live = node0 + nn < nodes;
+  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, nullptr};
+  qv_load_const(ctx, *dm, ws.k, [] {});
+  for (int idx = lane; idx < QL_NODES * NZ; idx += QL_THREADS) {
+    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
+    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
+    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
+  }
+  __syncthreads();
+  const double* xs = w.x[nn];
+  const double* us = w.u[nn];
+  const double* pn = par + ((size_t)b * (N + 1) + k) * NP;
+  QlNodeLds& nl = w.nl[nn];
+  const double dt = dts[node];
+  double* grec = rec + (size_t)node * REC_SIZE;
+  double* csn = &w.csn[0][lane][0];
+  constexpr int CSN_LD = QL_THREADS * 2;
+  QL_QUAD_OPS;
+  const int foot_step = ql_foot_step(*dm, L);
+  const int max_len = dm->limb_max_len;
+  QlCarry c;
+  for (int i = 0; i < 6; ++i) { c.vb[i] = 0.0; c.ap[i] = 0.0; }
+  QlBaseKin bk;
+  QlState st;
+  QlShared sh;
+  QlRows rw;
+  ql_base_kin(*dm, xs, 0, dt, c, bk);
+  ql_kin_to_leaf(*dm, ws.k, xs, us, L, bk, csn, CSN_LD, st, nl);
+  ql_shared_from_record(bk, grec, sh);
+  {
+    // the lane's foot and its share of the cost (pass A), then what needs every lane's pass A (pass B).  The four lanes of a node sit in one
+    // wave: a wave-level fence orders their LDS traffic
+    double cost, eq, cost2;
+    int any;
+    WV_SYNC();
+    ql_terms_a(*dm, xs, us, pn, L, dt, sh, nl, grec, live, cost, eq);
+    WV_SYNC();
+    ql_terms_b(*dm, xs, us, pn, L, dt, sh, nl, grec, live, cost2, any);
+    WV_SYNC();
+    cost = quad_sum(cost + cost2); eq = quad_sum(eq);
+    const int coll = quad_sum((double)any) > 0.0 ? 1 : 0;
+    ql_rows_setup(*dm, pn, L, dt, coll, rw);
+    if (live && L == 0) ql_write_misc(pn, dt, cost, eq, coll, grec + REC_MISC);
+  }
+  const double* gs = grec + REC_GS;
+#pragma unroll 1
+  for (int t = max_len - 1; t >= 0; --t) ql_rows_back_step(*dm, ws.k, rw, nl, xs, us, L, t, st, csn, CSN_LD, bk.w, foot_step, gs, grec, live);
+  ql_rows_base(*dm, rw, nl, us, L, bk, sh, gs, grec, live);
+}
+
+// ---- ... kernel 3 of 3: the RK4 chain and the defect: one workgroup per (instance, node), a lane per column of [A|B] (lq_chain_node, hsqp_lql.h)
+constexpr int LQC_THREADS = 128;
+__global__ __launch_bounds__(LQC_THREADS) void k_lq_chain(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N,
+                                                         double* __restrict__ rec) {
+  __shared__ LqChainWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
-  LqbWS& w = *reinterpret_cast<LqbWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
-  PH_TICK(ctx, 126);
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  lqb_node(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], rec + (size_t)node * REC_SIZE);
+  lq_chain_node(ctx, w, xk, u + (size_t)node * NU, xk + NX, dts[node], rec + (size_t)node * REC_SIZE);
 }
 
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
@@ -1036,6 +1100,8 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   h->d_scanst = reinterpret_cast<int*>(h->d_kkt + 3 * B);
   if (hipMemcpy(h->d_dm, &h->hdm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) return fail(HSQP_ERR_HIP, "model upload failed");
   if (hipMemset(h->d_prof, 0, 4 * 128 * sizeof(long long)) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
+  // the limb-lane LQ kernel never writes record entries that are zero for every state (hsqp_lql.h)
+  if (hipMemset(h->d_rec, 0, B * N * (size_t)REC_SIZE * 8) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
@@ -1229,10 +1295,11 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (cent) {
       hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
     }
-    else if (h->lq_limb) {   // limb lanes for the model (16 nodes per wave), then the node-term phases (hsqp_lql.h)
-      hipLaunchKernelGGL(k_lq_limb, dim3((nodes + QL_NODES * QL_WAVES - 1) / (QL_NODES * QL_WAVES)), dim3(QL_THREADS * QL_WAVES), 0, h->stream, h->d_dm, h->d_x, h->d_u,
-                         h->d_dt, N, nodes, h->d_rec);
-      hipLaunchKernelGGL(k_lq_terms, dim3(nodes), dim3(LQB_THREADS), sizeof(LqbWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec, h->d_prof);
+    else if (h->lq_limb) {   // limb lanes for the model and the node terms (16 nodes per wave), then the RK4 chain, a lane per column (hsqp_lql.h)
+      const dim3 qgrid((nodes + QL_NODES * QL_WAVES - 1) / (QL_NODES * QL_WAVES)), qblock(QL_THREADS * QL_WAVES);
+      hipLaunchKernelGGL(k_lq_limb, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_dt, N, nodes, h->d_rec, h->d_prof + 384);
+      hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, nodes, h->d_rec);
+      hipLaunchKernelGGL(k_lq_chain, dim3(nodes), dim3(LQC_THREADS), 0, h->stream, h->d_x, h->d_u, h->d_dt, N, h->d_rec);
     } else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
@@ -1702,12 +1769,12 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
           if (isH) {
             for (int b = 0; b < NZ; ++b) {
               double s = a == b ? r[REC_D + a] : 0.0;
-              for (int k = 0; k < nrows; ++k) s += r[REC_J + k * LDJ + a] * r[REC_J + k * LDJ + b];
+              for (int k = 0; k < nrows; ++k) s += rec_J_at(r, k, a) * rec_J_at(r, k, b);
               out[n * NZ * NZ + a * NZ + b] = s;
             }
           } else {
             double s = r[REC_GD + a];
-            for (int k = 0; k < nrows; ++k) s += r[REC_J + k * LDJ + a] * r[REC_RHO + k];
+            for (int k = 0; k < nrows; ++k) s += rec_J_at(r, k, a) * r[REC_RHO + k];
             out[n * NZ + a] = s;
           }
         }
@@ -1718,7 +1785,7 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
       if (!fetch_rec(rec)) return HSQP_ERR_HIP;
       out.resize(nodes * NE_MAX * (NZ + 1));
       for (size_t n = 0; n < nodes; ++n)
-        for (int r = 0; r < NE_MAX; ++r) memcpy(&out[(n * NE_MAX + r) * (NZ + 1)], &rec[n * REC_SIZE + REC_CDE + r * LDJ], (NZ + 1) * 8);
+        for (int r = 0; r < NE_MAX; ++r) for (int c = 0; c <= NZ; ++c) out[(n * NE_MAX + r) * (NZ + 1) + c] = rec_CDe_at(&rec[n * REC_SIZE], r, c);
       break;
     }
     case HSQP_BLK_NE: {

@@ -574,7 +574,7 @@ HSQP_HD void cent_lq_node2(const Ctx& ctx, const DevModel& dm, CentWST<DERIV>& w
     for (int i = 0; i < LDJ; ++i) cost += (&ws.part[0][0])[64 + i];
     misc[0] = ws.tv[3]; misc[1] = dt * cost; misc[2] = dt * ws.tv[1];
     misc[4] = ws.tv[4]; misc[5] = ws.tv[5]; misc[6] = ws.tv[6]; misc[7] = ws.tv[7];
-    if (DERIV) rec[REC_NROWS] = (double)NRS;   // this kernel fills every row slot (no compaction)
+    if (DERIV) { rec[REC_NROWS] = (double)NRS; rec[REC_LAYOUT] = 0.0; }   // this kernel fills every row slot (no compaction), row-major
   }
   if constexpr (DERIV) {
     // ---- chain the stage Jacobians per column: Ab_1 = G_1,  Ab_s = G_s + c_s G_s[:, 0..11] Ab_{s-1} (+ c_s G_s[:, q_j] for the column qd_j),

@@ -138,7 +138,8 @@ constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nb
 //   A[i][k] = X[k0 + (lane >> 4)][r0 + (lane & 15)],  B[k][j] = Y[k0 + (lane >> 4)][c0 + (lane & 15)],
 //   D: lane holds rows (lane >> 4) + 4 reg, column lane & 15  (reg = 0..3).
 // A job list is executed cooperatively: 16x16 output tiles are dealt round-robin to the waves of the workgroup.
-constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2, XTY_ROW_JUMP = 4;   // (XTY_ROW_JUMP: the jobs of the call use XtyJob::rsplit / rjump)
+constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2, XTY_ROW_JUMP = 4, XTY_ADD_T = 8;   // (XTY_ROW_JUMP: the jobs of the call use XtyJob::rsplit / rjump; XTY_ADD_T: the additive
+// term of every job of the call is stored transposed, Add[c * ldadd + r] — XtyJob::addt on the host)
 struct XtyJob {
   int M, N;                       // output size
   int L1; const double* X1; int ldx1; const double* Y1; int ldy1;
@@ -146,6 +147,7 @@ struct XtyJob {
   double sign2;
   double scale;                   // C = scale * acc + Add
   const double* Add; int ldadd;   // optional (may be global memory)
+  int addt;                       // Add is stored transposed: element (r, c) at Add[c * ldadd + r] (device tile path: with XTY_ADD_T)
   double* C; int ldc;             // destination (LDS or global)
   int sx1, sx2;                   // element stride of X along the output-row index (1 = row-major X[l][r]; ld = 1, sx = ld' reads X'[r][l])
   int sym;                        // M == N and the product is symmetric: only tiles on/above the diagonal are computed, C is mirrored
@@ -159,7 +161,7 @@ HSQP_HD XtyJob xty_job(int M, int N, int L, const double* X, int ldx, const doub
   XtyJob j;
   j.M = M; j.N = N; j.L1 = L; j.X1 = X; j.ldx1 = ldx; j.Y1 = Y; j.ldy1 = ldy;
   j.L2 = 0; j.X2 = X; j.ldx2 = ldx; j.Y2 = Y; j.ldy2 = ldy; j.sign2 = 1.0;
-  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0; j.nc2 = 0; j.rsplit = 0; j.rjump = 0;
+  j.scale = scale; j.Add = Add; j.ldadd = ldadd; j.C = C; j.ldc = ldc; j.sym = 0; j.sx1 = 1; j.sx2 = 1; j.C2 = nullptr; j.ldc2 = 0; j.nc2 = 0; j.rsplit = 0; j.rjump = 0; j.addt = 0;
   return j;
 }
 
@@ -239,7 +241,8 @@ __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, c
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rb + 4 * r, rc = (inside || row < j.M) ? row : j.M - 1;
-        if (SPACES & XTY_ADD_GLOBAL) addv[t][r] = ((hsqp_gcptr)j.Add)[rc * j.ldadd + cc];
+        if constexpr ((SPACES & XTY_ADD_T) != 0) addv[t][r] = ((hsqp_gcptr)j.Add)[cc * j.ldadd + rc];
+        else if (SPACES & XTY_ADD_GLOBAL) addv[t][r] = ((hsqp_gcptr)j.Add)[rc * j.ldadd + cc];
         else addv[t][r] = j.Add[rc * j.ldadd + cc];
       }
     }
@@ -439,7 +442,7 @@ HSQP_HD void wg_xty_jobs(const Ctx& ctx, const XtyJob* jobs, int njobs) {
     for (int r = 0; r < M; ++r)
       for (int c = j.sym ? r : 0; c < N; ++c) {   // symmetric jobs: elements on / above the diagonal, mirrored
         double v = j.scale * acc[(size_t)r * N + c];
-        if (j.Add) v += j.Add[r * j.ldadd + c];
+        if (j.Add) v += j.addt ? j.Add[c * j.ldadd + r] : j.Add[r * j.ldadd + c];
         j.C[(r + ((j.rsplit > 0 && r >= j.rsplit) ? j.rjump : 0)) * j.ldc + c] = v;
         if (j.sym && c != r) j.C[c * j.ldc + r] = v;
         if (j.C2 && c < j.nc2) j.C2[r * j.ldc2 + c] = v;

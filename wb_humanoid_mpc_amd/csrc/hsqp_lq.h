@@ -23,15 +23,16 @@ constexpr int REC_RHO = REC_J + NRS * LDJ;        // [NRS]
 constexpr int REC_D = REC_RHO + NRS;              // [LDJ]        Hessian diagonal (x dt)
 constexpr int REC_GD = REC_D + LDJ;               // [LDJ]        gradient, diagonal part (x dt)
 constexpr int REC_CDE = REC_GD + LDJ;             // [NE_MAX][LDJ] rows [C|D|e]
-constexpr int REC_MISC = REC_CDE + NE_MAX * LDJ;  // [16] ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt), contact flags (2), first equality row of each foot (2), [8] = NROWS
+constexpr int CDE_ROWS = 16;                      //              rows the equality block is allocated for (its transposed form keeps 16 per column)
+constexpr int REC_MISC = REC_CDE + CDE_ROWS * LDJ;  // [16] ne, cost (x dt), eq_sse (x dt), dyn_sse (x dt), contact flags (2), first equality row of each foot (2), [8] = NROWS, [9] = LAYOUT
 constexpr int REC_NROWS = REC_MISC + 8;           //      residual rows in use (compact layout, hsqp_node.h); the rows up to the end of their 24-row pass are zero
+constexpr int REC_LAYOUT = REC_MISC + 9;          //      0: REC_J [row][LDJ], REC_CDE [row][LDJ] (phase form, centroidal); 1: transposed, REC_J [column][NRS] with the row slots of
+                                                  //      hsqp_lql.h (ROWQ_*), REC_CDE [column][CDE_ROWS] — written column by column by the limb lanes
 constexpr int REC_FLOW = REC_MISC + 16;           // [64] xdot at (x,u)
 constexpr int REC_GS = REC_FLOW + 64;             // [4][6][LDJ] stage Jacobians d a_b/dz (scratch of the LQ kernel; limb-lane form: transposed, [4][LDJ][6])
-constexpr int REC_AS = REC_GS + 4 * 6 * LDJ;      // [4][6]      base accelerations of the RK4 stages   } limb-lane form (hsqp_lql.h): from the model kernel
-constexpr int REC_KIN = REC_AS + 24;              // [KIN_DOUBLES] kinematics image of stage 1          } to the node-term kernel
-constexpr int KIN_DOUBLES = 4 * (NJC + 1) * 6 + (NB + 1) * 12 + 9 + 6 + 3 + 6;
-constexpr int REC_SIZE = REC_KIN + KIN_DOUBLES;
-static_assert(REC_GS % 2 == 0 && REC_KIN % 2 == 0 && REC_SIZE % 2 == 0, "16-byte aligned pieces");
+constexpr int REC_AS = REC_GS + 4 * 6 * LDJ;      // [4][6]      base accelerations of the RK4 stages (limb-lane form: from the model kernel to the chain kernel)
+constexpr int REC_SIZE = REC_AS + 24;
+static_assert(REC_J % 2 == 0 && REC_CDE % 2 == 0 && REC_GS % 2 == 0 && REC_SIZE % 2 == 0, "16-byte aligned pieces");
 
 // Model constants: read from global memory through the vector L1 (every workgroup of a CU reads the same 9 KB), or,
 // with -DHSQP_DM_LDS=1, from a per-workgroup LDS copy (costs 9 KB of LDS = one workgroup of occupancy per CU).
@@ -219,7 +220,7 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
     for (int r = 0; r < w.nw.ne; ++r) eq += w.nw.eqv[r] * w.nw.eqv[r];
     misc[0] = (double)w.nw.ne;
     misc[1] = dt * node_cost(w.nw);
-    if (DERIV) misc[8] = (double)w.nw.nrows;   // (DERIV: misc = rec + REC_MISC, 16 wide)
+    if (DERIV) { misc[8] = (double)w.nw.nrows; misc[9] = 0.0; }   // (DERIV: misc = rec + REC_MISC, 16 wide; [9]: row-major layout)
     misc[2] = dt * eq;
     misc[3] = (dt > 0.0 ? dt : 1.0) * dyn;   // an event interval (dt = 0, identity jump map) counts its defect unscaled
     // structure of the equality rows for the projection: a swing foot's zero-wrench rows are unit rows of D (and have C = 0)
@@ -248,6 +249,10 @@ HSQP_HD void lq_node(const Ctx& ctx, const DevModel& dm_global, LqWST<DERIV>& w,
   PH_TICK(ctx, 8);
   }
 }
+
+// element (row, col) of the record's residual rows / equality rows in either layout (REC_LAYOUT) — debug / parity paths and tests
+inline double rec_J_at(const double* rec, int row, int col) { return rec[REC_LAYOUT] != 0.0 ? rec[REC_J + col * NRS + row] : rec[REC_J + row * LDJ + col]; }
+inline double rec_CDe_at(const double* rec, int row, int col) { return rec[REC_LAYOUT] != 0.0 ? rec[REC_CDE + col * CDE_ROWS + row] : rec[REC_CDE + row * LDJ + col]; }
 
 // Expand the structured record into the dense [A|B] (58 x 93) — used by the debug/parity path and by tests.
 inline void expand_AB(const double* rec, double dt, double* AB) {

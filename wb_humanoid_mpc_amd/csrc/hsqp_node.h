@@ -72,9 +72,9 @@ HSQP_HD bool supports(const SW& ws, int jc, int b) {
 // pairs of collision points per constraint row (FootCollisionConstraint.cpp:118-141); point ids follow DevModel::coll_body:
 // 0 ankle_l, 1 ankle_r, 2 f_l, 3 f_r, 4 l1, 5 r1, 6 l2, 7 r2, 8 k_l, 9 k_r
 HSQP_HD void coll_pair(int row, int& a, int& b) {
-  const int A[16] = {4, 4, 6, 6, 2, 2, 3, 3, 2, 8, 2, 4, 6, 3, 5, 7};
-  const int B[16] = {5, 7, 5, 7, 5, 7, 4, 6, 3, 9, 1, 1, 1, 0, 0, 0};
-  a = A[row]; b = B[row];
+  // (packed into two words: a table indexed by a run-time row would live in scratch memory)
+  constexpr unsigned long long A = 0x7536428233226644ull, B = 0x0001119364757575ull;
+  a = (int)((A >> (4 * row)) & 0xfull); b = (int)((B >> (4 * row)) & 0xfull);
 }
 // collision point p relative to O
 template <class SW>

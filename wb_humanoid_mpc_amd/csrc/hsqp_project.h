@@ -64,6 +64,7 @@ struct ProjWS {
     double CDe[NE_MAX][LDJ];     // the equality rows, until W = R1^-T [C|e] is formed (Tm is written after that)
   };
   int ne, nut, ok;
+  int jt;                        // the record's residual / equality rows are stored transposed (REC_LAYOUT)
   int nrows;                     // residual rows of the record in use (REC_NROWS); the third pass is skipped when they fit two
   // deflation of the unit rows of D (a swing foot's zero-wrench constraints W_f = 0 fix six inputs outright): the Householder
   // QR only sees the dense rows (ned of them) restricted to the free inputs (nub of them)
@@ -226,14 +227,15 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
     static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
-    static_assert(REC_D == REC_RHO + NRS && REC_GD == REC_D + LDJ && REC_CDE == REC_GD + LDJ && REC_MISC == REC_CDE + NE_MAX * LDJ, "record layout");
-    constexpr int n1 = 64, n2 = NRS + 2 * LDJ, n3 = NE_MAX * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
+    static_assert(REC_D == REC_RHO + NRS && REC_GD == REC_D + LDJ && REC_CDE == REC_GD + LDJ && REC_MISC == REC_CDE + CDE_ROWS * LDJ, "record layout");
+    constexpr int n1 = 64, n2 = NRS + 2 * LDJ, n3 = CDE_ROWS * LDJ, nld = n1 + n2 + n3, nb = nbatches(nld, 8);
     double* dst1 = &w.bvec[0];
     double* dst2 = &w.rho[0];
     double* dst3 = &w.CDe[0][0];
     // the scalars of the record that steer the structure items below: fetched WITH the block loads (behind the stores of the load loop they were a
     // second, dependent HBM round trip in front of the factorisation)
     const double m_ne = rec[REC_MISC], m_c0 = rec[REC_MISC + 4], m_c1 = rec[REC_MISC + 5], m_o0 = rec[REC_MISC + 6], m_o1 = rec[REC_MISC + 7], m_nr = rec[REC_NROWS];
+    const bool jt0 = rec[REC_LAYOUT] != 0.0;   // transposed residual / equality rows (limb-lane LQ kernel, hsqp_lql.h)
     WG_FOR(ctx, b, nb) {
       double t[8];
 #pragma unroll
@@ -243,7 +245,11 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         const int idx = b + j * nb;
         if (idx < n1) dst1[idx] = t[j];
         else if (idx < n1 + n2) dst2[idx - n1] = t[j];
-        else if (idx < nld) dst3[idx - n1 - n2] = t[j];
+        else if (idx < nld) {   // the equality rows; transposed record: element (row e % 16, column e / 16)
+          const int e = idx - n1 - n2;
+          if (!jt0) { if (e < NE_MAX * LDJ) dst3[e] = t[j]; }
+          else if (e % CDE_ROWS < NE_MAX) dst3[(e % CDE_ROWS) * LDJ + e / CDE_ROWS] = t[j];
+        }
       }
     }
     // structure of the equality rows (closed forms, one item per input / row): a swing foot f contributes the unit rows
@@ -274,11 +280,13 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
         w.ned = ne_ - nel;
         w.nub = NU - nel;
         w.nrows = (int)m_nr;
+        w.jt = jt0 ? 1 : 0;
       }
     }
   }
   WG_SYNC(ctx);
   const int ne = w.ne, nut = w.nut, ned = w.ned, nub = w.nub;
+  const bool jt = w.jt != 0;
   (void)ne;
   PH_TICK(ctx, 1);
   // ---- Householder QR of D^T.  Step k: every remaining column recomputes the reflector from column k (which is
@@ -536,7 +544,10 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   auto load_ju = [&](int r0, int nr) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads, ec = e < nr * NU ? e : 0; tju[j] = rec[REC_J + (r0 + ec / NU) * LDJ + NX + ec % NU]; }
+    for (int j = 0; j < TJU; ++j) {
+      const int e = ctx.tid + j * ctx.nthreads, ec = e < nr * NU ? e : 0;
+      tju[j] = jt ? rec[REC_J + (NX + ec / nr) * NRS + r0 + ec % nr] : rec[REC_J + (r0 + ec / NU) * LDJ + NX + ec % NU];   // (transposed: item = (input, row), rows contiguous)
+    }
 #else
     (void)r0; (void)nr;
 #endif
@@ -544,9 +555,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   auto store_ju = [&](int r0, int nr) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < nr * NU) w.ps.JuT[e % NU][e / NU] = tju[j]; }
+    for (int j = 0; j < TJU; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < nr * NU) { if (jt) w.ps.JuT[e / nr][e % nr] = tju[j]; else w.ps.JuT[e % NU][e / NU] = tju[j]; } }
 #else
-    WG_FOR(ctx, e, nr * NU) w.ps.JuT[e % NU][e / NU] = rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU];
+    WG_FOR(ctx, e, nr * NU) w.ps.JuT[e % NU][e / NU] = jt ? rec[REC_J + (NX + e % NU) * NRS + r0 + e / NU] : rec[REC_J + (r0 + e / NU) * LDJ + NX + e % NU];
 #endif
     WG_FOR(ctx, e, NRP) w.ps.JuT[NU][e] = e < nr ? w.rho[r0 + e] : 0.0;   // rho rides as one more row of the contraction (against e_NTW, row NU of Tm)
   };
@@ -640,9 +651,11 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   auto project_rows = [&](int r0, int nr) {
     // (the second product carries rho' = rho + J_u Pe as its 24th column: 36 = 9 x 4 contraction steps, as many as for 35 — round 3 formed it
     //  as 24 serial 35-term sums on one wave behind the tiles)
-    const XtyJob jobs[2] = {xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, rec + REC_J + r0 * LDJ, LDJ),
-                            xty_job(nr, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
-    wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
+    XtyJob jx = xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, jt ? rec + REC_J + r0 : rec + REC_J + r0 * LDJ, jt ? NRS : LDJ);
+    jx.addt = jt ? 1 : 0;
+    const XtyJob jobs[2] = {jx, xty_job(nr, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
+    if (jt) wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_ADD_T>(ctx, jobs, 2);
+    else wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
   };
   project_rows(0, NRP);
   WG_SYNC(ctx);
