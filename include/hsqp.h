@@ -363,9 +363,21 @@ const char* hsqp_last_error(const hsqp_handle* h);   /* h may be NULL: last crea
 /* Iterations since hsqp_create whose parallel-in-time sweep failed the KKT gate and were redone with the serial recursion (-1: h is NULL). */
 long long hsqp_scan_fallbacks(const hsqp_handle* h);
 /* Iterations that ran the serial recursion because the AUTOMATIC sweep choice was backing off after a rejected gate (a sweep forced by
- * HSQP_FLAG_PARALLEL_RICCATI / HSQP_FLAG_SEGMENTED_RICCATI is attempted every iteration; every upload resets the back-off). */
+ * HSQP_FLAG_PARALLEL_RICCATI / HSQP_FLAG_SEGMENTED_RICCATI is attempted every iteration; every upload resets the back-off unless
+ * hsqp_set_scan_backoff_persistent is on). */
 long long hsqp_scan_backoffs(const hsqp_handle* h);
+/* The gate's back-off across uploads.  Default (0): every hsqp_upload* starts a new problem and resets it — a handle's history never decides
+ * which sweep a problem takes.  1 (what a receding-horizon caller wants: ocs2's MPC_BASE::run uploads the shifted problem every cycle and
+ * runs sqpIteration = 1): the back-off survives uploads of the same (batch, n_nodes), so that a regime whose iterates keep failing the gate
+ * pays the rejected parallel-in-time sweep once in a while (after 1, 3, 7, .. 63 cycles) and not in every cycle; a change of shape resets it.
+ * host/HipSqpSolver.h switches it on. */
+int hsqp_set_scan_backoff_persistent(hsqp_handle* h, int on);
 const char* hsqp_version(void);
+/* Binary interface revision: bumped whenever a public struct or an entry point's meaning changes (5: hsqp_linesearch_settings::cost_tol,
+ * hsqp_set_scan_backoff_persistent).  A caller compares hsqp_abi_version() with the HSQP_ABI_VERSION it was compiled against before it
+ * passes structs (host/HipSqpSolver.h and the Python binding do). */
+#define HSQP_ABI_VERSION 5
+int hsqp_abi_version(void);
 int hsqp_device_count(void);
 
 #ifdef __cplusplus

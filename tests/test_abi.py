@@ -24,7 +24,7 @@ def test_header_declares_the_expected_entry_points():
         "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_scan_fallbacks", "hsqp_version", "hsqp_device_count",
         "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference", "hsqp_joint_torques", "hsqp_evaluate_policy",
         "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights", "hsqp_host_register", "hsqp_host_unregister",
-        "hsqp_scan_backoffs", "hsqp_get_term_weights", "hsqp_update_term_weights"])
+        "hsqp_scan_backoffs", "hsqp_get_term_weights", "hsqp_update_term_weights", "hsqp_set_scan_backoff_persistent", "hsqp_abi_version"])
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,6 +32,9 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(lib, name), name
     assert b"gfx950" in lib.hsqp_version()
+    # the binary interface revision: header, library and Python binding agree (a caller checks this before it passes structs: ADVICE r4)
+    hdr = int(re.search(r"#define\s+HSQP_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "hsqp.h")).read()).group(1))
+    assert lib.hsqp_abi_version() == hdr == _abi.ABI_VERSION and f"abi {hdr}".encode() in lib.hsqp_version()
 
 
 def test_struct_sizes_match_the_c_compiler(tmp_path):

@@ -686,6 +686,36 @@ def test_scan_back_off_is_per_problem_and_only_for_the_automatic_choice(model, o
     assert p1[1] == 0 and p1[0] >= a1[0], counts               # forced: attempted every time
 
 
+def test_scan_back_off_can_persist_over_the_cycles_of_a_receding_horizon(model):
+    """ADVICE r4 (medium): ocs2's MPC_BASE::run uploads the shifted problem every cycle and runs ONE iteration; with the back-off reset by every
+    upload a regime whose iterates fail the KKT gate paid the rejected parallel-in-time sweep in every cycle.  hsqp_set_scan_backoff_persistent
+    (host/HipSqpSolver.h switches it on) keeps the back-off over uploads of the same shape: the same four 'cycles' (upload + iterations from a
+    far-from-feasible iterate) attempt the scan less often and back off instead; the solutions are those of the serial recursion either way."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    N = 100
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=1, gait="walk")
+    counts, sols = {}, {}
+    for persistent in (False, True):
+        s = HipSqpSolver(model, max_nodes=N, max_batch=1, linesearch=True, riccati="auto")
+        try:
+            if persistent:
+                s.set_scan_backoff_persistent(True)
+            s.upload(x0, x, u, par, dt)
+            s.iterate(2, take_step=True, linesearch=True)      # leaves a far-from-feasible iterate: the next sweeps fail the gate
+            xs, us = s.download()["x"], s.download()["u"]
+            f0, b0 = s.scan_fallbacks(), s.scan_backoffs()
+            for _ in range(4):                                  # four cycles from that iterate: upload, one iteration
+                s.upload(x0, xs, us, par, dt)
+                s.iterate(1, take_step=False, linesearch=True)
+            counts[persistent] = (s.scan_fallbacks() - f0, s.scan_backoffs() - b0)
+            sols[persistent] = s.download()["dx"].copy()
+        finally:
+            s.close()
+    assert counts[False][1] == 0 and counts[False][0] >= 3, counts          # per problem: every cycle pays scan + fallback
+    assert counts[True][1] >= 2 and counts[True][0] < counts[False][0], counts   # persistent: backs off over the cycles
+    assert np.array_equal(sols[False], sols[True])                             # the serial recursion's step in both runs
+
+
 def test_value_pass_on_quads_of_lanes_equals_the_phase_form(model):
     """The whole-body value pass (performance index of the stepped trajectory, line-search trials) runs on quads of lanes — a lane per limb,
     16 nodes per wave (hsqp_lqv.h) — for handles sized to fill the GPU; HSQP_VALUE_PHASE_FORM / HSQP_VALUE_QUAD_FORM at hsqp_create force its phase form (one wave per

@@ -188,7 +188,9 @@ int main(int argc, char** argv) {
     f << "urdf package://g1_description/urdf/g1.urdf  // a remark behind a pair\n"
          "quoted \"a;b // c\" ; a real comment\n"
          "path //abs/dir\n"
-         "block { k1 v1 ; c\n k2 \"v 2\" }\n"; }
+         "block { k1 v1 ; c\n k2 \"v 2\" }\n"
+         "// a whole-line remark\n"
+         "outer { // remark behind a brace\n  key // a bare remark in the value position\n  k3 v3\n} // end\n"; }
   for (const auto& t : hsqp_host::detail::infoTokens(argv[1])) std::printf("[%s]", t.c_str());
   std::printf("\n");
   return 0;
@@ -204,4 +206,6 @@ def test_info_reader_comment_rules(tmp_path):
     exe = tmp_path / "i"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "wb_humanoid_mpc_amd", "host"), "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe), str(tmp_path / "t.info")], text=True).strip()
-    assert out == "[urdf][package://g1_description/urdf/g1.urdf][quoted][a;b // c][path][//abs/dir][block][{][k1][v1][k2][v 2][}]"
+    # (remarks at the start of a line, behind '{' / '}', and a bare "//" in the value position are remarks too)
+    assert out == ("[urdf][package://g1_description/urdf/g1.urdf][quoted][a;b // c][path][//abs/dir][block][{][k1][v1][k2][v 2][}]"
+                   "[outer][{][key][k3][v3][}]")

@@ -585,8 +585,11 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
 }
 
 // ---- ... kernel 3 of 3: the RK4 chain and the defect: one workgroup per (instance, node), a lane per column of [A|B] (lq_chain_node, hsqp_lql.h)
-constexpr int LQC_THREADS = 128;
-__global__ __launch_bounds__(LQC_THREADS) void k_lq_chain(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N,
+#ifndef HSQP_LQC_WPE
+#define HSQP_LQC_WPE 3
+#endif
+constexpr int LQC_THREADS = 128;   // (the 64 defect items must be one wave: lq_chain_node sums their squares with a butterfly)
+__global__ __launch_bounds__(LQC_THREADS, HSQP_LQC_WPE) void k_lq_chain(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N,
                                                          double* __restrict__ rec) {
   __shared__ LqChainWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
@@ -828,6 +831,7 @@ struct hsqp_handle {
   size_t vf0_capacity = 0;
   int seg_backoff = 0, seg_backoff_len = 0;   // after a rejected gated sweep (scan or two-level) the next seg_backoff iterations go straight to the serial recursion (doubling, <= 64);
                                               // state of the AUTOMATIC sweep choice only (a sweep forced by a flag is always attempted), reset by every upload
+  bool backoff_persistent = false;            // hsqp_set_scan_backoff_persistent: uploads of the same (B, N) keep the back-off
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
   bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_terms) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
@@ -991,7 +995,13 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
 
 extern "C" {
 
-const char* hsqp_version(void) { return "hsqp-hip 0.2 (gfx950, f64)"; }
+const char* hsqp_version(void) { return "hsqp-hip 0.3 (gfx950, f64, abi 5)"; }
+int hsqp_abi_version(void) { return HSQP_ABI_VERSION; }
+int hsqp_set_scan_backoff_persistent(hsqp_handle* h, int on) {
+  if (!h) return HSQP_ERR_BAD_ARG;
+  h->backoff_persistent = on != 0;
+  return HSQP_OK;
+}
 
 int hsqp_device_count(void) {
   int n = 0;
@@ -1194,9 +1204,10 @@ static int upload_impl(hsqp_handle* h, const hsqp_problem* p, bool device_src) {
   HCHECK(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, kind, h->stream));
   HCHECK(hipMemcpyAsync(h->d_par, p->node_params, B * (N + 1) * NP * 8, kind, h->stream));
   HCHECK(hipStreamSynchronize(h->stream));
+  const bool same_shape = h->B == p->batch && h->N == p->n_nodes;
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
-  h->seg_backoff = 0; h->seg_backoff_len = 0;   // the gate's history belongs to the problem that produced it
+  if (!(h->backoff_persistent && same_shape)) { h->seg_backoff = 0; h->seg_backoff_len = 0; }   // the gate's history belongs to the problem that produced it (receding-horizon callers opt out)
   return HSQP_OK;
 }
 
@@ -1268,9 +1279,10 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   release();
   if (rc != HSQP_OK) return rc;
   if (bad) { h->err = "a swing phase has no lift-off / touch-down inside the mode schedule"; return HSQP_ERR_BAD_ARG; }
+  const bool same_shape = h->B == p->batch && h->N == p->n_nodes;
   h->B = p->batch; h->N = p->n_nodes; h->dt = p->dt;
   h->have_problem = true; h->have_solution = false;
-  h->seg_backoff = 0; h->seg_backoff_len = 0;
+  if (!(h->backoff_persistent && same_shape)) { h->seg_backoff = 0; h->seg_backoff_len = 0; }
   return HSQP_OK;
 }
 
@@ -1526,8 +1538,8 @@ int hsqp_iteration_log(const hsqp_handle* h, int iteration, hsqp_perf* perf, dou
 
 int hsqp_update_weights(hsqp_handle* h, const double* Q, const double* R, const double* Qf) {
   if (!h) return HSQP_ERR_BAD_ARG;
-  // explicit lengths (Q: 58, R: 35, Qf: 58; the same buffer may be passed twice) and the conditions the model validation at hsqp_create
-  // applies: state weights finite and >= 0, input weights finite and > 0 (the reduced Hessian
+  // explicit lengths (Q: 58, R: 35, Qf: 58; the same buffer may be passed twice) and the conditions build_dev_model (hsqp_create, hsqp_update_term_weights)
+  // applies to them: state weights finite and >= 0, input weights finite and > 0 (the reduced Hessian
   // Lam = R~ + B~^T S B~ of every stage has to stay positive definite)
   const struct { const double* w; int n; bool positive; const char* name; } sets[3] = {{Q, NX, false, "Q"}, {R, NU, true, "R"}, {Qf, NX, false, "Qf"}};
   for (const auto& st : sets) {

@@ -1,5 +1,6 @@
 // Host-side construction of the device model image from the C-ABI model description.
 #pragma once
+#include <cmath>
 #include <string.h>
 
 #include <string>
@@ -215,6 +216,18 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
       }
   }
   if (!(dm.total_mass > 0.0)) return "total mass must be positive";
+  // weights, gains and barriers: ONE validation for hsqp_create and the live updaters (hsqp_update_weights / hsqp_update_term_weights).  State
+  // weights finite and >= 0; input weights finite and > 0 (the reduced Hessian Lam = R~ + B~^T S B~ of every stage has to stay positive
+  // definite); every task weight / gain finite; barrier mu and delta > 0
+  for (int i = 0; i < NX; ++i)
+    if (!std::isfinite(md.Q[i]) || md.Q[i] < 0.0 || !std::isfinite(md.Qf[i]) || md.Qf[i] < 0.0) return "Q / Qf must be finite and >= 0";
+  for (int i = 0; i < NU; ++i)
+    if (!std::isfinite(md.R[i]) || !(md.R[i] > 0.0)) return "R must be finite and > 0";
+  for (double v : md.foot_sqrt_w) if (!std::isfinite(v)) return "foot cost weights must be finite";
+  for (double v : {md.gain_pos_z, md.gain_ori, md.gain_linvel_z, md.gain_linvel_xy, md.gain_angvel, md.gain_linacc_z, md.gain_linacc_xy, md.gain_angacc})
+    if (!std::isfinite(v)) return "foot constraint gains must be finite";
+  for (const hsqp_barrier* b : {&md.friction_barrier, &md.moment_barrier, &md.joint_limit_barrier, &md.collision_barrier})
+    if (!std::isfinite(b->mu) || !std::isfinite(b->delta) || !(b->mu > 0.0) || !(b->delta > 0.0)) return "barrier mu and delta must be finite and > 0";
   return "";
 }
 

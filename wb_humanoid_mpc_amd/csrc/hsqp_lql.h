@@ -767,46 +767,47 @@ HSQP_HD void ql_put_coll(const DevModel& dm, const QlNodeLds& nl, const double* 
   }
 }
 
-// The rows of one JOINT column (KIND 0 / 1 / 2: d/dq, d/dqd, d/dqdd of joint i = body index, standing state st) of RK4 stage 1; g: the
-// column of the stage Jacobian, wE: the euler-rate axes (E g[3:6] = the column's angular base acceleration), sup: the joint moves the lane's foot
-template <int KIND>
-HSQP_HD void ql_rows_joint(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, const double* u, bool sup, int i, const double* S, const double* Sd,
+// The rows of one JOINT column (kind 0 / 1 / 2: d/dq, d/dqd, d/dqdd of joint i = body index, standing state st) of RK4 stage 1; g: the
+// column of the stage Jacobian, wE: the euler-rate axes (E g[3:6] = the column's angular base acceleration), sup: the joint moves the lane's foot.
+// kind is a run-time value on purpose: ONE copy of this code serves the three columns of a joint (as three template instances the kernel
+// was 15 k instructions = 120 KB, twice the instruction cache).
+HSQP_HD void ql_rows_joint(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, const double* u, int kind, bool sup, int i, const double* S, const double* Sd,
                            const QlState& st, const double (*wE)[3], const double* g, int col, double* rec, bool live) {
-  double dab[6], ef[2][7];
+  double dab[6], ef[2][7], out[2][18];
   for (int k = 0; k < 3; ++k) { dab[k] = wE[0][k] * g[3] + wE[1][k] * g[4] + wE[2][k] * g[5]; dab[3 + k] = g[k]; }
+  // every foot: the base acceleration moves its frame
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const QlFoot& ft = nl.ft[f];
-    const bool full = sup && f == rw.own;
-    double out[18];
-    if (full) {
-      double dv[6], da[6], drP[3] = {0.0, 0.0, 0.0};
-      if (KIND == 0) {
-        double dvv[6], daa[6], t[6], pc[3];
-        for (int k = 0; k < 6; ++k) { dvv[k] = ft.vl[k] - st.vl[k]; daa[k] = ft.al[k] - st.al[k]; }
-        mxm(S, dvv, dv);
-        mxm(S, daa, da);
-        mxm(Sd, dvv, t);
-        for (int k = 0; k < 6; ++k) da[k] += t[k];
-        for (int k = 0; k < 3; ++k) pc[k] = ft.rP[k] - st.r[k];
-        v3_cross(S, pc, drP);
-      } else if (KIND == 1) {
-        double t[6];
-        mxm(ft.vl, S, t);
-        for (int k = 0; k < 6; ++k) { dv[k] = S[k]; da[k] = 2.0 * Sd[k] - t[k]; }
-      } else {
-        for (int k = 0; k < 6; ++k) { dv[k] = 0.0; da[k] = S[k]; }
-      }
-      for (int k = 0; k < 6; ++k) da[k] += dab[k];
-      ql_frame_rows(ft, dv, da, drP, KIND == 0, S, out);
+  for (int f = 0; f < 2; ++f) ql_frame_rows_base(nl.ft[f], dab, out[f]);
+  const bool full = sup && rw.own >= 0;
+  if (full) {   // the lane's own foot hangs below the joint
+    const QlFoot& ft = nl.ft[rw.own];
+    double dv[6], da[6], drP[3] = {0.0, 0.0, 0.0}, o[18];
+    if (kind == 0) {
+      double dvv[6], daa[6], t[6], pc[3];
+      for (int k = 0; k < 6; ++k) { dvv[k] = ft.vl[k] - st.vl[k]; daa[k] = ft.al[k] - st.al[k]; }
+      mxm(S, dvv, dv);
+      mxm(S, daa, da);
+      mxm(Sd, dvv, t);
+      for (int k = 0; k < 6; ++k) da[k] += t[k];
+      for (int k = 0; k < 3; ++k) pc[k] = ft.rP[k] - st.r[k];
+      v3_cross(S, pc, drP);
+    } else if (kind == 1) {
+      double t[6];
+      mxm(ft.vl, S, t);
+      for (int k = 0; k < 6; ++k) { dv[k] = S[k]; da[k] = 2.0 * Sd[k] - t[k]; }
     } else {
-      ql_frame_rows_base(ft, dab, out);
+      for (int k = 0; k < 6; ++k) { dv[k] = 0.0; da[k] = S[k]; }
     }
-    ql_put_foot(dm, rw, f, full, out, col, rec, live, ef[f], -1);
+    for (int k = 0; k < 6; ++k) da[k] += dab[k];
+    ql_frame_rows(ft, dv, da, drP, kind == 0, S, o);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { if (rw.own == 0) out[0][k] = o[k]; else out[1][k] = o[k]; }
   }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) ql_put_foot(dm, rw, f, full && f == rw.own, out[f], col, rec, live, ef[f], -1);
   ql_put_cde(rw, ef[0], ef[1], col, rec, live);
-  if (KIND == 0 && sup && rw.own >= 0) ql_put_fm(dm, nl.ft[rw.own], rw.own, u, S, 0, col, rec, live);
-  if (KIND == 0 && rw.coll) ql_put_coll(dm, nl, S, st.r, i, i + dm.subtree_size[i], col, rec, live);
+  if (kind == 0 && full) ql_put_fm(dm, nl.ft[rw.own], rw.own, u, S, 0, col, rec, live);
+  if (kind == 0 && rw.coll) ql_put_coll(dm, nl, S, st.r, i, i + dm.subtree_size[i], col, rec, live);
 }
 
 // The rows of the BASE columns of stage 1, column by column as ql_base_columns forms them.
@@ -853,6 +854,7 @@ HSQP_HD void ql_rows_euler(const DevModel& dm, const QlRows& rw, const QlNodeLds
 // the base linear velocity columns and the base height column (the base acceleration depends on neither)
 HSQP_HD void ql_rows_base_linear(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, double* rec, bool live) {
   // base linear velocity c: S = {0, e_c}, dv = S, da = -(v_i x S) (foot_column "prismatic")
+#pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     double ef[2][7];
 #pragma unroll
@@ -963,16 +965,13 @@ HSQP_HD void ql_rows_back_step(const DevModel& dm, const QvConst& kc, const QlRo
   mxm(st.vl, S, Sd);
   if ((dm.limb_own[L] >> t) & 1u) {
     const bool sup = t <= foot_step;
-    double g[6];
-    const int cq = 3 + i + 2, cv = NV + 3 + i + 2, ca = NX + 12 + j;
-    for (int k = 0; k < 6; ++k) g[k] = gs[cq * GT_LD + k];
-    ql_rows_joint<0>(dm, rw, nl, u, sup, i, S, Sd, st, wE, g, cq, rec, live);
-    QV_SCHED_FENCE();
-    for (int k = 0; k < 6; ++k) g[k] = gs[cv * GT_LD + k];
-    ql_rows_joint<1>(dm, rw, nl, u, sup, i, S, Sd, st, wE, g, cv, rec, live);
-    QV_SCHED_FENCE();
-    for (int k = 0; k < 6; ++k) g[k] = gs[ca * GT_LD + k];
-    ql_rows_joint<2>(dm, rw, nl, u, sup, i, S, Sd, st, wE, g, ca, rec, live);
+#pragma unroll 1
+    for (int kind = 0; kind < 3; ++kind) {
+      const int col = kind == 0 ? 3 + i + 2 : (kind == 1 ? NV + 3 + i + 2 : NX + 12 + j);
+      double g[6];
+      for (int k = 0; k < 6; ++k) g[k] = gs[col * GT_LD + k];
+      ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, g, col, rec, live);
+    }
   }
   QV_SCHED_FENCE();
   ql_unwind(kc, i, S, Sd, qd, qdd, csn[t * csn_ld], csn[t * csn_ld + 1], st);
@@ -982,18 +981,19 @@ HSQP_HD void ql_rows_base(const DevModel& dm, const QlRows& rw, const QlNodeLds&
                           const double* gs, double* rec, bool live) {
   double g[6];
   if (L < 3) {
-    for (int k = 0; k < 6; ++k) g[k] = gs[(3 + L) * GT_LD + k];
-    ql_rows_euler(dm, rw, nl, u, 0, L, bk, sh, g, rec, live);
-    for (int k = 0; k < 6; ++k) g[k] = gs[(NV + 3 + L) * GT_LD + k];
-    ql_rows_euler(dm, rw, nl, u, 1, L, bk, sh, g, rec, live);
+#pragma unroll 1
+    for (int kind = 0; kind < 2; ++kind) {
+      for (int k = 0; k < 6; ++k) g[k] = gs[((kind == 0 ? 3 : NV + 3) + L) * GT_LD + k];
+      ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, g, rec, live);
+    }
   } else {
     ql_rows_base_linear(dm, rw, nl, rec, live);
   }
-  for (int f = 0; f < 2; ++f) {
-    if (dm.foot_limb[f] != L) continue;
+  if (rw.own >= 0) {
+#pragma unroll 1
     for (int k6 = 0; k6 < 6; ++k6) {
-      for (int k = 0; k < 6; ++k) g[k] = gs[(NX + 6 * f + k6) * GT_LD + k];
-      ql_rows_wrench(dm, rw, nl, u, f, k6, bk, g, rec, live);
+      for (int k = 0; k < 6; ++k) g[k] = gs[(NX + 6 * rw.own + k6) * GT_LD + k];
+      ql_rows_wrench(dm, rw, nl, u, rw.own, k6, bk, g, rec, live);
     }
   }
 }
@@ -1028,15 +1028,24 @@ HSQP_HD void lq_chain_node(const Ctx& ctx, LqChainWS& w, const double* x, const 
       b = x[i] + dt * a - xnext[i];
     }
     rec[REC_B + i] = b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the squared defect: a butterfly over the 64 lanes that hold it (wave 0) instead of a second barrier and one lane's 58-term sum
+    double sq = b * b;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    if (i == 0) rec[REC_MISC + 3] = (dt > 0.0 ? dt : 1.0) * sq;
+#else
     w.bvec[i] = b;
+#endif
   }
   WG_FOR(ctx, col, LDJ) lq_chain_column<true>(w.blk, rec + REC_GS, col, dt, rec);
-  WG_SYNC(ctx);
+#if !defined(__HIP_DEVICE_COMPILE__)
   WG_FOR(ctx, it, 1) {
     double dyn = 0.0;
     for (int i = 0; i < NX; ++i) dyn += w.bvec[i] * w.bvec[i];
     rec[REC_MISC + 3] = (dt > 0.0 ? dt : 1.0) * dyn;
   }
+#endif
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)

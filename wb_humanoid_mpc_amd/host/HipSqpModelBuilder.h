@@ -41,12 +41,17 @@ inline std::vector<std::string> infoTokens(const std::string& path) {
   while (std::getline(in, line)) {
     // Boost INFO: a comment starts at a ';' OUTSIDE a quoted string and runs to the end of the line.  "//" is NOT a comment marker there
     // (package:// URIs and paths are values) — but the reference's task files annotate entries as `key value  // remark`
-    // (g1_wb_mpc/config/mpc/task.info:3), so an unquoted token that STARTS with "//" behind a complete key-value pair of the same line ends it.
+    // (g1_wb_mpc/config/mpc/task.info:3), and user files also write `} // end`, `block { // remark`, `key // remark` or whole-line remarks.
     int words = 0;
     for (size_t i = 0; i < line.size();) {
       if (std::isspace((unsigned char)line[i])) { ++i; continue; }
       if (line[i] == ';') break;
-      if (words >= 2 && line.compare(i, 2, "//") == 0) break;
+      if (line.compare(i, 2, "//") == 0) {
+        // a remark: "//" anywhere but in the value position of a pair (first token of a line, behind a brace, behind a complete pair), or a
+        // bare "//" followed by white space even there (`key // remark`); `key //abs/dir` and `key package://...` stay values
+        const bool bare = i + 2 >= line.size() || std::isspace((unsigned char)line[i + 2]);
+        if (words != 1 || bare) break;
+      }
       if (line[i] == '{' || line[i] == '}') { toks.emplace_back(1, line[i++]); words = 0; continue; }
       ++words;
       if (line[i] == '"') { const size_t e = line.find('"', i + 1); toks.push_back(line.substr(i + 1, e == std::string::npos ? std::string::npos : e - i - 1)); i = e == std::string::npos ? line.size() : e + 1; continue; }

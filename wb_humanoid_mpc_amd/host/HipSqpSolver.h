@@ -34,6 +34,8 @@ class HipSqpSolver {
     hsqp_settings st{maxNodes, maxBatch, device, useLinesearch ? HSQP_FLAG_LINESEARCH : 0};
     const int rc = hsqp_create(&model, &st, &h_);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_create failed (" + std::to_string(rc) + "): " + hsqp_last_error(nullptr));
+    // receding-horizon use (MPC_BASE::run uploads the shifted problem every cycle, sqpIteration = 1): the KKT gate's back-off carries over the cycles
+    hsqp_set_scan_backoff_persistent(h_, 1);
   }
   ~HipSqpSolver() { hsqp_destroy(h_); }
   HipSqpSolver(const HipSqpSolver&) = delete;

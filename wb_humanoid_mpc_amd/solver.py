@@ -64,6 +64,9 @@ def load_library():
     lib.hsqp_scan_backoffs.argtypes = [C.c_void_p]
     lib.hsqp_scan_backoffs.restype = C.c_longlong
     lib.hsqp_version.restype = C.c_char_p
+    lib.hsqp_set_scan_backoff_persistent.argtypes = [C.c_void_p, C.c_int]
+    if lib.hsqp_abi_version() != _abi.ABI_VERSION:
+        raise RuntimeError(f"libhsqp_hip ABI {lib.hsqp_abi_version()} != the binding's {_abi.ABI_VERSION} (include/hsqp.h: HSQP_ABI_VERSION)")
     lib.hsqp_joint_torques.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.hsqp_evaluate_policy.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     lib.hsqp_linesearch_defaults.argtypes = [C.POINTER(_abi.LinesearchSettings)]
@@ -294,6 +297,10 @@ class HipSqpSolver:
         ms = np.zeros(5)
         self._check(self.lib.hsqp_last_kernel_ms(self.h, ms.ctypes.data_as(_dp)))
         return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
+
+    def set_scan_backoff_persistent(self, on=True):
+        """hsqp_set_scan_backoff_persistent: the KKT gate's back-off survives uploads of the same shape (receding-horizon use)."""
+        self._check(self.lib.hsqp_set_scan_backoff_persistent(self.h, 1 if on else 0))
 
     def scan_backoffs(self):
         """Iterations that ran the serial recursion because the automatic sweep choice was backing off (hsqp_scan_backoffs)."""
