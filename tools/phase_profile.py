@@ -27,7 +27,7 @@ for _ in range(iters):
 print("kernel ms (last iteration):", {k: round(v, 3) for k, v in s.kernel_ms().items()})
 t = np.zeros((4, 128), dtype=np.int64)
 s.lib.hsqp_debug_read(s.h, 100, t.ctypes.data_as(C.c_void_p), t.nbytes)
-names = ["k_lq<true>", "k_project", "k_riccati", "k_lq<false>"]
+names = ["k_lq<true>", "k_project", "k_riccati", "k_lq<false> | k_lq_limb (ids 0-4: base kin + forward + solve, -, back walk, base columns; x4 stages) + k_lq_rows (10: loads, 11: kinematics, 12: terms, 13: joint rows, 14: base rows)"]
 for k in range(4):
     # slots 0..39: phase ticks (PH_TICK); 40..111: per-wave barrier arrivals (PH_ARRIVE); 90..94: tile-call split; 112..119: PH_MARK stamps
     tot = t[k, :40].sum()

@@ -331,6 +331,31 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
   lq_node<false, true>(ctx, *dm, w, nullptr, nullptr, nullptr, par + ((size_t)b * (N + 1) + k) * NP, dts[node], nullptr, misc + (size_t)node * 8);
 }
 
+// (x, u) of the 16 nodes of a wave -> LDS: lane i < 64 takes entries i and i + 64 of every node's [x; u] row, 32 loads per lane issued back to back;
+// the node arithmetic is the wave's (scalar: node0 through readfirstlane, no division per element).  The first form — one entry per lane and
+// iteration with its indices by division — kept one load in flight per iteration and spent ~150 instructions per element on the indices.
+__device__ __forceinline__ void quad_load_xu(double (*xs)[NX], double (*us)[NU], const double* __restrict__ x, const double* __restrict__ u, int node0_, int nodes,
+                                             int N, int lane) {
+  static_assert(QV_NODES == 16 && NZ <= 128 && NX <= 64, "two entries per lane and node");
+  const int node0 = __builtin_amdgcn_readfirstlane(node0_);
+  int b = node0 / N, k = node0 - b * N;
+  double t0[QV_NODES], t1[QV_NODES];
+#pragma unroll
+  for (int n2 = 0; n2 < QV_NODES; ++n2) {
+    const bool pad = node0 + n2 >= nodes;                          // a padding quad repeats the last node
+    const int nd = pad ? nodes - 1 : node0 + n2;
+    const size_t xrow = pad ? (size_t)(nodes - 1) + (nodes - 1) / N : (size_t)b * (N + 1) + k;
+    t0[n2] = lane < NX ? x[xrow * NX + lane] : u[(size_t)nd * NU + (lane - NX)];
+    t1[n2] = u[(size_t)nd * NU + (lane + 64 - NX < NU ? lane + 64 - NX : NU - 1)];
+    if (++k == N) { k = 0; ++b; }
+  }
+#pragma unroll
+  for (int n2 = 0; n2 < QV_NODES; ++n2) {
+    if (lane < NX) xs[n2][lane] = t0[n2]; else us[n2][lane - NX] = t0[n2];
+    if (lane + 64 < NZ) us[n2][lane + 64 - NX] = t1[n2];
+  }
+}
+
 // ---- whole-body value pass on quads of lanes (hsqp_lqv.h): a wave evaluates QV_NODES nodes, one lane per limb; misc as k_lq<false> writes it.
 //      Nodes of instances whose line search is over (ls) are evaluated with the rest of their wave but not written.
 __global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_value_quad(const DevModel* __restrict__ dm, const double* __restrict__ x,
@@ -345,11 +370,7 @@ __global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_
   if (__syncthreads_or(live) == 0) return;
   const Ctx ctx{(int)threadIdx.x, QV_THREADS * QV_WAVES, nullptr};
   qv_load_const(ctx, *dm, ws.k, [] {});
-  for (int idx = lane; idx < QV_NODES * NZ; idx += QV_THREADS) {
-    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
-    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
-    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
-  }
+  quad_load_xu(w.x, w.u, x, u, node0, nodes, N, lane);
   __syncthreads();
   const double* xs = w.x[nn];
   const double* us = w.u[nn];
@@ -423,11 +444,7 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);
   qv_load_const(ctx, *dm, ws.k, [] {});
-  for (int idx = lane; idx < QL_NODES * NZ; idx += QL_THREADS) {
-    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
-    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
-    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
-  }
+  quad_load_xu(w.x, w.u, x, u, node0, nodes, N, lane);
   __syncthreads();
   const double* xs = w.x[nn];
   const double* us = w.u[nn];
@@ -436,8 +453,8 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   double* csn = &w.csn[0][lane][0];
   constexpr int CSN_LD = QL_THREADS * 2;
   QL_QUAD_OPS;
-  const int foot_step = ql_foot_step(*dm, L);
-  const int max_len = dm->limb_max_len;
+  const QlLimb lb = ql_limb(*dm, L);
+  const int max_len = lb.max_len;
   const bool own_root = (dm->limb_own[L] & 1u) != 0;
   QlCarry c;
   for (int i = 0; i < 6; ++i) { c.vb[i] = 0.0; c.ap[i] = 0.0; }
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
     ql_base_kin(*dm, xs, s, dt, c, bk);
     {
       double part[16];
-      ql_forward(*dm, ws.k, xs, us, L, s, dt, bk, st, part, csn, CSN_LD, rP, Ff);
+      ql_forward(*dm, ws.k, lb, xs, us, L, s, dt, bk, st, part, csn, CSN_LD, rP, Ff);
 #pragma unroll
       for (int e = 0; e < 16; ++e) part[e] = quad_sum(part[e]);
       ql_base_solve(part, bk, sh);
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
 #pragma unroll
         for (int e = 0; e < NCMP; ++e) cmp[e] += m * quad_x3(cmp[e]);
       }
-      ql_back_step(*dm, ws.k, xs, us, L, s, dt, t, st, cmp, sh, csn, CSN_LD, rP, Ff, foot_step, putg);
+      ql_back_step(*dm, ws.k, lb, xs, us, L, s, dt, t, st, cmp, sh, csn, CSN_LD, rP, Ff, putg);
     }
     PH_TICK(ctx, 3);
     // ---- the base: composite of the whole robot = the limbs that own their root-side body + the base body; its columns
@@ -528,21 +545,19 @@ struct QrWS {
 static_assert(sizeof(QrWS) * (4 / QL_WAVES) <= 163840, "four waves per CU");
 __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QR_WPE, HSQP_QR_WPE))) void k_lq_rows(
     const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts,
-    int N, int nodes, double* __restrict__ rec) {
+    int N, int nodes, double* __restrict__ rec, long long* prof) {
   __shared__ QrWS ws;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
   auto& w = ws.wv[wave];
   const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;
   const int b = node / N, k = node % N;
   const bool live = node0 + nn < nodes;
-  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, nullptr};
+  const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, blockIdx.x == 0 ? prof : nullptr};   // phase profile (profile builds): slot 3, ids 10..15
+  PH_TICK(ctx, 126);
   qv_load_const(ctx, *dm, ws.k, [] {});
-  for (int idx = lane; idx < QL_NODES * NZ; idx += QL_THREADS) {
-    const int n2 = idx / NZ, i = idx % NZ, nd = node0 + n2 < nodes ? node0 + n2 : nodes - 1, b2 = nd / N, k2 = nd % N;
-    if (i < NX) w.x[n2][i] = x[((size_t)b2 * (N + 1) + k2) * NX + i];
-    else w.u[n2][i - NX] = u[(size_t)nd * NU + i - NX];
-  }
+  quad_load_xu(w.x, w.u, x, u, node0, nodes, N, lane);
   __syncthreads();
+  PH_TICK(ctx, 10);
   const double* xs = w.x[nn];
   const double* us = w.u[nn];
   const double* pn = par + ((size_t)b * (N + 1) + k) * NP;
@@ -552,8 +567,8 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   double* csn = &w.csn[0][lane][0];
   constexpr int CSN_LD = QL_THREADS * 2;
   QL_QUAD_OPS;
-  const int foot_step = ql_foot_step(*dm, L);
-  const int max_len = dm->limb_max_len;
+  const QlLimb lb = ql_limb(*dm, L);
+  const int max_len = lb.max_len;
   QlCarry c;
   for (int i = 0; i < 6; ++i) { c.vb[i] = 0.0; c.ap[i] = 0.0; }
   QlBaseKin bk;
@@ -561,8 +576,9 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   QlShared sh;
   QlRows rw;
   ql_base_kin(*dm, xs, 0, dt, c, bk);
-  ql_kin_to_leaf(*dm, ws.k, xs, us, L, bk, csn, CSN_LD, st, nl);
+  ql_kin_to_leaf(*dm, ws.k, lb, xs, us, L, bk, csn, CSN_LD, st, nl);
   ql_shared_from_record(bk, grec, sh);
+  PH_TICK(ctx, 11);
   {
     // the lane's foot and its share of the cost (pass A), then what needs every lane's pass A (pass B).  The four lanes of a node sit in one
     // wave: a wave-level fence orders their LDS traffic
@@ -578,10 +594,20 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
     ql_rows_setup(*dm, pn, L, dt, coll, rw);
     if (live && L == 0) ql_write_misc(pn, dt, cost, eq, coll, grec + REC_MISC);
   }
+  PH_TICK(ctx, 12);
   const double* gs = grec + REC_GS;
+  QlG3 cur, nxt;
+  ql_rows_fetch(lb, max_len - 1, gs, cur);
 #pragma unroll 1
-  for (int t = max_len - 1; t >= 0; --t) ql_rows_back_step(*dm, ws.k, rw, nl, xs, us, L, t, st, csn, CSN_LD, bk.w, foot_step, gs, grec, live);
+  for (int t = max_len - 1; t >= 0; --t) {
+    ql_rows_fetch(lb, t - 1, gs, nxt);   // the next step's columns, in front of this step's stores
+    QV_SCHED_FENCE();
+    ql_rows_back_step(*dm, ws.k, lb, rw, nl, xs, us, t, st, csn, CSN_LD, bk.w, cur, grec, live);
+    cur = nxt;
+  }
+  PH_TICK(ctx, 13);
   ql_rows_base(*dm, rw, nl, us, L, bk, sh, gs, grec, live);
+  PH_TICK(ctx, 14);
 }
 
 // ---- ... kernel 3 of 3: the RK4 chain and the defect: one workgroup per (instance, node), a lane per column of [A|B] (lq_chain_node, hsqp_lql.h)
@@ -1310,7 +1336,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     else if (h->lq_limb) {   // limb lanes for the model and the node terms (16 nodes per wave), then the RK4 chain, a lane per column (hsqp_lql.h)
       const dim3 qgrid((nodes + QL_NODES * QL_WAVES - 1) / (QL_NODES * QL_WAVES)), qblock(QL_THREADS * QL_WAVES);
       hipLaunchKernelGGL(k_lq_limb, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_dt, N, nodes, h->d_rec, h->d_prof + 384);
-      hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, nodes, h->d_rec);
+      hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, nodes, h->d_rec, h->d_prof + 384);
       hipLaunchKernelGGL(k_lq_chain, dim3(nodes), dim3(LQC_THREADS), 0, h->stream, h->d_x, h->d_u, h->d_dt, N, h->d_rec);
     } else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,

@@ -162,6 +162,7 @@ struct DevModel {
   // bit k (1..3) of limb_merge[t][L] — the limbs that hang off body path_L[t] below the part of the path the two lanes share.  ql_ok = 0: the tree
   // does not fit that scheme (no limbs, or a foot's ancestors shared with another limb) and the LQ kernel keeps its phase form
   unsigned char limb_merge[NANC][QV_LIMBS];
+  int limb_foot_step[QV_LIMBS];   // the step of the limb's path on which its foot body sits (-1: the limb carries no foot)
   int ql_ok;
 };
 

@@ -160,6 +160,13 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
           if (b == md.contact[f].body) break;
         }
       }
+      for (int l = 0; l < QV_LIMBS; ++l) {
+        dm.limb_foot_step[l] = -1;
+        for (int f = 0; f < 2; ++f)
+          if (dm.foot_limb[f] == l)
+            for (int t = 0; t < dm.limb_len[l]; ++t)
+              if (body_at(l, t) == md.contact[f].body) dm.limb_foot_step[l] = t;
+      }
       dm.ql_ok = ok ? 1 : 0;
     }
   }

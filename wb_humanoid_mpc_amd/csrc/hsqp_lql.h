@@ -44,6 +44,9 @@ struct QlCarry {      // from one RK4 stage to the next
 };
 
 struct QlState { double R[9], r[3], vl[6], al[6]; };   // the body a lane stands on
+// the lane's limb, read from the model image ONCE (registers): these sit in front of every step's operand addresses
+struct QlLimb { unsigned long long path; int len, max_len, foot_step; unsigned own; };
+HSQP_HD QlLimb ql_limb(const DevModel& dm, int L) { return QlLimb{dm.limb_path[L], dm.limb_len[L], dm.limb_max_len, dm.limb_foot_step[L], dm.limb_own[L]}; }
 
 // node data of RK4 stage 1 shared by the four lanes of a node (LDS); see "Node terms on the limb lanes" below
 struct QlFoot {                      // per (node, foot), LDS
@@ -68,7 +71,8 @@ struct QlRows {                      // what a lane knows about its node's rows 
 
 
 // ---- per-body quantities (stage_eval: "per-body spatial inertia about O and net force")
-HSQP_HD void ql_inertia(const QvConst& kc, int i, const double* Rb, const double* r, double* In) {
+template <class KC>
+HSQP_HD void ql_inertia(const KC& kc, int i, const double* Rb, const double* r, double* In) {
   double c[3], t[9], Iw[9];
   m3_mulv(Rb, kc.com[i], c);
   for (int k = 0; k < 3; ++k) c[k] += r[k];
@@ -218,7 +222,8 @@ HSQP_HD void ql_base_kin(const DevModel& dm, const double* x, int s, double dt, 
 // ---- forward pass of limb L at RK4 stage s: leaves the lane on its leaf (st), its share of the totals in part[16] (qv_limb_stage's layout:
 // F_ext - F {moment, force}, inertia), the cos / sin of its joints in csn[step * csn_ld + {0, 1}] for the way back, the contact point and
 // force of the lane's foot in rP / Ff.
-HSQP_HD void ql_forward(const DevModel& dm, const QvConst& kc, const double* x, const double* u, int L, int s, double dt, const QlBaseKin& bk, QlState& st,
+template <class KC>
+HSQP_HD void ql_forward(const DevModel& dm, const KC& kc, const QlLimb& lb, const double* x, const double* u, int L, int s, double dt, const QlBaseKin& bk, QlState& st,
                         double* part, double* csn, int csn_ld, double* rP, double* Ff) {
   for (int e = 0; e < 16; ++e) part[e] = 0.0;
   for (int k = 0; k < 9; ++k) st.R[k] = bk.R[k];
@@ -244,10 +249,10 @@ HSQP_HD void ql_forward(const DevModel& dm, const QvConst& kc, const double* x, 
     }
   };
   if (L == 0) body(0, true);
-  const unsigned long long path = dm.limb_path[L];
-  const int len = dm.limb_len[L];
-  const unsigned own = dm.limb_own[L];
-  for (int t = 0; t < dm.limb_max_len; ++t) {
+  const unsigned long long path = lb.path;
+  const int len = lb.len;
+  const unsigned own = lb.own;
+  for (int t = 0; t < lb.max_len; ++t) {
     if (t >= len) continue;
     const int i = (int)((path >> (8 * t)) & 0xffull), j = i - 1;
     double qj, qd, qdd;
@@ -296,7 +301,8 @@ HSQP_HD void ql_carry_advance(const double* x, int s, double dt, const QlShared&
 }
 
 // step up to the parent of body i: v_p = v_i - S qd, a_p = a_i - S qdd - Sd qd, R_p = R_i Mq^T, r_p = r_i - R_p pfix (cn, sn: cos / sin of joint i)
-HSQP_HD void ql_unwind(const QvConst& kc, int i, const double* S, const double* Sd, double qd, double qdd, double cn, double sn, QlState& st) {
+template <class KC>
+HSQP_HD void ql_unwind(const KC& kc, int i, const double* S, const double* Sd, double qd, double qdd, double cn, double sn, QlState& st) {
   for (int k = 0; k < 6; ++k) { st.al[k] -= S[k] * qdd + Sd[k] * qd; st.vl[k] -= S[k] * qd; }
   double Rq[9], Mq[9], Rp[9], t3[3];
   rot_axis_cs(kc.axis[i], cn, sn, Rq);
@@ -310,11 +316,12 @@ HSQP_HD void ql_unwind(const QvConst& kc, int i, const double* S, const double* 
 
 // ---- one step of the way back: the lane stands on body i = path[t] with the composite of i's strict descendants in cmp; adds i, forms the
 // three columns of joint i (emit(column, g6)), and steps up to the parent.  Lanes whose limb is shorter than t + 1 do nothing.
-template <class Emit>
-HSQP_HD void ql_back_step(const DevModel& dm, const QvConst& kc, const double* x, const double* u, int L, int s, double dt, int t, QlState& st, double* cmp,
-                          const QlShared& sh, const double* csn, int csn_ld, const double* rP, const double* Ff, int foot_step, Emit&& emit) {
-  if (t >= dm.limb_len[L]) return;
-  const int i = (int)((dm.limb_path[L] >> (8 * t)) & 0xffull), j = i - 1;
+template <class KC, class Emit>
+HSQP_HD void ql_back_step(const DevModel& dm, const KC& kc, const QlLimb& lb, const double* x, const double* u, int L, int s, double dt, int t, QlState& st, double* cmp,
+                          const QlShared& sh, const double* csn, int csn_ld, const double* rP, const double* Ff, Emit&& emit) {
+  if (t >= lb.len) return;
+  const int foot_step = lb.foot_step;
+  const int i = (int)((lb.path >> (8 * t)) & 0xffull), j = i - 1;
   double qj, qd, qdd;
   ql_joint_inputs(x, u, j, s, dt, qj, qd, qdd);
   (void)qj;
@@ -336,7 +343,7 @@ HSQP_HD void ql_back_step(const DevModel& dm, const QvConst& kc, const double* x
     mxm(st.vl, Sd, t2);
     for (int k = 0; k < 6; ++k) Sdd[k] = t1[k] + t2[k];
   }
-  const bool mine = ((dm.limb_own[L] >> t) & 1u) != 0;
+  const bool mine = ((lb.own >> t) & 1u) != 0;
   {
     // d(F_ext moment)/dq: the lane's contact point moves with every joint above it
     double dext[3] = {0.0, 0.0, 0.0};
@@ -403,14 +410,8 @@ HSQP_HD void ql_base_columns(const DevModel& dm, int L, const QlBaseKin& bk, con
   }
 }
 
-// the step of the lane's limb on which its foot body sits (-1: the limb carries no foot)
-HSQP_HD int ql_foot_step(const DevModel& dm, int L) {
-  for (int f = 0; f < 2; ++f)
-    if (dm.foot_limb[f] == L)
-      for (int t = 0; t < dm.limb_len[L]; ++t)
-        if ((int)((dm.limb_path[L] >> (8 * t)) & 0xffull) == dm.contact_body[f]) return t;
-  return -1;
-}
+// the step of the lane's limb on which its foot body sits (-1: the limb carries no foot): DevModel::limb_foot_step
+HSQP_HD int ql_foot_step(const DevModel& dm, int L) { return dm.limb_foot_step[L]; }
 
 // ------------------------------------------------------------------------------------------------
 // Node terms on the limb lanes (RK4 stage 1): the values and penalties of hsqp_node.h's node_values / node_scalars dealt to the four lanes of a
@@ -900,7 +901,8 @@ HSQP_HD void ql_rows_wrench(const DevModel& dm, const QlRows& rw, const QlNodeLd
 // the row arithmetic does not fit the register file (345 spilled registers in one kernel; registers are allotted per kernel).
 // placement / velocity / trick acceleration of the lane's leaf at RK4 stage 1 (ql_forward without the bodies' inertia work); leaves the cos / sin
 // of the lane's joints in csn for the way back, the foot body's state and the collision points the lane owns in the node's shared data
-HSQP_HD void ql_kin_to_leaf(const DevModel& dm, const QvConst& kc, const double* x, const double* u, int L, const QlBaseKin& bk, double* csn, int csn_ld,
+template <class KC>
+HSQP_HD void ql_kin_to_leaf(const DevModel& dm, const KC& kc, const QlLimb& lb, const double* x, const double* u, int L, const QlBaseKin& bk, double* csn, int csn_ld,
                             QlState& st, QlNodeLds& nl) {
   for (int k = 0; k < 9; ++k) st.R[k] = bk.R[k];
   for (int k = 0; k < 3; ++k) st.r[k] = 0.0;
@@ -925,10 +927,10 @@ HSQP_HD void ql_kin_to_leaf(const DevModel& dm, const QvConst& kc, const double*
     }
   };
   if (L == 0) capture(0, true);
-  const unsigned long long path = dm.limb_path[L];
-  const int len = dm.limb_len[L];
-  const unsigned own = dm.limb_own[L];
-  for (int t = 0; t < dm.limb_max_len; ++t) {
+  const unsigned long long path = lb.path;
+  const int len = lb.len;
+  const unsigned own = lb.own;
+  for (int t = 0; t < lb.max_len; ++t) {
     if (t >= len) continue;
     const int i = (int)((path >> (8 * t)) & 0xffull), j = i - 1;
     const double qd = x[NV + 6 + j], qdd = u[12 + j];
@@ -953,23 +955,39 @@ HSQP_HD void ql_kin_to_leaf(const DevModel& dm, const QvConst& kc, const double*
     capture(i, ((own >> t) & 1u) != 0);
   }
 }
-// one step of the rows pass: the rows of the three columns of joint i = path[t] (their Jacobian columns: gs[column * GT_LD ..]), then up to the parent
-HSQP_HD void ql_rows_back_step(const DevModel& dm, const QvConst& kc, const QlRows& rw, const QlNodeLds& nl, const double* x, const double* u, int L, int t,
-                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], int foot_step, const double* gs, double* rec, bool live) {
-  if (t >= dm.limb_len[L]) return;
-  const int i = (int)((dm.limb_path[L] >> (8 * t)) & 0xffull), j = i - 1;
+// the stage Jacobian columns of the three columns of joint i = path[t] of limb L (zeros if the lane has no step t): what ql_rows_back_step(t) consumes.
+// Loaded one step AHEAD of their use, i.e. in front of the previous step's stores: the memory counter retires in order, so a load issued
+// behind ~60 stores waits for all of them to be acknowledged (measured: 18 k cycles per column).
+struct QlG3 { double g[3][6]; };
+HSQP_HD void ql_rows_fetch(const QlLimb& lb, int t, const double* gs, QlG3& q) {
+  const bool has = t >= 0 && t < lb.len;
+  const int i = has ? (int)((lb.path >> (8 * t)) & 0xffull) : 1, j = i - 1;
+  const int col[3] = {3 + i + 2, NV + 3 + i + 2, NX + 12 + j};
+#pragma unroll
+  for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q.g[kind][k] = gs[col[kind] * GT_LD + k];
+}
+// one step of the rows pass: the rows of the three columns of joint i = path[t] (their Jacobian columns: cur), then up to the parent
+template <class KC>
+HSQP_HD void ql_rows_back_step(const DevModel& dm, const KC& kc, const QlLimb& lb, const QlRows& rw, const QlNodeLds& nl, const double* x, const double* u, int t,
+                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], const QlG3& cur, double* rec, bool live) {
+  if (t >= lb.len) return;
+  const int foot_step = lb.foot_step;
+  const int i = (int)((lb.path >> (8 * t)) & 0xffull), j = i - 1;
   const double qd = x[NV + 6 + j], qdd = u[12 + j];
   double S[6], Sd[6];
   m3_mulv(st.R, kc.axis[i], S);
   v3_cross(st.r, S, S + 3);
   mxm(st.vl, S, Sd);
-  if ((dm.limb_own[L] >> t) & 1u) {
+  if ((lb.own >> t) & 1u) {
     const bool sup = t <= foot_step;
 #pragma unroll 1
     for (int kind = 0; kind < 3; ++kind) {
       const int col = kind == 0 ? 3 + i + 2 : (kind == 1 ? NV + 3 + i + 2 : NX + 12 + j);
       double g[6];
-      for (int k = 0; k < 6; ++k) g[k] = gs[col * GT_LD + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = kind == 0 ? cur.g[0][k] : (kind == 1 ? cur.g[1][k] : cur.g[2][k]);   // (selects: an array indexed by `kind` would live in scratch memory)
       ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, g, col, rec, live);
     }
   }
@@ -979,11 +997,22 @@ HSQP_HD void ql_rows_back_step(const DevModel& dm, const QvConst& kc, const QlRo
 // the rows of the base columns (the division of labour of ql_base_columns)
 HSQP_HD void ql_rows_base(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, const double* u, int L, const QlBaseKin& bk, const QlShared& sh,
                           const double* gs, double* rec, bool live) {
-  double g[6];
+  // (all Jacobian columns the lane needs are fetched in front of the first store: see ql_rows_fetch)
+  double ge[2][6], gw[6][6];
+  const int je = L < 3 ? L : 0, fo = rw.own >= 0 ? rw.own : 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { ge[0][k] = gs[(3 + je) * GT_LD + k]; ge[1][k] = gs[(NV + 3 + je) * GT_LD + k]; }
+#pragma unroll
+  for (int k6 = 0; k6 < 6; ++k6)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gw[k6][k] = gs[(NX + 6 * fo + k6) * GT_LD + k];
+  QV_SCHED_FENCE();
   if (L < 3) {
 #pragma unroll 1
     for (int kind = 0; kind < 2; ++kind) {
-      for (int k = 0; k < 6; ++k) g[k] = gs[((kind == 0 ? 3 : NV + 3) + L) * GT_LD + k];
+      double g[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = kind == 0 ? ge[0][k] : ge[1][k];
       ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, g, rec, live);
     }
   } else {
@@ -992,7 +1021,9 @@ HSQP_HD void ql_rows_base(const DevModel& dm, const QlRows& rw, const QlNodeLds&
   if (rw.own >= 0) {
 #pragma unroll 1
     for (int k6 = 0; k6 < 6; ++k6) {
-      for (int k = 0; k < 6; ++k) g[k] = gs[(NX + 6 * rw.own + k6) * GT_LD + k];
+      double g[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = k6 == 0 ? gw[0][k] : (k6 == 1 ? gw[1][k] : (k6 == 2 ? gw[2][k] : (k6 == 3 ? gw[3][k] : (k6 == 4 ? gw[4][k] : gw[5][k]))));
       ql_rows_wrench(dm, rw, nl, u, rw.own, k6, bk, g, rec, live);
     }
   }
@@ -1064,7 +1095,7 @@ inline void ql_node_host(const DevModel& dm, const double* x, const double* u, d
     double part[QV_LIMBS][16], tot[16], csn[QV_LIMBS][QL_MAXLEN][2], rP[QV_LIMBS][3], Ff[QV_LIMBS][3], cmp[QV_LIMBS][NCMP];
     for (int L = 0; L < QV_LIMBS; ++L) {
       ql_base_kin(dm, x, s, dt, c[L], bk[L]);
-      ql_forward(dm, *kc, x, u, L, s, dt, bk[L], st[L], part[L], &csn[L][0][0], 2, rP[L], Ff[L]);
+      ql_forward(dm, *kc, ql_limb(dm, L), x, u, L, s, dt, bk[L], st[L], part[L], &csn[L][0][0], 2, rP[L], Ff[L]);
     }
     for (int e = 0; e < 16; ++e) tot[e] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
     for (int L = 0; L < QV_LIMBS; ++L) ql_base_solve(tot, bk[L], sh[L]);
@@ -1079,7 +1110,7 @@ inline void ql_node_host(const DevModel& dm, const double* x, const double* u, d
         for (int k = 1; k < QV_LIMBS; ++k)
           if ((dm.limb_merge[t][L] >> k) & 1u) for (int e = 0; e < NCMP; ++e) cmp[L][e] += snap[L ^ k][e];
       for (int L = 0; L < QV_LIMBS; ++L)
-        ql_back_step(dm, *kc, x, u, L, s, dt, t, st[L], cmp[L], sh[L], &csn[L][0][0], 2, rP[L], Ff[L], ql_foot_step(dm, L), putg);
+        ql_back_step(dm, *kc, ql_limb(dm, L), x, u, L, s, dt, t, st[L], cmp[L], sh[L], &csn[L][0][0], 2, rP[L], Ff[L], putg);
     }
     // the base: the limbs that own their root-side body, plus the base body itself
     double ctot[NCMP], dext_e[9];
@@ -1127,7 +1158,7 @@ inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, c
   double csn[QV_LIMBS][QL_MAXLEN][2];
   for (int L = 0; L < QV_LIMBS; ++L) {
     ql_base_kin(dm, x, 0, dt, c0, bk[L]);
-    ql_kin_to_leaf(dm, *kc, x, u, L, bk[L], &csn[L][0][0], 2, st[L], *nl);
+    ql_kin_to_leaf(dm, *kc, ql_limb(dm, L), x, u, L, bk[L], &csn[L][0][0], 2, st[L], *nl);
     ql_shared_from_record(bk[L], rec, sh[L]);
   }
   // pass A of every lane, then pass B (the device: a wave-level fence in between)
@@ -1142,8 +1173,11 @@ inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, c
   ql_write_misc(par, dt, ctot, etot, coll, rec + REC_MISC);
   const double* G = rec + REC_GS;
   for (int t = dm.limb_max_len - 1; t >= 0; --t)
-    for (int L = 0; L < QV_LIMBS; ++L)
-      ql_rows_back_step(dm, *kc, rw[L], *nl, x, u, L, t, st[L], &csn[L][0][0], 2, bk[L].w, ql_foot_step(dm, L), G, rec, true);
+    for (int L = 0; L < QV_LIMBS; ++L) {
+      QlG3 cur;
+      ql_rows_fetch(ql_limb(dm, L), t, G, cur);
+      ql_rows_back_step(dm, *kc, ql_limb(dm, L), rw[L], *nl, x, u, t, st[L], &csn[L][0][0], 2, bk[L].w, cur, rec, true);
+    }
   for (int L = 0; L < QV_LIMBS; ++L) ql_rows_base(dm, rw[L], *nl, u, L, bk[L], sh[L], G, rec, true);
   delete kc;
   delete nl;

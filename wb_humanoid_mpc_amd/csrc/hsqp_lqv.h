@@ -12,6 +12,7 @@
 // Same formulas as stage_eval<false> / node_values / node_scalars (each block cites them); the sums over bodies and cost terms are
 // taken in another order, so the results agree with lq_node<false> to rounding (host build: tests/hostemu; device: tests/test_gpu_parity.py).
 #pragma once
+#include <cstddef>
 #include "hsqp_lq.h"
 
 namespace hsqp {
@@ -25,8 +26,9 @@ namespace hsqp {
 constexpr int QV_NODES = 16, QV_THREADS = 64;   // a wave evaluates 16 nodes, four lanes each
 static_assert(QV_NODES * QV_LIMBS == QV_THREADS && QV_LIMBS == 4, "a node is a DPP quad");
 
-struct QvConst {   // body constants (one copy per workgroup: lanes index them by the body of their step)
-  double Rfix[NB][9], pfix[NB][3], axis[NB][3], axis_p[NB][3], com[NB][3], inertia[NB][9], mass[NB];
+struct QvConst {   // body constants (one copy per workgroup: lanes index them by the body of their step).  Two pieces in DevModel's own order and
+  double Rfix[NB][9], pfix[NB][3], axis[NB][3], axis_p[NB][3];   // layout — {Rfix .. axis_p} and {mass .. inertia} — so that loading them is two flat copies
+  double mass[NB], com[NB][3], inertia[NB][9];
 };
 constexpr int QV_WAVES = 2;         // waves per workgroup: they share the body constants (37 KB per workgroup: eight waves per CU)
 struct QvWS {
@@ -40,16 +42,13 @@ static_assert(sizeof(QvWS) * 4 <= 163840, "four workgroups per CU");
 
 template <class F>
 HSQP_HD void qv_load_const(const Ctx& ctx, const DevModel& dm, QvConst& k, F&& sync) {
-  WG_FOR(ctx, i, NB * 31) {
-    const int b = i / 31, e = i % 31;
-    if (e < 9) k.Rfix[b][e] = dm.Rfix[b][e];
-    else if (e < 12) k.pfix[b][e - 9] = dm.pfix[b][e - 9];
-    else if (e < 15) k.axis[b][e - 12] = dm.axis[b][e - 12];
-    else if (e < 18) k.axis_p[b][e - 15] = dm.axis_p[b][e - 15];
-    else if (e < 21) k.com[b][e - 18] = dm.com[b][e - 18];
-    else if (e < 30) k.inertia[b][e - 21] = dm.inertia[b][e - 21];
-    else k.mass[b] = dm.mass[b];
-  }
+  constexpr int NA = NB * 18, NBK = NB * 13;
+  static_assert(offsetof(DevModel, axis_p) - offsetof(DevModel, Rfix) == (NA - NB * 3) * sizeof(double) && offsetof(DevModel, inertia) - offsetof(DevModel, mass) == (NBK - NB * 9) * sizeof(double) &&
+                offsetof(QvConst, mass) == NA * sizeof(double) && sizeof(QvConst) == (NA + NBK) * sizeof(double), "two flat pieces");
+  const double* sa = &dm.Rfix[0][0];
+  const double* sb = &dm.mass[0];
+  double* d = &k.Rfix[0][0];
+  WG_FOR(ctx, i, NA + NBK) d[i] = i < NA ? sa[i] : sb[i - NA];
   sync();
 }
 
