@@ -52,7 +52,7 @@ PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
 
 
-PROFILE_ROUND = "r04"            # which committed PMC passes the per-kernel HBM bytes / matrix-pipe shares are read from (profiles/<round>_pmc_*)
+PROFILE_ROUND = "r05"            # which committed PMC passes the per-kernel HBM bytes / matrix-pipe shares are read from (profiles/<round>_pmc_*)
 
 
 def pmc_kernel_info():
@@ -122,6 +122,13 @@ def cpu_baseline(model, n_nodes, seed, cent=False):
 
     done, wall = leg(cores, 1, n_inst, 8.0)
     done4, wall4 = leg(1, 4, 1, 4.0)
+    # does the per-core rate hold as the cores fill up?  (the all-core extrapolation below assumes it does): 1, 2, 4, 8, .. concurrent instances,
+    # ~1.5 s each; efficiency = rate(c) / (c x rate(1))
+    scaling = {}
+    for c in [c for c in (1, 2, 4, 8, 16, 32, 64) if c < cores] + [cores]:
+        d, w = (done, wall) if c == cores else leg(c, 1, max(c, 2), 1.5)
+        scaling[c] = d / w
+    eff = {str(c): round(scaling[c] / (c * scaling[1]), 3) for c in scaling}
     res = {"value": done / wall, "unit": "SQP iters/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
            "hardware_threads_visible": hw_threads, "cgroup_cpu_quota": quota, "value_per_core": done / wall / cores,
            "cores_note": "cores = hardware threads this process can use = min(affinity mask, cgroup cpu.max quota); the GPU boxes of this pool cap the "
@@ -132,6 +139,10 @@ def cpu_baseline(model, n_nodes, seed, cent=False):
                      "performance index before/after (no KKT check)",
            "all_core_extrapolation": {"value": done / wall / cores * (physical_cores() or hw_threads), "cores": physical_cores() or hw_threads,
                                       "value_all_hardware_threads": done / wall / cores * hw_threads,
+                                      "measured_scaling": {"concurrent_instances": {str(c): round(v, 1) for c, v in scaling.items()}, "efficiency_vs_one_core": eff,
+                                                           "note": "iters/s with c single-threaded instances side by side on this container's cores; the "
+                                                                   "extrapolation multiplies the rate per core AT THE LARGEST c measured, so memory-bandwidth "
+                                                                   "saturation up to that c is already in it"},
                                       "note": "per-core rate x physical cores of this host (linear scaling assumed; value_all_hardware_threads counts SMT siblings as cores: "
                                               "an upper bound).  BASELINE.md asks >= 10x the ALL-core baseline: compare `value` of the line with THIS number; the "
                                               "measured `cpu_baseline.value` is what the container's cgroup quota allows"},
@@ -405,18 +416,25 @@ def main():
         # the RK4 sensitivity product only — its real work (four analytic rigid-body model evaluations per node) is vector FP64 and is
         # not part of SURVEY's count, so its fraction is reported against the same FP64 peak but its bound is VALU issue, not the matrix pipe.
         pmc, pmc_prov = pmc_kernel_info()
-        kern = {"k_lq_cent2" if cent else "k_lq<true>": (kms[0], f_rk4, "valu-issue"),
+        forms = solver.kernel_forms()   # which kernels this handle runs (decided at hsqp_create from its size: HSQP_BLK_FORMS)
+        lq_name = "k_lq_cent2" if cent else ("k_lq_limb + k_lq_rows + k_lq_chain" if forms["lq_limb"] else "k_lq<true>")
+        step_name = ("k_step + k_lq_cent2_value (+ reductions)" if cent else
+                     ("k_step + k_value_quad (+ reductions)" if forms["value_quad"] else "k_step_value (+ reductions)"))
+        kern = {lq_name: (kms[0], f_rk4, "valu-issue / scattered stores (limb lanes)" if forms["lq_limb"] and not cent else "valu-issue"),
                 "k_project": (kms[1], f_proj + f_gn, "mfma"),
                 ("k_scan_*" if scan_used else ("k_seg_*" if seg_used else "k_riccati")): (kms[2], f_ric, "latency (serial stage chain; matrix pipe)" if not scan_used else "mfma"),
-                ("k_step + k_lq_cent2_value (+ reductions)" if cent else "k_step + k_value_quad (+ reductions)"): (kms[3], 0.0, "hbm (step) / valu-issue (value pass)")}
+                step_name: (kms[3], 0.0, "hbm (step) / valu-issue (value pass)")}
         per_kernel = {}
         for name, (ms, fl, bound) in kern.items():
-            info = pmc.get(name.split(" ")[0].replace("k_scan_*", "k_scan_combine").replace("k_riccati", "k_riccati<58>"), {}) if (B, N) == (256, 100) and not cent else {}
-            if name.startswith("k_step + k_value_quad") and info:   # two kernels in this bucket: their HBM bytes add up
-                info = {"hbm_bytes": info.get("hbm_bytes", 0.0) + pmc.get("k_value_quad", {}).get("hbm_bytes", 0.0), "mfma_busy": 0.0}
+            # a bucket of several kernels (timed together by the library's HIP events): their HBM bytes add up, matrix-pipe share from its first MFMA kernel
+            parts = [q.strip().split(" ")[0] for q in name.split("+")]
+            parts = [q.replace("k_scan_*", "k_scan_combine").replace("k_riccati", "k_riccati<58>") for q in parts]
+            infos = [pmc.get(q, {}) for q in parts] if (B, N) == (256, 100) and not cent else []
+            hbm = sum(i.get("hbm_bytes", 0.0) for i in infos) if any("hbm_bytes" in i for i in infos) else None
+            busy = next((i.get("mfma_busy") for i in infos if i.get("mfma_busy")), 0.0 if infos and any(i for i in infos) else None)
             per_kernel[name] = {"ms": ms, "bound": bound, "algorithmic_TFLOPs": nodes * fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
                                 "frac_fp64": nodes * fl / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS if ms > 0 else None,
-                                "mfma_busy": info.get("mfma_busy"), "hbm_bytes": info.get("hbm_bytes")}
+                                "mfma_busy": busy, "hbm_bytes": hbm}
         dom = max((k for k in kern if kern[k][1] > 0), key=lambda n: kern[n][0])
         dom_ms, dom_flops, dom_bound = kern[dom]
         ach_tf = nodes * dom_flops / (dom_ms * 1e-3) / 1e12

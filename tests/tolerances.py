@@ -1,4 +1,5 @@
-"""Parity tolerances of the GPU tests = BASELINE.md §6, f64 end to end, no relaxation:
+"""Parity tolerances of the GPU tests = BASELINE.md §6, f64 end to end.  On the BASELINE configurations (and the golden fixtures) they hold
+without relaxation; OFF them they are, in general, not attainable as ABSOLUTE bounds and are not claimed (see "Where 1e-8 absolute ends" below):
 
   * state / input trajectories and QP steps against the CPU oracle on identical inputs: max-abs <= 1e-8, ABSOLUTE (not scaled by
     the step, whose inputs reach |du| ~ 350 N on the walk configs);
@@ -13,8 +14,18 @@ performance-index error 5.3e-11, worst normalised stationarity 6.3e-13 on the se
 test_config3_exactly_against_the_oracle[auto] and [serial] use the same yardstick), worst primal residual 4.4e-14 — over BASELINE configs 1,
 2, 3, 4 (instances 0, 37, 128, 255 of the 256) and a config-5 slice (N = 200, slow_walk, 8 instances).
 
+Where 1e-8 absolute ends.  The solution error of an f64 solve is (condition of the QP) x eps x (step scale), not an absolute
+number: tools/gpu_fuzz.py's random problems (profiles/r04_fuzz.txt, r05_fuzz.txt: perturbed gaits / horizons with |step| up to 1e3) leave 17 of 40
+above 1e-8 absolute — up to 2.9e-7 at |step| ~ 1e3, e.g. `wb seed 1 N=18` on the SERIAL sweep 2.1e-8 — while all of them are within 1e-10 of
+the step's scale.  That population is therefore judged RELATIVE (gpu_fuzz.py: 1e-9 x scale), and tests that leave the BASELINE inputs on purpose
+pass `rel=` to assert_step / assert_perf below and say why.  Margins inside the bounds: config 3's default path is the parallel-in-time sweep,
+which inverts I + C1 J2 of partial horizons (cond ~ 1e9): its |du| error is 0.6 of TRAJ_ABS and its stationarity 0.6 of KKT_REL (serial: 3e-12
+/ 4e-13); refinement passes of the gains do not contract it (tests/experiments/scan_refinement_experiment.py: 3.7e-9 -> 8.5e-9 -> 5.4e-9 over 0,
+1, 2 passes), so a change of rounding upstream of the sweep can move it across the bound — the KKT gate then sends that iteration to the serial
+recursion, which is what keeps the RESULT inside the tolerance; the tests of that path assert the bound on the gated result.
+
 Kernel variants of ONE quantity are held to each other more tightly than to the oracle: the value pass on quads of lanes against its
-phase form 1e-12 relative (sums over bodies / cost terms in another order), the blocked matrix-core factorisation against numpy's
+phase form 1e-12 relative (sums over bodies / cost terms in another order), the limb-lane form of the LQ approximation against its phase form 1e-10 of the step's scale (LQ blocks: 1e-11 against the oracle, 1e-13 against each other on the host), the blocked matrix-core factorisation against numpy's
 Cholesky 50 eps sqrt(cond) (tests/test_hostemu.py), reference-compiled assembly rows against the oracle 1e-12 (tests/test_ref_assembly.py)."""
 import numpy as np
 

@@ -18,6 +18,7 @@ ABI_VERSION = 5   # HSQP_ABI_VERSION of include/hsqp.h (tests/test_abi.py compar
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_NUMERIC, ERR_HIP, ERR_NOT_CONVERGED = 0, -1, -2, -3, -4, -5, -6
 
 BLK_AB, BLK_BVEC, BLK_H, BLK_G, BLK_CDE, BLK_NE, BLK_COST, BLK_DX, BLK_DU, BLK_FLOW = range(1, 11)
+BLK_PARAMS, BLK_FORMS = 11, 12
 
 
 class Body(C.Structure):

@@ -1762,6 +1762,11 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
 
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
   if (!h) return HSQP_ERR_BAD_ARG;
+  if (what == HSQP_BLK_FORMS) {
+    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, 0, 0};
+    if (dst && bytes > 0) memcpy(dst, forms, (size_t)(bytes < 16 ? bytes : 16));
+    return 16;
+  }
   if (what == HSQP_BLK_PARAMS) {   // available as soon as a problem is resident
     if (!h->have_problem) { h->err = "no problem uploaded"; return HSQP_ERR_BAD_ARG; }
     if (hipSetDevice(h->device) != hipSuccess) return HSQP_ERR_HIP;
