@@ -57,6 +57,46 @@ def test_lq_record_expands_to_the_oracle_blocks(model, oracle, emu, gait, n):
             assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("gait,n", [("stance", 3), ("walk", 10), ("run", 14)])
+def test_limb_lane_form_of_the_lq_approximation_equals_the_phase_form(model, emu, gait, n):
+    """hsqp_lql.h (a lane per limb: forward walk, unwinding walk back with the composites in registers, rows by the column owners, stored transposed;
+    then the column-lane RK4 chain) against lq_node<true> (one workgroup per node, ~70 phases over an LDS workspace, row-major rows): the records
+    expand to the same LQ blocks — the two forms share formulas, not code paths or summation orders — far inside the 1e-11 either holds against the
+    oracle.  `run` has active collision rows (64 row slots in use); node 1 is also taken as an event interval (dt = 0)."""
+    lib, h = emu
+    assert lib.emu_ql_ok(h) == 1
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=5)
+    RS, off, fo = lib.emu_rec_size(), lib.emu_rec_misc_offset(), lib.emu_rec_flow_offset()
+
+    def expand(rec, dtk):
+        AB, H, g, CDe = np.zeros((58, 93)), np.zeros((93, 93)), np.zeros(93), np.zeros((14, 94))
+        lib.emu_expand(P(rec), C.c_double(dtk), P(AB), P(H), P(g), P(CDe))
+        return AB, H, g, CDe
+
+    nrows = set()
+    try:
+        for k in range(n):
+            for dtk in (dt, 0.0) if k == 1 else (dt,):
+                recs = []
+                for limb in (1, 0):
+                    lib.emu_set_lq_limb(limb)
+                    rec = np.zeros(RS)
+                    lib.emu_lq_node(h, P(x[k]), P(u[k]), P(x[k + 1]), P(par[k]), C.c_double(dtk), 1, P(rec))
+                    recs.append(rec)
+                for a, b in zip(expand(recs[0], dtk), expand(recs[1], dtk)):
+                    assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+                ma, mb = recs[0][off:off + 8], recs[1][off:off + 8]          # ne, cost, eq / dyn SSE, contact flags, row offsets
+                assert np.abs(ma - mb).max() <= 1e-12 * max(1.0, np.abs(mb).max())
+                assert np.abs(recs[0][fo:fo + 64] - recs[1][fo:fo + 64]).max() <= 1e-12 * max(1.0, np.abs(recs[1][fo:fo + 64]).max())
+                assert recs[0][off + 9] == 1.0 and recs[1][off + 9] == 0.0      # REC_LAYOUT: transposed / row-major
+                nrows.add((recs[0][off + 8], recs[1][off + 8]))
+    finally:
+        lib.emu_set_lq_limb(1)
+    assert nrows <= {(48.0, 46.0), (48.0, 38.0), (48.0, 30.0), (64.0, 54.0), (64.0, 62.0), (64.0, 46.0)}
+    if gait == "run":
+        assert any(a == 64.0 for a, _ in nrows)
+
+
 def test_limb_tables_of_the_quad_value_pass(model, emu):
     """build_dev_model's limbs (hsqp_host.h): the G1 tree has four root-to-leaf paths (two legs, waist + arm twice), the feet sit on different limbs,
     and every moving body is owned — counted in the sums over bodies — by exactly one limb (the waist bodies, walked by both arm lanes, by the first)."""

@@ -427,6 +427,9 @@ static_assert(ROWQ_COLL + 16 == NRS && ROWQ_FM + 16 == ROWQ_COLL, "row slots");
 // record is zero-filled when it is allocated (hsqp_create) and only this kernel writes these regions.
 
 HSQP_HD void ql_st2(double* p, double a, double b) {
+#if defined(HSQP_EXP_FEWSTORES)   /* timing experiment only (wrong results): one store in eight reaches memory */
+  if ((reinterpret_cast<unsigned long long>(p) >> 4) & 7ull) return;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
   *reinterpret_cast<double2*>(p) = make_double2(a, b);
 #else
