@@ -60,6 +60,42 @@ def test_adaptor_compiles_and_fails_loudly_without_a_device(tmp_path, model):
     assert r.returncode == 3 and "runtime_error" in r.stdout and "(-2)" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+PUBLISHER = "/root/reference/humanoid_nmpc/humanoid_common_mpc_ros2/src/benchmarks/SqpBenchmarksPublisher.cpp"
+PUBLISHER_MAIN = r"""
+#include <cstdio>
+#include <humanoid_common_mpc_ros2/benchmarks/SqpBenchmarksPublisher.h>
+// the reference's publisher object file is linked in; this driver only proves that its types resolve to the adaptor's
+static_assert(std::is_same<ocs2::SqpSolver, ocs2::humanoid::HipSqpSolverAdaptor>::value, "alias");
+static_assert(std::is_same<ocs2::SqpSolver::Benchmarks, ocs2::humanoid::HipSqpBenchmarks>::value, "nested Benchmarks type");
+int main() {
+  auto node = std::make_shared<rclcpp::Node>();
+  ocs2::humanoid::SqpBenchmarksPublisher pub(node, nullptr);       // (stores the pointer; a solver needs a GPU)
+  ocs2::PrimalSolution empty;
+  pub.postSolverRun(empty);                                        // empty trajectory: returns before it touches the solver
+  std::printf("%s\n", node->topic.c_str());
+  return 0;
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(PUBLISHER), reason="/root/reference is only present in the build container")
+def test_reference_benchmarks_publisher_compiles_unchanged_against_the_adaptor(tmp_path):
+    """SURVEY §8f-3 / VERDICT r4 'missing 5': humanoid_common_mpc_ros2's SqpBenchmarksPublisher takes a `const ocs2::SqpSolver*` and reads
+    `SqpSolver::Benchmarks` (SqpBenchmarksPublisher.cpp:34,44-57).  With the one-line alias of tests/stubs/ros2/ocs2_sqp/SqpSolver.h and the adaptor's
+    nested `Benchmarks` type the reference's file compiles UNCHANGED, in place, and links; ROS 2 itself is a stand-in (tests/stubs/ros2)."""
+    solver.load_library()
+    inc = ["-I", os.path.join(ROOT, "tests", "stubs", "ros2"), "-I", os.path.join(ROOT, "tests", "stubs", "ocs2"), "-I", os.path.join(LIBDIR, "host"),
+           "-I", os.path.join(ROOT, "include"), "-I", "/root/reference/humanoid_nmpc/humanoid_common_mpc_ros2/include"]
+    obj = tmp_path / "publisher.o"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-c", *inc, PUBLISHER, "-o", str(obj)])
+    main = tmp_path / "main.cpp"
+    main.write_text(PUBLISHER_MAIN)
+    exe = tmp_path / "pub"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", *inc, str(main), str(obj), "-L", LIBDIR, "-lhsqp_hip", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "/humanoid/mpc_benchmarks"
+
+
 def interp_rows(t, v, time):
     """ocs2 LinearInterpolation with duplicated (event) stamps: the post-event row at an event time."""
     if time <= t[0]:

@@ -596,15 +596,10 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   }
   PH_TICK(ctx, 12);
   const double* gs = grec + REC_GS;
-  QlG3 cur, nxt;
-  ql_rows_fetch(lb, max_len - 1, gs, cur);
+  double gcur[6];
+  ql_rows_fetch(gs, ql_rows_column(lb, max_len - 1, 0), gcur);
 #pragma unroll 1
-  for (int t = max_len - 1; t >= 0; --t) {
-    ql_rows_fetch(lb, t - 1, gs, nxt);   // the next step's columns, in front of this step's stores
-    QV_SCHED_FENCE();
-    ql_rows_back_step(*dm, ws.k, lb, rw, nl, xs, us, t, st, csn, CSN_LD, bk.w, cur, grec, live);
-    cur = nxt;
-  }
+  for (int t = max_len - 1; t >= 0; --t) ql_rows_back_step(*dm, ws.k, lb, rw, nl, xs, us, t, st, csn, CSN_LD, bk.w, gs, gcur, grec, live);
   PH_TICK(ctx, 13);
   ql_rows_base(*dm, rw, nl, us, L, bk, sh, gs, grec, live);
   PH_TICK(ctx, 14);

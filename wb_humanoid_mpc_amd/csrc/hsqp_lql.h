@@ -482,18 +482,24 @@ HSQP_HD void ql_terms_a(const DevModel& dm, const double* x, const double* u, co
     QlFoot& ft = nl.ft[f];
     const int cf = f == 0 ? c0 : c1;
     double a[6], o[18], t[3], t2[3];
+    #pragma unroll
     for (int k = 0; k < 3; ++k) { a[k] = ft.al[k] + sh.y[k]; a[3 + k] = ft.al[3 + k] + sh.ab[k]; }
     a[5] -= dm.gravity;
+    #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = x[k] + ft.rP[k];
     ori_error(ft.R, o + 3);
     v3_cross(ft.vl, ft.rP, t);
+    #pragma unroll
     for (int k = 0; k < 3; ++k) { o[6 + k] = ft.vl[3 + k] + t[k]; o[9 + k] = ft.vl[k]; }
     v3_cross(a, ft.rP, t);
     v3_cross(ft.vl, o + 6, t2);
+    #pragma unroll
     for (int k = 0; k < 3; ++k) { o[12 + k] = a[3 + k] + t[k] + t2[k]; o[15 + k] = a[k]; }
+    #pragma unroll
     for (int k = 0; k < 3; ++k) { ft.vP[k] = o[6 + k]; ft.alpha[k] = o[15 + k]; }
     // EndEffectorDynamicsFootCost.cpp:91-124
     double* rho = rec + REC_RHO;
+    #pragma unroll
     for (int k = 0; k < 15; ++k) {
       const double r = dm.foot_sqrt_w[3 + k] * par[HSQP_P_IMPACT + f] * o[3 + k];
       cst += 0.5 * r * r;
@@ -516,12 +522,14 @@ HSQP_HD void ql_terms_a(const DevModel& dm, const double* x, const double* u, co
       m3_tmulv(ft.R, u + 6 * f, lf);
       m3_tmulv(ft.R, u + 6 * f + 3, lm);
       const double hm[4] = {lm[0] - dm.rect_y_min * lf[2], -lm[0] + dm.rect_y_max * lf[2], -lm[1] - dm.rect_x_min * lf[2], lm[1] + dm.rect_x_max * lf[2]};
+      #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const Pen3 pm = relaxed_barrier(dm.moment_bmu, dm.moment_bdelta, hm[k]);
         scfm[4 + k] = sqrt(pm.d2); rfm[4 + k] = pm.d1 / scfm[4 + k];
         cst += pm.p;
       }
       // EndEffectorDynamicsAccelerationsConstraint.cpp:82-103, gains WBMpcInterface.cpp:205-229
+      #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int cc = k % 3;
         const double gp = k < 2 ? 0.0 : (k == 2 ? dm.gain_pos_z : dm.gain_ori);
@@ -531,10 +539,12 @@ HSQP_HD void ql_terms_a(const DevModel& dm, const double* x, const double* u, co
       }
     } else {
       // ZeroWrenchConstraint.cpp:59-84, EndEffectorDynamicsLinearAccConstraint.cpp:69-83 (config WBMpcPreComputation.cpp:91-104)
+      #pragma unroll
       for (int k = 0; k < 6; ++k) e[k] = u[6 * f + k];
       const double* sw = par + HSQP_P_SWING + 3 * f;
       e[6] = -dm.gain_linvel_z * sw[1] - dm.gain_linacc_z * sw[2] - dm.gain_pos_z * sw[0] + dm.gain_pos_z * o[2] + dm.gain_linvel_z * o[8] + dm.gain_linacc_z * o[14];
     }
+    #pragma unroll
     for (int k = 0; k < 7; ++k) eq += e[k] * e[k];
     if (live) {   // the foot's part of the column of the equality values; the second foot also clears the rows behind the last one
       const int n0 = c0 ? 6 : 7, r0 = f == 0 ? 0 : n0, nf = cf ? 6 : 7;
@@ -543,6 +553,7 @@ HSQP_HD void ql_terms_a(const DevModel& dm, const double* x, const double* u, co
       for (int k = 0; k < 7; ++k) if (k < nf) ce[r0 + k] = e[k];   // (fixed trip count: e stays in registers)
       if (f == 1) for (int k = r0 + nf; k < CDE_ROWS; ++k) ce[k] = 0.0;
     }
+    #pragma unroll
     for (int k = 0; k < 8; ++k) { ft.scfm[k] = sdt * scfm[k]; if (live) rho[ROWQ_FM + 8 * f + k] = sdt * rfm[k]; }
     ft.fshift = shift;
   }
@@ -609,9 +620,13 @@ HSQP_HD void ql_terms_b(const DevModel& dm, const double* x, const double* u, co
     for (int i = L; i < 64; i += QV_LIMBS) {
       double f = 0.0;
       if (i < NV) f = x[NV + i];
-      else if (i < NV + 6) f = sh.ab[i - NV];
+      else if (i < NV + 6) continue;   // (the base acceleration: below, with compile-time indices — sh indexed by i would live in scratch memory)
       else if (i < NX) f = u[12 + i - NV - 6];
       rec[REC_FLOW + i] = f;
+    }
+    if (L == 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rec[REC_FLOW + NV + k] = sh.ab[k];
     }
   }
   cost = cst;
@@ -958,76 +973,72 @@ HSQP_HD void ql_kin_to_leaf(const DevModel& dm, const KC& kc, const QlLimb& lb, 
     capture(i, ((own >> t) & 1u) != 0);
   }
 }
-// the stage Jacobian columns of the three columns of joint i = path[t] of limb L (zeros if the lane has no step t): what ql_rows_back_step(t) consumes.
-// Loaded one step AHEAD of their use, i.e. in front of the previous step's stores: the memory counter retires in order, so a load issued
-// behind ~60 stores waits for all of them to be acknowledged (measured: 18 k cycles per column).
-struct QlG3 { double g[3][6]; };
-HSQP_HD void ql_rows_fetch(const QlLimb& lb, int t, const double* gs, QlG3& q) {
+// column `kind` (0 / 1 / 2: d/dq, d/dqd, d/dqdd) of the joint at step t of the lane's limb (a valid column if the lane has no step t)
+HSQP_HD int ql_rows_column(const QlLimb& lb, int t, int kind) {
   const bool has = t >= 0 && t < lb.len;
   const int i = has ? (int)((lb.path >> (8 * t)) & 0xffull) : 1, j = i - 1;
-  const int col[3] = {3 + i + 2, NV + 3 + i + 2, NX + 12 + j};
-#pragma unroll
-  for (int kind = 0; kind < 3; ++kind)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) q.g[kind][k] = gs[col[kind] * GT_LD + k];
+  return kind == 0 ? 3 + i + 2 : (kind == 1 ? NV + 3 + i + 2 : NX + 12 + j);
 }
-// one step of the rows pass: the rows of the three columns of joint i = path[t] (their Jacobian columns: cur), then up to the parent
+HSQP_HD void ql_rows_fetch(const double* gs, int col, double* g) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = gs[col * GT_LD + k];
+}
+// one step of the rows pass: the rows of the three columns of joint i = path[t], then up to the parent.  gcur: the stage Jacobian column of
+// (t, kind 0) on entry, of (t - 1, kind 0) on exit — every column is fetched ONE COLUMN AHEAD of its use, i.e. in front of the previous column's
+// stores: the memory counter retires in order, so a load issued behind a column's ~24 stores waits for all of them to be acknowledged.
 template <class KC>
 HSQP_HD void ql_rows_back_step(const DevModel& dm, const KC& kc, const QlLimb& lb, const QlRows& rw, const QlNodeLds& nl, const double* x, const double* u, int t,
-                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], const QlG3& cur, double* rec, bool live) {
-  if (t >= lb.len) return;
-  const int foot_step = lb.foot_step;
-  const int i = (int)((lb.path >> (8 * t)) & 0xffull), j = i - 1;
+                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], const double* gs, double* gcur, double* rec, bool live) {
+  const bool active = t < lb.len;
+  const int i = active ? (int)((lb.path >> (8 * t)) & 0xffull) : 1, j = i - 1;
   const double qd = x[NV + 6 + j], qdd = u[12 + j];
   double S[6], Sd[6];
   m3_mulv(st.R, kc.axis[i], S);
   v3_cross(st.r, S, S + 3);
   mxm(st.vl, S, Sd);
-  if ((lb.own >> t) & 1u) {
-    const bool sup = t <= foot_step;
+  const bool mine = active && ((lb.own >> t) & 1u) != 0;
+  const bool sup = t <= lb.foot_step;
 #pragma unroll 1
-    for (int kind = 0; kind < 3; ++kind) {
-      const int col = kind == 0 ? 3 + i + 2 : (kind == 1 ? NV + 3 + i + 2 : NX + 12 + j);
-      double g[6];
+  for (int kind = 0; kind < 3; ++kind) {
+    double gn[6];
+    ql_rows_fetch(gs, kind < 2 ? ql_rows_column(lb, t, kind + 1) : ql_rows_column(lb, t - 1, 0), gn);
+    QV_SCHED_FENCE();
+    if (mine) ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, gcur, ql_rows_column(lb, t, kind), rec, live);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) g[k] = kind == 0 ? cur.g[0][k] : (kind == 1 ? cur.g[1][k] : cur.g[2][k]);   // (selects: an array indexed by `kind` would live in scratch memory)
-      ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, g, col, rec, live);
-    }
+    for (int k = 0; k < 6; ++k) gcur[k] = gn[k];
   }
   QV_SCHED_FENCE();
-  ql_unwind(kc, i, S, Sd, qd, qdd, csn[t * csn_ld], csn[t * csn_ld + 1], st);
+  if (active) ql_unwind(kc, i, S, Sd, qd, qdd, csn[t * csn_ld], csn[t * csn_ld + 1], st);
 }
 // the rows of the base columns (the division of labour of ql_base_columns)
 HSQP_HD void ql_rows_base(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, const double* u, int L, const QlBaseKin& bk, const QlShared& sh,
                           const double* gs, double* rec, bool live) {
-  // (all Jacobian columns the lane needs are fetched in front of the first store: see ql_rows_fetch)
-  double ge[2][6], gw[6][6];
-  const int je = L < 3 ? L : 0, fo = rw.own >= 0 ? rw.own : 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { ge[0][k] = gs[(3 + je) * GT_LD + k]; ge[1][k] = gs[(NV + 3 + je) * GT_LD + k]; }
-#pragma unroll
-  for (int k6 = 0; k6 < 6; ++k6)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gw[k6][k] = gs[(NX + 6 * fo + k6) * GT_LD + k];
-  QV_SCHED_FENCE();
+  // (every Jacobian column is fetched one column ahead of its use, in front of the previous column's stores: see ql_rows_back_step)
+  const int fo = rw.own >= 0 ? rw.own : 0, cw0 = NX + 6 * fo;
+  double gc[6], gn[6];
   if (L < 3) {
+    ql_rows_fetch(gs, 3 + L, gc);
 #pragma unroll 1
     for (int kind = 0; kind < 2; ++kind) {
-      double g[6];
+      ql_rows_fetch(gs, kind == 0 ? NV + 3 + L : cw0, gn);
+      QV_SCHED_FENCE();
+      ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, gc, rec, live);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) g[k] = kind == 0 ? ge[0][k] : ge[1][k];
-      ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, g, rec, live);
+      for (int k = 0; k < 6; ++k) gc[k] = gn[k];
     }
   } else {
+    ql_rows_fetch(gs, cw0, gc);
+    QV_SCHED_FENCE();
     ql_rows_base_linear(dm, rw, nl, rec, live);
   }
   if (rw.own >= 0) {
 #pragma unroll 1
     for (int k6 = 0; k6 < 6; ++k6) {
-      double g[6];
+      ql_rows_fetch(gs, cw0 + (k6 < 5 ? k6 + 1 : 5), gn);
+      QV_SCHED_FENCE();
+      ql_rows_wrench(dm, rw, nl, u, rw.own, k6, bk, gc, rec, live);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) g[k] = k6 == 0 ? gw[0][k] : (k6 == 1 ? gw[1][k] : (k6 == 2 ? gw[2][k] : (k6 == 3 ? gw[3][k] : (k6 == 4 ? gw[4][k] : gw[5][k]))));
-      ql_rows_wrench(dm, rw, nl, u, rw.own, k6, bk, g, rec, live);
+      for (int k = 0; k < 6; ++k) gc[k] = gn[k];
     }
   }
 }
@@ -1177,9 +1188,9 @@ inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, c
   const double* G = rec + REC_GS;
   for (int t = dm.limb_max_len - 1; t >= 0; --t)
     for (int L = 0; L < QV_LIMBS; ++L) {
-      QlG3 cur;
-      ql_rows_fetch(ql_limb(dm, L), t, G, cur);
-      ql_rows_back_step(dm, *kc, ql_limb(dm, L), rw[L], *nl, x, u, t, st[L], &csn[L][0][0], 2, bk[L].w, cur, rec, true);
+      double gcur[6];
+      ql_rows_fetch(G, ql_rows_column(ql_limb(dm, L), t, 0), gcur);
+      ql_rows_back_step(dm, *kc, ql_limb(dm, L), rw[L], *nl, x, u, t, st[L], &csn[L][0][0], 2, bk[L].w, G, gcur, rec, true);
     }
   for (int L = 0; L < QV_LIMBS; ++L) ql_rows_base(dm, rw[L], *nl, u, L, bk[L], sh[L], G, rec, true);
   delete kc;

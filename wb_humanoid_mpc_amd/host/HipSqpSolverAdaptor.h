@@ -124,7 +124,9 @@ class HipSqpSolverAdaptor final : public SolverBase {
   MultiplierCollection getSolutionMultipliers(scalar_t) const override {
     throw std::runtime_error("[HipSqpSolverAdaptor] getSolutionMultipliers() not implemented");
   }
-  /** SqpSolver::getBenchmarks() of the fork. */
+  /** SqpSolver::getBenchmarks() of the fork; `Benchmarks`: the nested type name code written against ocs2::SqpSolver uses (SqpBenchmarksPublisher.cpp:44) —
+   *  with `namespace ocs2 { using SqpSolver = humanoid::HipSqpSolverAdaptor; }` that file compiles unchanged (tests/stubs/ros2, tests/test_adaptor.py). */
+  using Benchmarks = HipSqpBenchmarks;
   const HipSqpBenchmarks& getBenchmarks() const { return benchmarks_; }
   std::string getBenchmarkingInfo() const override {
     const scalar_t n = std::max<size_t>(benchmarks_.numCalls, 1);
