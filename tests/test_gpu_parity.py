@@ -643,6 +643,26 @@ def test_update_term_weights_equals_a_handle_created_with_them(model):
         again = s.run(x0, x, u, par, dt)
     finally:
         s.close()
+    # ... and hsqp_create applies the SAME validation (it used to accept what the updaters reject): a relaxed barrier with mu = 0, a
+    # non-positive input weight and a NaN gain are refused; a piecewise-polynomial penalty switched off with mu = 0 is a valid model
+    for field, value in (("friction_barrier.mu", 0.0), ("moment_barrier.delta", -1.0), ("gain_ori", float("nan"))):
+        mb = copy.copy(model)
+        mb.desc = type(model.desc).from_buffer_copy(model.desc)
+        obj, name = mb.desc, field
+        while "." in name:
+            head, name = name.split(".", 1)
+            obj = getattr(obj, head)
+        setattr(obj, name, value)
+        with pytest.raises(HsqpError):
+            HipSqpSolver(mb, max_nodes=4, max_batch=1)
+    mb = copy.copy(model)
+    mb.desc = type(model.desc).from_buffer_copy(model.desc)
+    mb.desc.R[3] = 0.0
+    with pytest.raises(HsqpError):
+        HipSqpSolver(mb, max_nodes=4, max_batch=1)
+    mb.desc.R[3] = model.desc.R[3]
+    mb.desc.collision_barrier.mu = 0.0
+    HipSqpSolver(mb, max_nodes=4, max_batch=1).close()
     m2 = copy.copy(model)
     m2.desc = type(model.desc).from_buffer_copy(model.desc)
     for i in range(18):

@@ -1606,8 +1606,7 @@ int hsqp_update_term_weights(hsqp_handle* h, const hsqp_term_weights* w) {
   const double* all = reinterpret_cast<const double*>(w);
   for (size_t i = 0; i < sizeof(hsqp_term_weights) / sizeof(double); ++i)
     if (!std::isfinite(all[i])) { h->err = "hsqp_update_term_weights: every entry must be finite"; return HSQP_ERR_BAD_ARG; }
-  for (const hsqp_barrier* b : {&w->friction_barrier, &w->moment_barrier, &w->joint_limit_barrier, &w->collision_barrier})
-    if (!(b->mu > 0.0) || !(b->delta > 0.0)) { h->err = "hsqp_update_term_weights: barrier mu and delta must be > 0"; return HSQP_ERR_BAD_ARG; }
+  // (the barrier parameters, weights and gains are validated by build_dev_model below: the same checks as hsqp_create)
   hsqp_model_desc m = h->md;
   memcpy(m.foot_sqrt_w, w->foot_sqrt_w, sizeof(m.foot_sqrt_w));
   m.gain_pos_z = w->gain_pos_z; m.gain_ori = w->gain_ori; m.gain_linvel_z = w->gain_linvel_z; m.gain_linvel_xy = w->gain_linvel_xy;

@@ -233,8 +233,12 @@ inline std::string build_dev_model(const hsqp_model_desc& md, DevModel& dm) {
   for (double v : md.foot_sqrt_w) if (!std::isfinite(v)) return "foot cost weights must be finite";
   for (double v : {md.gain_pos_z, md.gain_ori, md.gain_linvel_z, md.gain_linvel_xy, md.gain_angvel, md.gain_linacc_z, md.gain_linacc_xy, md.gain_angacc})
     if (!std::isfinite(v)) return "foot constraint gains must be finite";
-  for (const hsqp_barrier* b : {&md.friction_barrier, &md.moment_barrier, &md.joint_limit_barrier, &md.collision_barrier})
-    if (!std::isfinite(b->mu) || !std::isfinite(b->delta) || !(b->mu > 0.0) || !(b->delta > 0.0)) return "barrier mu and delta must be finite and > 0";
+  // relaxed barriers (friction cone, contact moment): mu > 0 — their rows are scaled by sqrt(p'') and carry p' / sqrt(p''); the piecewise-polynomial
+  // penalties (joint limits, foot collision) may be switched off with mu = 0
+  for (const hsqp_barrier* b : {&md.friction_barrier, &md.moment_barrier})
+    if (!std::isfinite(b->mu) || !std::isfinite(b->delta) || !(b->mu > 0.0) || !(b->delta > 0.0)) return "friction / moment barrier: mu and delta must be finite and > 0";
+  for (const hsqp_barrier* b : {&md.joint_limit_barrier, &md.collision_barrier})
+    if (!std::isfinite(b->mu) || !std::isfinite(b->delta) || b->mu < 0.0 || !(b->delta > 0.0)) return "joint-limit / collision barrier: mu must be finite and >= 0, delta finite and > 0";
   return "";
 }
 
