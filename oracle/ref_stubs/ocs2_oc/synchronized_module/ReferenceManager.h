@@ -19,6 +19,15 @@ struct TargetTrajectories {
     const scalar_t a = (timeTrajectory[i] - time) / (timeTrajectory[i] - timeTrajectory[i - 1]);
     return vector_t(a * stateTrajectory[i - 1] + (1.0 - a) * stateTrajectory[i]);
   }
+  vector_t getDesiredInput(scalar_t time) const {   // (upstream: the same interpolation of the input trajectory)
+    if (timeTrajectory.empty() || inputTrajectory.empty()) throw std::runtime_error("[TargetTrajectories] empty");
+    if (time <= timeTrajectory.front() || timeTrajectory.size() == 1) return inputTrajectory.front();
+    if (time >= timeTrajectory.back()) return inputTrajectory.back();
+    size_t i = 1;
+    while (timeTrajectory[i] < time) ++i;
+    const scalar_t a = (timeTrajectory[i] - time) / (timeTrajectory[i] - timeTrajectory[i - 1]);
+    return vector_t(a * inputTrajectory[i - 1] + (1.0 - a) * inputTrajectory[i]);
+  }
   scalar_array_t timeTrajectory;
   vector_array_t stateTrajectory;
   vector_array_t inputTrajectory;

@@ -1,0 +1,3 @@
+// MOCK (test infrastructure): see pinocchio/mock.hpp
+#pragma once
+#include <pinocchio/mock.hpp>
