@@ -57,10 +57,13 @@ def suffix_scan(elements):
     return e, levels
 
 
-def solve_qp(stages, QN, qN, dx0):
+def solve_qp(stages, QN, qN, dx0, prepended=False):
     """stages: list of dicts A, B, b, Q, P, R, q, r.  Returns dx [N+1, nx], u [N, nu], S [N+1], s [N+1], scan levels."""
     N = len(stages)
-    elems = [stage_element(**st) for st in stages] + [terminal_element(QN, qN)]
+    # prepended: the stage elements the device forms since round 5 (hsqp_scan.h::scan_init_node): the stage prepended to the empty interval —
+    # R = L L', Z = L^-1 P, W = B L^-T, A - W Z, C = W W', J = Q - Z'Z — instead of products with the explicit R^-1 (cond(R) ~ 1e7 on the whole-body problem)
+    n = QN.shape[0]
+    elems = [(prepend_stage(st, identity_element(n)) if prepended else stage_element(**st)) for st in stages] + [terminal_element(QN, qN)]
     suf, levels = suffix_scan(elems)
     S = [e[4] for e in suf]
     s = [-e[3] for e in suf]
@@ -130,19 +133,42 @@ def riccati_segment(stages, S, s):
     return gains[::-1], S, s
 
 
-def solve_qp_segmented(stages, QN, qN, dx0, n_segments):
-    """Returns dx, u, the boundary indices, the boundary value functions and the number of scan levels over the segments."""
+# Guess shift (round 5).  A quadratic 1/2 x' G x at a boundary node is the element c(G) = (I, 0, 0, 0, G); c(-G) o c(G) is the identity, so the
+# chain of elements e_0 o e_1 o .. equals  e_0 o c(G_1)  o  c(-G_1) o e_1 o c(G_2)  o  c(-G_2) o e_2 ..: every segment gets the guess of the value
+# function at its END as a terminal cost (its recursion then starts from S = G_{p+1} instead of S = 0: Lam = R + B' G B is as well conditioned
+# as in the serial recursion, where R alone has condition 1e7 on the whole-body problem) and hands the guess at its START back (c(-G) o e: J - G,
+# nothing else changes, exactly).  The scan then carries J_p = S_p - G_p: the CORRECTION of the guess.  With the boundary value functions of the
+# previous SQP iteration as guesses |C J| << 1 and M = I + C1 J2 is near the identity; with any guess the suffixes are the same in exact
+# arithmetic.  Measured (whole-body, N = 100, walk): step error against the serial recursion 8e-9 without guesses, 7e-10 with G = 0 but the
+# elements formed this way, 1e-9 with the value functions of a differently perturbed problem, 3e-11 with guesses 0.1 % off.
+def shifted_segment_element(stages, G_end, G_start):
+    n = G_end.shape[0]
+    e = (np.eye(n), np.zeros(n), np.zeros((n, n)), np.zeros(n), G_end)
+    for st in reversed(stages):
+        e = prepend_stage(st, e)
+    return (e[0], e[1], e[2], e[3], e[4] - G_start)
+
+
+def solve_qp_segmented(stages, QN, qN, dx0, n_segments, guesses=None):
+    """Returns dx, u, the boundary indices, the boundary value functions and the number of scan levels over the segments.
+    guesses (optional): n_segments + 1 symmetric matrices, guesses of the value function's Hessian at the segment boundaries."""
     N, n = len(stages), QN.shape[0]
     bounds = [round(p * N / n_segments) for p in range(n_segments + 1)]
+    G = [np.zeros((n, n))] * (n_segments + 1) if guesses is None else list(guesses)
     # (1) segment elements, independent of each other
     elems = []
     for p in range(n_segments):
-        e = identity_element(n)
-        for k in range(bounds[p + 1] - 1, bounds[p] - 1, -1):
-            e = prepend_stage(stages[k], e)
+        if guesses is None:
+            e = identity_element(n)
+            for k in range(bounds[p + 1] - 1, bounds[p] - 1, -1):
+                e = prepend_stage(stages[k], e)
+        else:
+            e = shifted_segment_element(stages[bounds[p]:bounds[p + 1]], G[p + 1], G[p])
         elems.append(e)
     # (2) suffix scan over the segment elements + the terminal element: value function at every boundary
-    suf, levels = suffix_scan(elems + [terminal_element(QN, qN)])
+    te = terminal_element(QN, qN)
+    suf, levels = suffix_scan(elems + [(te[0], te[1], te[2], te[3], te[4] - G[n_segments])])
+    suf = [(e[0], e[1], e[2], e[3], e[4] + G[p]) for p, e in enumerate(suf)]
     # (3) gains per segment from the value function at its END, (4) roll-out
     gains = []
     for p in range(n_segments):

@@ -268,9 +268,23 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True)
     s = HipSqpSolver(model, max_nodes=N, max_batch=B)
     try:
+        assert s.kernel_forms() == {"lq_limb": True, "value_quad": True, "lq_ranges": 2}
         out = s.run(x0, x, u, par, dt)
     finally:
         s.close()
+    # the limb-lane LQ kernels ran in two node ranges on two streams (a launch of 25 600 nodes is more than one round of the chip): the
+    # same numbers, bit for bit, as one launch per kernel
+    os.environ["HSQP_LQ_SPLIT"] = "1"
+    try:
+        s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+    finally:
+        os.environ.pop("HSQP_LQ_SPLIT", None)
+    try:
+        assert s.kernel_forms()["lq_ranges"] == 1
+        one = s.run(x0, x, u, par, dt)
+    finally:
+        s.close()
+    assert np.array_equal(one["dx"], out["dx"]) and np.array_equal(one["du"], out["du"])
     for b in (0, 37, 128, 255):
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4)
         assert_step(out, r, b, "config 4")

@@ -197,6 +197,28 @@ def test_whole_body_parallel_scan_backward_sweep_equals_the_serial_recursion(mod
         assert not accepted, kkt1                   # ... but flagged: the gate's criterion sees it
 
 
+def test_scan_elements_keep_their_digits_on_a_long_horizon(model, emu):
+    """Round 5: the scan's stage elements are formed with the Cholesky factor of R~ applied to both factors of every product (hsqp_scan.h::
+    scan_init_node) instead of products with the explicit R~^-1 (cond 1e7).  On this perturbed walk QP over 100 stages the emulated scan was 6.5e-7 of
+    the step's scale from the serial recursion (stationarity 6.7e-6) with the explicit inverse; it is 1.1e-9 (6e-8) now."""
+    lib, h = emu
+    n = 100
+    x0, x, u, par, dt = perturbed_problem(model, n, "walk", seed=5)
+    res = []
+    for scan in (0, 1):
+        lib.emu_set_scan(scan)
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        qp = np.zeros((n, lib.emu_qp_size()))
+        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None)
+        lib.emu_set_scan(0)
+        assert rc == 0
+        res.append((dx, du, kkt))
+    sc = max(1.0, np.abs(res[0][0]).max(), np.abs(res[0][1]).max())
+    err = max(np.abs(res[1][0] - res[0][0]).max(), np.abs(res[1][1] - res[0][1]).max())
+    assert err <= 1e-8 * sc and res[1][2][0] <= 5e-7, (err / sc, res[1][2])
+
+
 def test_scan_gate_decisions(emu):
     """scan_gate_accepts (hsqp_scan.h) on the measured populations: accurate scans pass, inaccurate ones, flagged ones and NaN do not."""
     lib, _ = emu

@@ -159,12 +159,17 @@ constexpr int SCAN_INIT_THREADS = 256, SCAN_COMB_THREADS = 512, SCAN_FWD_THREADS
 static_assert(4 * NX <= SCAN_FWD_THREADS, "closed_loop_forward: one item per thread");
 template <int n>
 __global__ __launch_bounds__(SCAN_INIT_THREADS) void k_scan_init(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par,
-                                                                 const double* __restrict__ qp, int N, double* __restrict__ el) {
+                                                                 const double* __restrict__ qp, int N, double* __restrict__ el, int* __restrict__ status) {
   ScanInitWS<n>& w = *reinterpret_cast<ScanInitWS<n>*>(hsqp_smem);
   const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
   scan_init_node<n>(ctx, w, qp + ((size_t)b * N + (k < N ? k : 0)) * QP_SIZE, el + (size_t)id * ScanEl<n>::SIZE, k == N, dm->Qf,
-                    x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP);
+                    x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, &ok);
+  __syncthreads();
+  if (threadIdx.x == 0 && !ok) atomicOr(&status[b], 2);   // R~ of a stage not positive definite (the gate sees the flag)
 }
 template <int n>
 __global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double* __restrict__ ein, double* __restrict__ eout, int N, int d, int* __restrict__ status,
@@ -404,6 +409,9 @@ __global__ __launch_bounds__(QV_THREADS * QV_WAVES) __attribute__((amdgpu_waves_
 
 // ---- whole-body LQ approximation on limb lanes (hsqp_lql.h), kernel 1 of 3: the rigid-body model and its Jacobian at the four RK4 stages.  A wave
 //      evaluates QL_NODES nodes, one lane per limb; writes REC_GS (transposed) and REC_AS of the node's record.
+#ifndef HSQP_LQ_SPLIT_DEFAULT
+#define HSQP_LQ_SPLIT_DEFAULT 2   /* node ranges of the limb-lane LQ kernels on streams of their own (hsqp_iterate_device) */
+#endif
 #ifndef HSQP_QL_WAVES
 #define HSQP_QL_WAVES 2          /* waves per workgroup: they share the body constants */
 #endif
@@ -435,11 +443,11 @@ struct QlWS {
 #endif
 __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QL_WPE, HSQP_QL_WPE))) void k_lq_limb(
     const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N, int nodes,
-    double* __restrict__ rec, long long* prof) {
+    double* __restrict__ rec, long long* prof, int node_base) {   // the launch covers the nodes [node_base, nodes)
   __shared__ QlWS ws;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
   auto& w = ws.wv[wave];
-  const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
+  const int node0 = node_base + (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;   // (a padding quad repeats the last node)
   const bool live = node0 + nn < nodes;
   const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);
@@ -545,11 +553,11 @@ struct QrWS {
 static_assert(sizeof(QrWS) * (4 / QL_WAVES) <= 163840, "four waves per CU");
 __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QR_WPE, HSQP_QR_WPE))) void k_lq_rows(
     const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts,
-    int N, int nodes, double* __restrict__ rec, long long* prof) {
+    int N, int nodes, double* __restrict__ rec, long long* prof, int node_base) {
   __shared__ QrWS ws;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
   auto& w = ws.wv[wave];
-  const int node0 = (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;
+  const int node0 = node_base + (blockIdx.x * QL_WAVES + wave) * QL_NODES, node = node0 + nn < nodes ? node0 + nn : nodes - 1;
   const int b = node / N, k = node % N;
   const bool live = node0 + nn < nodes;
   const Ctx ctx{(int)threadIdx.x, QL_THREADS * QL_WAVES, blockIdx.x == 0 ? prof : nullptr};   // phase profile (profile builds): slot 3, ids 10..15
@@ -611,9 +619,9 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
 #endif
 constexpr int LQC_THREADS = 128;   // (the 64 defect items must be one wave: lq_chain_node sums their squares with a butterfly)
 __global__ __launch_bounds__(LQC_THREADS, HSQP_LQC_WPE) void k_lq_chain(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N,
-                                                         double* __restrict__ rec) {
+                                                         double* __restrict__ rec, int node_base) {
   __shared__ LqChainWS w;
-  const int node = blockIdx.x, b = node / N, k = node % N;
+  const int node = node_base + blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   lq_chain_node(ctx, w, xk, u + (size_t)node * NU, xk + NX, dts[node], rec + (size_t)node * REC_SIZE);
@@ -834,6 +842,11 @@ struct hsqp_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
+  static constexpr int LQ_SPLIT_MAX = 8;
+  int lq_round_blocks = 512;                   // workgroups of k_lq_limb / k_lq_rows the chip holds at once (4 waves per CU, QL_WAVES per workgroup)
+  int lq_split = 1;                            // node ranges of the limb-lane LQ kernels, each on its own stream (HSQP_LQ_SPLIT in the environment at hsqp_create)
+  hipStream_t aux[LQ_SPLIT_MAX - 1] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[LQ_SPLIT_MAX - 1] = {};
   DevModel* d_dm = nullptr;
   double *d_xinit = nullptr, *d_x = nullptr, *d_u = nullptr, *d_par = nullptr;
   double *d_rec = nullptr, *d_qp = nullptr, *d_ric = nullptr;
@@ -925,7 +938,7 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
       if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
     h->el_capacity = need;
   }
-  hipLaunchKernelGGL(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0]);
+  hipLaunchKernelGGL(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0], h->d_scanst);
   int cur = 0;
   for (int d = 1; d < N + 1; d *= 2) {
     hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_scanst, h->d_prof + 256);
@@ -1046,6 +1059,11 @@ void hsqp_destroy(hsqp_handle* h) {
   if (h->h_gate) (void)hipHostFree(h->h_gate);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (auto& e : h->ev_join)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& st : h->aux)
+    if (st) (void)hipStreamDestroy(st);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1112,6 +1130,18 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
   for (auto& ev : h->ev)
     if (hipEventCreate(&ev) != hipSuccess) return fail(HSQP_ERR_HIP, "hipEventCreate failed");
+  if (h->lq_limb) {
+    const char* sp = getenv("HSQP_LQ_SPLIT");
+    h->lq_split = sp ? atoi(sp) : HSQP_LQ_SPLIT_DEFAULT;
+    if (h->lq_split < 1) h->lq_split = 1;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->lq_round_blocks = cus * 4 / QL_WAVES;
+    if (h->lq_split > hsqp_handle::LQ_SPLIT_MAX) h->lq_split = hsqp_handle::LQ_SPLIT_MAX;
+    if (h->lq_split > 1 && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(HSQP_ERR_HIP, "hipEventCreate failed");
+    for (int s = 0; s + 1 < h->lq_split; ++s)
+      if (hipStreamCreateWithFlags(&h->aux[s], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_join[s], hipEventDisableTiming) != hipSuccess)
+        return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
+  }
   const size_t B = settings->max_batch, N = settings->max_nodes;
   struct Alloc { void** p; size_t bytes; };
   const Alloc allocs[] = {
@@ -1329,10 +1359,27 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
     }
     else if (h->lq_limb) {   // limb lanes for the model and the node terms (16 nodes per wave), then the RK4 chain, a lane per column (hsqp_lql.h)
-      const dim3 qgrid((nodes + QL_NODES * QL_WAVES - 1) / (QL_NODES * QL_WAVES)), qblock(QL_THREADS * QL_WAVES);
-      hipLaunchKernelGGL(k_lq_limb, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_dt, N, nodes, h->d_rec, h->d_prof + 384);
-      hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, nodes, h->d_rec, h->d_prof + 384);
-      hipLaunchKernelGGL(k_lq_chain, dim3(nodes), dim3(LQC_THREADS), 0, h->stream, h->d_x, h->d_u, h->d_dt, N, h->d_rec);
+      // Two of the three kernels run one wave per SIMD (limb, rows), so a launch of config 4 is 1.56 rounds of the chip's 1024 SIMDs and the
+      // last round of each leaves 44 % of them idle.  With lq_split = 2 the nodes are cut into two ranges, each going through its three
+      // kernels on a stream of its own: a range's next kernel fills the SIMDs the other range's previous kernel leaves (measured, 256 x 100:
+      // the three kernels 1.07 -> 0.97 ms; the bound of the arrangement, every SIMD busy throughout, is 0.92; three and more ranges lose
+      // again: 1.02 / 1.10 / 1.38 ms at 3 / 4 / 8).  Only when a launch is more than one round.
+      const dim3 qblock(QL_THREADS * QL_WAVES);
+      constexpr int QG = QL_NODES * QL_WAVES;
+      const int S = h->lq_split > 1 && (nodes + QG - 1) / QG > h->lq_round_blocks ? h->lq_split : 1;
+      if (S > 1) {
+        HCHECK(hipEventRecord(h->ev_fork, h->stream));
+        for (int s = 1; s < S; ++s) HCHECK(hipStreamWaitEvent(h->aux[s - 1], h->ev_fork, 0));
+      }
+      for (int s = 0; s < S; ++s) {
+        const int n0 = (int)(((long long)nodes * s / S) / QG * QG), n1 = s == S - 1 ? nodes : (int)(((long long)nodes * (s + 1) / S) / QG * QG);
+        hipStream_t st = s == 0 ? h->stream : h->aux[s - 1];
+        const dim3 qgrid((n1 - n0 + QG - 1) / QG);
+        hipLaunchKernelGGL(k_lq_limb, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
+        hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
+        hipLaunchKernelGGL(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0);
+        if (s > 0) { HCHECK(hipEventRecord(h->ev_join[s - 1], st)); HCHECK(hipStreamWaitEvent(h->stream, h->ev_join[s - 1], 0)); }
+      }
     } else
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
@@ -1757,7 +1804,7 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (what == HSQP_BLK_FORMS) {
-    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, 0, 0};
+    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, h->lq_limb ? h->lq_split : 0, 0};
     if (dst && bytes > 0) memcpy(dst, forms, (size_t)(bytes < 16 ? bytes : 16));
     return 16;
   }

@@ -277,14 +277,24 @@ __device__ inline void gauss_jordan_pipeline(const Ctx& ctx, GjPipe& g, LoadM lo
 #endif
 
 // ---- stage -> element
+// The element of one stage is its conditional value function with the input eliminated by R~ ALONE, and cond(R~) reaches 1e7 on the whole-body
+// problem (input weights 1e-3 dt against the rows the projection leaves).  Round 2-4 formed R~^-1 explicitly (Gauss-Jordan) and multiplied:
+// A - B R^-1 P, B R^-1 B', Q - P' R^-1 P.  That is where the scan lost its digits, not in the combinations (oracle/parallel_scan.py, numpy:
+// the step error against the serial recursion on config 3's iterates 1.5e-11 / 4.7e-5 / 1.6e-3 with the explicit inverse, 1.8e-11 / 1.6e-8 /
+// 2.9e-9 with the form below; symmetric "square-root" variants of the combination changed nothing: 6.2e-8 -> 6.3e-8).  The element is now
+// formed the way the Riccati stage forms its own quantities — the stage PREPENDED to the empty interval (hsqp_segment.h), S = 0:
+//     R~ = L L',  Z = L^-1 P~,  z = L^-1 r~,  W' = L^-1 B~'      (the blocked elimination of the Riccati stage, hsqp_elim.h, on [R~ | I | P~ | r~])
+//     A = A~ - W Z,  b = b~ - W z,  C = W W',  J = Q~ - Z' Z,  eta = -(q~ - Z' z)
+// every product a Gram-type contraction with L^-1 applied to both factors; C and J are symmetric by construction.
 template <int n>
 struct ScanInitWS {
-  double G[NUT][2 * NUT + 2];     // [R | I] -> R^-1 in the right half
-  double Ri[NUT][NUT + 1];
-  double BT[NUT][n + 1], Pm[NUT][n + 1];
-  double WB[NUT][n + 1], WP[NUT][n + 1];   // R^-1 B', R^-1 P
-  double wr[NUT], rv[NUT];
-  GjWS gj;
+  double Ef[LDB][LDF];            // [R~ | . | L^-1]
+  double LinvT[LDB][LDB];
+  double PG[NUT][n + 2];          // [P~ | r~]
+  double Zs[NUT][n + 2];          // [Z | z]
+  double BT[NUT][n + 1], Wt[NUT][n + 1];   // B~', W' = L^-1 B~'
+  double zv[LDB];
+  int ok;
 };
 
 // the element of the terminal cost 1/2 x'diag(Qf)x + qN'x
@@ -301,54 +311,61 @@ HSQP_HD void scan_terminal_element(const Ctx& ctx, double* el, const double* Qf,
 }
 
 // q: QP record of the stage (hsqp_project.h), el: element out.  terminal: the element of the terminal cost instead.
+// *ok (optional) is cleared when R~ has a pivot that is not positive.
 template <int n>
 HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, double* el, bool terminal, const double* Qf, const double* xN,
-                            const double* parN) {
+                            const double* parN, int* ok = nullptr) {
   using E = ScanEl<n>;
   if (terminal) { scan_terminal_element<n>(ctx, el, Qf, xN, parN); return; }
-  constexpr int LG = 2 * NUT + 2;
-  WG_FOR(ctx, i, NUT * LG + 2 * NUT * (n + 1) + NUT) {
-    if (i < NUT * LG) {
-      const int r = i / LG, c = i % LG;
-      w.G[r][c] = c < NUT ? q[QP_R + r * NUT + c] : (c - NUT == r ? 1.0 : 0.0);
-    } else if (i < NUT * LG + NUT * (n + 1)) {
-      const int j = i - NUT * LG, r = j / (n + 1), c = j % (n + 1);
+  constexpr int LP = n + 2;
+  WG_FOR(ctx, i, NUT * LDF + LDB * LDB + NUT * LP + NUT * (n + 1) + 1) {
+    if (i < NUT * LDF) {
+      const int r = i / LDF, c = i % LDF;
+      w.Ef[r][c] = c < NUT ? q[QP_R + r * NUT + c] : 0.0;
+    } else if (i < NUT * LDF + LDB * LDB) {
+      const int j = i - NUT * LDF;
+      w.LinvT[j / LDB][j % LDB] = 0.0;
+    } else if (i < NUT * LDF + LDB * LDB + NUT * LP) {
+      const int j = i - NUT * LDF - LDB * LDB, r = j / LP, c = j % LP;
+      w.PG[r][c] = c < n ? q[QP_P + r * NX + c] : (c == n ? q[QP_RV + r] : 0.0);
+    } else if (i < NUT * LDF + LDB * LDB + NUT * LP + NUT * (n + 1)) {
+      const int j = i - NUT * LDF - LDB * LDB - NUT * LP, r = j / (n + 1), c = j % (n + 1);
       w.BT[r][c] = c < n ? q[QP_B + c * NUT + r] : 0.0;
-    } else if (i < NUT * LG + 2 * NUT * (n + 1)) {
-      const int j = i - NUT * LG - NUT * (n + 1), r = j / (n + 1), c = j % (n + 1);
-      w.Pm[r][c] = c < n ? q[QP_P + r * NX + c] : 0.0;
-    } else {
-      w.rv[i - NUT * LG - 2 * NUT * (n + 1)] = q[QP_RV + i - NUT * LG - 2 * NUT * (n + 1)];
+    } else w.ok = 1;
+  }
+  WG_SYNC(ctx);
+  {
+    const ElimIO io{&w.Ef[0][0], LDF, &w.PG[0][0], &w.PG[0][n], LP, &w.Ef[0][EF_MI], LDF, &w.LinvT[0][0], LDB, &w.Zs[0][0], LP, w.zv, &w.ok};
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ctx.nthreads >= 128) {   // two waves, as in the Riccati stage
+      const int wv = ctx.tid >> 6;
+      const DevWave dw{ctx.tid & 63};
+      if (wv == 0) eliminate_blocked<n, 0>(dw, io);
+      else if (wv == 1) eliminate_blocked<n, 1>(dw, io);
+    } else
+#endif
+    {
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (ctx.tid == 0) { const HostWave hw; eliminate_blocked<n, 0>(hw, io); eliminate_blocked<n, 1>(hw, io); }
+#endif
     }
   }
   WG_SYNC(ctx);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (ctx.nthreads >= 128) {
-    int okflag = 1;   // R~ is positive definite by construction (the serial sweep reports a failed Lam; here a bad pivot only degrades the element)
-    gauss_jordan_rows<NUT, NUT, 2, false>(ctx, [&](int r, int c) { return w.G[r][c]; }, [&](int r, int c) { return w.G[r][NUT + c]; }, &w.Ri[0][0], NUT + 1, &okflag);
-  } else
-#endif
-  {
-  gauss_jordan<NUT, LG, 2 * NUT, false>(ctx, &w.G[0][0], w.gj);
-  WG_FOR(ctx, i, NUT * NUT) { const int r = i / NUT, c = i % NUT; w.Ri[r][c] = w.G[r][NUT + c] / w.G[r][r]; }
+  {  // W' = L^-1 B~'  (X^T Y with X = (L^-1)^T)
+    const XtyJob job = xty_job(NUT, n, NUT, &w.LinvT[0][0], LDB, &w.BT[0][0], n + 1, &w.Wt[0][0], n + 1);
+    wg_xty_jobs<true, 0, SCAN_PF>(ctx, &job, 1);
   }
   WG_SYNC(ctx);
-  {  // WB = R^-1 B', WP = R^-1 P (R^-1 symmetric: X = Ri), wr = R^-1 r
-    const XtyJob jobs[2] = {xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1),
-                            xty_job(NUT, n, NUT, &w.Ri[0][0], NUT + 1, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1)};
-    wg_xty_jobs<true, 0, SCAN_PF>(ctx, jobs, 2);
-    WG_FOR(ctx, r, NUT) { double s = 0.0; for (int l = 0; l < NUT; ++l) s += w.Ri[r][l] * w.rv[l]; w.wr[r] = s; }
-  }
-  WG_SYNC(ctx);
-  {  // A - B WP, C = B WB, J = Q - P' WP  (X^T Y with X = BT resp. Pm; the additive terms come from the QP record)
-    const XtyJob jobs[3] = {xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WP[0][0], n + 1, el + E::A, n, q + QP_A, NX, -1.0),
-                            xty_job(n, n, NUT, &w.BT[0][0], n + 1, &w.WB[0][0], n + 1, el + E::C, n),
-                            xty_job(n, n, NUT, &w.Pm[0][0], n + 1, &w.WP[0][0], n + 1, el + E::J, n, q + QP_Q, NX, -1.0)};
+  {  // A~ - W Z, C = W W', J = Q~ - Z' Z  (X^T Y with X = W' resp. Z; the additive terms come from the QP record)
+    const XtyJob jobs[3] = {xty_job(n, n, NUT, &w.Wt[0][0], n + 1, &w.Zs[0][0], LP, el + E::A, n, q + QP_A, NX, -1.0),
+                            xty_job(n, n, NUT, &w.Wt[0][0], n + 1, &w.Wt[0][0], n + 1, el + E::C, n),
+                            xty_job(n, n, NUT, &w.Zs[0][0], LP, &w.Zs[0][0], LP, el + E::J, n, q + QP_Q, NX, -1.0)};
     wg_xty_jobs<true, 0, SCAN_PF>(ctx, jobs, 3);
-    WG_FOR(ctx, i, 2 * n + (E::SIZE - E::ETA - n)) {
-      if (i < n) { double s = q[QP_BV + i]; for (int l = 0; l < NUT; ++l) s -= w.BT[l][i] * w.wr[l]; el[E::B + i] = s; }
-      else if (i < 2 * n) { const int r = i - n; double s = q[QP_QV + r]; for (int l = 0; l < NUT; ++l) s -= w.Pm[l][r] * w.wr[l]; el[E::ETA + r] = -s; }
-      else el[E::ETA + n + (i - 2 * n)] = 0.0;
+    WG_FOR(ctx, i, 2 * n + (E::SIZE - E::ETA - n) + 1) {
+      if (i < n) { double s = q[QP_BV + i]; for (int l = 0; l < NUT; ++l) s -= w.Wt[l][i] * w.zv[l]; el[E::B + i] = s; }
+      else if (i < 2 * n) { const int r = i - n; double s = q[QP_QV + r]; for (int l = 0; l < NUT; ++l) s -= w.Zs[l][r] * w.zv[l]; el[E::ETA + r] = -s; }
+      else if (i < 2 * n + (E::SIZE - E::ETA - n)) el[E::ETA + n + (i - 2 * n)] = 0.0;
+      else if (ok && !w.ok) *ok = 0;
     }
   }
   WG_SYNC(ctx);
