@@ -379,11 +379,46 @@ long long hsqp_scan_backoffs(const hsqp_handle* h);
 int hsqp_set_scan_backoff_persistent(hsqp_handle* h, int on);
 const char* hsqp_version(void);
 /* Binary interface revision: bumped whenever a public struct or an entry point's meaning changes (5: hsqp_linesearch_settings::cost_tol,
- * hsqp_set_scan_backoff_persistent).  A caller compares hsqp_abi_version() with the HSQP_ABI_VERSION it was compiled against before it
+ * hsqp_set_scan_backoff_persistent; 6: hsqp_comm_*, HSQP_BLK_FORMS[2]).  A caller compares hsqp_abi_version() with the HSQP_ABI_VERSION it was compiled against before it
  * passes structs (host/HipSqpSolver.h and the Python binding do). */
-#define HSQP_ABI_VERSION 5
+#define HSQP_ABI_VERSION 6
 int hsqp_abi_version(void);
 int hsqp_device_count(void);
+
+/* ---- the batch axis over the GPUs of one node: one process per GPU, contiguous blocks of ceil(B / world) instances.
+ * The reference has no counterpart (its solver runs ONE instance on the host: /root/reference/humanoid_nmpc/humanoid_wb_mpc/src/
+ * WBMpcInterface.cpp:113-121 constructs one ocs2::SqpMpc); BASELINE.json's north_star asks for "a batch axis over independent MPC
+ * instances ... sharded across the 8 GPUs of one node with RCCL over xGMI only for the batch broadcast/gather".  These entry points are
+ * that exchange for a host without torch.distributed: every pointer named d_* is DEVICE memory of the communicator's GPU, so a shard goes
+ * HBM -> xGMI -> HBM -> hsqp_upload_device without host staging.  Nothing here runs inside a solve.  RCCL is loaded at the first call
+ * (librccl.so.1; HSQP_RCCL_LIB in the environment names another copy): a single-GPU host never needs it.
+ *   rank 0:  hsqp_comm_unique_id(id)  -> ship the 128 bytes to the other processes (the host's own means: a file, a socket, MPI)
+ *   all:     hsqp_comm_create(&c, id, rank, world, device)
+ *            hsqp_comm_broadcast(c, d_shared, bytes, 0)                       shared problem image (model constants, shared node parameters)
+ *            hsqp_comm_scatter_rows(c, d_global_x, d_x, (N + 1) * 58, B, 0)   one call per array of hsqp_problem; then hsqp_upload_device
+ *            ... hsqp_iterate_device ... hsqp_download_device ...
+ *            hsqp_comm_gather_rows(c, d_x, d_global_x, (N + 1) * 58, B, 0)    the solutions back to rank 0
+ * All calls are collective (every rank of the communicator makes the same call with the same sizes) and return once the transfer is
+ * complete on this rank.  Errors: the HSQP_ERR_* codes; text through hsqp_comm_last_error (hsqp_comm_create_error for the two creators). */
+typedef struct hsqp_comm hsqp_comm;
+#define HSQP_COMM_ID_BYTES 128
+int hsqp_comm_unique_id(void* id /* HSQP_COMM_ID_BYTES */);
+int hsqp_comm_create(hsqp_comm** out, const void* id, int rank, int world, int device);
+void hsqp_comm_destroy(hsqp_comm* c);
+const char* hsqp_comm_create_error(void);
+const char* hsqp_comm_last_error(const hsqp_comm* c);
+int hsqp_comm_rank(const hsqp_comm* c);
+int hsqp_comm_world(const hsqp_comm* c);
+/* the block [lo, hi) of a global batch this rank owns (the same split the scatter / gather use; the last ranks may own nothing) */
+int hsqp_comm_shard(const hsqp_comm* c, int global_batch, int* lo, int* hi);
+int hsqp_comm_shard_of(int global_batch, int world, int rank, int* lo, int* hi);   /* the same split without a communicator */
+int hsqp_comm_broadcast(hsqp_comm* c, void* d_buf, long long bytes, int root);
+/* d_global (root only; may be NULL elsewhere): [global_batch][row_doubles]; d_local: [hi - lo][row_doubles] */
+int hsqp_comm_scatter_rows(hsqp_comm* c, const double* d_global, double* d_local, long long row_doubles, int global_batch, int root);
+int hsqp_comm_gather_rows(hsqp_comm* c, const double* d_local, double* d_global, long long row_doubles, int global_batch, int root);
+/* element-wise maximum over the ranks of n HOST values, in place (max-over-ranks timing); hsqp_comm_barrier is the same with one value */
+int hsqp_comm_max(hsqp_comm* c, double* values, int n);
+int hsqp_comm_barrier(hsqp_comm* c);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,9 @@ def test_header_declares_the_expected_entry_points():
         "hsqp_debug_read", "hsqp_last_kernel_ms", "hsqp_last_error", "hsqp_scan_fallbacks", "hsqp_version", "hsqp_device_count",
         "hsqp_linesearch_defaults", "hsqp_set_linesearch", "hsqp_upload_reference", "hsqp_joint_torques", "hsqp_evaluate_policy",
         "hsqp_upload_device", "hsqp_download_device", "hsqp_last_iterations", "hsqp_iteration_log", "hsqp_update_weights", "hsqp_host_register", "hsqp_host_unregister",
-        "hsqp_scan_backoffs", "hsqp_get_term_weights", "hsqp_update_term_weights", "hsqp_set_scan_backoff_persistent", "hsqp_abi_version"])
+        "hsqp_scan_backoffs", "hsqp_get_term_weights", "hsqp_update_term_weights", "hsqp_set_scan_backoff_persistent", "hsqp_abi_version",
+        "hsqp_comm_unique_id", "hsqp_comm_create", "hsqp_comm_destroy", "hsqp_comm_create_error", "hsqp_comm_last_error", "hsqp_comm_rank", "hsqp_comm_world",
+        "hsqp_comm_shard", "hsqp_comm_shard_of", "hsqp_comm_broadcast", "hsqp_comm_scatter_rows", "hsqp_comm_gather_rows", "hsqp_comm_max", "hsqp_comm_barrier"])
 
 
 def test_library_exports_every_declared_symbol():
@@ -35,6 +37,33 @@ def test_library_exports_every_declared_symbol():
     # the binary interface revision: header, library and Python binding agree (a caller checks this before it passes structs: ADVICE r4)
     hdr = int(re.search(r"#define\s+HSQP_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "hsqp.h")).read()).group(1))
     assert lib.hsqp_abi_version() == hdr == _abi.ABI_VERSION and f"abi {hdr}".encode() in lib.hsqp_version()
+
+
+def test_comm_split_equals_the_python_hosts_and_creation_fails_loudly_without_a_gpu():
+    """hsqp_comm_* (the batch axis over GPUs behind the C ABI): the block of a rank is the one wb_humanoid_mpc_amd/distributed.py::shard_range
+    gives the torch.distributed host (contiguous ceil(B / world) instances, empty blocks for the last ranks of a small batch); arguments are
+    checked; and without a HIP device hsqp_comm_create reports HSQP_ERR_NO_DEVICE (no host path) — RCCL is not even loaded for that."""
+    import ctypes as C
+    from wb_humanoid_mpc_amd.distributed import shard_range
+    lib = solver.load_library()
+    lo, hi = C.c_int(), C.c_int()
+    for B in (0, 1, 5, 32, 256, 1000, 1024):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                assert lib.hsqp_comm_shard_of(B, world, rank, C.byref(lo), C.byref(hi)) == _abi.OK
+                assert (lo.value, hi.value) == shard_range(B, world, rank), (B, world, rank)
+    assert lib.hsqp_comm_shard_of(8, 2, 2, C.byref(lo), C.byref(hi)) == _abi.ERR_BAD_ARG
+    assert lib.hsqp_comm_shard_of(-1, 2, 0, C.byref(lo), C.byref(hi)) == _abi.ERR_BAD_ARG
+    assert lib.hsqp_comm_unique_id(None) == _abi.ERR_BAD_ARG
+    comm = C.c_void_p()
+    ident = C.create_string_buffer(_abi.COMM_ID_BYTES)
+    assert lib.hsqp_comm_create(C.byref(comm), ident, 2, 2, 0) == _abi.ERR_BAD_ARG and not comm.value     # rank outside the world
+    assert lib.hsqp_comm_create(C.byref(comm), None, 0, 1, 0) == _abi.ERR_BAD_ARG
+    if lib.hsqp_device_count() == 0:
+        assert lib.hsqp_comm_create(C.byref(comm), ident, 0, 1, 0) == _abi.ERR_NO_DEVICE and not comm.value
+        assert b"no HIP device" in lib.hsqp_comm_create_error()
+    assert lib.hsqp_comm_rank(None) == -1 and lib.hsqp_comm_world(None) == 0
+    lib.hsqp_comm_destroy(None)
 
 
 def test_struct_sizes_match_the_c_compiler(tmp_path):

@@ -53,6 +53,42 @@ def test_cpp_wrapper_compiles_and_fails_loudly_without_device_or_model(tmp_path)
     assert ("(-2)" in r.stdout) or ("(-1)" in r.stdout)
 
 
+COMM_SRC = r'''
+#include <array>
+#include <cstdio>
+#include "HipSqpComm.h"
+int main() {
+  // the split of a global batch needs no communicator (and no GPU)
+  for (int r = 0; r < 8; ++r) {
+    const auto [lo, hi] = hsqp_host::HipSqpComm::shardOf(256, 8, r);
+    if (lo != 32 * r || hi != 32 * (r + 1)) { std::printf("bad shard %d: %d %d\n", r, lo, hi); return 1; }
+  }
+  const auto last = hsqp_host::HipSqpComm::shardOf(5, 8, 7);
+  if (last.first != 5 || last.second != 5) return 1;
+  try {
+    std::array<char, HSQP_COMM_ID_BYTES> id{};
+    hsqp_host::HipSqpComm comm(id.data(), 3, 2, 0);          // rank outside the world: refused before anything is loaded
+    return 0;
+  } catch (const std::runtime_error& e) {
+    std::printf("runtime_error: %s\n", e.what());
+    return 3;
+  }
+}
+'''
+
+
+def test_cpp_comm_wrapper_compiles_and_reports_bad_arguments(tmp_path):
+    solver.load_library()
+    src = tmp_path / "c.cpp"
+    src.write_text(COMM_SRC)
+    exe = tmp_path / "c"
+    libdir = os.path.join(ROOT, "wb_humanoid_mpc_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(libdir, "host"), str(src), "-L", libdir, "-lhsqp_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 3 and "bad argument (-1)" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 LOADER_SRC = r'''
 #include <cstdio>
 #include "HipSqpModelIO.h"

@@ -13,12 +13,13 @@ P_XDES, P_ARMSWING, P_CONTACT, P_SWING, P_IMPACT = 0, 58, 59, 61, 67
 FORM_WB, FORM_CENTROIDAL = 0, 1
 CNX, PC_TORSO = 35, 35
 
-ABI_VERSION = 5   # HSQP_ABI_VERSION of include/hsqp.h (tests/test_abi.py compares them)
+ABI_VERSION = 6   # HSQP_ABI_VERSION of include/hsqp.h (tests/test_abi.py compares them)
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_NUMERIC, ERR_HIP, ERR_NOT_CONVERGED = 0, -1, -2, -3, -4, -5, -6
 
 BLK_AB, BLK_BVEC, BLK_H, BLK_G, BLK_CDE, BLK_NE, BLK_COST, BLK_DX, BLK_DU, BLK_FLOW = range(1, 11)
 BLK_PARAMS, BLK_FORMS = 11, 12
+COMM_ID_BYTES = 128   # HSQP_COMM_ID_BYTES
 
 
 class Body(C.Structure):

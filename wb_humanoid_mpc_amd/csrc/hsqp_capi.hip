@@ -1029,7 +1029,7 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
 
 extern "C" {
 
-const char* hsqp_version(void) { return "hsqp-hip 0.3 (gfx950, f64, abi 5)"; }
+const char* hsqp_version(void) { return "hsqp-hip 0.3 (gfx950, f64, abi 6)"; }
 int hsqp_abi_version(void) { return HSQP_ABI_VERSION; }
 int hsqp_set_scan_backoff_persistent(hsqp_handle* h, int on) {
   if (!h) return HSQP_ERR_BAD_ARG;

@@ -65,6 +65,23 @@ def load_library():
     lib.hsqp_scan_backoffs.restype = C.c_longlong
     lib.hsqp_version.restype = C.c_char_p
     lib.hsqp_set_scan_backoff_persistent.argtypes = [C.c_void_p, C.c_int]
+    # hsqp_comm_*: the batch axis over the GPUs of one node behind the C ABI (the Python host uses torch.distributed instead: distributed.py)
+    lib.hsqp_comm_unique_id.argtypes = [C.c_void_p]
+    lib.hsqp_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.hsqp_comm_destroy.argtypes = [C.c_void_p]
+    lib.hsqp_comm_destroy.restype = None
+    lib.hsqp_comm_create_error.restype = C.c_char_p
+    lib.hsqp_comm_last_error.argtypes = [C.c_void_p]
+    lib.hsqp_comm_last_error.restype = C.c_char_p
+    lib.hsqp_comm_rank.argtypes = [C.c_void_p]
+    lib.hsqp_comm_world.argtypes = [C.c_void_p]
+    lib.hsqp_comm_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hsqp_comm_shard_of.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hsqp_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
+    lib.hsqp_comm_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int]
+    lib.hsqp_comm_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int]
+    lib.hsqp_comm_max.argtypes = [C.c_void_p, _dp, C.c_int]
+    lib.hsqp_comm_barrier.argtypes = [C.c_void_p]
     if lib.hsqp_abi_version() != _abi.ABI_VERSION:
         raise RuntimeError(f"libhsqp_hip ABI {lib.hsqp_abi_version()} != the binding's {_abi.ABI_VERSION} (include/hsqp.h: HSQP_ABI_VERSION)")
     lib.hsqp_joint_torques.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
