@@ -80,8 +80,13 @@ def pmc_kernel_info():
         with open(path) as fh:
             kernels = json.load(fh)["kernels"]
         if names_match(kernels):
+            # a kernel launched more than once per iteration (the limb-lane LQ kernels run in two node ranges, k_perf_reduce twice): its bytes per
+            # ITERATION = mean per launch x launches per iteration, counted against k_project's dispatches (one per iteration)
+            ref = max(1, int(kernels.get("k_project", {}).get("FETCH_SIZE", {}).get("dispatches", 1)))
             for k, v in kernels.items():
-                out.setdefault(k, {})["hbm_bytes"] = v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]
+                per_it = max(1, round(v["FETCH_SIZE"].get("dispatches", ref) / ref)) if k.startswith("k_") else 1
+                out.setdefault(k, {})["hbm_bytes"] = per_it * (v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+                out[k]["launches_per_iteration"] = per_it
             prov["source"].append(os.path.relpath(path, ROOT))
     except Exception:
         pass

@@ -365,6 +365,10 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         {
           double pb[NPB];
           const double qv = pt < NX ? q[QP_QV + pt] : 0.0;
+          // (r~ of the next stage with the other loads: issued behind the LDS stores below it was a second HBM round trip of wave 5, which then
+          //  arrived at the phase's barrier with the slower eliminating wave — 12.0 instead of 10.2 k cycles; k_riccati 1.535 -> 1.516 ms)
+          const bool has_rv = k > 0 && pt >= 64 && pt < 64 + NUT;
+          const double rvn = qn[QP_RV + (has_rv ? pt - 64 : 0)];
           if (k > 0) {
 #pragma unroll
             for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
@@ -376,7 +380,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
             }
           }
           if (pt < NX) w.dx[pt] = qv;
-          if (k > 0 && pt >= 64 && pt < 64 + NUT) w.kv[pt - 64] = qn[QP_RV + pt - 64];   // r~ of the next stage (Ph2's g sums)
+          if (has_rv) w.kv[pt - 64] = rvn;   // r~ of the next stage (Ph2's g sums)
         }
 #else
         if (k > 0) {
