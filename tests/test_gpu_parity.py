@@ -260,7 +260,7 @@ def test_instances_of_a_large_batch_equal_their_solo_solves(model):
 
 
 def test_config4_instances_against_oracle_at_full_size(model, oracle):
-    """BASELINE config 4 at full size (N = 100, 256 perturbed instances, every CU busy): four instances of the batch against the CPU oracle
+    """BASELINE config 4 at full size (N = 100, 256 perturbed instances, every CU busy): seventeen instances of the batch against the CPU oracle
     (step max-abs <= 1e-8; performance index before / after the step — at this size the value pass runs on quads of lanes, 16 nodes per wave), and
     EVERY instance through the size-independent property the device reports itself: the KKT residual of its QP within 1e-9 max(1, |g|_inf)."""
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
@@ -285,7 +285,7 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
     finally:
         s.close()
     assert np.array_equal(one["dx"], out["dx"]) and np.array_equal(one["du"], out["du"])
-    for b in (0, 37, 128, 255):
+    for b in list(range(0, B, 17)) + [255]:          # 17 instances spread over the batch (both node ranges of the LQ kernels, every XCD)
         r = oracle.sqp_iteration(dt, x0[b], x[b], u[b], par[b], threads=os.cpu_count() or 4)
         assert_step(out, r, b, "config 4")
         assert_perf(out["perf_before"][b], r["perf_before"], f"config 4 instance {b} before")
@@ -563,18 +563,15 @@ def test_two_level_sweep_against_the_serial_recursion(model, oracle, B, N, seed)
     a, b = outs["serial"], outs["segmented"]
     assert np.array_equal(b["dx"], outs["again"]["dx"]) and np.array_equal(b["du"], outs["again"]["du"])     # no atomics, fixed combine order
     assert b["backoffs"] == 0          # a FORCED sweep is attempted every iteration
-    if b["fallbacks"]:
-        # the gate sits where the populations separate (about one perturbed 32-instance batch in five has an instance whose
-        # boundary-stage KKT residual crosses it; which batch depends on the last bits of the factorisation): a rejected sweep is the
-        # serial recursion's result, bit for bit
-        assert (B, seed) == (32, 1) and b["fallbacks"] == 1
-        assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["du"], b["du"])
-        return
+    # What holds whatever the gate decided: the step within SEG_REL of its scale of the serial recursion's.  (The gate sits where the populations
+    # separate — DESIGN.md §6: about one perturbed 32-instance batch in five has an instance whose boundary-stage KKT residual crosses it; a rejected
+    # sweep is redone with the serial recursion and is then its result bit for bit, so the bound below covers both outcomes with ONE assertion.)
     sc = max(1.0, np.abs(a["dx"]).max(), np.abs(a["du"]).max())
     err = max(np.abs(a["dx"] - b["dx"]).max(), np.abs(a["du"] - b["du"]).max())
-    print(f"two-level sweep B={B} N={N} seed {seed}: |step - serial| = {err:.2e} ({err / sc:.1e} of the scale), KKT {b['kkt'].max():.1e} (serial {a['kkt'].max():.1e})")
+    print(f"two-level sweep B={B} N={N} seed {seed}: |step - serial| = {err:.2e} ({err / sc:.1e} of the scale), KKT {b['kkt'].max():.1e} (serial {a['kkt'].max():.1e}), fallbacks {b['fallbacks']}")
     assert err <= SEG_REL * sc
-    assert not np.array_equal(a["dx"], b["dx"])          # it really is the other algorithm
+    assert b["fallbacks"] <= (1 if (B, seed) == (32, 1) else 0)       # no fallback on the other batches
+    assert np.array_equal(a["dx"], b["dx"]) == (b["fallbacks"] == 1)  # the other algorithm unless the gate sent the iteration back
     for i in range(B):
         assert b["kkt"][i].max() <= 1e-7, f"instance {i}: KKT residual {b['kkt'][i].max():.2e} passed the gate"
         assert_perf(b["perf_after"][i], a["perf_after"][i], f"instance {i}", rel=1e-9)
