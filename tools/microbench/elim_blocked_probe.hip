@@ -1,11 +1,11 @@
 // The Riccati stage's factorisation alone on an idle GPU: the column-by-column in-register elimination of round 3 (eliminate_begin +
-// eliminate_end, hsqp_riccati.h) against the blocked matrix-core form (eliminate_blocked, hsqp_elim.h).  Shader-clock ticks per call for
+// eliminate_end, elim_columnwise.h) against the blocked matrix-core form (eliminate_blocked, hsqp_elim.h).  Shader-clock ticks per call for
 // one wave (wave 0's role), both roles on two SIMDs, and — what the stage looks like — both roles next to waves that stream matrix
 // instructions on the same / on the other SIMDs; plus the largest difference between the two forms' L^-1, Z, z.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
-#include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
+#include "elim_columnwise.h"
 using namespace hsqp;
 extern __shared__ double smem[];
 

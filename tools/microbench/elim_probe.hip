@@ -1,8 +1,8 @@
-// How long does the in-register elimination of [Lam | I | G | g] (hsqp_riccati.h, eliminate_begin + eliminate_end) take by itself?
+// How long does the in-register elimination of [Lam | I | G | g] (elim_columnwise.h, eliminate_begin + eliminate_end) take by itself?
 // One workgroup of 64 (wave 0's role) or 128 threads (both roles); shader-clock ticks around the call, a well-conditioned synthetic Lam.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
+#include "elim_columnwise.h"
 using namespace hsqp;
 extern __shared__ double smem[];
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void k(long long* out, int reps) {

@@ -108,32 +108,13 @@ HSQP_HD void ric_products(const Ctx& ctx, int first_wave, int n_waves, const Xty
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* hsqp_ldsptr;
-// Ph3 on the device: the whole elimination of [Lam | I | G | g] inside two waves, no barrier and no LDS traffic per step.  A lane holds one
-// column (23 registers).  Both waves carry the 23 columns of Lam in their lanes 0 .. 22 (the multipliers of a step come from them: row j
-// of the symmetric upper part, lane i = the multiplier of row i), so the waves never talk to each other.  Wave 0: lanes 23 .. 45 the
-// columns of I, 46 .. 63 the columns 0 .. 17 of G; wave 1: lanes 23 .. 23 + NXE - 19 the columns 18 .. NXE - 1 of G, lane 63 g.  The pivot
-// of step j and the multipliers come through v_readlane with compile-time lane numbers.  On the way out every row i is scaled with
-// d_i^-1/2 (Cholesky scaling of the unit-lower inverse), which turns the eliminated blocks into L^-1, Z = L^-1 G and z = L^-1 g.
-constexpr int ELIM_G0 = 64 - 2 * NUT;          // columns of G in wave 0 (18)
-constexpr int ELIM_SPLIT = 8;                  // steps before the mid-phase barrier (58 % of the row updates: S A~ finishes about then)
-struct ElimLane { bool isLam, isI, isG, isg; int gcol; };
-template <int NXE>
-HSQP_D ElimLane elim_lane(int wave, int lane) {
-  static_assert(NXE - ELIM_G0 <= 64 - NUT - 1, "the remaining columns of G and g fit the second wave");
-  ElimLane l;
-  l.isLam = lane < NUT;
-  l.isI = wave == 0 && lane >= NUT && lane < 2 * NUT;
-  l.gcol = wave == 0 ? lane - 2 * NUT : ELIM_G0 + lane - NUT;
-  l.isG = !l.isLam && !l.isI && (wave == 0 ? true : (l.gcol < NXE));
-  l.isg = wave == 1 && lane == 63;
-  return l;
-}
-// first part: the lane's column -> registers, steps [0, ELIM_SPLIT)
-// a_next / a_dst (a_next != nullptr): the eliminating waves also start the copy of the next stage's A~ into the other LDS buffer —
-// asynchronous 16-byte copies straight into LDS (no staging registers, no store pass): the LDS image of A~ is the record's [58][58]
-// block byte for byte; a wave instruction moves 64 x 16 B to (wave-uniform base) + lane x 16.  The compiler makes a wave wait for its
-// copies before that wave's next LDS access; these two waves have none until the mid-phase barrier (every other wave reads LDS all the time).
-// the copy of the next stage's A~ (see above), issued by the two eliminating waves
+// Ph3 on the device: the whole elimination of [Lam | I | G | g] inside two waves on the FP64 matrix cores (eliminate_blocked, hsqp_elim.h), no barrier and
+// no LDS traffic per step; both waves carry Lam, so they never talk to each other.  On the way out every row i is scaled with d_i^-1/2
+// (Cholesky scaling of the unit-lower inverse), which turns the eliminated blocks into L^-1, Z = L^-1 G and z = L^-1 g.
+// The eliminating waves also start the copy of the next stage's A~ into the other LDS buffer — asynchronous 16-byte copies straight into LDS
+// (no staging registers, no store pass): the LDS image of A~ is the record's [58][58] block byte for byte; a wave instruction moves 64 x 16 B
+// to (wave-uniform base) + lane x 16.  The compiler makes a wave wait for its copies before that wave's next LDS access; these two waves have
+// none until the write-out (every other wave reads LDS all the time).
 HSQP_D void next_a_to_lds(const double* a_next, double* a_dst, int wave, int lane) {
   if (a_next) {
     constexpr int NCH = NX * NX / 2;                         // 16-byte chunks
@@ -142,58 +123,6 @@ HSQP_D void next_a_to_lds(const double* a_next, double* a_dst, int wave, int lan
     for (int t = 0; t < (NCH + 127) / 128; ++t) {
       const int c0 = (t * 2 + wave) * 64;                    // first chunk of this wave instruction
       if (c0 + lane < NCH) __builtin_amdgcn_global_load_lds((hsqp_gcptr)a_next + 2 * (c0 + lane), (hsqp_ldsptr)(a_dst + 2 * c0), 16, 0, 0);
-    }
-  }
-}
-template <int NXE>
-HSQP_D void eliminate_begin(const RicWS& w, int wave, int lane, double (&e)[NUT], const double* a_next, double* a_dst) {
-  const ElimLane l = elim_lane<NXE>(wave, lane);
-  const double* src = l.isLam ? &w.fac.Ef[0][lane] : (l.isg ? &w.Em[0][EM_GVP] : (l.isG ? &w.Em[0][EM_G + l.gcol] : &w.fac.Ef[0][0]));
-  const int stride = (l.isLam || !(l.isG || l.isg)) ? LDF : LDE;
-#pragma unroll
-  for (int i = 0; i < NUT; ++i) {
-    const double v = src[i * stride];
-    e[i] = l.isI ? (i == lane - NUT ? 1.0 : 0.0) : v;
-  }
-  next_a_to_lds(a_next, a_dst, wave, lane);
-#pragma unroll
-  for (int j = 0; j < ELIM_SPLIT; ++j) {
-    const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));   // lane i: the multiplier of row i (one multiply per step, not per row)
-#pragma unroll
-    for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
-  }
-}
-// second part: the remaining steps, then every row i scaled with d_i^-1/2 on its way to LDS
-template <int NXE>
-HSQP_D void eliminate_end(RicWS& w, int wave, int lane, double (&e)[NUT]) {
-  const ElimLane l = elim_lane<NXE>(wave, lane);
-#pragma unroll
-  for (int j = ELIM_SPLIT; j < NUT - 1; ++j) {
-    const double fv = e[j] * fast_rcp(readlane_f64(e[j], j));
-#pragma unroll
-    for (int i = j + 1; i < NUT; ++i) e[i] -= readlane_f64(fv, i) * e[j];
-  }
-  // pivots: d_i sits in lane i (row i of column i is final after step i - 1)
-  double dv = 1.0;
-#pragma unroll
-  for (int i = 0; i < NUT; ++i) dv = lane == i ? e[i] : dv;
-  const bool bad = l.isLam && !(dv > 0.0);
-  if (bad) dv = 1.0;
-  if (__builtin_amdgcn_ballot_w64(bad) != 0 && wave == 0 && lane == 0) w.ok = 0;
-  const double rs = inv_sqrt(dv);
-  const int ic = lane - NUT;
-#pragma unroll
-  for (int i = 0; i < NUT; ++i) {
-    const double v = e[i] * readlane_f64(rs, i);
-    if (l.isI) {
-      const double vv = ic <= i ? v : 0.0;
-      w.fac.Ef[i][EF_MI + ic] = vv;
-      w.fac.LinvT[ic][i] = vv;
-    } else if (l.isg) {
-      w.zv[i] = v;
-      w.Zs[i][NXE] = v;
-    } else if (l.isG) {
-      w.Zs[i][l.gcol] = v;
     }
   }
 }
@@ -340,11 +269,6 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       const int pt = ctx.tid - 256;
       if (wv < 2) {
         __builtin_amdgcn_s_setprio(3);
-#if defined(HSQP_ELIM_COLUMNWISE)
-        double e[NUT];
-        eliminate_begin<NXE>(w, wv, ctx.tid & 63, e, k > 0 ? qn + QP_A : nullptr, &An[0][0]);
-        eliminate_end<NXE>(w, wv, ctx.tid & 63, e);
-#else
         const int lane = ctx.tid & 63;
         const DevWave dw{lane};
         const ElimIO io{&w.fac.Ef[0][0], LDF, &w.Em[0][EM_G], &w.Em[0][EM_GVP], LDE, &w.fac.Ef[0][EF_MI], LDF, &w.fac.LinvT[0][0], LDB, &w.Zs[0][0], LDZ, w.zv, &w.ok};
@@ -353,10 +277,8 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         auto prefetch = [&]() { next_a_to_lds(a_next, a_dst, wv, lane); };
         if (wv == 0) eliminate_blocked<NXE, 0>(dw, io, prefetch);
         else eliminate_blocked<NXE, 1>(dw, io, prefetch);
-#endif
         __builtin_amdgcn_s_setprio(0);
       } else if (trank < 0) {
-#if !defined(HSQP_RIC_HELPERS_PH3)
         // These two waves share their SIMDs with the eliminating waves, and a SIMD runs the FP64 vector and matrix instructions of its waves
         // one after the other: arithmetic done here (round 3: q~ + A~^T sb, 232 fifteen-term sums) lengthens the phase by its own duration.
         // They are the stage's MEMORY waves now: global -> LDS staging of everything the later phases would otherwise fetch from HBM inside
@@ -382,28 +304,6 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
           if (pt < NX) w.dx[pt] = qv;
           if (has_rv) w.kv[pt - 64] = rvn;   // r~ of the next stage (Ph2's g sums)
         }
-#else
-        if (k > 0) {
-          double pb[NPB];
-#pragma unroll
-          for (int t = 0; t < NPB; ++t) { const int idx = pt + 128 * t; pb[t] = idx < NX * NUT ? qn[QP_B + idx] : (idx < NX * NUT + NX ? qn[QP_BV + idx - NX * NUT] : 0.0); }
-#pragma unroll
-          for (int t = 0; t < NPB; ++t) {
-            const int idx = pt + 128 * t;
-            if (idx < NX * NUT) w.B[idx / NUT][idx % NUT] = pb[t];
-            else if (idx < NX * NUT + NX) w.B[idx - NX * NUT][NUT] = pb[t];
-          }
-        }
-        // the part of the new s that does not wait for the factorisation: q~ + A~^T sb in four partial sums per row (Ph4 subtracts Z^T z)
-        for (int it = ctx.tid - 256; it < 4 * NX; it += 128) {
-          const int r = it >> 2, p = it & 3;
-          constexpr int LA = (NXE + 3) / 4;
-          double s = p == 0 ? q[QP_QV + r] : 0.0;
-#pragma unroll
-          for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NXE ? ll : NXE - 1; const double a = A[lc][r], b = w.sb[lc]; s += ll < NXE ? a * b : 0.0; }
-          w.part[it] = s;
-        }
-#endif
       } else ric_products_ranked(ctx, trank, 4, jsa);
     } else
 #endif
@@ -473,10 +373,6 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         const int r = it >> 2, p = it & 3;
         constexpr int LA = (NXE + 3) / 4, LZ = (NUT + 3) / 4;
         double s;
-#if defined(HSQP_RIC_HELPERS_PH3)
-        if (dev512) s = w.part[it];   // q~ + A^T sb: formed under the elimination (Ph3) by the waves that only moved B~
-        else
-#endif
         {
 #if defined(__HIP_DEVICE_COMPILE__)
           s = p == 0 ? (dev512 ? w.dx[r] : q[QP_QV + r]) : 0.0;   // (staged by the memory waves in Ph3)
@@ -490,7 +386,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
         for (int l = 0; l < LZ; ++l) { const int ll = p * LZ + l, lc = ll < NUT ? ll : NUT - 1; const double a = w.Zs[lc][r], b = w.zv[lc]; s -= ll < NUT ? a * b : 0.0; }
         w.part[it] = (NXE == NX || r < NXE) ? s : 0.0;
       };
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_RIC_HELPERS_PH3)
+#if defined(__HIP_DEVICE_COMPILE__)
       if (dev512) {   // waves 6, 7 (two short tiles in this phase), two passes; waves 4, 5 go straight to their tiles
         if (ctx.tid >= 384) for (int it = ctx.tid - 384; it < 4 * NX; it += 128) s_item(it);
       }
@@ -498,7 +394,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (is_helper_half(ctx)) {
         const Ctx hc = helper_ctx(ctx);
         static_assert(4 * NX <= RIC_HELPERS, "one pass");
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_RIC_HELPERS_PH3)
+#if defined(__HIP_DEVICE_COMPILE__)
         if (!dev512)
 #endif
         WG_FOR(hc, it, 4 * NX) s_item(it);
