@@ -1,5 +1,5 @@
 #!/bin/bash
-# (GPU) A/B of the whole-body LQ approximation: limb-lane form (k_lq_limb + k_lq_terms, hsqp_lql.h) against the phase form (k_lq<true>,
+# (GPU) A/B of the whole-body LQ approximation: limb-lane form (k_lq_limb + k_lq_rows + k_lq_chain, hsqp_lql.h) against the phase form (k_lq<true>,
 # HSQP_LQ_PHASE_FORM=1) and against every library under wb_humanoid_mpc_amd/variants/: parity subset first, then bench lines, then the
 # rocprofv3 kernel stats of the product library (the split between the two limb-form kernels).
 # Usage: gpurun -- 'TESTS="tests/test_gpu_parity.py -k lq_blocks" bash tools/gpu_lq_ab.sh'

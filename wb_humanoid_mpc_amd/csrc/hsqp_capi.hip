@@ -868,7 +868,7 @@ struct hsqp_handle {
   bool backoff_persistent = false;            // hsqp_set_scan_backoff_persistent: uploads of the same (B, N) keep the back-off
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
-  bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_terms) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
+  bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_rows + k_lq_chain) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
   bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
