@@ -119,6 +119,16 @@ int emu_segment_element58(void* h, const double* qp, int k0, int L, double* el) 
   seg_accumulate<NX>(ctx, *aw, qp + (size_t)k0 * QP_SIZE, ric2.data(), linv.data(), L, vf0.data(), el);
   return 1;
 }
+// the scan's element of ONE stage (scan_init_node, hsqp_scan.h) from its QP record
+int emu_scan_stage_element58(void* h, const double* qp_record, double* el) {
+  const DevModel& dm = *static_cast<DevModel*>(h);
+  Ctx ctx{0, 1, nullptr};
+  auto iw = std::make_unique<ScanInitWS<NX>>();
+  std::vector<double> xN(NX, 0.0), parN(NP, 0.0);
+  int ok = 1;
+  scan_init_node<NX>(ctx, *iw, qp_record, el, false, dm.Qf, xN.data(), parN.data(), &ok);
+  return ok;
+}
 int emu_scan_combine58(const double* e1, const double* e2, double* out) {
   Ctx ctx{0, 1, nullptr};
   auto cw = std::make_unique<ScanCombWS<NX>>();

@@ -134,3 +134,34 @@ def test_segmented_sweep_reproduces_the_serial_riccati_solution(model, cmodel, f
         guesses.append(F @ Sb @ F.T)
     gdx, gut, _, _, _ = parallel_scan.solve_qp_segmented(stages, np.diag(Qf), qN, (x0 - x[0])[:nxe], segments, guesses)
     assert np.abs(gdx - dx[:, :nxe]).max() / sc <= 10 * TOL[form] * 1e-3 + 1e-9
+
+
+def test_device_stage_elements_equal_the_prepended_form(model):
+    """hsqp_scan.h::scan_init_node (the kernel source, host build: the blocked elimination of [R~ | I | P~ | r~] on the emulated wave, then the
+    Gram-type products) against the numpy prototype's element of the same stage — the stage prepended to the empty interval, Cholesky factor on
+    both sides of every product — entry by entry, on the QP records of a perturbed walk; and C, J symmetric to the bit."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostemu"), "all"])
+    lib = C.CDLL(os.path.join(HERE, "hostemu", "libhsqp_hostemu.so"))
+    lib.emu_create.restype = C.c_void_p
+    err = C.create_string_buffer(256)
+    h = C.c_void_p(lib.emu_create(C.byref(model.desc), err, 256))
+    n = 12
+    x0, x, u, par, dt = perturbed_problem(model, n, "walk", seed=5)
+    xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+    kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+    qp = np.zeros((n, lib.emu_qp_size()))
+    assert lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), P(qp), None) == 0
+    stages = stages_from_records(qp, NX)
+    SZ = lib.emu_el_size58()
+    oA, oC, oJ = 0, NX * NX, 2 * NX * NX
+    oB, oE = 3 * NX * NX, 3 * NX * NX + NX
+    for k in (0, 5, n - 1):
+        el = np.zeros(SZ)
+        assert lib.emu_scan_stage_element58(h, P(np.ascontiguousarray(qp[k])), P(el)) == 1
+        A, b, Cm, eta, J = parallel_scan.prepend_stage(stages[k], parallel_scan.identity_element(NX))
+        for name, got, want in (("A", el[oA:oA + NX * NX].reshape(NX, NX), A), ("C", el[oC:oC + NX * NX].reshape(NX, NX), Cm), ("J", el[oJ:oJ + NX * NX].reshape(NX, NX), J),
+                                ("b", el[oB:oB + NX], b), ("eta", el[oE:oE + NX], eta)):
+            assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (k, name, np.abs(got - want).max(), np.abs(want).max())
+        Cd, Jd = el[oC:oC + NX * NX].reshape(NX, NX), el[oJ:oJ + NX * NX].reshape(NX, NX)
+        assert np.array_equal(Cd, Cd.T) and np.array_equal(Jd, Jd.T)
+    lib.emu_destroy(h)
