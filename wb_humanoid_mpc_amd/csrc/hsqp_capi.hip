@@ -628,9 +628,8 @@ __global__ __launch_bounds__(LQC_THREADS, HSQP_LQC_WPE) void k_lq_chain(const do
 }
 
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
-__global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
-                                                const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
-  const int b = blockIdx.x;
+__device__ inline void ls_init_instance(int b, const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
+                                        const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
   __shared__ double red[3][64];
   double a = 0.0, nx2 = 0.0, nu2 = 0.0;
   for (int k = threadIdx.x; k < N; k += blockDim.x) {
@@ -653,6 +652,10 @@ __global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm,
     st.active = 1; st.dirty = 0; st.step_type = HSQP_STEP_FULL; st.trials = 0;
     ls[b] = st;
   }
+}
+__global__ __launch_bounds__(64) void k_ls_init(const DevModel* __restrict__ dm, const double* __restrict__ info, const double* __restrict__ x,
+                                                const double* __restrict__ dx, const double* __restrict__ par, int N, LsState* __restrict__ ls) {
+  ls_init_instance(blockIdx.x, dm, info, x, dx, par, N, ls);
 }
 
 // ---- line search: decide the pending trials; counts[0] = instances that need a new trajectory, counts[1] = still active
@@ -809,9 +812,8 @@ __global__ __launch_bounds__(128) void k_policy_torques(const DevModel* __restri
 }
 
 // ---- per-instance performance index from per-node {ne, dt*cost, dt*eq^2, dt*dyn^2} + terminal cost
-__global__ void k_perf_reduce(const DevModel* __restrict__ dm, const double* __restrict__ misc, int misc_stride, const double* __restrict__ x,
-                              const double* __restrict__ par, int N, hsqp_perf* __restrict__ out, const LsState* __restrict__ ls) {
-  const int b = blockIdx.x;
+__device__ inline void perf_reduce_instance(int b, const DevModel* __restrict__ dm, const double* __restrict__ misc, int misc_stride, const double* __restrict__ x,
+                                            const double* __restrict__ par, int N, hsqp_perf* __restrict__ out, const LsState* __restrict__ ls) {
   if (ls && !ls[b].active) return;
   __shared__ double red[3][64];
   double c = 0.0, e = 0.0, d = 0.0;
@@ -830,6 +832,20 @@ __global__ void k_perf_reduce(const DevModel* __restrict__ dm, const double* __r
     for (int i = 0; i < 64; ++i) { cs += red[0][i]; es += red[1][i]; ds += red[2][i]; }
     out[b].cost = cs; out[b].merit = cs; out[b].equality_sse = es; out[b].dynamics_sse = ds;
   }
+}
+__global__ void k_perf_reduce(const DevModel* __restrict__ dm, const double* __restrict__ misc, int misc_stride, const double* __restrict__ x,
+                              const double* __restrict__ par, int N, hsqp_perf* __restrict__ out, const LsState* __restrict__ ls) {
+  perf_reduce_instance(blockIdx.x, dm, misc, misc_stride, x, par, N, out, ls);
+}
+// the three per-instance reductions that follow the full-step trial in ONE launch (blockIdx.y: performance index of the iterate, of the trial, the
+// line-search state): three back-to-back launches of 5 us kernels cost their launch gaps
+__global__ __launch_bounds__(64) void k_perf_trio(const DevModel* __restrict__ dm, const double* __restrict__ misc0, int stride0, const double* __restrict__ x,
+                                                  const double* __restrict__ misc1, int stride1, const double* __restrict__ x_new, const double* __restrict__ par, int N,
+                                                  hsqp_perf* __restrict__ before, hsqp_perf* __restrict__ after, const double* __restrict__ info,
+                                                  const double* __restrict__ dx, LsState* __restrict__ ls) {
+  if (blockIdx.y == 0) perf_reduce_instance(blockIdx.x, dm, misc0, stride0, x, par, N, before, nullptr);
+  else if (blockIdx.y == 1) perf_reduce_instance(blockIdx.x, dm, misc1, stride1, x_new, par, N, after, nullptr);
+  else ls_init_instance(blockIdx.x, dm, info, x, dx, par, N, ls);
 }
 
 }  // namespace
@@ -1462,11 +1478,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       if (cent)
         hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
                            (const LsState*)nullptr);
-      hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_par, N, h->d_perf_before,
-                         (const LsState*)nullptr);
-      hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
-                         (const LsState*)nullptr);
-      hipLaunchKernelGGL(k_ls_init, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_stepinfo, h->d_x, h->d_dx, h->d_par, N, h->d_ls);
+      hipLaunchKernelGGL(k_perf_trio, dim3(B, 3), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_misc, 8, h->d_xnew, h->d_par, N,
+                         h->d_perf_before, h->d_perf_after, h->d_stepinfo, h->d_dx, h->d_ls);
     };
     launch_perf();   // speculatively on the scan's step: the gate is read only now, so the host round trip hides behind these kernels
     const bool ev4_early = last && !linesearch;
