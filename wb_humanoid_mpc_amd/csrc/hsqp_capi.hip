@@ -55,6 +55,9 @@ constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 #endif
 constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 51 KB workspace: three workgroups of four waves per CU
 static_assert(PROJ_THREADS >= 256 && PROJ_THREADS % 64 == 0, "project_node hoists its staging loads assuming >= 256 threads; the Gram tiles are dealt to waves 0..3");
+// Every kernel hands its workgroup size to the device functions as the CONSTANT it is launched with (Ctx::nthreads), not as blockDim.x: the item loops
+// (WG_FOR) then have constant strides and trip counts, and the paths written for other workgroup shapes (the host build's) are not compiled into the
+// kernels — k_riccati alone shrank from 16.7 k to 9 k instructions and from 1.518 to 1.463 ms (256 instances; 1.378 -> 1.317 at 32).
 constexpr int RIC_THREADS = 512;
 constexpr int LQV_THREADS = HSQP_LQV_THREADS;   // value-only LQ pass (19.2 KB workspace: 8 one-wave workgroups per CU)
 static_assert(sizeof(LqWST<false>) <= 163840 / 8, "value-only workspace: eight workgroups per CU");
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_W
   const int node = blockIdx.x, b = node / N, k = node % N;
   if (ls && !ls[b].active) return;   // line search: only the instances whose trial is pending are re-evaluated
   LqWST<DERIV>& w = *reinterpret_cast<LqWST<DERIV>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};   // (the constant crashes this compiler's register allocator on k_lq<false>)
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   lq_node<DERIV>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node],
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(CLQ_THREADS, 2) void k_lq_cent2(const DevModel* __r
                                                              const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   CentWST<true>& w = *reinterpret_cast<CentWST<true>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, CLQ_THREADS, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   double* r = rec + (size_t)node * REC_SIZE;
   cent_lq_node2<true>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], r, r + REC_MISC);
@@ -99,21 +102,21 @@ __global__ __launch_bounds__(64) void k_lq_cent2_value(const DevModel* __restric
   const int node = blockIdx.x, b = node / N, k = node % N;
   if (ls && !ls[b].active) return;
   CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   cent_lq_node2<false>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], nullptr, misc + (size_t)node * 8);
 }
 // ---- torso task-space reference of the node parameters of a centroidal handle (behind k_params): one wave per (instance, node)
 __global__ __launch_bounds__(64) void k_params_cent_torso(const DevModel* __restrict__ dm, double* __restrict__ par) {
   CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   cent_params_torso(ctx, *dm, w, par + (size_t)blockIdx.x * NP);
 }
 
 // ---- projection: one workgroup per (instance, node)
 __global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  const Ctx ctx{(int)threadIdx.x, PROJ_THREADS, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0);
 }
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const d
 __global__ __launch_bounds__(256) void k_jump(const double* __restrict__ dts, const double* __restrict__ rec, double* __restrict__ qp) {
   const int node = blockIdx.x;
   if (dts[node] != 0.0) return;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 256, nullptr};
   jump_node_qp(ctx, rec + (size_t)node * REC_SIZE, qp + (size_t)node * QP_SIZE);
 }
 
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                          double* __restrict__ vf, double* __restrict__ ut) {
   const int b = blockIdx.x;
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
   const double* xb = x + (size_t)b * (N + 1) * NX;
   const double* parN = par + ((size_t)b * (N + 1) + N) * NP;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(SCAN_INIT_THREADS) void k_scan_init(const DevModel*
                                                                  const double* __restrict__ qp, int N, double* __restrict__ el, int* __restrict__ status) {
   ScanInitWS<n>& w = *reinterpret_cast<ScanInitWS<n>*>(hsqp_smem);
   const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, SCAN_INIT_THREADS, nullptr};
   __shared__ int ok;
   if (threadIdx.x == 0) ok = 1;
   __syncthreads();
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(SCAN_COMB_THREADS) void k_scan_combine(const double
                                                                     long long* prof) {
   ScanCombWS<n>& w = *reinterpret_cast<ScanCombWS<n>*>(hsqp_smem);
   const int id = blockIdx.x, b = id / (N + 1), k = id % (N + 1);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};
+  const Ctx ctx{(int)threadIdx.x, SCAN_COMB_THREADS, blockIdx.x == 0 ? prof : nullptr};
   constexpr int SZ = ScanEl<n>::SIZE;
   if (k + d <= N) {
     __shared__ int ok;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                             double* __restrict__ ric, int N, int* __restrict__ status, double* __restrict__ vf, double* __restrict__ acl) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int node = blockIdx.x, b = node / N, k = node % N;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, nullptr};
   const double* en = el + ((size_t)b * (N + 1) + k + 1) * ScanEl<n>::SIZE;
   const double* vn = vf_in ? vf_in + ((size_t)b * (N + 1) + k + 1) * VF_SIZE : nullptr;
   const double* q = qp + (size_t)node * QP_SIZE;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(SCAN_FWD_THREADS) void k_scan_forward(const double*
                                                               int N, double* __restrict__ dx) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, SCAN_FWD_THREADS, nullptr};
   closed_loop_forward<n>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, acl + (size_t)b * N * ACL_SIZE<n>, N, dx + (size_t)b * (N + 1) * NX);
 }
 
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                               double* __restrict__ linv, double* __restrict__ vf0, int N, int P, int* __restrict__ status) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, nullptr};
   const size_t s0 = (size_t)b * N + k0;
   riccati_backward<n>(ctx, w, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP, qp + s0 * QP_SIZE, ric_tmp + s0 * RIC_SIZE, L,
                       vf0 + (size_t)seg * VF_SIZE, zero, zero + n * n, false, 1.0, n, linv + s0 * LDB * LDB, 1);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(SEG_ACC_THREADS) __attribute__((amdgpu_waves_per_eu
                                                                    const double* __restrict__ vf0, int N, int P, double* __restrict__ el) {
   SegAccWS& w = *reinterpret_cast<SegAccWS*>(hsqp_smem);
   const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, SEG_ACC_THREADS, nullptr};
   const size_t s0 = (size_t)b * N + k0;
   seg_accumulate<n>(ctx, w, qp + s0 * QP_SIZE, ric_tmp + s0 * RIC_SIZE, linv + s0 * LDB * LDB, L, vf0 + (size_t)seg * VF_SIZE,
                     el + ((size_t)b * (P + 1) + p) * ScanEl<n>::SIZE);
@@ -251,7 +254,7 @@ template <int n>
 __global__ __launch_bounds__(256) void k_seg_terminal(const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ par, int N, int P,
                                                       double* __restrict__ el) {
   const int b = blockIdx.x;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 256, nullptr};
   scan_terminal_element<n>(ctx, el + ((size_t)b * (P + 1) + P) * ScanEl<n>::SIZE, dm->Qf, x + ((size_t)b * (N + 1) + N) * NX, par + ((size_t)b * (N + 1) + N) * NP);
 }
 // 3: the gains of the segment's stages from the value function at its end (suffix element p + 1 of the scanned array)
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                              int* __restrict__ status, double* __restrict__ vf, int vf_mode) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int seg = blockIdx.x, b = seg / P, p = seg % P, k0 = seg_bound(p, N, P), L = seg_bound(p + 1, N, P) - k0;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, nullptr};
   const size_t s0 = (size_t)b * N + k0;
   const double* en = el + ((size_t)b * (P + 1) + p + 1) * ScanEl<n>::SIZE;
   int mybad = 0;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(RIC_THREADS) void k_ric_forward(const double* __res
                                                              const double* __restrict__ ric, int N, double* __restrict__ dx, double* __restrict__ ut) {
   RicWS& w = *reinterpret_cast<RicWS*>(hsqp_smem);
   const int b = blockIdx.x;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, nullptr};
   riccati_forward<NXE>(ctx, w, x_init + (size_t)b * NX, x + (size_t)b * (N + 1) * NX, qp + (size_t)b * N * QP_SIZE, ric + (size_t)b * N * RIC_SIZE, N,
                        dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT);
 }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, cons
                                              double* __restrict__ u_new, double* __restrict__ info, int ut_given) {
   __shared__ StepWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, w, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
             du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
   LqWST<false>& w = *reinterpret_cast<LqWST<false>*>(hsqp_smem);
   static_assert(sizeof(StepWS) <= sizeof(w.st), "the step scratch aliases the stage workspace");
   StepWS& sw = *reinterpret_cast<StepWS*>(&w.st);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, blockIdx.x == 0 ? prof : nullptr};   // phase profile (profile builds): slot 3, labelled k_lq<false>
+  const Ctx ctx{(int)threadIdx.x, LQV_THREADS, blockIdx.x == 0 ? prof : nullptr};   // phase profile (profile builds): slot 3, labelled k_lq<false>
   PH_TICK(ctx, 126);
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, sw, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(LQC_THREADS, HSQP_LQC_WPE) void k_lq_chain(const do
                                                          double* __restrict__ rec, int node_base) {
   __shared__ LqChainWS w;
   const int node = node_base + blockIdx.x, b = node / N, k = node % N;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, LQC_THREADS, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   lq_chain_node(ctx, w, xk, u + (size_t)node * NU, xk + NX, dts[node], rec + (size_t)node * REC_SIZE);
 }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256, 4) void k_kkt(const double* __restrict__ x_ini
   __shared__ KktWS w;
   __shared__ double dx0[NX], r2[2], gred[128];
   const int node = blockIdx.x, b = node / N, k = node % N;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 256, nullptr};
   if (k == 0) {
     for (int i = threadIdx.x; i < NX; i += blockDim.x) dx0[i] = x_init[(size_t)b * NX + i] - x[(size_t)b * (N + 1) * NX + i];
     __syncthreads();
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256, 4) void k_kkt_boundaries(const double* __restr
   __shared__ KktWS w;
   __shared__ double r2[2], gred[128];
   const int b = blockIdx.x / (P - 1), p = 1 + blockIdx.x % (P - 1), k = seg_bound(p, N, P) - 1;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 256, nullptr};
   const double* vfb = vf + (size_t)b * (N + 1) * VF_SIZE;
   const double* dxb = dx + (size_t)b * (N + 1) * NX;
   const size_t node = (size_t)b * N + k;
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(64) void k_policy_inputs(const double* __restrict__
                                                       const double* __restrict__ s, const double* __restrict__ xin, const double* __restrict__ uin,
                                                       double* __restrict__ xout, double* __restrict__ uout) {
   const int b = blockIdx.x;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   if (xt) {
     if (dts) policy_interpolate_grid(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dts + (size_t)b * N, s[b], xout + (size_t)b * NX, uout + (size_t)b * NU);
     else policy_interpolate(ctx, xt + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NU, N, dt, s[b], xout + (size_t)b * NX, uout + (size_t)b * NU);
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(64) void k_cent_policy_map(const DevModel* __restri
                                                         double* __restrict__ xwb, double* __restrict__ uwb) {
   const int b = blockIdx.x;
   CentWST<false>& w = *reinterpret_cast<CentWST<false>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   const double* x = xc + (size_t)b * NX;
   const double* u = uc + (size_t)b * NU;
   double* xo = xwb + (size_t)b * NX;
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(128) void k_policy_torques(const DevModel* __restri
                                                         double* __restrict__ tau) {
   PolicyWS& w = *reinterpret_cast<PolicyWS*>(hsqp_smem);
   const int b = blockIdx.x;
-  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};
+  const Ctx ctx{(int)threadIdx.x, 128, nullptr};
   for (int i = threadIdx.x; i < NX + NU; i += blockDim.x) { if (i < NX) w.x[i] = xwb[(size_t)b * NX + i]; else w.u[i - NX] = uwb[(size_t)b * NU + i - NX]; }
   __syncthreads();
   policy_node(ctx, *dm, w.st, w.x, w.u, tau + (size_t)b * NJ);
