@@ -31,7 +31,8 @@ def _build(LIB, force, verbose, extra):
     # -amdgpu-sched-strategy=iterative-ilp: the kernels are chains of short dependent phases at an occupancy fixed by LDS and
     # launch bounds, so scheduling for ILP instead of for occupancy pays (measured A/B in one run, tools/gpu_variants.sh:
     # 9.53 vs 9.88 ms per iteration; max-ilp: no gain; iterative-minreg: 11.2 ms; any -unroll-threshold change: Riccati 2.5x slower)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-std=c++17", "-shared", "-fPIC",
+    sched = os.environ.get("HSQP_SCHED_STRATEGY", "iterative-ilp")   # (tuning builds: "" = the compiler's default)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", *(["-mllvm", "-amdgpu-sched-strategy=" + sched] if sched else []), "-std=c++17", "-shared", "-fPIC",
            os.path.join(CSRC, "hsqp_capi.hip"), os.path.join(CSRC, "hsqp_comm.hip"), "-ldl", "-o", LIB, *extra]
     if verbose:
         print(" ".join(cmd))
