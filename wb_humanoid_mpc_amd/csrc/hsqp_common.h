@@ -46,6 +46,15 @@ struct Ctx {
   long long* prof;   // phase-profile buffer of workgroup 0 (only in -DHSQP_PHASE_PROFILE builds), else null
 };
 
+// The wave a thread belongs to, as a SCALAR on the device: every lane of a wave has the same tid >> 6, but the compiler does not know it — role branches
+// (which wave eliminates, which wave takes which tile) and the tile coordinates derived from the wave index would otherwise be vector arithmetic and
+// exec-masked branches in every lane.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_NO_SCALAR_WAVE)
+__device__ inline int wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+#else
+HSQP_HD int wave_index(int tid) { return tid >> 6; }
+#endif
+
 // Phase profiling (tools/phase_profile.py): thread 0 of workgroup 0 accumulates shader-clock ticks per phase id.
 #if defined(HSQP_PHASE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define PH_TICK(ctx, id)                                                             \

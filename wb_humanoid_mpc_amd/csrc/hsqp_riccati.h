@@ -85,7 +85,7 @@ template <int SPACES = 0, int NJ = 1>
 HSQP_HD void ric_products(const Ctx& ctx, int first_wave, int n_waves, const XtyJob j0, const XtyJob j1 = xty_no_job(), const XtyJob j2 = xty_no_job()) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads == 512 && n_waves > 0) {
-    const int r0 = (ctx.tid >> 6) - first_wave, r = r0 < n_waves ? r0 : -1, lane = ctx.tid & 63;
+    const int r0 = wave_index(ctx.tid) - first_wave, r = r0 < n_waves ? r0 : -1, lane = ctx.tid & 63;
     if (r < 0) return;
 #if defined(HSQP_PHASE_PROFILE)
     long long* prof = (ctx.tid >> 6) == PROF_WAVE ? ctx.prof : nullptr;
@@ -263,7 +263,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       // wave w sits on SIMD w % 4, and FP64 matrix and vector instructions of one SIMD do not overlap (measured: the elimination took
       // 18 k cycles next to a wave with 75 matrix instructions, 12 k alone): SIMDs 0, 1 eliminate (waves 0, 1; waves 4, 5 only move the
       // next stage's [B~ | b~]), SIMDs 2, 3 carry the tiles of S A~ (waves 2, 3, 6, 7)
-      const int wv = ctx.tid >> 6;
+      const int wv = wave_index(ctx.tid);
       const int trank = (wv & 3) >= 2 ? (wv & 1) + (wv >> 2) * 2 : -1;
       constexpr int NPB = 12;                       // 128 threads x 12 >= 58 * 23 + 58
       const int pt = ctx.tid - 256;
@@ -405,7 +405,7 @@ HSQP_HD void riccati_backward(const Ctx& ctx, RicWS& w, const double* Qf, const 
       if (dev512) {
         // per SIMD (waves w, w + 4) about the same number of matrix instructions, fewer on the waves with the vector items:
         // S: waves 0-3 two tiles, 4-5 one; [K | k]: waves 6-7 two tiles, 2-5 one
-        const int wv = ctx.tid >> 6;
+        const int wv = wave_index(ctx.tid);
         ric_products_ranked<XTY_ADD_GLOBAL>(ctx, wv < 6 ? wv : -1, 6, js);
         ric_products_ranked(ctx, wv >= 6 ? wv - 6 : (wv >= 4 ? wv - 2 : (wv >= 2 ? wv + 2 : -1)), 6, jk);
       } else

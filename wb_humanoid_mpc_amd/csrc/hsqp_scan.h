@@ -157,7 +157,7 @@ __device__ inline unsigned wave_umax(unsigned v) {
 template <int n, int nrhs, int NW, bool PIVOT, class LoadM, class LoadR>
 __device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR load_r, double* X, int ldx, int* okflag) {
   constexpr int NO = (nrhs + NW - 1) / NW;
-  const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
+  const int wave = wave_index(ctx.tid), lane = ctx.tid & 63;
   if (wave >= NW) return;
   const int row = lane < n ? lane : n - 1;
   const int c0 = wave * NO;
@@ -210,7 +210,7 @@ __device__ inline void gauss_jordan_rows(const Ctx& ctx, LoadM load_m, LoadR loa
 template <int n, int nrhs, class LoadM, class LoadR>
 __device__ inline void gauss_jordan_pipeline(const Ctx& ctx, GjPipe& g, LoadM load_m, LoadR load_r, double* X, int ldx, int* okflag) {
   constexpr int CH = GjPipe::CH, NCHK = (n + CH - 1) / CH, NRW = 7, NO = (nrhs + NRW - 1) / NRW;
-  const int wave = ctx.tid >> 6, lane = ctx.tid & 63;
+  const int wave = wave_index(ctx.tid), lane = ctx.tid & 63;
   const int row = lane < n ? lane : n - 1;
   const int c0 = (wave - 1) * NO;
   double m[n], o[NO];
@@ -338,7 +338,7 @@ HSQP_HD void scan_init_node(const Ctx& ctx, ScanInitWS<n>& w, const double* q, d
     const ElimIO io{&w.Ef[0][0], LDF, &w.PG[0][0], &w.PG[0][n], LP, &w.Ef[0][EF_MI], LDF, &w.LinvT[0][0], LDB, &w.Zs[0][0], LP, w.zv, &w.ok};
 #if defined(__HIP_DEVICE_COMPILE__)
     if (ctx.nthreads >= 128) {   // two waves, as in the Riccati stage
-      const int wv = ctx.tid >> 6;
+      const int wv = wave_index(ctx.tid);
       const DevWave dw{ctx.tid & 63};
       if (wv == 0) eliminate_blocked<n, 0>(dw, io);
       else if (wv == 1) eliminate_blocked<n, 1>(dw, io);
