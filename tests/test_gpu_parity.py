@@ -294,6 +294,29 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
         assert_kkt(out["kkt"][b], out["grad_inf"][b], f"config 4 instance {b}")
 
 
+def test_node_ranges_of_the_limb_lane_kernels_on_an_odd_shape(model):
+    """173 instances x 97 nodes = 16 781 nodes = 525 workgroups of the limb-lane LQ kernels (more than one round of 512): the two node ranges on two streams
+    (range boundary at node 8384, inside an instance; the last workgroup part padding) give bit for bit what one launch per kernel gives."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    B, N = 173, 97
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True, seed=3)
+    outs = []
+    for split in ("2", "1"):
+        os.environ["HSQP_LQ_SPLIT"] = split
+        try:
+            s = HipSqpSolver(model, max_nodes=N, max_batch=B)
+        finally:
+            os.environ.pop("HSQP_LQ_SPLIT", None)
+        try:
+            assert s.kernel_forms()["lq_ranges"] == int(split)
+            outs.append(s.run(x0, x, u, par, dt))
+        finally:
+            s.close()
+    assert np.array_equal(outs[0]["dx"], outs[1]["dx"]) and np.array_equal(outs[0]["du"], outs[1]["du"])
+    for b in range(B):
+        assert_kkt(outs[0]["kkt"][b], outs[0]["grad_inf"][b], f"instance {b}")
+
+
 @pytest.mark.parametrize("riccati", ["serial", "auto"])
 def test_config3_exactly_against_the_oracle(model, oracle, riccati):
     """BASELINE config 3 as specified: whole-body, N = 100, ONE unperturbed instance, walk, cold start — against the CPU oracle at
