@@ -9,6 +9,7 @@
 
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_host.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati.h"
+#include "../../wb_humanoid_mpc_amd/csrc/hsqp_riccati_fact.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_cent_lq.h"
 #include "../../wb_humanoid_mpc_amd/csrc/hsqp_lqv.h"
@@ -20,6 +21,7 @@ using namespace hsqp;
 
 static int g_scan_refinements = 0;   // whole-body scan: refinement passes (HSQP_SCAN_WB_REFINEMENTS in hsqp_capi.hip; emu_set_scan_refinements)
 static int g_lq_limb = 1;   // whole-body LQ approximation: limb-lane form (hsqp_lql.h) as the product runs it; 0: the phase form (lq_node<true>)
+static int g_ric_fact = 1;   // whole-body serial sweep on the factors of [A~ | B~] (hsqp_riccati_fact.h) as the product runs it; 0: the dense stage (riccati_backward<58>)
 static int g_scan = 0;   // centroidal formulation: backward sweep by the parallel scan (hsqp_scan.h) instead of the serial recursion
 
 // the parallel-in-time backward sweep through the kernel sources, executed level by level as the device launches it
@@ -164,6 +166,7 @@ int emu_eliminate_blocked(int nxe, const double* lam, const double* G, const dou
 }
 int emu_scan_gate_accepts(double r_stat, double r_prim, double g_inf, int flags) { return scan_gate_accepts(r_stat, r_prim, g_inf, flags) ? 1 : 0; }
 void emu_set_scan(int on) { g_scan = on; }
+void emu_set_ric_fact(int on) { g_ric_fact = on; }
 void emu_set_scan_refinements(int r) { g_scan_refinements = r; }
 
 // Gauss-Jordan of hsqp_scan.h on a 35 x 106 system [M | RHS] (row-major, leading dimension 106; the shape of the combination step):
@@ -341,13 +344,19 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto rw = std::make_unique<RicWS>();
   double pb[3] = {0, 0, 0};
   const double dt_uniform = dt;
+  const bool fact = !cent && g_ric_fact && !g_scan && !g_segments;
+  std::vector<double> dtv(N);
+  for (int k = 0; k < N; ++k) dtv[k] = dts ? dts[k] : dt_uniform;
+  auto fw = std::make_unique<RicFWS>();
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
     if (cent) { auto cw = std::make_unique<CentWST<true>>(); double* r = &rec[(size_t)k * REC_SIZE]; cent_lq_node2<true>(ctx, dm, *cw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC); }
     else if (g_lq_limb && dm.ql_ok) {
       lq_limb_node(dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);   // (rec: zero-filled vector)
     } else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
-    project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent);
+    // (the factored sweep reads the dense base rows, Px, Pu, b~ only: the joint rows of A~ / B~ stay unwritten — NaN here — until the KKT check below)
+    if (fact) for (int i = 0; i < QP_BV; ++i) qp[(size_t)k * QP_SIZE + i] = std::nan("");
+    project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent, !fact);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) return HSQP_ERR_NUMERIC;
     pb[0] += rec[(size_t)k * REC_SIZE + REC_MISC + 1]; pb[1] += rec[(size_t)k * REC_SIZE + REC_MISC + 3]; pb[2] += rec[(size_t)k * REC_SIZE + REC_MISC + 2];
@@ -367,11 +376,19 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
     rw->ok = 1;
   }
   else if (cent) riccati_backward<CNX>(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
+  else if (fact) { riccati_backward_fact(ctx, *fw, dm.Qf, x + N * NX, par + N * NP, qp.data(), dtv.data(), ric.data(), N, vf.data()); rw->ok = fw->ok; }
   else riccati_backward(ctx, *rw, dm.Qf, x + N * NX, par + N * NP, qp.data(), ric.data(), N, vf.data());
   if (!rw->ok) return HSQP_ERR_NUMERIC;
   if (cent && g_scan && !g_segments) closed_loop_forward<CNX>(ctx, *rw, x_init, x, acl.data(), N, dx);   // k_scan_forward
   else if (g_scan && !g_segments) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
   else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
+  else if (fact) {
+    riccati_forward_fact(ctx, *fw, x_init, x, qp.data(), dtv.data(), ric.data(), N, dx, ut.data());
+    for (int k = 0; k < N; ++k) {   // the dense joint rows for the KKT check (what k_project writes when the report is asked for)
+      project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dtv[k], &qp[(size_t)k * QP_SIZE], cent, true);
+      if (dtv[k] == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
+    }
+  }
   else riccati_forward(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
   const bool ut_given = !(g_scan && !g_segments);   // the serial roll-out leaves ut = k + K dx of every node (as k_riccati / k_ric_forward do)
   auto sw = std::make_unique<StepWS>();

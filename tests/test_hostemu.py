@@ -164,6 +164,31 @@ def test_phases_are_free_of_intra_phase_dependencies(model, emu, gait, n):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("gait,n", [("stance", 5), ("walk", 24), ("run", 40)])
+def test_factored_serial_sweep_equals_the_dense_stage(model, emu, gait, n):
+    """hsqp_riccati_fact.h (the whole-body serial sweep on the factors [A~ | B~] = [E_J | 0] + F [Vx | Vu]: 35-deep contractions with row
+    combinations formed while the operands are fetched, S A~ and W under the elimination, roll-out on the factors — what k_riccati_fact
+    runs) against the dense stage of hsqp_riccati.h on the same kernel sources: same minimiser to rounding, same KKT residual.  The
+    factored run also proves that the joint rows of A~ / B~ are never read: the emulation leaves them NaN until its KKT check."""
+    lib, h = emu
+    x0, x, u, par, dt = perturbed_problem(model, n, gait, seed=11)
+    res = []
+    for fact in (0, 1):
+        lib.emu_set_ric_fact(fact)
+        xn, un, dx, du = np.zeros_like(x), np.zeros_like(u), np.zeros_like(x), np.zeros_like(u)
+        kkt, pb, pa = np.zeros(2), np.zeros(3), np.zeros(3)
+        rc = lib.emu_sqp_iteration(h, n, C.c_double(dt), P(x0), P(x), P(u), P(par), P(xn), P(un), P(dx), P(du), P(kkt), P(pb), P(pa), None, None)
+        lib.emu_set_ric_fact(1)
+        assert rc == 0
+        res.append((dx, du, kkt, pa))
+    (dx0, du0, kkt0, pa0), (dx1, du1, kkt1, pa1) = res
+    sc = max(1.0, np.abs(dx0).max(), np.abs(du0).max())
+    assert np.isfinite(dx1).all() and np.isfinite(du1).all()
+    assert max(np.abs(dx1 - dx0).max(), np.abs(du1 - du0).max()) <= 2e-11 * sc, (np.abs(dx1 - dx0).max(), np.abs(du1 - du0).max(), sc)
+    assert kkt1[0] <= max(3.0 * kkt0[0], 1e-10 * sc) and kkt1[1] <= max(3.0 * kkt0[1], 1e-12 * sc), (kkt0, kkt1)
+    assert np.allclose(pa1, pa0, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("gait,n,accurate", [("walk", 16, True), ("walk", 37, True), ("run", 37, False)])
 def test_whole_body_parallel_scan_backward_sweep_equals_the_serial_recursion(model, emu, gait, n, accurate):
     """hsqp_scan.h at n = 58 (elements of all stages, ceil(log2(N+1)) levels of combinations, single-stage gains, closed-loop roll-out)

@@ -13,6 +13,7 @@
 
 #include "hsqp_host.h"
 #include "hsqp_riccati.h"
+#include "hsqp_riccati_fact.h"
 #include "hsqp_params.h"
 #include "hsqp_policy.h"
 #include "hsqp_cent.h"
@@ -114,11 +115,11 @@ __global__ __launch_bounds__(64) void k_params_cent_torso(const DevModel* __rest
 }
 
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent) {
+__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent, int joint_rows) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, PROJ_THREADS, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
-  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0);
+  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0, joint_rows != 0);
 }
 
 // ---- event intervals (jump_node_qp, hsqp_project.h): one workgroup per node; only launched when the grid has such intervals
@@ -154,6 +155,32 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
   PH_TICK(ctx, 10);
   // OR-accumulated over the iterations of one hsqp_iterate_device call (the host clears it once per call): a numeric failure
   // in an early iteration must not be masked by a later clean one
+  if (threadIdx.x == 0) { const int st = (bad ? 1 : 0) | (w.ok ? 0 : 2); if (st) atomicOr(&status[b], st); }
+}
+
+// ---- the whole-body serial sweep on the FACTORS of [A~ | B~] (hsqp_riccati_fact.h): what every whole-body handle's serial recursion runs
+__global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati_fact(const DevModel* __restrict__ dm, const double* __restrict__ x_init,
+                                                         const double* __restrict__ x, const double* __restrict__ par,
+                                                         const double* __restrict__ qp, const double* __restrict__ dts, double* __restrict__ ric, int N,
+                                                         double* __restrict__ dx, int* __restrict__ status, long long* prof,
+                                                         double* __restrict__ vf, double* __restrict__ ut) {
+  const int b = blockIdx.x;
+  RicFWS& w = *reinterpret_cast<RicFWS*>(hsqp_smem);
+  const Ctx ctx{(int)threadIdx.x, RIC_THREADS, blockIdx.x == 0 ? prof : nullptr};
+  PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
+  const double* xb = x + (size_t)b * (N + 1) * NX;
+  const double* parN = par + ((size_t)b * (N + 1) + N) * NP;
+  const double* qpb = qp + (size_t)b * N * QP_SIZE;
+  const double* dtb = dts + (size_t)b * N;
+  double* ricb = ric + (size_t)b * N * RIC_SIZE;
+  int mybad = 0;  // projection failures of this instance (rank-deficient D)
+  for (int k = threadIdx.x; k < N; k += RIC_THREADS)
+    if (qpb[(size_t)k * QP_SIZE + QP_NUT] < 0.0) mybad = 1;
+  const int bad = __syncthreads_or(mybad);
+  riccati_backward_fact(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, dtb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
+  PH_TICK(ctx, 0);
+  riccati_forward_fact(ctx, w, x_init + (size_t)b * NX, xb, qpb, dtb, ricb, N, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT);
+  PH_TICK(ctx, 10);
   if (threadIdx.x == 0) { const int st = (bad ? 1 : 0) | (w.ok ? 0 : 2); if (st) atomicOr(&status[b], st); }
 }
 
@@ -888,6 +915,7 @@ struct hsqp_handle {
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
   bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_rows + k_lq_chain) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
+  bool ric_fact = false;                      // whole-body serial sweep on the factors of [A~ | B~] (hsqp_riccati_fact.h: k_riccati_fact; HSQP_RICCATI_DENSE in the environment at hsqp_create: the dense stage k_riccati<58>, for A/B runs)
   bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)
   hsqp_perf *d_perf_before = nullptr, *d_perf_after = nullptr;
   int* d_status = nullptr;
@@ -1130,6 +1158,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (settings->device < 0 || settings->device >= ndev) { g_create_error = "device ordinal out of range"; return HSQP_ERR_BAD_ARG; }
   hsqp_handle* h = new hsqp_handle;
   h->seg_debug = getenv("HSQP_SEG_DEBUG") != nullptr;
+  h->ric_fact = model->formulation == HSQP_FORM_WB && getenv("HSQP_RICCATI_DENSE") == nullptr;
   h->md = *model;
   h->st = *settings;
   h->device = settings->device;
@@ -1189,6 +1218,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_lq_cent2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CentWST<true>));
   hipError_t a3 = hipFuncSetAttribute((const void*)k_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProjWS));
   hipError_t a4 = hipFuncSetAttribute((const void*)k_riccati<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
+  if (a4 == hipSuccess) a4 = hipFuncSetAttribute((const void*)k_riccati_fact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicFWS));
   hipError_t a5 = hipFuncSetAttribute((const void*)k_riccati<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RicWS));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_init<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanInitWS<CNX>));
   if (a5 == hipSuccess) a5 = hipFuncSetAttribute((const void*)k_scan_combine<CNX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanCombWS<CNX>));
@@ -1403,13 +1433,6 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0);
-    if (h->has_events) hipLaunchKernelGGL(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
-    if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
-    if (want_kkt && !h->d_vf) {
-      const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
-      if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
-    }
     // The backward sweep: serial recursion, or — one or two instances on a long horizon, or on request — the associative scan over the
     // stages (hsqp_scan.h).  The scan inverts I + C1 J2 of partial horizons (condition number up to 1e5 centroidal, 1e9 whole-body): on
     // the QPs of a cold start or of a tracking MPC it reproduces the serial recursion to 1e-11 of the step's scale, on a far-from-
@@ -1430,6 +1453,16 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // iterates that fail the gate — far-from-feasible line-search iterates — come in runs
     if (pscan && !forced_scan && h->seg_backoff > 0) { --h->seg_backoff; ++h->backoff_iterations; pscan = false; }
     const bool scan = pscan || segP > 0;        // either way a KKT-gated sweep with the serial recursion as fallback
+    // The joint rows of A~ / B~ (46 of 58: scaled copies of rows of [Px | Pu]) are written only for those who read A~ / B~ as dense blocks: the
+    // parallel-in-time and two-level sweeps, the KKT report, the centroidal stage.  The whole-body serial sweep works on the factors.
+    const bool joint_rows = cent || !h->ric_fact || scan || want_kkt;
+    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0, joint_rows ? 1 : 0);
+    if (h->has_events) hipLaunchKernelGGL(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
+    if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
+    if (want_kkt && !h->d_vf) {
+      const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
+      if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+    }
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
     int ut_given = 0;   // the last sweep's roll-out left ut = k + K dx of every node in d_ut (the serial roll-out does, the scan's closed-loop roll-out does not)
@@ -1439,6 +1472,9 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
         hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
+      else if (h->ric_fact)
+        hipLaunchKernelGGL(k_riccati_fact, dim3(B), dim3(RIC_THREADS), sizeof(RicFWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dt,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       else
         hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
@@ -1916,6 +1952,8 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
       if (dst && bytes > 0) memcpy(dst, t.data(), (size_t)(bytes < (long long)t.size() * 8 ? bytes : (long long)t.size() * 8));
       return (long long)t.size() * 8;
     }
+    case 101: out.resize(nodes * (size_t)RIC_SIZE); if (hipMemcpy(out.data(), h->d_ric, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;   // raw gains record (debug tools)
+    case 102: out.resize(nodes * (size_t)QP_SIZE); if (hipMemcpy(out.data(), h->d_qp, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return HSQP_ERR_HIP; break;    // raw QP record (debug tools)
     default: h->err = "unknown block id"; return HSQP_ERR_BAD_ARG;
   }
   const long long size = iout.empty() ? (long long)out.size() * 8 : (long long)iout.size() * 4;

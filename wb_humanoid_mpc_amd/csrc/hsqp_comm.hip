@@ -11,13 +11,40 @@
 // returns after hipStreamSynchronize: the buffers may be handed to hsqp_upload_device / freed right away.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
+
+// RCCL's development header is used where the ROCm install has it; a ROCm without it still builds the solver library: the handful of
+// declarations the exchange needs are restated below (the values are RCCL's public ABI, nccl.h: ncclChar = 0, ncclDouble = 8, ncclMax = 2,
+// a 128-byte identifier), and the entry points are bound by name at run time either way.
+#if defined(__has_include) && __has_include(<rccl/rccl.h>) && !defined(HSQP_NO_RCCL_HEADER)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclChar = 0, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclMax = 2 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+const char* ncclGetErrorString(ncclResult_t);
+ncclResult_t ncclBroadcast(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+}
+#endif
+static_assert((int)ncclChar == 0 && (int)ncclDouble == 8 && (int)ncclMax == 2 && NCCL_UNIQUE_ID_BYTES == 128, "RCCL's public constants");
 
 #include "../../include/hsqp.h"
 
@@ -43,18 +70,24 @@ RcclApi& rccl() {
   return api;
 }
 
-// HSQP_RCCL_LIB names the library explicitly; otherwise the soname, then the ROCm install
+// HSQP_RCCL_LIB names the library explicitly (then nothing else is tried: a test or a site that substitutes the transport means it);
+// otherwise the soname, then the ROCm install.  One thread binds; concurrent first calls wait for it.
+std::mutex& rccl_mutex() { static std::mutex m; return m; }
 bool rccl_load() {
+  std::lock_guard<std::mutex> lock(rccl_mutex());
   RcclApi& a = rccl();
   if (a.lib) return true;
   const char* env = getenv("HSQP_RCCL_LIB");
-  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) {
-    if (!n || !*n) continue;
+  const char* fallbacks[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  std::string why;
+  auto try_open = [&](const char* n) {
     a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (a.lib) break;
-  }
-  if (!a.lib) { a.err = std::string("librccl not found (") + (dlerror() ? dlerror() : "dlopen failed") + "); set HSQP_RCCL_LIB"; return false; }
+    if (!a.lib) { const char* de = dlerror(); why = de ? de : "dlopen failed"; }   // (dlerror() clears the message: read it once)
+    return a.lib != nullptr;
+  };
+  if (env && *env) try_open(env);
+  else for (const char* n : fallbacks) if (try_open(n)) break;
+  if (!a.lib) { a.err = std::string("librccl not found (") + why + "); set HSQP_RCCL_LIB"; return false; }
   bool ok = true;
   auto sym = [&](auto& fn, const char* name) {
     fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(a.lib, name));

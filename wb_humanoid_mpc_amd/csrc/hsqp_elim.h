@@ -222,7 +222,7 @@ HSQP_HD void eliminate_blocked(const W& wv, const ElimIO& io, Hook after_load = 
             if (col < NUT) {
               const double vv = col <= row ? v : 0.0;
               io.linv[row * io.ldli + col] = vv;
-              io.linvT[col * io.ldt + row] = vv;
+              if (io.linvT) io.linvT[col * io.ldt + row] = vv;   // (optional: the factored stage, hsqp_riccati_fact.h, has no use for the transpose)
             }
           } else if (col < NXE) {
             io.z[row * io.ldz + col] = v;

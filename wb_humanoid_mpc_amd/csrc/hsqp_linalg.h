@@ -138,7 +138,7 @@ constexpr int nbatches(int count, int nbatch) { return (count + nbatch - 1) / nb
 //   A[i][k] = X[k0 + (lane >> 4)][r0 + (lane & 15)],  B[k][j] = Y[k0 + (lane >> 4)][c0 + (lane & 15)],
 //   D: lane holds rows (lane >> 4) + 4 reg, column lane & 15  (reg = 0..3).
 // A job list is executed cooperatively: 16x16 output tiles are dealt round-robin to the waves of the workgroup.
-constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2, XTY_ROW_JUMP = 4, XTY_ADD_T = 8;   // (XTY_ROW_JUMP: the jobs of the call use XtyJob::rsplit / rjump; XTY_ADD_T: the additive
+constexpr int XTY_ADD_GLOBAL = 1, XTY_C_GLOBAL = 2, XTY_ROW_JUMP = 4, XTY_ADD_T = 8, XTY_ADD_LDS = 16;   // (XTY_ADD_LDS: the additive term of every job of the call is in LDS; XTY_ROW_JUMP: the jobs of the call use XtyJob::rsplit / rjump; XTY_ADD_T: the additive
 // term of every job of the call is stored transposed, Add[c * ldadd + r] — XtyJob::addt on the host)
 struct XtyJob {
   int M, N;                       // output size
@@ -206,6 +206,7 @@ __device__ inline double readlane_f64(double v, int lane) {
 typedef double hsqp_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) * hsqp_gcptr;
 typedef double __attribute__((address_space(1))) * hsqp_gptr;
+typedef const double __attribute__((address_space(3))) * hsqp_lcptr;
 // NT = 1 or 2 output tiles of one job processed together: two independent accumulator chains keep the FP64 matrix
 // pipe busy from a single wave (a dependent v_mfma_f64 chain alone leaves it half idle).
 // SPACES (XTY_ADD_GLOBAL | XTY_C_GLOBAL): the additive term / the destination of every job of the call is known to be in
@@ -243,6 +244,7 @@ __attribute__((always_inline)) HSQP_D void xty_job_tiles_mfma(const XtyJob& j, c
         const int row = rb + 4 * r, rc = (inside || row < j.M) ? row : j.M - 1;
         if constexpr ((SPACES & XTY_ADD_T) != 0) addv[t][r] = ((hsqp_gcptr)j.Add)[cc * j.ldadd + rc];
         else if (SPACES & XTY_ADD_GLOBAL) addv[t][r] = ((hsqp_gcptr)j.Add)[rc * j.ldadd + cc];
+        else if constexpr ((SPACES & XTY_ADD_LDS) != 0) addv[t][r] = ((hsqp_lcptr)j.Add)[rc * j.ldadd + cc];
         else addv[t][r] = j.Add[rc * j.ldadd + cc];
       }
     }

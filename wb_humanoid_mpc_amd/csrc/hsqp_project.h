@@ -223,7 +223,9 @@ HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int n
 
 // cent = true: the record comes from the centroidal LQ kernel (hsqp_cent.h): the dense rows of [A|B] - [I|0] are rows 0..11
 // (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
-HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false) {
+// joint_rows = false: the 46 joint rows of A~ / B~ (scaled copies of rows 12 .. of [Px | Pu]: q_j+ = q_j + dt v_j + dt^2/2 qdd_j, v_j+ = v_j + dt qdd_j) are NOT
+// written — the factored Riccati sweep (hsqp_riccati_fact.h) forms them from Px, Pu on the fly; b~ is always complete.  30 of the record's 101 KB.
+HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false, bool joint_rows = true) {
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
     static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
@@ -624,6 +626,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
       // joint j: q_j+ = q_j + dt v_j + dt^2/2 qdd_j (row 6 + j), v_j+ = v_j + dt qdd_j (row NV + 6 + j), qdd_j = input 12 + j: both rows
       // are scaled copies of row 12 + j of T, read once
       const double hq = 0.5 * dt * dt;
+      if (joint_rows || c == NTW)
       for (int j = g; j < NJ; j += NCG) {
         const int rq = 6 + j, rv = NV + 6 + j;
         const double t = w.Tm[12 + j][c];
