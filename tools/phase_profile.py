@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["HSQP_LIB"] = os.path.join(ROOT, "wb_humanoid_mpc_amd", "libhsqp_hip_prof.so")
+os.environ["HSQP_LIB"] = os.environ.get("HSQP_PROF_LIB") or os.path.join(ROOT, "wb_humanoid_mpc_amd", "libhsqp_hip_prof.so")
 os.environ.setdefault("HSQP_LQ_SPLIT", "1")   # one launch per LQ kernel: workgroup 0 of every range would tick into the same slots
 import numpy as np  # noqa: E402
 

@@ -24,6 +24,9 @@
 #pragma once
 #include <cstddef>
 #include "hsqp_riccati.h"
+#ifndef HSQP_EXP
+#define HSQP_EXP 0   /* timing experiments of tuning builds (WRONG results): bit 0 memory waves without trailing copies / Q~, 1 no Vx copy, 2 memory waves idle, 3 no W' tiles, 4 no hook; (correct results:) 5 no s_setprio */
+#endif
 
 namespace hsqp {
 
@@ -123,26 +126,30 @@ __attribute__((always_inline)) HSQP_D void fact_mfma(hsqp_d4 (&acc)[NT], XF xf, 
 // instruction of a piece starts at n - 64 and re-copies what it overlaps.  (With a per-lane tail predicate `c0 + lane < n` the compiler merged
 // the tail of one piece with the head of the next under the predicate and took the LDS base of the merged copy from the first active lane:
 // lanes beyond the tail wrote the next piece to the wrong place.  Found by the GPU parity run; the builtin's LDS pointer must stay wave-uniform
-// through every transformation, which straight-line code guarantees.)  `turn` alternates the instructions between the two waves.
-template <int N>
+// through every transformation, which straight-line code guarantees.)  NW = 2: `turn` alternates the instructions between two waves.
+template <int N, int NW>
 HSQP_D void fact_async_piece(const double* src, double* dst, int wave, int lane, int& turn) {
-  static_assert(N >= 64, "a piece is at least one full wave instruction");
+  static_assert(N >= 64 && (NW == 1 || NW == 2), "a piece is at least one full wave instruction; one or two waves share the pieces");
   constexpr int NI = (N + 63) / 64;
   static_for<NI>([&](auto ic) {
     constexpr int i = decltype(ic)::value, c0 = (i + 1) * 64 <= N ? i * 64 : N - 64;
-    if (((turn + i) & 1) == wave) __builtin_amdgcn_global_load_lds((hsqp_gcptr)src + 2 * (c0 + lane), (hsqp_ldsptr)(dst + 2 * c0), 16, 0, 0);
+    if (NW == 1 || ((turn + i) & 1) == wave) __builtin_amdgcn_global_load_lds((hsqp_gcptr)src + 2 * (c0 + lane), (hsqp_ldsptr)(dst + 2 * c0), 16, 0, 0);
   });
   turn += NI;
 }
-// the next stage's Vx, P~, R~ -> LDS (33 wave instructions over the two eliminating waves)
-HSQP_D void fact_next_stage_to_lds(const double* qn, double* va, double* pn, double* rn, int wave, int lane) {
+// the next stage's Vx -> LDS (17 wave instructions) and P~, R~ (16), all issued by wave 0: the faster of the two eliminating waves
+HSQP_D void fact_next_vx_to_lds(const double* qn, double* va, int lane) {
   if (!qn) return;
   int turn = 0;
-  fact_async_piece<6 * NX / 2>(qn + QP_A, va, wave, lane, turn);
-  fact_async_piece<6 * NX / 2>(qn + QP_A + NV * NX, va + 6 * NX, wave, lane, turn);
-  fact_async_piece<NJ * NX / 2>(qn + QP_PX + 12 * NX, va + 12 * NX, wave, lane, turn);
-  fact_async_piece<NUT * NX / 2>(qn + QP_P, pn, wave, lane, turn);
-  fact_async_piece<(NUT * NUT + 1) / 2>(qn + QP_R, rn, wave, lane, turn);
+  fact_async_piece<6 * NX / 2, 1>(qn + QP_A, va, 0, lane, turn);
+  fact_async_piece<6 * NX / 2, 1>(qn + QP_A + NV * NX, va + 6 * NX, 0, lane, turn);
+  fact_async_piece<NJ * NX / 2, 1>(qn + QP_PX + 12 * NX, va + 12 * NX, 0, lane, turn);
+}
+HSQP_D void fact_next_cost_to_lds(const double* qn, double* pn, double* rn, int lane) {
+  if (!qn) return;
+  int turn = 0;
+  fact_async_piece<NUT * NX / 2, 1>(qn + QP_P, pn, 0, lane, turn);
+  fact_async_piece<(NUT * NUT + 1) / 2, 1>(qn + QP_R, rn, 0, lane, turn);
 }
 // tiles on / above the diagonal of a 4 x 4 tile grid, row by row
 HSQP_D int fact_sym_tr(int id) { return id < 4 ? 0 : (id < 7 ? 1 : (id < 9 ? 2 : 3)); }
@@ -185,6 +192,42 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
   }
   WG_SYNC(ctx);
   const Ctx& ctx_outer = ctx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Loop-invariant address tables of the waves that only move data in Ph3 (and of the Q~ fetch), formed ONCE: offsets relative to the record of the
+  // NEXT stage (records are contiguous: this stage's q~ is QP_SIZE further) and LDS destinations.  Inside the stage loop the thread index is opaque
+  // (see below), so everything derived from it is recomputed per stage — for these waves that was ~400 vector instructions of index arithmetic per
+  // stage, issued in the gaps the eliminating wave of the same SIMD leaves (it is older and nearly always ready): the memory waves reached the
+  // phase's barrier 1 - 2 k cycles AFTER the elimination, whatever they loaded (profiles/r06_ric_experiments.txt).
+  constexpr int FM_NPB = 8, FM_NVB = NF * NUT;
+  static_assert(128 * FM_NPB >= FM_NVB + 2 * NX + NUT, "one pass of the two memory waves");
+  int fm_src[FM_NPB], fm_dst[FM_NPB];     // source offset (doubles, from the next stage's record), LDS destination (doubles, from &w.VA[0][0][0]; -1: none)
+  int fq_off[3][4];                       // Q~ fetch of the S-update tiles this wave forms in Ph4 (offset from the stage's record)
+  int f_sfirst, f_scount;
+  {
+    const int tid0 = ctx_outer.tid, wv0 = tid0 >> 6, lane0 = tid0 & 63, li0 = lane0 & 15, kk0 = lane0 >> 4, pt = tid0 - 256;
+    double* const lbase = &w.VA[0][0][0];
+#pragma unroll
+    for (int t = 0; t < FM_NPB; ++t) {
+      const int idx = pt + 128 * t;
+      int so = 0, dd = -1;
+      if (idx >= 0 && idx < FM_NVB) { const int kf = idx / NUT, c = idx - kf * NUT; so = (int)(fact_vb_row(qp, kf) - qp) + c; dd = (int)(&w.VB[kf][c] - lbase); }
+      else if (idx >= FM_NVB && idx < FM_NVB + NX) { so = QP_BV + idx - FM_NVB; dd = (int)(&w.bt[idx - FM_NVB] - lbase); }
+      else if (idx >= FM_NVB + NX && idx < FM_NVB + 2 * NX) { so = QP_SIZE + QP_QV + idx - FM_NVB - NX; dd = (int)(&w.dx[idx - FM_NVB - NX] - lbase); }
+      else if (idx >= FM_NVB + 2 * NX && idx < FM_NVB + 2 * NX + NUT) { so = QP_RV + idx - FM_NVB - 2 * NX; dd = (int)(&w.kv[idx - FM_NVB - 2 * NX] - lbase); }
+      fm_src[t] = so; fm_dst[t] = dd;
+    }
+    // S tiles (ids 0 .. 9 of the upper triangle, row by row) of waves 0, 1, 4, 5: three, ONE, three, three — wave 1 carries the larger share of the
+    // elimination and is the phase's critical path
+    f_sfirst = wv0 == 0 ? 0 : (wv0 == 1 ? 3 : (wv0 == 4 ? 4 : 7)); f_scount = wv0 == 1 ? 1 : 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
+      const int cc = 16 * tc + li0 < NX ? 16 * tc + li0 : NX - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * tr + kk0 + 4 * r, rc = row < NX ? row : NX - 1; fq_off[t][r] = QP_Q + rc * NX + cc; }
+    }
+  }
+#endif
   for (int k = N - 1; k >= 0; --k) {
     // (the thread index is made opaque once per stage: see riccati_backward)
     Ctx ctx = ctx_outer;
@@ -205,10 +248,11 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     // ---- Ph1: SB = (F^T S)^T Vu — one tile per wave; the waves of the first column tile also keep the combinations they fetch (FS);
     //      the helper half first: sb = s + S b~ (four partial sums per row, closed by DPP quad permutes), k of the previous stage -> record
     {
-      if (ctx.tid >= 256) {
-        const int it = ctx.tid - 256;
-        if (it < 4 * NX) {
-          const int r = it >> 2, p = it & 3;
+      // (the vector items are dealt to ALL waves, 32 lanes = eight rows each, in front of the wave's tile: on the helper half alone they were
+      //  1.4 k cycles in front of four of the eight tiles — a phase lasts as long as its slowest wave)
+      if (lane < 32) {
+        const int r = 8 * wv + (lane >> 2), p = lane & 3;
+        if (r < NX) {     // (whole quads: r depends on lane >> 2)
           constexpr int LA = (NX + 3) / 4;
           double sacc = 0.0;
           if (p == 0) { const double* sp = &w.part[4 * r]; sacc = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
@@ -217,8 +261,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           sacc += quad_perm_f64<0xB1>(sacc);
           sacc += quad_perm_f64<0x4E>(sacc);
           if (p == 0) { w.sb[r] = sacc; w.SB[r][NUT] = sacc; }
-        } else if (it < 4 * NX + NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + it - 4 * NX] = w.PG[it - 4 * NX][FG_GV];
-      }
+        }
+      } else if (wv == 7 && lane - 32 < NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + lane - 32] = w.PG[lane - 32][FG_GV];
       const int rt = wv & 3, ct = wv >> 2, r0 = rt << 4, c0 = ct << 4;
       const int xr = r0 + li < NX ? r0 + li : NX - 1, yc = c0 + li < LDB ? c0 + li : LDB - 1;
       hsqp_d4 acc[1] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}};
@@ -262,56 +306,53 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     // ---- Ph2: G = P~ + SB^T E_J + (F^T SB)^T Vx;  [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb]);  fsb = F^T sb
 #if defined(__HIP_DEVICE_COMPILE__)
     {
-      // G: one tile per wave (2 row tiles x 4 column tiles); no global load in the phase: P~, R~ arrived in LDS a stage ahead
+      // G: one tile per wave (2 row tiles x 4 column tiles); [Lam | g]: four tiles on waves 4 .. 7 (every SIMD then carries three tiles) — as the
+      // second tile of ONE call (a tile call is ~2.5 k cycles whatever it contracts: two calls in a row were the phase's critical path).  No global
+      // load in the phase: P~, R~ arrived in LDS a stage ahead.  Wave 4 first leaves fsb.
+      if (wv == 4 && lane < NFS * 4) w.fsb[lane] = lane < NF ? fact_combo(lane >> 2, lane & 3, w.sb, 1, 0, dt, hq) : 0.0;
+      const int grt = wv >> 2, gct = wv & 3, gr0 = grt << 4, gc0 = gct << 4;
+      const int gxr = gr0 + li < NUT ? gr0 + li : NUT - 1, gyc = gc0 + li < NX ? gc0 + li : NX - 1, gycp = fact_partner(gyc);
+      const int lrt = (wv - 4) >> 1, lct = (wv - 4) & 1, lr0 = lrt << 4, lc0 = lct << 4;                // (waves 4 .. 7 only)
+      const int lxr = lr0 + li < NUT ? lr0 + li : NUT - 1, lyc = lc0 + li < LDB ? lc0 + li : LDB - 1;
+      auto xf = [&](auto sc, int t) {
+        constexpr int s = decltype(sc)::value;
+        const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1;
+        const double v = t == 0 ? fact_combo(sc, kk, &w.SB[0][0], LDB, gxr, dt, hq) : w.VB[kc][lxr];
+        return 4 * s + kk < NF ? v : 0.0;
+      };
+      auto yf = [&](auto sc, int t) {
+        constexpr int s = decltype(sc)::value;
+        const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1;
+        return t == 0 ? VA[kc][gyc] : fact_combo(sc, kk, &w.SB[0][0], LDB, lyc, dt, hq);
+      };
+      hsqp_d4 acc[2] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}, hsqp_d4{0.0, 0.0, 0.0, 0.0}};
+      if (wv >= 4) fact_mfma<2, RIC_PF, NFS>(acc, xf, yf);
+      else { hsqp_d4 a1[1] = {acc[0]}; fact_mfma<1, RIC_PF, NFS>(a1, xf, yf); acc[0] = a1[0]; }
       {
-        const int rt = wv >> 2, ct = wv & 3, r0 = rt << 4, c0 = ct << 4;
-        const int xr = r0 + li < NUT ? r0 + li : NUT - 1, yc = c0 + li < NX ? c0 + li : NX - 1, ycp = fact_partner(yc);
-        hsqp_d4 acc[1] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}};
-        auto xf = [&](auto sc, int) {
-          constexpr int s = decltype(sc)::value;
-          double v = fact_combo(sc, kk, &w.SB[0][0], LDB, xr, dt, hq);
-          if (4 * s + 3 >= NF) v = 4 * s + kk < NF ? v : 0.0;
-          return v;
-        };
-        auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return VA[kc][yc]; };
-        fact_mfma<1, RIC_PF, NFS>(acc, xf, yf);
         // (SB^T E_J)[row][col]: column `col` of E_J picks row col (and row col - 29) of SB
         double pv[4], ea[4], eb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r, rc = row < NUT ? row : NUT - 1; pv[r] = w.Pn[rc][yc]; ea[r] = w.SB[yc][rc]; eb[r] = w.SB[ycp][rc]; }
-        const int col = c0 + li;
+        for (int r = 0; r < 4; ++r) { const int row = gr0 + kk + 4 * r, rc = row < NUT ? row : NUT - 1; pv[r] = w.Pn[rc][gyc]; ea[r] = w.SB[gyc][rc]; eb[r] = w.SB[gycp][rc]; }
+        const int col = gc0 + li;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r; if (col < NX && row < NUT) w.PG[row][col] = (acc[0][r] + pv[r]) + fact_ej_mix(ea[r], eb[r], yc, dt); }
+        for (int r = 0; r < 4; ++r) { const int row = gr0 + kk + 4 * r; if (col < NX && row < NUT) w.PG[row][col] = (acc[0][r] + pv[r]) + fact_ej_mix(ea[r], eb[r], gyc, dt); }
       }
-      // [Lam | g]: the four tiles on waves 4 .. 7 (every SIMD then carries three tiles); wave 4 first leaves fsb
       if (wv >= 4) {
-        if (wv == 4 && lane < NFS * 4) w.fsb[lane] = lane < NF ? fact_combo(lane >> 2, lane & 3, w.sb, 1, 0, dt, hq) : 0.0;
-        const int rt = (wv - 4) >> 1, ct = (wv - 4) & 1, r0 = rt << 4, c0 = ct << 4;
-        const int xr = r0 + li < NUT ? r0 + li : NUT - 1, yc = c0 + li < LDB ? c0 + li : LDB - 1;
-        hsqp_d4 acc[1] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}};
-        auto xf = [&](auto sc, int) {
-          constexpr int s = decltype(sc)::value;
-          const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1;
-          const double v = w.VB[kc][xr];
-          return 4 * s + kk < NF ? v : 0.0;
-        };
-        auto yf = [&](auto sc, int) { return fact_combo(sc, kk, &w.SB[0][0], LDB, yc, dt, hq); };
-        fact_mfma<1, RIC_PF, NFS>(acc, xf, yf);
         double av[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // (both reads unconditional, then a select)
-          const int row = r0 + kk + 4 * r, rc = row < NUT ? row : NUT - 1;
-          const double a1 = Rn[rc * NUT + (yc < NUT ? yc : NUT - 1)], a2 = w.kv[rc];
-          av[r] = yc < NUT ? a1 : a2;
+          const int row = lr0 + kk + 4 * r, rc = row < NUT ? row : NUT - 1;
+          const double a1 = Rn[rc * NUT + (lyc < NUT ? lyc : NUT - 1)], a2 = w.kv[rc];
+          av[r] = lyc < NUT ? a1 : a2;
         }
-        const int col = c0 + li;
+        const int col = lc0 + li;
         if (col <= NUT) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = r0 + kk + 4 * r;
+            const int row = lr0 + kk + 4 * r;
             if (row < NUT) {
-              if (col < NUT) w.Ef[row][col] = acc[0][r] + av[r];
-              else w.PG[row][FG_GV] = acc[0][r] + av[r];   // g = r~ + B~^T sb (r~ staged in kv a stage ahead)
+              if (col < NUT) w.Ef[row][col] = acc[1][r] + av[r];
+              else w.PG[row][FG_GV] = acc[1][r] + av[r];   // g = r~ + B~^T sb (r~ staged in kv a stage ahead)
             }
           }
         }
@@ -348,53 +389,48 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) qpre[t][r] = 0.0;
-    const int sbase = wv < 2 ? wv : wv - 2;          // S tiles of waves 0, 1, 4, 5: ids sbase + 4 j
+    const int sfirst = __builtin_amdgcn_readfirstlane(f_sfirst), scount = __builtin_amdgcn_readfirstlane(f_scount);
     auto fetch_qpre = [&]() {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int id = sbase + 4 * t < 10 ? sbase + 4 * t : sbase, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
-        const int cc = 16 * tc + li < NX ? 16 * tc + li : NX - 1;
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * tr + kk + 4 * r, rc = row < NX ? row : NX - 1; qpre[t][r] = ((hsqp_gcptr)q)[QP_Q + rc * NX + cc]; }
-      }
+        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[fq_off[t][r]];
     };
     {
       if (wv < 2) {
-        __builtin_amdgcn_s_setprio(3);
+        if (!(HSQP_EXP & 32)) __builtin_amdgcn_s_setprio(3);
         const DevWave dw{lane};
         const ElimIO io{&w.Ef[0][0], LDF, &w.PG[0][0], &w.PG[0][FG_GV], LDG, &w.Ef[0][EF_MI], LDF, nullptr, 0, &w.Zs[0][0], LDZ, w.zv, &w.ok};
         double* v_dst = &VAn[0][0];
-        auto prefetch = [&]() { fetch_qpre(); fact_next_stage_to_lds(qn, v_dst, &w.Pn[0][0], &w.Rn[0][0], wv, lane); };
+        // wave 0 (the faster of the two) issues every asynchronous copy of the next stage: Vx, P~, R~
+        auto prefetch = [&]() {
+          if (HSQP_EXP & 16) return;
+          fetch_qpre();
+          if (wv == 0 && !(HSQP_EXP & 2)) { fact_next_vx_to_lds(qn, v_dst, lane); fact_next_cost_to_lds(qn, &w.Pn[0][0], &w.Rn[0][0], lane); }
+        };
         if (wv == 0) eliminate_blocked<NXE, 0>(dw, io, prefetch);
         else eliminate_blocked<NXE, 1>(dw, io, prefetch);
         __builtin_amdgcn_s_setprio(0);
       } else if ((wv & 3) < 2) {
-        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  Next stage's Vu, b~, r~ and this stage's q~ (for Ph4): every
-        // load unconditional (one address select per element, no branch), all of them in flight before the first store
-        constexpr int NPB = 8, NVB = NF * NUT;
-        static_assert(128 * NPB >= NVB + 2 * NX + NUT, "one pass of the two memory waves");
-        const int pt = ctx.tid - 256;
-        const double* qs = qn ? qn : q;     // (the last stage has no successor: the loads go to this stage's record and nothing is stored)
-        double pb[NPB];
-#pragma unroll
-        for (int t = 0; t < NPB; ++t) {
-          const int idx = pt + 128 * t;
-          const int e = idx < NVB ? idx : 0, kf = e / NUT, c = e - kf * NUT;
-          const double* src = fact_vb_row(qs, kf) + c;
-          src = idx >= NVB ? qs + QP_BV + (idx - NVB < NX ? idx - NVB : 0) : src;
-          src = idx >= NVB + NX ? q + QP_QV + (idx - NVB - NX < NX ? idx - NVB - NX : 0) : src;
-          src = idx >= NVB + 2 * NX ? qs + QP_RV + (idx - NVB - 2 * NX < NUT ? idx - NVB - 2 * NX : 0) : src;
-          pb[t] = *(hsqp_gcptr)src;
-        }
-#pragma unroll
-        for (int t = 0; t < NPB; ++t) {
-          const int idx = pt + 128 * t;
-          if (idx < NVB) { if (qn) { const int kf = idx / NUT, c = idx - kf * NUT; w.VB[kf][c] = pb[t]; } }
-          else if (idx < NVB + NX) { if (qn) w.bt[idx - NVB] = pb[t]; }
-          else if (idx < NVB + 2 * NX) w.dx[idx - NVB - NX] = pb[t];
-          else if (idx < NVB + 2 * NX + NUT) { if (qn) w.kv[idx - NVB - 2 * NX] = pb[t]; }
-        }
+        if (HSQP_EXP & 4) {} else {
+        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  Q~ of their S tiles first, then the next stage's Vu, b~, r~ and this
+        // stage's q~ (for Ph4) through the address tables: every load in flight before the first store, no index arithmetic in here
         fetch_qpre();
+        double pb[FM_NPB];
+        double* const lbase = &w.VA[0][0][0];
+        if (qn) {
+#pragma unroll
+          for (int t = 0; t < FM_NPB; ++t) pb[t] = ((hsqp_gcptr)qn)[fm_src[t]];
+#pragma unroll
+          for (int t = 0; t < FM_NPB; ++t) if (fm_dst[t] >= 0) lbase[fm_dst[t]] = pb[t];
+        } else {
+          // the last stage to be processed has no successor: q~ alone (its table entry is relative to the record before this one)
+#pragma unroll
+          for (int t = 0; t < FM_NPB; ++t) { const bool isq = fm_src[t] >= QP_SIZE; pb[t] = ((hsqp_gcptr)q)[isq ? fm_src[t] - QP_SIZE : 0]; }
+#pragma unroll
+          for (int t = 0; t < FM_NPB; ++t) if (fm_src[t] >= QP_SIZE) lbase[fm_dst[t]] = pb[t];
+        }
+        }
       } else {
         // waves 2, 6 (SIMD 2) own column tiles 0, 3, waves 3, 7 (SIMD 3) column tiles 1, 2: 45 + 72 and 54 + 63 matrix instructions.  No global
         // access at all in here.
@@ -424,7 +460,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         }
         WV_SYNC();
         // W' tiles (rt <= ct, ct) from the wave's own column of SA; the accumulators wait in registers until the column is consumed
-        {
+        if (!(HSQP_EXP & 8)) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
           auto yf = [&](auto sc, int) { return fact_combo(sc, kk, &w.SA[0][0], NX, yc, dt, hq); };
@@ -542,15 +578,16 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
       };
       const XtyJob jk = xty_also_to(xty_job(NUT, NXE + 1, NUT, &w.Ef[0][EF_MI], LDF, &w.Zs[0][0], LDZ, &w.PG[0][0], LDG, nullptr, 0, -1.0), rk + RIC_K, NX, NXE);
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (ctx.tid >= 384) for (int it = ctx.tid - 384; it < 4 * NX; it += 128) s_item(it);
+      // (one pass over the four waves that carry the two short K tiles each — on waves 6, 7 alone they were two passes in front of those tiles)
+      if ((wv & 3) >= 2) { const int it = ((wv >> 2) * 2 + (wv & 1)) * 64 + lane; if (it < 4 * NX) s_item(it); }
       if ((wv & 3) < 2) {
-        // S tiles on waves 0, 1 (three each) and 4, 5 (two each): six 23-deep steps, W' from LDS and Q~ from the registers loaded in Ph3
+        // S tiles on waves 0, 4, 5 (three each) and 1 (one): six 23-deep steps, W' from LDS and Q~ from the registers loaded in Ph3
         constexpr int NSZ = (NUT + 3) / 4;
         auto run = [&](auto ntc) {
           constexpr int NT = decltype(ntc)::value;
           int tr[NT], tc[NT];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) { const int id = sbase + 4 * t; tr[t] = fact_sym_tr(id); tc[t] = fact_sym_tc(id); }
+          for (int t = 0; t < NT; ++t) { const int id = sfirst + t; tr[t] = fact_sym_tr(id); tc[t] = fact_sym_tc(id); }
           hsqp_d4 acc[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
@@ -587,8 +624,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
             }
           }
         };
-        if (sbase < 2) run(std::integral_constant<int, 3>{});
-        else run(std::integral_constant<int, 2>{});
+        if (scount == 3) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 1>{});
       } else {
         // [K | k]: eight tiles on waves 2, 3, 6, 7 (two each)
         ric_products_ranked(ctx, (wv & 1) + (wv >> 2) * 2, 4, jk);
