@@ -343,7 +343,8 @@ int hsqp_download_device(hsqp_handle* h, hsqp_solution* solution);
                                                     on limb lanes (k_lq_limb + k_lq_rows + k_lq_chain) instead of k_lq<true>, [1] value pass on quads of lanes
                                                     (k_value_quad) instead of k_step_value; [2] node ranges the limb-lane LQ kernels are launched in, each on a
                                                     stream of its own, once a launch exceeds one round of the chip (0: phase form; HSQP_LQ_SPLIT in the
-                                                    environment at hsqp_create overrides the default 2); [3] reserved.  Available at any time               */
+                                                    environment at hsqp_create overrides the default 2); [3] the whole-body serial sweep runs on the factors of [A~ | B~]
+                                                    (k_riccati_fact; HSQP_RICCATI_DENSE in the environment at hsqp_create: the dense stage k_riccati<58>).  Available at any time */
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes);
 
 /* Elapsed device time (ms) of the kernels of the last hsqp_iterate_device call,

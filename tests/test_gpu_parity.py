@@ -268,7 +268,7 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True)
     s = HipSqpSolver(model, max_nodes=N, max_batch=B)
     try:
-        assert s.kernel_forms() == {"lq_limb": True, "value_quad": True, "lq_ranges": 2}
+        assert s.kernel_forms() == {"lq_limb": True, "value_quad": True, "lq_ranges": 2, "ric_fact": True}
         out = s.run(x0, x, u, par, dt)
     finally:
         s.close()
@@ -339,7 +339,45 @@ def test_config3_exactly_against_the_oracle(model, oracle, riccati):
     assert_perf(out["perf_after"][0], r["perf_after"], "config 3 after")
     assert_kkt(out["kkt"][0], np.abs(g[0]).max(), "config 3")
     assert out["alpha"][0] == 1.0 and out["step_type"][0] == _abi.STEP_FULL
-    assert fallbacks == 0
+    # The scan's stationarity on this QP sits at 0.8 of the gate's bound (tests/tolerances.py): a change of rounding upstream of the sweep may send the
+    # iteration to the serial recursion.  What is asserted above is the GATED result — inside BASELINE.md §6 either way; the sweep that produced it
+    # is reported, not required (round 5 review, item 8).  The serial handle never scans.
+    assert fallbacks in ((0,) if riccati == "serial" else (0, 1)), fallbacks
+
+
+@pytest.mark.parametrize("B,N,gait", [(3, 40, "walk"), (33, 100, "run")])
+def test_factored_serial_sweep_equals_the_dense_stage_on_the_device(model, B, N, gait):
+    """k_riccati_fact (csrc/hsqp_riccati_fact.h: the whole-body serial sweep on the factors of [A~ | B~], what every whole-body handle runs) against
+    the dense stage k_riccati<58> (HSQP_RICCATI_DENSE in the environment at hsqp_create) on the same device, same inputs: the same minimiser to
+    1e-10 of the step's scale, and bit-identical whether or not the joint rows of A~ / B~ are written (with the KKT report k_project writes them,
+    without it does not: the factored sweep may not read them)."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=gait, perturb=True, seed=77)
+    outs = {}
+    for name in ("dense", "fact"):
+        if name == "dense":
+            os.environ["HSQP_RICCATI_DENSE"] = "1"
+        try:
+            s = HipSqpSolver(model, max_nodes=N, max_batch=B, riccati="serial")
+        finally:
+            os.environ.pop("HSQP_RICCATI_DENSE", None)
+        try:
+            assert s.kernel_forms()["ric_fact"] == (name == "fact")
+            s.upload(x0, x, u, par, dt)
+            s.iterate(1, take_step=False, kkt=False)
+            a = s.download()
+            s.iterate(1, take_step=False, kkt=True)
+            b = s.download()
+            assert np.array_equal(a["dx"], b["dx"]) and np.array_equal(a["du"], b["du"]), name
+            outs[name] = b
+        finally:
+            s.close()
+    d, f = outs["dense"], outs["fact"]
+    for i in range(B):
+        sc = max(1.0, np.abs(d["dx"][i]).max(), np.abs(d["du"][i]).max())
+        err = max(np.abs(d["dx"][i] - f["dx"][i]).max(), np.abs(d["du"][i] - f["du"][i]).max())
+        assert err <= 1e-10 * sc, (i, err, sc)
+        assert_kkt(f["kkt"][i], f["grad_inf"][i], f"factored sweep, instance {i}")
 
 
 def test_parallel_in_time_sweep_is_repeatable(model):

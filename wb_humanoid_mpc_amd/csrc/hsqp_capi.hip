@@ -1856,7 +1856,7 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (what == HSQP_BLK_FORMS) {
-    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, h->lq_limb ? h->lq_split : 0, 0};
+    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, h->lq_limb ? h->lq_split : 0, h->ric_fact ? 1 : 0};
     if (dst && bytes > 0) memcpy(dst, forms, (size_t)(bytes < 16 ? bytes : 16));
     return 16;
   }
