@@ -122,3 +122,23 @@ def test_parallel_riccati_flag_is_validated_before_the_device_is_touched(model):
         assert rc != _abi.ERR_BAD_ARG            # no GPU here: HSQP_ERR_NO_DEVICE; on a GPU box: HSQP_OK
         if rc == 0:
             lib.hsqp_destroy(h)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
+    """with no RCCL to bind, hsqp_comm_unique_id must return HSQP_ERR_HIP with a message (round 5 read dlerror() twice: the second
+    read is NULL and std::string + NULL is a crash).  HSQP_RCCL_LIB names the library exclusively, so a path that does not exist is a host without
+    RCCL; run in a process of its own (the binding is cached per process).  No GPU needed: the identifier is made on the host."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from wb_humanoid_mpc_amd import _abi, solver\n"
+        "lib = solver.load_library()\n"
+        "ident = C.create_string_buffer(_abi.COMM_ID_BYTES)\n"
+        "rc = lib.hsqp_comm_unique_id(ident)\n"
+        "msg = lib.hsqp_comm_create_error().decode()\n"
+        "print(rc, '|', msg)\n"
+        "sys.exit(0 if rc == _abi.ERR_HIP and 'librccl not found' in msg and 'HSQP_RCCL_LIB' in msg else 1)\n")
+    env = dict(os.environ, HSQP_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, (r.stdout, r.stderr)

@@ -349,7 +349,8 @@ def test_config3_exactly_against_the_oracle(model, oracle, riccati):
 def test_factored_serial_sweep_equals_the_dense_stage_on_the_device(model, B, N, gait):
     """k_riccati_fact (csrc/hsqp_riccati_fact.h: the whole-body serial sweep on the factors of [A~ | B~], what every whole-body handle runs) against
     the dense stage k_riccati<58> (HSQP_RICCATI_DENSE in the environment at hsqp_create) on the same device, same inputs: the same minimiser to
-    1e-10 of the step's scale, and bit-identical whether or not the joint rows of A~ / B~ are written (with the KKT report k_project writes them,
+    1e-9 of the step's scale (the yardstick of the randomly perturbed population, tests/tolerances.py: two correct f64 sweeps of the ill-conditioned
+    run-gait QPs — |step| 1e3 — differ by 1.5e-10 of scale; on the walk problems by 1e-11), and bit-identical whether or not the joint rows of A~ / B~ are written (with the KKT report k_project writes them,
     without it does not: the factored sweep may not read them)."""
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=gait, perturb=True, seed=77)
@@ -376,7 +377,7 @@ def test_factored_serial_sweep_equals_the_dense_stage_on_the_device(model, B, N,
     for i in range(B):
         sc = max(1.0, np.abs(d["dx"][i]).max(), np.abs(d["du"][i]).max())
         err = max(np.abs(d["dx"][i] - f["dx"][i]).max(), np.abs(d["du"][i] - f["du"][i]).max())
-        assert err <= 1e-10 * sc, (i, err, sc)
+        assert err <= 1e-9 * sc, (i, err, sc)
         assert_kkt(f["kkt"][i], f["grad_inf"][i], f"factored sweep, instance {i}")
 
 
