@@ -1180,10 +1180,23 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
     if (hipEventCreate(&ev) != hipSuccess) return fail(HSQP_ERR_HIP, "hipEventCreate failed");
   if (h->lq_limb) {
     const char* sp = getenv("HSQP_LQ_SPLIT");
-    h->lq_split = sp ? atoi(sp) : HSQP_LQ_SPLIT_DEFAULT;
-    if (h->lq_split < 1) h->lq_split = 1;
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->lq_round_blocks = cus * 4 / QL_WAVES;
+    h->lq_split = HSQP_LQ_SPLIT_DEFAULT;
+    if (sp) {
+      char* end = nullptr;
+      const long v = strtol(sp, &end, 10);
+      if (end == sp || *end != '\0' || v < 1 || v > hsqp_handle::LQ_SPLIT_MAX)
+        return fail(HSQP_ERR_BAD_ARG, std::string("HSQP_LQ_SPLIT=\"") + sp + "\": expected an integer in [1, " + std::to_string(hsqp_handle::LQ_SPLIT_MAX) + "]");
+      h->lq_split = (int)v;
+    }
+    // one round of the chip = the workgroups of the two one-wave-per-SIMD kernels it holds at once: asked of the runtime for the kernels as built
+    // (tuning builds change their waves per SIMD: HSQP_QL_WPE / HSQP_QR_WPE), not assumed from the CU count
+    int cus = 0, per_cu_limb = 0, per_cu_rows = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_limb, (const void*)k_lq_limb, QL_THREADS * QL_WAVES, 0) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_rows, (const void*)k_lq_rows, QL_THREADS * QL_WAVES, 0) == hipSuccess &&
+        per_cu_limb > 0 && per_cu_rows > 0)
+      h->lq_round_blocks = cus * std::min(per_cu_limb, per_cu_rows);
+    else if (cus > 0) h->lq_round_blocks = cus * 4 / QL_WAVES;
     if (h->lq_split > hsqp_handle::LQ_SPLIT_MAX) h->lq_split = hsqp_handle::LQ_SPLIT_MAX;
     if (h->lq_split > 1 && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(HSQP_ERR_HIP, "hipEventCreate failed");
     for (int s = 0; s + 1 < h->lq_split; ++s)

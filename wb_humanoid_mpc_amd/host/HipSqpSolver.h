@@ -29,13 +29,19 @@ struct PrimalSolution {
 
 class HipSqpSolver {
  public:
-  /** useLinesearch: run() applies the filter line search (ocs2 SqpSolver::takeStep) instead of the full step. */
-  HipSqpSolver(const hsqp_model_desc& model, int maxNodes, int maxBatch = 1, int device = 0, bool useLinesearch = false) {
+  /** useLinesearch: run() applies the filter line search (ocs2 SqpSolver::takeStep) instead of the full step.
+   *  recedingHorizon: the handle solves the SHIFTED problem of one MPC loop every cycle (MPC_BASE::run, sqpIteration = 1), so the KKT gate's back-off
+   *  carries over the uploads (hsqp_set_scan_backoff_persistent).  Off by default: a batch / offline user uploads unrelated problems, and for those
+   *  include/hsqp.h documents per-problem determinism (the same problem takes the same sweep whatever the handle solved before). */
+  HipSqpSolver(const hsqp_model_desc& model, int maxNodes, int maxBatch = 1, int device = 0, bool useLinesearch = false, bool recedingHorizon = false) {
     hsqp_settings st{maxNodes, maxBatch, device, useLinesearch ? HSQP_FLAG_LINESEARCH : 0};
-    const int rc = hsqp_create(&model, &st, &h_);
+    int rc = hsqp_create(&model, &st, &h_);
     if (rc != HSQP_OK) throw std::runtime_error("[HipSqpSolver] hsqp_create failed (" + std::to_string(rc) + "): " + hsqp_last_error(nullptr));
-    // receding-horizon use (MPC_BASE::run uploads the shifted problem every cycle, sqpIteration = 1): the KKT gate's back-off carries over the cycles
-    hsqp_set_scan_backoff_persistent(h_, 1);
+    if (recedingHorizon && (rc = hsqp_set_scan_backoff_persistent(h_, 1)) != HSQP_OK) {
+      const std::string msg = hsqp_last_error(h_);
+      hsqp_destroy(h_);
+      throw std::runtime_error("[HipSqpSolver] hsqp_set_scan_backoff_persistent failed (" + std::to_string(rc) + "): " + msg);
+    }
   }
   ~HipSqpSolver() { hsqp_destroy(h_); }
   HipSqpSolver(const HipSqpSolver&) = delete;

@@ -74,7 +74,7 @@ class HipSqpSolverAdaptor final : public SolverBase {
 
   HipSqpSolverAdaptor(const HipSqpAdaptorConfig& config, sqp::Settings settings, const Initializer& initializer)
       : cfg_(config), settings_(std::move(settings)), initializer_(initializer.clone()),
-        impl_(config.model, config.maxNodes, /*maxBatch*/ 1, config.device, /*useLinesearch*/ true) {
+        impl_(config.model, config.maxNodes, /*maxBatch*/ 1, config.device, /*useLinesearch*/ true, /*recedingHorizon*/ true) {
     hsqp_linesearch_settings ls;
     hsqp_linesearch_defaults(&ls);
     ls.g_max = settings_.g_max; ls.g_min = settings_.g_min; ls.gamma_c = settings_.gamma_c; ls.armijo_factor = settings_.armijoFactor;
