@@ -31,11 +31,13 @@ s.lib.hsqp_debug_read(s.h, 100, t.ctypes.data_as(C.c_void_p), t.nbytes)
 names = ["k_lq<true>", "k_project", "k_riccati", "k_lq<false> | k_lq_limb (ids 0-4: base kin + forward + solve, -, back walk, base columns; x4 stages) + k_lq_rows (10: loads, 11: kinematics, 12: terms, 13: joint rows, 14: base rows)"]
 for k in range(4):
     # slots 0..39: phase ticks (PH_TICK); 40..111: per-wave barrier arrivals (PH_ARRIVE); 90..94: tile-call split; 112..119: PH_MARK stamps
-    tot = t[k, :40].sum()
+    tot = t[k, :20].sum()
     print(f"== {names[k]}: {tot / iters:.0f} ticks per launch (workgroup 0)  [~{tot / iters / 2.4e3:.1f} us at 2.4 GHz]")
-    for i in range(40):
+    for i in range(20):
         if t[k, i]:
             print(f"   phase {i:3d}: {t[k, i] / iters:12.0f} ticks  {100.0 * t[k, i] / tot:5.1f}%")
+    if k == 2 and t[k, 20:39].any():
+        print("   laps of the chosen wave (slots 20..38):", [int(v / iters) for v in t[k, 20:39] if v])
     if k == 2 and t[k, 40:112].any():   # k_riccati: per-wave arrival at the barriers ending Ph1, Ph2, Ph4, Ph3 (ticks per launch)
         for slot, name in enumerate(("Ph1", "Ph2", "Ph4", "Ph3")):
             print(f"   {name} arrival per wave:", [int(v / iters) for v in t[k, 40 + 8 * slot:48 + 8 * slot]])

@@ -73,10 +73,17 @@ HSQP_HD int wave_index(int tid) { return tid >> 6; }
   do {                                                                                                   \
     if (((ctx).tid & 63) == 0 && (ctx).prof) (ctx).prof[40 + 8 * (slot) + ((ctx).tid >> 6)] += clock64() - (ctx).prof[112 + ((ctx).tid >> 6)]; \
   } while (0)
+// laps inside a phase, for ONE chosen wave (its lane 0): PH_LAP0 arms the lap clock (slot 39), PH_LAP(id) adds the time since the last lap to slot id (20 .. 38)
+#define PH_LAP0(ctx, wave)                                                                               \
+  do { if ((ctx).prof && (ctx).tid == 64 * (wave)) (ctx).prof[39] = clock64(); } while (0)
+#define PH_LAP(ctx, wave, id)                                                                            \
+  do { if ((ctx).prof && (ctx).tid == 64 * (wave)) { const long long t_ = clock64(); (ctx).prof[id] += t_ - (ctx).prof[39]; (ctx).prof[39] = t_; } } while (0)
 #else
 #define PH_TICK(ctx, id) ((void)0)
 #define PH_MARK(ctx) ((void)0)
 #define PH_ARRIVE(ctx, slot) ((void)0)
+#define PH_LAP0(ctx, wave) ((void)0)
+#define PH_LAP(ctx, wave, id) ((void)0)
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -24,6 +24,9 @@
 #pragma once
 #include <cstddef>
 #include "hsqp_riccati.h"
+#ifndef HSQP_LAP_WAVE
+#define HSQP_LAP_WAVE 4   /* -DHSQP_PHASE_PROFILE builds: the wave whose Ph4 is split into laps (slots 20 .. 25) */
+#endif
 #ifndef HSQP_EXP
 #define HSQP_EXP 0   /* timing experiments of tuning builds (WRONG results): bit 0 memory waves without trailing copies / Q~, 1 no Vx copy, 2 memory waves idle, 3 no W' tiles, 4 no hook; (correct results:) 5 no s_setprio */
 #endif
@@ -216,9 +219,9 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
       else if (idx >= FM_NVB + 2 * NX && idx < FM_NVB + 2 * NX + NUT) { so = QP_RV + idx - FM_NVB - 2 * NX; dd = (int)(&w.kv[idx - FM_NVB - 2 * NX] - lbase); }
       fm_src[t] = so; fm_dst[t] = dd;
     }
-    // S tiles (ids 0 .. 9 of the upper triangle, row by row) of waves 0, 1, 4, 5: three, ONE, three, three — wave 1 carries the larger share of the
-    // elimination and is the phase's critical path
-    f_sfirst = wv0 == 0 ? 0 : (wv0 == 1 ? 3 : (wv0 == 4 ? 4 : 7)); f_scount = wv0 == 1 ? 1 : 3;
+    // Ph4 per SIMD: ONE wave forms S tiles (ids 0 .. 9 of the upper triangle, row by row: waves 0, 2 three each, waves 1, 3 two each — wave 1 carries the
+    // larger share of the elimination), the other one (waves 4 .. 7) two K tiles and a quarter of the vector items
+    f_sfirst = wv0 == 0 ? 0 : (wv0 == 1 ? 3 : (wv0 == 2 ? 5 : 8)); f_scount = wv0 >= 4 ? 0 : ((wv0 & 1) ? 2 : 3);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
@@ -231,7 +234,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
   for (int k = N - 1; k >= 0; --k) {
     // (the thread index is made opaque once per stage: see riccati_backward)
     Ctx ctx = ctx_outer;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HSQP_FACT_NO_OPAQUE)
     asm volatile("" : "+v"(ctx.tid));
 #endif
     const double* q = qp + (size_t)k * QP_SIZE;
@@ -248,11 +251,13 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     // ---- Ph1: SB = (F^T S)^T Vu — one tile per wave; the waves of the first column tile also keep the combinations they fetch (FS);
     //      the helper half first: sb = s + S b~ (four partial sums per row, closed by DPP quad permutes), k of the previous stage -> record
     {
-      // (the vector items are dealt to ALL waves, 32 lanes = eight rows each, in front of the wave's tile: on the helper half alone they were
-      //  1.4 k cycles in front of four of the eight tiles — a phase lasts as long as its slowest wave)
-      if (lane < 32) {
-        const int r = 8 * wv + (lane >> 2), p = lane & 3;
-        if (r < NX) {     // (whole quads: r depends on lane >> 2)
+      // (ONE wave per SIMD carries the vector items, all 64 lanes: a SIMD runs the vector instructions of its two waves one after the other, so what a
+      //  phase costs a SIMD is the SUM over its waves — the same items dealt to all eight waves at 32 lanes each were twice the instructions per SIMD
+      //  and measurably slower)
+      if (wv >= 4) {
+        const int it = ctx.tid - 256;
+        if (it < 4 * NX) {
+          const int r = it >> 2, p = it & 3;
           constexpr int LA = (NX + 3) / 4;
           double sacc = 0.0;
           if (p == 0) { const double* sp = &w.part[4 * r]; sacc = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
@@ -261,8 +266,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           sacc += quad_perm_f64<0xB1>(sacc);
           sacc += quad_perm_f64<0x4E>(sacc);
           if (p == 0) { w.sb[r] = sacc; w.SB[r][NUT] = sacc; }
-        }
-      } else if (wv == 7 && lane - 32 < NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + lane - 32] = w.PG[lane - 32][FG_GV];
+        } else if (it < 4 * NX + NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + it - 4 * NX] = w.PG[it - 4 * NX][FG_GV];
+      }
       const int rt = wv & 3, ct = wv >> 2, r0 = rt << 4, c0 = ct << 4;
       const int xr = r0 + li < NX ? r0 + li : NX - 1, yc = c0 + li < LDB ? c0 + li : LDB - 1;
       hsqp_d4 acc[1] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}};
@@ -413,9 +418,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         __builtin_amdgcn_s_setprio(0);
       } else if ((wv & 3) < 2) {
         if (HSQP_EXP & 4) {} else {
-        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  Q~ of their S tiles first, then the next stage's Vu, b~, r~ and this
-        // stage's q~ (for Ph4) through the address tables: every load in flight before the first store, no index arithmetic in here
-        fetch_qpre();
+        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  The next stage's Vu, b~, r~ and this stage's q~ (for Ph4) through the
+        // address tables: every load in flight before the first store, no index arithmetic in here
         double pb[FM_NPB];
         double* const lbase = &w.VA[0][0][0];
         if (qn) {
@@ -489,6 +493,9 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
               if (t <= ct && col < NX && row < NX) w.SA[row][col] = acc[t][r] + fact_ej_mix(ea[t][r], eb[t][r], rc, dt);
             }
         }
+        // waves 2, 3 form one S tile each in Ph4: its Q~ is fetched here, behind the wave's last LDS read of the phase (they finish 2 - 3 k cycles
+        // before the elimination: the round trip runs under their wait at the barrier)
+        if (wv < 4) fetch_qpre();
       }
     }
 #else
@@ -578,11 +585,10 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
       };
       const XtyJob jk = xty_also_to(xty_job(NUT, NXE + 1, NUT, &w.Ef[0][EF_MI], LDF, &w.Zs[0][0], LDZ, &w.PG[0][0], LDG, nullptr, 0, -1.0), rk + RIC_K, NX, NXE);
 #if defined(__HIP_DEVICE_COMPILE__)
-      // (one pass over the four waves that carry the two short K tiles each — on waves 6, 7 alone they were two passes in front of those tiles)
-      if ((wv & 3) >= 2) { const int it = ((wv >> 2) * 2 + (wv & 1)) * 64 + lane; if (it < 4 * NX) s_item(it); }
-      if ((wv & 3) < 2) {
-        // S tiles on waves 0, 4, 5 (three each) and 1 (one): six 23-deep steps, W' from LDS and Q~ from the registers loaded in Ph3
-        constexpr int NSZ = (NUT + 3) / 4;
+      constexpr int NSZ = (NUT + 3) / 4;
+      PH_LAP0(ctx, HSQP_LAP_WAVE);
+      if (wv < 4) {
+        // S tiles: six 23-deep steps, W' from LDS and Q~ from the registers loaded in Ph3
         auto run = [&](auto ntc) {
           constexpr int NT = decltype(ntc)::value;
           int tr[NT], tc[NT];
@@ -609,7 +615,9 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int row = 16 * tr[t] + kk + 4 * r; wp[t][r] = w.SA[row < NX ? row : NX - 1][cc]; }
           }
+          PH_LAP(ctx, HSQP_LAP_WAVE, 21);
           fact_mfma<NT, RIC_PF, NSZ>(acc, xf, yf);
+          PH_LAP(ctx, HSQP_LAP_WAVE, 22);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int c = 16 * tc[t] + li;
@@ -625,10 +633,14 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           }
         };
         if (scount == 3) run(std::integral_constant<int, 3>{});
-        else run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+        PH_LAP(ctx, HSQP_LAP_WAVE, 23);
       } else {
-        // [K | k]: eight tiles on waves 2, 3, 6, 7 (two each)
-        ric_products_ranked(ctx, (wv & 1) + (wv >> 2) * 2, 4, jk);
+        // waves 4 .. 7: a quarter of the vector items (all 64 lanes), then [K | k] = -L^-T [Z | z]: two of the eight tiles each, one call
+        { const int it = (wv - 4) * 64 + lane; if (it < 4 * NX) s_item(it); }
+        PH_LAP(ctx, HSQP_LAP_WAVE, 20);
+        ric_products_ranked(ctx, wv - 4, 4, jk);
+        PH_LAP(ctx, HSQP_LAP_WAVE, 23);
       }
 #else
       WG_FOR(ctx, it, 4 * NX) s_item(it);
