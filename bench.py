@@ -52,7 +52,7 @@ PEAK_FP64_TFLOPS = 78.6          # = FP32 vector/matrix peak 157.3 TF / 2 (MI355
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured)
 
 
-PROFILE_ROUND = "r05"            # which committed PMC passes the per-kernel HBM bytes / matrix-pipe shares are read from (profiles/<round>_pmc_*)
+PROFILE_ROUND = "r06"            # which committed PMC passes the per-kernel HBM bytes / matrix-pipe shares are read from (profiles/<round>_pmc_*)
 
 
 def pmc_kernel_info():

@@ -7,6 +7,7 @@ cp $G/kernel_stats.csv $P/${R}_kernel_stats.csv; cp $G/pmc_summary.json $P/${R}_
 cp $G/pmc_sq_summary.json $P/${R}_pmc_sq_summary.json; cp $G/pmc_insts_summary.txt $P/${R}_pmc_insts_summary.txt
 cp $G/pmc_sq_counter_collection.csv $P/${R}_pmc_sq_counter_collection.csv; cp $G/pmc_insts_counter_collection.csv $P/${R}_pmc_insts_counter_collection.csv
 cp $G/pmc_FETCH_SIZE/pmc_counter_collection.csv $P/${R}_pmc_FETCH_SIZE_counter_collection.csv; cp $G/pmc_WRITE_SIZE/pmc_counter_collection.csv $P/${R}_pmc_WRITE_SIZE_counter_collection.csv
+[ -s $G/strong_prediction.json ] && cp $G/strong_prediction.json $P/${R}_strong_prediction.json
 for f in bench_wb bench_cfg3 bench_cfg3_serial bench_cfg5 bench_cent_cfg1 bench_cent_cfg2 bench_strong32 bench_strong64 bench_strong128 bench_strong128_n200; do [ -f $G/$f.log ] && cp $G/$f.log $P/${R}_$f.json; done
 [ -f $G/phase.log ] && cp $G/phase.log $P/${R}_phase_profile.txt
 [ -f $G/parity_report.json ] && cp $G/parity_report.json $P/${R}_parity_report.json && cp $G/parity_report.log $P/${R}_parity_report.txt

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 rm -rf "$OUT/prof" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_sq" "$OUT/pmc_insts"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $OUT/../bench.py --no-cpu-baseline"
+BENCH="python $OUT/../bench.py --no-cpu-baseline --sustained 0"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- $BENCH --steps 5 --warmup 1 > "$OUT/prof.log" 2>&1
 echo "rocprof stats exit: $?"
 for C in FETCH_SIZE WRITE_SIZE; do

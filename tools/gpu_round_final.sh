@@ -26,6 +26,7 @@ run bench_strong64 --steps 10 --warmup 3 --no-cpu-baseline --force-strong --glob
 # the shards nobody had timed: 128 x 100 = one GPU of a 2-GPU run of config 4; 128 x 200 slow_walk = one GPU of an 8-GPU run of config 5
 run bench_strong128 --steps 10 --warmup 3 --no-cpu-baseline --force-strong --global-batch 128 --batch 128
 run bench_strong128_n200 --steps 5 --warmup 2 --no-cpu-baseline --force-strong --global-batch 128 --batch 128 --nodes 200 --gait slow_walk
+timeout 900 python tools/strong_prediction.py > "$OUT/strong_prediction.json" 2> "$OUT/strong_prediction.err"; echo "strong prediction rc=$?"
 timeout 900 python tools/parity_report.py > "$OUT/parity_report.log" 2>&1; echo "parity rc=$?"; tail -12 "$OUT/parity_report.log"
 timeout 300 python tools/phase_profile.py > "$OUT/phase.log" 2>&1; echo "phase rc=$?"
 bash tools/gpu_profiles.sh > "$OUT/profiles.log" 2>&1; echo "profiles rc=$?"; tail -40 "$OUT/profiles.log"
