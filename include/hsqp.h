@@ -134,7 +134,7 @@ typedef struct hsqp_model_desc {
 /* Backward sweep of the stage QP.  Default: the serial Riccati recursion, one workgroup per instance.  With at most
  * HSQP_SCAN_AUTO_BATCH instances and at least HSQP_SCAN_AUTO_MIN_NODES shooting intervals (both formulations) the parallel-in-time
  * sweep (associative scan over the stages, ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because one or two serial
- * chains leave the device idle (N = 100: centroidal 0.39 vs 0.81 ms, whole-body 1.0 vs 1.67 ms).  Its result agrees with the serial
+ * chains leave the device idle (N = 100, sweep + roll-out, round 6: whole-body 0.52 vs 1.20 ms; centroidal 0.30 vs 0.8 ms).  Its result agrees with the serial
  * recursion's to ~1e-11 of the step's scale on the QPs of a cold start or of a tracking MPC; it degrades on far-from-feasible
  * line-search iterates and on badly scaled QPs (cond(I + C1 J2) up to 1e9), so every scan result is GATED by the KKT residual of the
  * QP (min(1e-9 max(1, |g|_inf), 2e-8)) and the iteration is redone with the serial recursion when it fails: hsqp_scan_fallbacks()
@@ -143,7 +143,7 @@ typedef struct hsqp_model_desc {
 #define HSQP_FLAG_PARALLEL_RICCATI 4   /* the scan for every batch size and horizon (still gated); excludes HSQP_FLAG_SERIAL_RICCATI */
 /* Cost of the gate: it is all-or-nothing per call — one rejected instance redoes the serial sweep, the step, the KKT report and the
  * performance indices for the whole batch.  Up to 256 instances nothing would be saved by redoing only the rejected ones (the serial
- * sweep is one workgroup per instance on 256 CUs: 1.6 ms for 1 or 256 of them); beyond that, and on far-from-feasible line-search
+ * sweep is one workgroup per instance on 256 CUs: 1.2 - 1.3 ms for 1 or 256 of them); beyond that, and on far-from-feasible line-search
  * iterates that fail the gate regularly, a forced scan roughly doubles the iteration time — and it holds two value-function buffers of
  * max_batch * (max_nodes + 1) * 3 422 doubles (1.4 GB at 256 x 100).  The flag is for measurements; the automatic choice is
  * max_batch <= HSQP_SCAN_AUTO_BATCH.  After a rejection the handle backs off: the next 1, 3, 7, .. 63 iterations go straight through the
@@ -151,10 +151,10 @@ typedef struct hsqp_model_desc {
 #define HSQP_SCAN_AUTO_BATCH 2
 #define HSQP_SCAN_AUTO_MIN_NODES 48
 /* Two-level (segmented) sweep for the batches in between (csrc/hsqp_segment.h) — OPT-IN.  One workgroup per instance leaves 256 - B CUs idle
- * during the N dependent stages (BASELINE config 4 as written puts 32 instances on each of 8 GPUs: 1.72 of the 2.48 ms of a step).  With this
+ * during the N dependent stages (BASELINE config 4 as written puts 32 instances on each of 8 GPUs: 1.22 of the 1.83 ms of a step, round 6).  With this
  * flag the horizon of every instance is cut into P = 7 (or 3) segments: segment elements (Riccati recursion from J = 0 + prepended closed
  * loops) on B P workgroups, a suffix scan over the P + 1 elements, ordinary recursions per segment from the boundary value functions, the
- * roll-out: 1.14 ms per sweep at 32 instances.  Gated like the scan — by the KKT residual of the segments' last stages — with the serial
+ * roll-out: 0.93 ms per sweep at 32 instances (step 1.57 against 1.83 ms).  Gated like the scan — by the KKT residual of the segments' last stages — with the serial
  * recursion as fallback (hsqp_scan_fallbacks counts; after a rejection the handle backs off for 1, 3, 7, .. iterations).  DECLARED RELAXATION
  * of BASELINE.md §6: its step differs from the serial recursion's by 4e-11 .. 4e-10 of the step's scale (measured on perturbed config-4
  * batches: up to 7e-8 absolute where the bound on trajectories is 1e-8), which is why no default path takes it. */
@@ -309,8 +309,8 @@ int hsqp_update_term_weights(hsqp_handle* h, const hsqp_term_weights* w);
  * runtime stages them through its own bounce buffers, from registered buffers they are one DMA each.  The library does not copy into a staging area of its own: that would add a host memcpy of the same size.  Register the
  * trajectory / parameter / solution arrays once, reuse them every MPC cycle, unregister before freeing them.
  * HSQP_OK, HSQP_ERR_NO_DEVICE, HSQP_ERR_BAD_ARG (null / zero bytes) or HSQP_ERR_HIP (the runtime refused, e.g. the memlock limit).
- * Measured (bench.py `pcie_inclusive`, buffers reused every call): 9.1 ms per hsqp_solve from pageable memory, 8.9 ms page-locked, of which
- * the iteration with its KKT report is 7.3 ms — the runtime's pageable path already reaches ~40 GB/s on this host. */
+ * Measured (bench.py `pcie_inclusive`, buffers reused every call, round 6): 7.0 ms per hsqp_solve from pageable memory, 6.7 ms page-locked, of which
+ * the iteration with its KKT report is 5.0 ms — the runtime's pageable path already reaches ~40 GB/s on this host. */
 int hsqp_host_register(void* buffer, size_t bytes);
 int hsqp_host_unregister(void* buffer);
 /* Line-search settings of the handle (defaults: task.info g_max 1e-2, g_min 1e-6, deltaTol 1e-4; upstream gamma_c 1e-6,
