@@ -11,6 +11,9 @@
 #include <cstddef>
 #include <vector>
 #include "hsqp_linalg.h"
+#ifndef HSQP_PEXP
+#define HSQP_PEXP 0   /* timing experiments of tuning builds (WRONG results): bit 0 no Px / Pu / Pe and b~ stores, 1 no Gram store, 2 no second pass, 3 no QR, 4 no dense-row jobs, 5 no weight rows, 6 no first pass */
+#endif
 #include "hsqp_lq.h"
 
 namespace hsqp {
@@ -152,8 +155,10 @@ HSQP_HD void gram_rows(const Ctx& ctx, GramAcc& g, const double* X, int ldx, con
       }
     }
   }
-  if (ctx.tid < 2 * NTW) {
-    const int a = ctx.tid < NTW ? ctx.tid : ctx.tid - NTW, cb = ctx.tid < NTW ? NTW - 1 : NTW;
+  // (the 162 per-thread sums sit on the LAST threads of the workgroup: wave 3 carries three of the fifteen tiles, the others four)
+  const int vt = ctx.nthreads - 1 - ctx.tid;
+  if (vt < 2 * NTW) {
+    const int a = vt < NTW ? vt : vt - NTW, cb = vt < NTW ? NTW - 1 : NTW;
     double s = g.vs;
 #pragma unroll 4
     for (int r = 0; r < NR; ++r) {
@@ -210,8 +215,9 @@ HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int n
       }
     }
   }
-  if (ctx.tid < NTW) put(ctx.tid, NTW - 1, g.vs);
-  else if (ctx.tid < 2 * NTW) put_grad(ctx.tid - NTW, g.vs);
+  const int vt = ctx.nthreads - 1 - ctx.tid;
+  if (vt < NTW) put(vt, NTW - 1, g.vs);
+  else if (vt < 2 * NTW) put_grad(vt - NTW, g.vs);
 #else
   (void)ctx;
   for (int a = 0; a < NTW; ++a) {
@@ -318,7 +324,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // norm, the dot product and the own column's row-k entry through one butterfly over the four row groups.  The partial sums are those of the
   // round-3 form (rows i mod 4, ascending; ((0 + 1) + (2 + 3))).  Same arithmetic per element as the two-phase form below
   // (which the host build runs), summation order aside.
-  if (ctx.tid < 64) {
+  if (ctx.tid < 64 && !(HSQP_PEXP & 8)) {
     const int lane = ctx.tid, g = lane >> 4, c = lane & 15;
     constexpr int NT9 = (NU + 1) / 4;
     static_assert(NT9 * 4 == NU + 1 && LDR == 16, "four row groups of nine rows, one column per lane of a DPP row");
@@ -596,11 +602,12 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     ja.sx1 = LDJ; jb.sx1 = LDJ;
     ja.rsplit = 6; ja.rjump = r1 - 6; jb.rsplit = 6; jb.rjump = r1 - 6;
     const XtyJob jobs[2] = {ja, jb};
-    wg_xty_jobs<true, XTY_C_GLOBAL | XTY_ROW_JUMP>(ctx, jobs, 2);
+    if (!(HSQP_PEXP & 16)) wg_xty_jobs<true, XTY_C_GLOBAL | XTY_ROW_JUMP>(ctx, jobs, 2);
   }
   constexpr int NCG = 3;   // row groups per column
   constexpr int NCI = NCG * (NTW + 1), NBI = 256 - NCI;   // column items; the items left of one 256-thread round share the twelve b~ rows
   static_assert(NBI >= 1 && NBI <= 12, "one round of the 256-thread workgroup (a second round would be wave 0's alone)");
+  if (!(HSQP_PEXP & 1))
   WG_FOR(ctx, it, 256) {
     if (it >= NCI) {   // b~ of the dense rows
       for (int i = it - NCI; i < 12; i += NBI) {
@@ -651,44 +658,71 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   //      accumulators while the input block of the next pass is fetched
   GramAcc g;
   gram_init(ctx, g);
-  auto project_rows = [&](int r0, int nr) {
+  // In the limb-lane layout the row slots are fixed (hsqp_lql.h: ROWQ_FOOT + 16 f: ori, vlin, vang, alin, aang, one zero row; ROWQ_FM + 8 f: friction cone and
+  // contact moment of foot f; ROWQ_COLL: collision), and most of the INPUT block of J is zero for every state: only the six acceleration rows of a foot
+  // depend on all inputs, a foot's friction / moment rows on its own wrench (inputs 6 f .. 6 f + 5), nothing else on any input.  So the rows of a pass
+  // beyond its first 16-row tile need no product with [Px | Pu | Pe] at all (pass 0: rows 16 .. 23 = orientation / velocities of foot 1; pass 2: the
+  // collision rows) or one over six inputs (pass 1: rows 40 .. 47 = friction / moment of foot 1): J~ = J_x (+ rho) there.  96 of the 216 matrix
+  // instructions of J~ = J T per node; the skipped products are sums of exact zeros.  head = rows of the pass with the full contraction; the tail
+  // contracts the inputs [tk0, tk0 + tL).
+  auto project_rows = [&](int r0, int nr, int head, int tk0, int tL) {
     // (the second product carries rho' = rho + J_u Pe as its 24th column: 36 = 9 x 4 contraction steps, as many as for 35 — round 3 formed it
     //  as 24 serial 35-term sums on one wave behind the tiles)
-    XtyJob jx = xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, jt ? rec + REC_J + r0 : rec + REC_J + r0 * LDJ, jt ? NRS : LDJ);
-    jx.addt = jt ? 1 : 0;
-    const XtyJob jobs[2] = {jx, xty_job(nr, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
-    if (jt) wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_ADD_T>(ctx, jobs, 2);
-    else wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
+    const double* addp = jt ? rec + REC_J + r0 : rec + REC_J + r0 * LDJ;
+    const int ldadd = jt ? NRS : LDJ;
+    if (!jt || head >= nr) {
+      XtyJob jx = xty_job(nr, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, addp, ldadd);
+      jx.addt = jt ? 1 : 0;
+      const XtyJob jobs[2] = {jx, xty_job(nr, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM)};
+      if (jt) wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_ADD_T>(ctx, jobs, 2);
+      else wg_xty_jobs<true, XTY_ADD_GLOBAL>(ctx, jobs, 2);
+      return;
+    }
+    // (transposed layout only: the additive term of rows >= head starts `head` elements further along a column)
+    XtyJob jt0 = xty_job(nr - head, NX, tL, &w.ps.JuT[tk0][head], NRP, &w.Tm[tk0][0], LDTM, &w.ps.Jt[head][0], LDTM, addp + head, ldadd);
+    jt0.addt = 1;
+    XtyJob jt1 = xty_job(nr - head, NUT + 1, tL, &w.ps.JuT[tk0][head], NRP, &w.Tm[tk0][NX], LDTM, &w.ps.Jt[head][NX], LDTM);
+    jt1.L2 = 1; jt1.X2 = &w.ps.JuT[NU][head]; jt1.ldx2 = NRP; jt1.Y2 = &w.Tm[NU][NX]; jt1.ldy2 = LDTM; jt1.sign2 = 1.0;   // rho against e_NTW
+    // (job counts are compile-time constants per branch: the unrolled form keeps the descriptors in registers)
+    if (head > 0) {
+      XtyJob jh0 = xty_job(head, NX, NU, &w.ps.JuT[0][0], NRP, &w.Tm[0][0], LDTM, &w.ps.Jt[0][0], LDTM, addp, ldadd);
+      jh0.addt = 1;
+      const XtyJob jobs[4] = {jh0, xty_job(head, NUT + 1, NU + 1, &w.ps.JuT[0][0], NRP, &w.Tm[0][NX], LDTM, &w.ps.Jt[0][NX], LDTM), jt0, jt1};
+      wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_ADD_T>(ctx, jobs, 4);
+    } else {
+      const XtyJob jobs[2] = {jt0, jt1};
+      wg_xty_jobs<true, XTY_ADD_GLOBAL | XTY_ADD_T>(ctx, jobs, 2);
+    }
   };
-  project_rows(0, NRP);
+  if (!(HSQP_PEXP & 64)) project_rows(0, NRP, 16, 0, 0);
   WG_SYNC(ctx);
   PH_TICK(ctx, 6);
   load_ju(NRP, NRP);
-  gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  if (!(HSQP_PEXP & 64)) gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
   store_ju(NRP, NRP);
   WG_SYNC(ctx);
   PH_TICK(ctx, 14);
-  project_rows(NRP, NRP);
+  if (!(HSQP_PEXP & 4)) project_rows(NRP, NRP, 16, 6, 6);
   WG_SYNC(ctx);
   PH_TICK(ctx, 11);
   // the third pass only if rows beyond the first two passes are in use (the whole-body LQ kernel writes its rows compactly: 46 in
   // double support, 38 in single support; the collision rows, which would make it 54 / 62, are absent unless one of them is active)
   const bool pass3 = w.nrows > 2 * NRP;
   if (pass3) load_ju(2 * NRP, NRS - 2 * NRP);
-  gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
+  if (!(HSQP_PEXP & 4)) gram_rows<false, NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
   if (pass3) {
     store_ju(2 * NRP, NRS - 2 * NRP);
     WG_SYNC(ctx);
     PH_TICK(ctx, 15);
-    project_rows(2 * NRP, NRS - 2 * NRP);
+    project_rows(2 * NRP, NRS - 2 * NRP, 0, 0, 0);
     WG_SYNC(ctx);
     PH_TICK(ctx, 7);
     gram_rows<false, NRS - 2 * NRP>(ctx, g, &w.ps.Jt[0][0], LDTM, nullptr, nullptr);
   }
   // the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the diagonal part of the gradient, straight from Tm
-  gram_rows<true, NU>(ctx, g, &w.Tm[0][0], LDTM, &w.d[NX], &w.gd[NX]);
+  if (!(HSQP_PEXP & 32)) gram_rows<true, NU>(ctx, g, &w.Tm[0][0], LDTM, &w.d[NX], &w.gd[NX]);
   PH_TICK(ctx, 12);
-  gram_store(ctx, g, w, nut, qp);
+  if (!(HSQP_PEXP & 2)) gram_store(ctx, g, w, nut, qp);
   WG_SYNC(ctx);
   PH_TICK(ctx, 10);
 }
