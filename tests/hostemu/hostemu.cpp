@@ -348,6 +348,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   std::vector<double> dtv(N);
   for (int k = 0; k < N; ++k) dtv[k] = dts ? dts[k] : dt_uniform;
   auto fw = std::make_unique<RicFWS>();
+  std::vector<double> fj((size_t)N * NJ, std::nan(""));   // rows 12 .. 34 of Px dx + Pu ut as the factored roll-out leaves them (step_node then skips those rows of Px / Pu)
   for (int k = 0; k < N; ++k) {
     const double dt = dts ? dts[k] : dt_uniform;
     if (cent) { auto cw = std::make_unique<CentWST<true>>(); double* r = &rec[(size_t)k * REC_SIZE]; cent_lq_node2<true>(ctx, dm, *cw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, r, r + REC_MISC); }
@@ -383,7 +384,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   else if (g_scan && !g_segments) closed_loop_forward<NX>(ctx, *rw, x_init, x, acl.data(), N, dx);
   else if (cent) riccati_forward<CNX>(ctx, *rw, x_init, x, qp.data(), ric.data(), N, dx, ut.data());
   else if (fact) {
-    riccati_forward_fact(ctx, *fw, x_init, x, qp.data(), dtv.data(), ric.data(), N, dx, ut.data());
+    riccati_forward_fact(ctx, *fw, x_init, x, qp.data(), dtv.data(), ric.data(), N, dx, ut.data(), fj.data());
     for (int k = 0; k < N; ++k) {   // the dense joint rows for the KKT check (what k_project writes when the report is asked for)
       project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dtv[k], &qp[(size_t)k * QP_SIZE], cent, true);
       if (dtv[k] == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
@@ -394,7 +395,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
   auto sw = std::make_unique<StepWS>();
   for (int k = 0; k < N; ++k)
     step_node(ctx, *sw, &qp[(size_t)k * QP_SIZE], &ric[(size_t)k * RIC_SIZE], dx + k * NX, x + k * NX, u + k * NU, 1.0, &ut[(size_t)k * NUT],
-              du + k * NU, x_new + k * NX, u_new + k * NU, nullptr, ut_given ? &ut[(size_t)k * NUT] : nullptr);
+              du + k * NU, x_new + k * NX, u_new + k * NU, nullptr, ut_given ? &ut[(size_t)k * NUT] : nullptr, fact ? &fj[(size_t)k * NJ] : nullptr);
   for (int i = 0; i < NX; ++i) x_new[N * NX + i] = x[N * NX + i] + dx[N * NX + i];
   auto kw = std::make_unique<KktWS>();
   kkt[0] = kkt[1] = 0.0;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                                                          const double* __restrict__ x, const double* __restrict__ par,
                                                          const double* __restrict__ qp, const double* __restrict__ dts, double* __restrict__ ric, int N,
                                                          double* __restrict__ dx, int* __restrict__ status, long long* prof,
-                                                         double* __restrict__ vf, double* __restrict__ ut) {
+                                                         double* __restrict__ vf, double* __restrict__ ut, double* __restrict__ fj) {
   const int b = blockIdx.x;
   RicFWS& w = *reinterpret_cast<RicFWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, RIC_THREADS, blockIdx.x == 0 ? prof : nullptr};
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(RIC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
   const int bad = __syncthreads_or(mybad);
   riccati_backward_fact(ctx, w, dm->Qf, xb + (size_t)N * NX, parN, qpb, dtb, ricb, N, vf ? vf + (size_t)b * (N + 1) * VF_SIZE : nullptr);
   PH_TICK(ctx, 0);
-  riccati_forward_fact(ctx, w, x_init + (size_t)b * NX, xb, qpb, dtb, ricb, N, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT);
+  riccati_forward_fact(ctx, w, x_init + (size_t)b * NX, xb, qpb, dtb, ricb, N, dx + (size_t)b * (N + 1) * NX, ut + (size_t)b * N * NUT, fj + (size_t)b * N * NJ);
   PH_TICK(ctx, 10);
   if (threadIdx.x == 0) { const int st = (bad ? 1 : 0) | (w.ok ? 0 : 2); if (st) atomicOr(&status[b], st); }
 }
@@ -320,13 +320,13 @@ __global__ __launch_bounds__(RIC_THREADS) void k_ric_forward(const double* __res
 __global__ __launch_bounds__(64) void k_step(const double* __restrict__ qp, const double* __restrict__ ric, const double* __restrict__ dx,
                                              const double* __restrict__ x, const double* __restrict__ u, int N, double alpha,
                                              double* ut, double* __restrict__ du, double* __restrict__ x_new,
-                                             double* __restrict__ u_new, double* __restrict__ info, int ut_given) {
+                                             double* __restrict__ u_new, double* __restrict__ info, int ut_given, const double* __restrict__ fj) {
   __shared__ StepWS w;
   const int node = blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, 64, nullptr};
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, w, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
-            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr);
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr, fj ? fj + (size_t)node * NJ : nullptr);
   if (k == N - 1)
     for (int i = threadIdx.x; i < NX; i += blockDim.x) x_new[xo + NX + i] = x[xo + NX + i] + alpha * dx[xo + NX + i];
 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
                                                                           const double* __restrict__ par, const double* __restrict__ dts, int N, double alpha,
                                                                           double* ut, double* __restrict__ du, double* __restrict__ x_new,
                                                                           double* __restrict__ u_new, double* __restrict__ info, double* __restrict__ misc, long long* prof,
-                                                                          int ut_given) {
+                                                                          int ut_given, const double* __restrict__ fj) {
   const int node = blockIdx.x, b = node / N, k = node % N;
   LqWST<false>& w = *reinterpret_cast<LqWST<false>*>(hsqp_smem);
   static_assert(sizeof(StepWS) <= sizeof(w.st), "the step scratch aliases the stage workspace");
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(LQV_THREADS, HSQP_LQV_WPE) void k_step_value(const 
   PH_TICK(ctx, 126);
   const size_t xo = ((size_t)b * (N + 1) + k) * NX, uo = (size_t)node * NU;
   step_node(ctx, sw, qp + (size_t)node * QP_SIZE, ric + (size_t)node * RIC_SIZE, dx + xo, x + xo, u + uo, alpha, ut + (size_t)node * NUT,
-            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr);
+            du + uo, x_new + xo, u_new + uo, info + (size_t)node * 4, ut_given ? ut + (size_t)node * NUT : nullptr, fj ? fj + (size_t)node * NJ : nullptr);
   WG_SYNC(ctx);
   WG_FOR(ctx, i, NX + NU + NX) {
     if (i < NX) w.nw.x[i] = x[xo + i] + alpha * sw.dx[i];
@@ -897,6 +897,7 @@ struct hsqp_handle {
   double *d_xinit = nullptr, *d_x = nullptr, *d_u = nullptr, *d_par = nullptr;
   double *d_rec = nullptr, *d_qp = nullptr, *d_ric = nullptr;
   double *d_dx = nullptr, *d_du = nullptr, *d_ut = nullptr, *d_xnew = nullptr, *d_unew = nullptr;
+  double* d_fj = nullptr;         // [B][N][NJ] rows 12 .. 34 of Px dx + Pu ut as the factored roll-out forms them (k_step then reads the wrench rows of Px / Pu only)
   double *d_misc = nullptr, *d_kkt = nullptr, *d_ginf = nullptr;
   double* d_dt = nullptr;         // [B][N] length of every interval (uniform grids: filled with dt)
   std::vector<double> h_dt;       // host copy (debug reads), empty for device-resident uploads
@@ -1098,7 +1099,7 @@ const char* hsqp_last_error(const hsqp_handle* h) { return h ? h->err.c_str() : 
 void hsqp_destroy(hsqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_xnew,
+  void* bufs[] = {h->d_dm, h->d_xinit, h->d_x, h->d_u, h->d_par, h->d_rec, h->d_qp, h->d_ric, h->d_dx, h->d_du, h->d_ut, h->d_fj, h->d_xnew,
                   h->d_unew, h->d_misc, h->d_kkt, h->d_dt, h->d_perf_before, h->d_perf_after, h->d_status, h->d_prof, h->d_stepinfo, h->d_ls, h->d_counts, h->d_vf, h->d_stage,
                   h->d_el[0], h->d_el[1], h->d_vf2, h->d_acl, h->d_ric2, h->d_linv, h->d_vf0, h->d_zero};
   for (void* p : bufs)
@@ -1210,7 +1211,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_xinit, B * NX * 8}, {(void**)&h->d_x, B * (N + 1) * NX * 8}, {(void**)&h->d_u, B * N * NU * 8},
       {(void**)&h->d_par, B * (N + 1) * NP * 8}, {(void**)&h->d_rec, B * N * (size_t)REC_SIZE * 8},
       {(void**)&h->d_qp, B * N * (size_t)QP_SIZE * 8}, {(void**)&h->d_ric, B * N * (size_t)RIC_SIZE * 8},
-      {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8},
+      {(void**)&h->d_dx, B * (N + 1) * NX * 8}, {(void**)&h->d_du, B * N * NU * 8}, {(void**)&h->d_ut, B * N * NUT * 8}, {(void**)&h->d_fj, B * N * NJ * 8},
       {(void**)&h->d_xnew, B * (N + 1) * NX * 8}, {(void**)&h->d_unew, B * N * NU * 8}, {(void**)&h->d_misc, B * N * 8 * 8},
       {(void**)&h->d_kkt, B * 3 * 8 + ((B * sizeof(int) + 7) / 8) * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
       {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
@@ -1479,16 +1480,18 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
     int ut_given = 0;   // the last sweep's roll-out left ut = k + K dx of every node in d_ut (the serial roll-out does, the scan's closed-loop roll-out does not)
+    int fj_given = 0;   // ... and rows 12 .. 34 of Px dx + Pu ut in d_fj (the factored roll-out does)
     auto launch_sweep = [&](bool use_scan, bool need_vf) -> int {
       ut_given = (use_scan && segP == 0) ? 0 : 1;
+      fj_given = 0;
       if (use_scan && segP > 0) return cent ? launch_segmented<CNX>(h, B, N, segP, want_kkt != 0) : launch_segmented<NX>(h, B, N, segP, want_kkt != 0);
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
         hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       else if (h->ric_fact)
-        hipLaunchKernelGGL(k_riccati_fact, dim3(B), dim3(RIC_THREADS), sizeof(RicFWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dt,
-                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
+        { hipLaunchKernelGGL(k_riccati_fact, dim3(B), dim3(RIC_THREADS), sizeof(RicFWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dt,
+                           h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut, h->d_fj); fj_given = 1; }
       else
         hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
@@ -1497,15 +1500,16 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     auto launch_step = [&]() {
       if (cent)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given);
+                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given, fj_given ? (const double*)h->d_fj : (const double*)nullptr);
       else if (h->value_quad) {   // whole-body: the step (HBM-bound), then the value pass on quads of lanes (hsqp_lqv.h)
         hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
-                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given);
+                           h->d_xnew, h->d_unew, h->d_stepinfo, ut_given, fj_given ? (const double*)h->d_fj : (const double*)nullptr);
         hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                            N, nodes, h->d_misc, (const LsState*)nullptr);
       } else   // a tree with more than four limbs: the phase form of the value pass, fused with the step (k_step_value)
         hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
-                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384, ut_given);
+                           h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384, ut_given,
+                           fj_given ? (const double*)h->d_fj : (const double*)nullptr);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
       if (!from_scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // kkt, |g|_inf (and the scan flags) are one block; the scan path has zeroed it before its kernels

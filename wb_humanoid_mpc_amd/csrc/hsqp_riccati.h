@@ -662,8 +662,11 @@ struct StepWS {
 // info (optional, 3 doubles): {q~.dx + r~.ut (Armijo descent metric of the projected QP, ocs2 multiple_shooting::
 // armijoDescentMetric on the projected cost), |dx|^2, |du|^2} of this node.
 // ut_in (optional): ut of this node as the serial roll-out left it (riccati_forward's ut_out); the gains are then not read.
+// fj_in (optional, NJ doubles; whole-body records only): rows 12 .. 34 of Px dx + Pu ut as the factored roll-out left them (riccati_forward_fact's fj_out: it forms
+// exactly these sums to advance the joint states); rows 12 .. of Px / Pu are then not read — 15 of the node's 24 KB.
 HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double* rk, const double* dx, const double* x, const double* u,
-                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr, const double* ut_in = nullptr) {
+                       double alpha, double* ut_out, double* du_out, double* x_new, double* u_new, double* info = nullptr, const double* ut_in = nullptr,
+                       const double* fj_in = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ctx.nthreads == 64) {
     // One-wave kernels (k_step, k_step_value): the phase-by-phase form below exposes four dependent HBM round trips (dx; the rows of K;
@@ -682,13 +685,15 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
 #pragma unroll
       for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; kk[j][c] = (!ut_in && it < NUT * 4 && cc < NX) ? rk[RIC_K + r * NX + cc] : 0.0; }
     }
+    const double fjl = (fj_in && l < NJ) ? fj_in[l] : 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int it = l + 64 * j, r = it >> 2, pp = it & 3;
+      const bool rowl = it < NU * 4 && (!fj_in || r < 12);   // (with fj_in only the twelve wrench rows are formed here: the first pass of 64 lanes)
 #pragma unroll
-      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; px[j][c] = (it < NU * 4 && cc < NX) ? q[QP_PX + r * NX + cc] : 0.0; }
+      for (int c = 0; c < NCX; ++c) { const int cc = pp + 4 * c; px[j][c] = 0.0; if (!fj_in || j == 0) px[j][c] = (rowl && cc < NX) ? q[QP_PX + r * NX + cc] : 0.0; }
 #pragma unroll
-      for (int c = 0; c < NCU; ++c) { const int cc = pp + 4 * c; pu[j][c] = (it < NU * 4 && cc < NUT) ? q[QP_PU + r * NUT + cc] : 0.0; }
+      for (int c = 0; c < NCU; ++c) { const int cc = pp + 4 * c; pu[j][c] = 0.0; if (!fj_in || j == 0) pu[j][c] = (rowl && cc < NUT) ? q[QP_PU + r * NUT + cc] : 0.0; }
     }
     if (l < NX) { w.dx[l] = dxl; x_new[l] = xl + alpha * dxl; }
     WG_SYNC(ctx);
@@ -722,8 +727,10 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
       }
     }
     WG_SYNC(ctx);
+    if (fj_in && l < NJ) w.t[l] = fjl;
+    WG_SYNC(ctx);
     if (l < NU) {
-      const double sv = pel + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3]));
+      const double sv = (fj_in && l >= 12) ? pel + w.t[l - 12] : pel + ((w.part[4 * l] + w.part[4 * l + 1]) + (w.part[4 * l + 2] + w.part[4 * l + 3]));
       du_out[l] = sv; u_new[l] = ul + alpha * sv; w.du[l] = sv;
     }
     WG_SYNC(ctx);
@@ -763,7 +770,7 @@ HSQP_HD void step_node(const Ctx& ctx, StepWS& w, const double* q, const double*
   }
   WG_SYNC(ctx);
   WG_FOR(ctx, r, NU) {
-    const double s = q[QP_PE + r] + ((w.part[4 * r] + w.part[4 * r + 1]) + (w.part[4 * r + 2] + w.part[4 * r + 3]));
+    const double s = (fj_in && r >= 12) ? q[QP_PE + r] + fj_in[r - 12] : q[QP_PE + r] + ((w.part[4 * r] + w.part[4 * r + 1]) + (w.part[4 * r + 2] + w.part[4 * r + 3]));
     du_out[r] = s;
     u_new[r] = u[r] + alpha * s;
     w.du[r] = s;

@@ -674,8 +674,9 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 
 // Forward sweep on the factors: ut = k + K dx;  f = Vx dx + Vu ut  (35 numbers: the base rows' share and qdd_j);  dx+ = E_J dx + F f + b~.
 // Two barriers per stage as riccati_forward; a stage reads 35 x 81 + 23 x 58 numbers instead of 58 x 81 + 23 x 58.
+// fj_out (optional, [N][NJ]): f of the joint rows = rows 12 .. 34 of Px dx + Pu ut, for step_node (which then reads the twelve wrench rows of Px / Pu only).
 HSQP_HD void riccati_forward_fact(const Ctx& ctx, RicFWS& w, const double* x_init, const double* x, const double* qp, const double* dts, const double* ric, int N,
-                                  double* dx_out, double* ut_out = nullptr) {
+                                  double* dx_out, double* ut_out = nullptr, double* fj_out = nullptr) {
   WG_FOR(ctx, i, NX) {
     const double d = x_init[i] - x[i];
     w.dx[i] = d;
@@ -746,6 +747,7 @@ HSQP_HD void riccati_forward_fact(const Ctx& ctx, RicFWS& w, const double* x_ini
               else v = (dcur[row + 23] + dt * s) + sc[u];
               dnxt[out_state] = v;
               dx_out[(size_t)(k + 1) * NX + out_state] = v;
+              if (fj_out && joint && p == 0) fj_out[(size_t)k * NJ + row - 12] = s;
             }
           }
           if (k + PF < N) fetch(k + PF, a[u], bq[u], sc[u], dtk[u]);
@@ -773,6 +775,7 @@ HSQP_HD void riccati_forward_fact(const Ctx& ctx, RicFWS& w, const double* x_ini
       double pp[4];
       for (int p = 0; p < 4; ++p) pp[p] = matvec_part<NX>(va, w.dx, p) + matvec_part<NUT>(vb, w.zv, p);
       w.fsb[kf] = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+      if (fj_out && kf >= 12) fj_out[(size_t)k * NJ + kf - 12] = w.fsb[kf];
     }
     WG_SYNC(ctx);
     WG_FOR(ctx, i, NX) {
