@@ -356,7 +356,7 @@ int emu_sqp_iteration(void* h, int N, double dt, const double* x_init, const dou
       lq_limb_node(dm, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE]);   // (rec: zero-filled vector)
     } else lq_node<true>(ctx, dm, *lw, x + k * NX, u + k * NU, x + (k + 1) * NX, par + k * NP, dt, &rec[(size_t)k * REC_SIZE], &rec[(size_t)k * REC_SIZE + REC_MISC]);
     // (the factored sweep reads the dense base rows, Px, Pu, b~ only: the joint rows of A~ / B~ stay unwritten — NaN here — until the KKT check below)
-    if (fact) for (int i = 0; i < QP_BV; ++i) qp[(size_t)k * QP_SIZE + i] = std::nan("");
+    if (fact) { for (int i = 0; i < QP_BV; ++i) qp[(size_t)k * QP_SIZE + i] = std::nan(""); for (int i = QP_Q; i < QP_P; ++i) qp[(size_t)k * QP_SIZE + i] = std::nan(""); }   // (also Q~: its strictly lower triangle stays unwritten)
     project_node(ctx, *pw, &rec[(size_t)k * REC_SIZE], dt, &qp[(size_t)k * QP_SIZE], cent, !fact);
     if (dt == 0.0) jump_node_qp(ctx, &rec[(size_t)k * REC_SIZE], &qp[(size_t)k * QP_SIZE]);
     if (qp[(size_t)k * QP_SIZE + QP_NUT] < 0) return HSQP_ERR_NUMERIC;

@@ -184,12 +184,14 @@ HSQP_HD void gram_rows(const Ctx& ctx, GramAcc& g, const double* X, int ldx, con
 }
 
 // The accumulated blocks to the QP record: Q~ (+ diag d_x), P~, R~ (identity on the unused projected inputs), q~ (+ g_x), r~.
-HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int nut, double* qp) {
+// lower_q = false: the strictly lower triangle of Q~ is not written (the factored Riccati sweep reads the tiles on / above the diagonal only; the mirrored
+// stores are the scattered ones of this epilogue: 13 KB per node)
+HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int nut, double* qp, bool lower_q = true) {
   auto put = [&](int r, int c, double v) {             // r <= c <= 80
     if (c < NX) {
       if (r == c) v += w.d[r];
       qp[QP_Q + r * NX + c] = v;
-      if (r != c) qp[QP_Q + c * NX + r] = v;
+      if (r != c && lower_q) qp[QP_Q + c * NX + r] = v;
     } else if (r < NX) {
       qp[QP_P + (c - NX) * NX + r] = v;
     } else {
@@ -229,8 +231,8 @@ HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int n
 
 // cent = true: the record comes from the centroidal LQ kernel (hsqp_cent.h): the dense rows of [A|B] - [I|0] are rows 0..11
 // (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
-// joint_rows = false: the 46 joint rows of A~ / B~ (scaled copies of rows 12 .. of [Px | Pu]: q_j+ = q_j + dt v_j + dt^2/2 qdd_j, v_j+ = v_j + dt qdd_j) are NOT
-// written — the factored Riccati sweep (hsqp_riccati_fact.h) forms them from Px, Pu on the fly; b~ is always complete.  30 of the record's 101 KB.
+// joint_rows = false: the 46 joint rows of A~ / B~ (scaled copies of rows 12 .. of [Px | Pu]: q_j+ = q_j + dt v_j + dt^2/2 qdd_j, v_j+ = v_j + dt qdd_j) and the
+// strictly lower triangle of Q~ are NOT written — the factored Riccati sweep (hsqp_riccati_fact.h) forms them from Px, Pu on the fly; b~ is always complete.  30 of the record's 101 KB.
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false, bool joint_rows = true) {
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
@@ -722,7 +724,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // the input-weight rows sqrt(d_u) [Px | Pu | Pe] and the diagonal part of the gradient, straight from Tm
   if (!(HSQP_PEXP & 32)) gram_rows<true, NU>(ctx, g, &w.Tm[0][0], LDTM, &w.d[NX], &w.gd[NX]);
   PH_TICK(ctx, 12);
-  if (!(HSQP_PEXP & 2)) gram_store(ctx, g, w, nut, qp);
+  if (!(HSQP_PEXP & 2)) gram_store(ctx, g, w, nut, qp, joint_rows);
   WG_SYNC(ctx);
   PH_TICK(ctx, 10);
 }
