@@ -9,18 +9,22 @@
 // So every product of the stage with A~ or B~ is a product with F^T (a row COMBINATION: copy a base row, or hq * row q_j + dt * row v_j,
 // formed while the operand is fetched) and a 35-deep contraction with V — nine 16 x 16 x 4 steps instead of fifteen — plus an E_J term
 // that is a shifted copy added in the tile epilogue.  What that buys is not the flops as such (a phase of the stage is overhead-bound)
-// but a different SCHEDULE: S A~ and W = Q~ + A~^T S A~ together are 117 matrix instructions per SIMD instead of 195 and fit UNDER the
+// but a different SCHEDULE: S A~ and W' = A~^T S A~ together are 117 matrix instructions per SIMD instead of 195 and run UNDER the
 // elimination on the two SIMDs it leaves free, with no synchronisation between the four waves that form them: a wave owns one column
-// tile of S A~ (four tiles) and forms, from it alone, the tiles of W in that column (accumulators in registers, written over the
-// upper-triangle tiles of S A~ once the column is consumed).  The stage is then
-//   Ph1  S B~ = (F^T S)^T Vu  (8 tiles x 9 steps; the combinations F^T S are kept: FS),  sb = s + S b~  (vector items)
-//   Ph2  G = P~ + SB^T E_J + (F^T SB)^T Vx,   [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb])                       (12 tiles x 9 steps)
-//   Ph3  blocked elimination of [Lam | I | G | g] on two waves (hsqp_elim.h, unchanged)  ||  S A~, W on the other two SIMDs  ||  the
-//        next stage's factors -> LDS (asynchronous copies + the two memory waves)
-//   Ph4  S = W - Z^T Z  (6 steps),  [K | k] = -L^-T [Z | z],  s = q~ + E_J^T sb + Vx^T (F^T sb) - Z^T z
-// i.e. 637 matrix instructions per stage against 909 (1.57 x the algorithmic count instead of 2.24 x), the two 58-deep phases gone
+// tile of S A~ (four tiles) and forms, from it alone, the tiles of W' in that column (accumulators in registers, written over the
+// upper-triangle tiles of S A~ once the column is consumed).  The stage (eight waves; per SIMD the waves w and w + 4):
+//   Ph1  S B~ = (F^T S)^T Vu  (8 tiles x 9 steps, one per wave; the combinations F^T S are KEPT: FS),  sb = s + S b~  (vector items, waves 4 .. 7)
+//   Ph2  G = P~ + SB^T E_J + (F^T SB)^T Vx  (8 tiles),  [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb])  (4 tiles, second tile of waves 4 .. 7's call);
+//        P~, R~, r~ from LDS: no global load in the phase
+//   Ph3  waves 0, 1: blocked elimination of [Lam | I | G | g] (hsqp_elim.h, unchanged); wave 0's hook issues every asynchronous copy of the next
+//        stage (Vx, P~, R~) and both fetch Q~ of their S tiles into registers  ||  waves 2, 3, 6, 7: S A~, then W'  ||  waves 4, 5: the next stage's
+//        Vu, b~, r~ and this stage's q~ through address tables formed once in front of the stage loop
+//   Ph4  waves 0 .. 3: S = Q~ + W' - Z^T Z  (six 23-deep steps; 3 / 2 / 3 / 2 tiles, Q~ from registers);  waves 4 .. 7: two tiles each of
+//        [K | k] = -L^-T [Z | z] and a quarter of the vector items  s = q~ + E_J^T sb + Vx^T (F^T sb) - Z^T z
+// i.e. 633 matrix instructions per stage against 909 (1.56 x the algorithmic count instead of 2.24 x), the two 58-deep phases gone
 // from the serial path, and per stage 35 x 81 + 58 numbers of dynamics read instead of 58 x 82.  The forward sweep applies the factors
-// as well (34 instead of 48 KB per stage).  The centroidal formulation (35 states: F would have full rank) keeps hsqp_riccati.h.
+// as well (34 instead of 48 KB per stage) and hands rows 12 .. 34 of Px dx + Pu ut to the step kernel.  The centroidal formulation (35 states:
+// F would have full rank) keeps hsqp_riccati.h.  What the device taught while this was built: DESIGN.md §4 "k_riccati_fact".
 #pragma once
 #include <cstddef>
 #include "hsqp_riccati.h"
