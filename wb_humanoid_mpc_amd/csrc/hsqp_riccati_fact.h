@@ -80,7 +80,7 @@ struct RicFWS {
   double VB[NF][LDB];                          // Vu (column 23 unused, zero)
   union {
     double SB[NX][LDB];                        // [S B~ | sb]
-    double Zs[NUT][LDZ];                       // [L^-1 G | z] (SB is dead once Lam, G are formed)
+    double Zs[NUT + 1][LDZ];                   // [L^-1 G | z] (SB is dead once Lam, G are formed); row NUT: padding of the last contraction step (finite, multiplied by zero)
   };
   double PG[NUT][LDG];                         // [G | g] -> [K | k]
   double Ef[LDB][LDF];                         // [Lam | . | L^-1]
@@ -208,7 +208,10 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
   constexpr int FM_NPB = 8, FM_NVB = NF * NUT;
   static_assert(128 * FM_NPB >= FM_NVB + 2 * NX + NUT, "one pass of the two memory waves");
   int fm_src[FM_NPB], fm_dst[FM_NPB];     // source offset (doubles, from the next stage's record), LDS destination (doubles, from &w.VA[0][0][0]; -1: none)
-  int fq_off[3][4];                       // Q~ fetch of the S-update tiles this wave forms in Ph4 (offset from the stage's record)
+  // the S-update tiles this wave forms in Ph4 (waves 0 .. 3), per tile: Q~ fetch offset (from the stage's record; rows + 4 r are 4 NX further), operand
+  // offsets into Zs (steps + 4 s are 4 LDZ further), offset of the tile's element in SA / S, of its mirror image in S, and which of its four elements
+  // are stored (bit r)
+  int fs_q[3], fs_zx[3], fs_zy[3], fs_w[3], fs_m[3], fs_mask[3];
   int f_sfirst, f_scount;
   {
     const int tid0 = ctx_outer.tid, wv0 = tid0 >> 6, lane0 = tid0 & 63, li0 = lane0 & 15, kk0 = lane0 >> 4, pt = tid0 - 256;
@@ -229,9 +232,15 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
-      const int cc = 16 * tc + li0 < NX ? 16 * tc + li0 : NX - 1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * tr + kk0 + 4 * r, rc = row < NX ? row : NX - 1; fq_off[t][r] = QP_Q + rc * NX + cc; }
+      const int c = 16 * tc + li0, cc = c < NX ? c : NX - 1, rr = 16 * tr + li0 < NX ? 16 * tr + li0 : NX - 1, row0 = 16 * tr + kk0;
+      fs_q[t] = QP_Q + row0 * NX + cc;          // (rows beyond the matrix — the last tile row — address valid memory of the record; their values are never stored)
+      fs_zx[t] = kk0 * LDZ + rr;
+      fs_zy[t] = kk0 * LDZ + cc;
+      fs_w[t] = row0 * NX + cc;
+      fs_m[t] = cc * NX + row0;
+      int mask = 0;
+      for (int r = 0; r < 4; ++r) { const int row = row0 + 4 * r; if (t < f_scount && c < NX && row < NX && (tr != tc || row <= c)) mask |= 1 << r; }
+      fs_mask[t] = mask;
     }
   }
 #endif
@@ -403,7 +412,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[fq_off[t][r]];
+        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[fs_q[t] + 4 * NX * r];
     };
     {
       if (wv < 2) {
@@ -595,46 +604,35 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         // S tiles: six 23-deep steps, W' from LDS and Q~ from the registers loaded in Ph3
         auto run = [&](auto ntc) {
           constexpr int NT = decltype(ntc)::value;
-          int tr[NT], tc[NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) { const int id = sfirst + t; tr[t] = fact_sym_tr(id); tc[t] = fact_sym_tc(id); }
+          const double* lz = &w.Zs[0][0];
+          const double* lsa = &w.SA[0][0];
+          double* ls = &w.S[0][0];
           hsqp_d4 acc[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
           auto xf = [&](auto sc, int t) {
             constexpr int s = decltype(sc)::value;
-            const int kc = 4 * s + kk < NUT ? 4 * s + kk : NUT - 1, r = 16 * tr[t] + li;
-            const double v = w.Zs[kc][r < NX ? r : NX - 1];
-            return 4 * s + kk < NUT ? v : 0.0;
+            const double v = lz[fs_zx[t] + 4 * s * LDZ];
+            if constexpr (4 * s + 3 >= NUT) return 4 * s + kk < NUT ? v : 0.0; else return v;
           };
-          auto yf = [&](auto sc, int t) {
-            constexpr int s = decltype(sc)::value;
-            const int kc = 4 * s + kk < NUT ? 4 * s + kk : NUT - 1, c = 16 * tc[t] + li;
-            return w.Zs[kc][c < NX ? c : NX - 1];
-          };
+          auto yf = [&](auto sc, int t) { constexpr int s = decltype(sc)::value; return lz[fs_zy[t] + 4 * s * LDZ]; };
           double wp[NT][4];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = 16 * tc[t] + li, cc = c < NX ? c : NX - 1;
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int row = 16 * tr[t] + kk + 4 * r; wp[t][r] = w.SA[row < NX ? row : NX - 1][cc]; }
-          }
+            for (int r = 0; r < 4; ++r) wp[t][r] = lsa[fs_w[t] + 4 * NX * r];
           PH_LAP(ctx, HSQP_LAP_WAVE, 21);
           fact_mfma<NT, RIC_PF, NSZ>(acc, xf, yf);
           PH_LAP(ctx, HSQP_LAP_WAVE, 22);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = 16 * tc[t] + li;
-            const bool diag = tr[t] == tc[t];
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = 16 * tr[t] + kk + 4 * r;
               const double v = (wp[t][r] + qpre[t][r]) - acc[t][r];
               // tiles above the diagonal: stored and mirrored; diagonal tiles: the elements on / above the diagonal, each also at its mirrored
-              // place, so that S is symmetric to the bit
-              if (c < NX && row < NX && (!diag || row <= c)) { w.S[row][c] = v; w.S[c][row] = v; }
+              // place, so that S is symmetric to the bit (which elements: the mask formed in front of the stage loop)
+              if ((fs_mask[t] >> r) & 1) { ls[fs_w[t] + 4 * NX * r] = v; ls[fs_m[t] + 4 * r] = v; }
             }
-          }
         };
         if (scount == 3) run(std::integral_constant<int, 3>{});
         else run(std::integral_constant<int, 2>{});
