@@ -210,3 +210,18 @@ def test_parallel_in_time_backward_sweep_equals_the_serial_recursion(cmodel, cor
         assert_perf(b["perf_after"][i], a["perf_after"][i], f"scan vs serial, instance {i}")
     r = coracle.cent_sqp_iteration(dt, x0[0], x[0], u[0], par[0], threads=4)
     assert_step(b, r, 0, "scan vs oracle")
+
+
+@pytest.mark.parametrize("riccati", ["serial", "parallel"])
+def test_no_kernel_reads_lds_it_did_not_write(cmodel, riccati):
+    """The centroidal kernels with NaN bit patterns in every LDS word in front of every launch (HSQP_POISON_LDS, csrc/hsqp_capi.hip): the same bits
+    as without (see the whole-body test of the same name)."""
+    from test_gpu_parity import _poisoned_and_clean
+
+    def make():
+        return [make_centroidal_problem(cmodel, n_nodes=n, batch=b, gait=g, perturb=True, seed=7 + n) for n, b, g in ((100, 2, "walk"), (14, 3, "run"))]
+    poisoned, clean = _poisoned_and_clean(cmodel, make, max_nodes=100, max_batch=4, riccati=riccati)
+    for a, b in zip(poisoned, clean):
+        for key in ("dx", "du", "x", "u", "kkt"):
+            assert np.isfinite(a[key]).all(), key
+            assert np.array_equal(a[key], b[key]), key

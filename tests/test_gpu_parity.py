@@ -837,3 +837,54 @@ def test_value_pass_on_quads_of_lanes_equals_the_phase_form(model):
         for pa, pb in zip(a["perf_after"], b["perf_after"]):
             for key in ("cost", "dynamics_sse", "equality_sse"):
                 assert abs(pa[key] - pb[key]) <= 1e-12 * max(1.0, abs(pb[key])), (key, pa, pb)
+
+
+def _poisoned_and_clean(model, make, **solver_kw):
+    """Two solves of the same problem: on a handle created with HSQP_POISON_LDS (every kernel launch preceded by one that fills the LDS of every
+    CU with NaN bit patterns: csrc/hsqp_capi.hip, k_poison_lds) and on a clean one (created second: the flag is process-wide and set at hsqp_create)."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    outs = []
+    for poison in (True, False):
+        if poison:
+            os.environ["HSQP_POISON_LDS"] = "1"
+        try:
+            s = HipSqpSolver(model, **solver_kw)
+        finally:
+            os.environ.pop("HSQP_POISON_LDS", None)
+        try:
+            outs.append([s.run(*p) for p in make()])
+        finally:
+            s.close()
+    return outs
+
+
+@pytest.mark.parametrize("form", ["serial", "limb_lanes", "linesearch", "parallel", "segmented"])
+def test_no_kernel_reads_lds_it_did_not_write(model, form):
+    """LDS keeps what the previous kernel left in it.  A kernel that reads a word it never wrote — the padding row of an operand that is `multiplied
+    by zero`, the tail of a union — works until the leftover is a NaN: the serial sweep's Ph4 did exactly that (row NUT of Zs beyond SB's storage)
+    and failed about one run in ten with `reduced Hessian not positive definite`.  With NaN patterns in every LDS word in front of every launch the
+    iteration has to give the same bits as without."""
+    kw = dict(max_nodes=100, max_batch=4)
+    env = None
+    if form == "limb_lanes":
+        env = "HSQP_LQ_LIMB_FORM"
+    elif form == "linesearch":
+        kw["linesearch"] = True
+    elif form in ("parallel", "segmented"):
+        kw["riccati"] = form
+    else:
+        kw["riccati"] = "serial"
+
+    def make():
+        return [make_problem(model, n_nodes=n, batch=b, gait=g, perturb=True, seed=5 + n) for n, b, g in ((100, 2, "walk"), (37, 4, "run"), (8, 1, "stance"))]
+    if env:
+        os.environ[env] = "1"
+    try:
+        poisoned, clean = _poisoned_and_clean(model, make, **kw)
+    finally:
+        if env:
+            os.environ.pop(env, None)
+    for a, b in zip(poisoned, clean):
+        for key in ("dx", "du", "x", "u", "kkt"):
+            assert np.isfinite(a[key]).all(), (form, key)
+            assert np.array_equal(a[key], b[key]), (form, key)

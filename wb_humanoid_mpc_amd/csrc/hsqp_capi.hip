@@ -65,6 +65,23 @@ static_assert(sizeof(LqWST<false>) <= 163840 / 8, "value-only workspace: eight w
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hsqp_smem[];
 
+// ---- test aid (HSQP_POISON_LDS in the environment at hsqp_create; process-wide): every kernel launch is preceded by one that fills the LDS of every CU
+// with NaN bit patterns.  LDS keeps what the previous kernel left there, so a kernel that reads a word it never wrote (say a padding row that is
+// "multiplied by zero") works until the leftover happens to be a NaN — tests/test_gpu_parity.py runs the iteration with and without the poison
+// and asks for the same bits.
+constexpr int POISON_LDS_BYTES = 163400;   // what hipFuncSetAttribute(MaxDynamicSharedMemorySize) accepts on gfx950: one such workgroup per CU at a time
+__global__ __launch_bounds__(256) void k_poison_lds() {
+  volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(hsqp_smem);
+  for (int i = threadIdx.x; i < POISON_LDS_BYTES / 8; i += 256) p[i] = 0x7ff8dead7ff8deadull;   // a NaN as a double and as two floats
+}
+bool g_poison_lds = false;
+int g_poison_blocks = 512;                 // two per CU (set from the device's CU count at hsqp_create)
+#define HSQP_LAUNCH(kernel, grid, block, lds, st, ...)                                                                  \
+  do {                                                                                                                 \
+    if (g_poison_lds) hipLaunchKernelGGL(k_poison_lds, dim3(g_poison_blocks), dim3(256), POISON_LDS_BYTES, (st));      \
+    hipLaunchKernelGGL(kernel, (grid), (block), (lds), (st), __VA_ARGS__);                                             \
+  } while (0)
+
 // ---- LQ approximation: one workgroup per (instance, node)
 template <bool DERIV>
 __global__ __launch_bounds__(DERIV ? LQ_THREADS : LQV_THREADS, DERIV ? HSQP_LQ_WPE : HSQP_LQV_WPE) void k_lq(const DevModel* __restrict__ dm, const double* __restrict__ x,
@@ -986,10 +1003,10 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
       if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
     h->el_capacity = need;
   }
-  hipLaunchKernelGGL(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0], h->d_scanst);
+  HSQP_LAUNCH(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0], h->d_scanst);
   int cur = 0;
   for (int d = 1; d < N + 1; d *= 2) {
-    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_scanst, h->d_prof + 256);
+    HSQP_LAUNCH(k_scan_combine<n>, dim3(B * (N + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], N, d, h->d_scanst, h->d_prof + 256);
     cur = 1 - cur;
   }
   for (double** pv : {&h->d_vf, &h->d_vf2})
@@ -1005,11 +1022,11 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
   double* vbuf[2] = {(refinements & 1) ? h->d_vf : h->d_vf2, (refinements & 1) ? h->d_vf2 : h->d_vf};
   for (int pass = 0; pass <= refinements; ++pass) {
     const bool lastp = pass == refinements;
-    hipLaunchKernelGGL(k_scan_gains<n>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
+    HSQP_LAUNCH(k_scan_gains<n>, dim3(nodes), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, h->d_el[cur],
                        pass == 0 ? (const double*)nullptr : (const double*)vbuf[(pass - 1) & 1], h->d_ric, N, h->d_scanst,
                        (lastp && !want_kkt) ? (double*)nullptr : vbuf[pass & 1], lastp ? h->d_acl : (double*)nullptr);
   }
-  hipLaunchKernelGGL(k_scan_forward<n>, dim3(B), dim3(SCAN_FWD_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);   // 4 n <= 256 items per stage: four waves
+  HSQP_LAUNCH(k_scan_forward<n>, dim3(B), dim3(SCAN_FWD_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_acl, N, h->d_dx);   // 4 n <= 256 items per stage: four waves
   return HSQP_OK;
 }
 
@@ -1058,20 +1075,20 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
     if (hipMalloc(&h->d_vf2, bytes) != hipSuccess) { h->d_vf2 = nullptr; h->err = "hipMalloc failed (value functions of the segmented sweep, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
   }
   const int segs = B * P;
-  hipLaunchKernelGGL(k_seg_elem_ric<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_zero, h->d_ric2,
+  HSQP_LAUNCH(k_seg_elem_ric<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_zero, h->d_ric2,
                      h->d_linv, h->d_vf0, N, P, h->d_scanst);
-  hipLaunchKernelGGL(k_seg_accumulate<n>, dim3(segs), dim3(SEG_ACC_THREADS), sizeof(SegAccWS), h->stream, (const double*)h->d_qp, (const double*)h->d_ric2,
+  HSQP_LAUNCH(k_seg_accumulate<n>, dim3(segs), dim3(SEG_ACC_THREADS), sizeof(SegAccWS), h->stream, (const double*)h->d_qp, (const double*)h->d_ric2,
                      (const double*)h->d_linv, (const double*)h->d_vf0, N, P, h->d_el[0]);
-  hipLaunchKernelGGL(k_seg_terminal<n>, dim3(B), dim3(256), 0, h->stream, h->d_dm, h->d_x, h->d_par, N, P, h->d_el[0]);
+  HSQP_LAUNCH(k_seg_terminal<n>, dim3(B), dim3(256), 0, h->stream, h->d_dm, h->d_x, h->d_par, N, P, h->d_el[0]);
   int cur = 0;
   for (int d = 1; d < P + 1; d *= 2) {
-    hipLaunchKernelGGL(k_scan_combine<n>, dim3(B * (P + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], P, d, h->d_scanst,
+    HSQP_LAUNCH(k_scan_combine<n>, dim3(B * (P + 1)), dim3(SCAN_COMB_THREADS), sizeof(ScanCombWS<n>), h->stream, h->d_el[cur], h->d_el[1 - cur], P, d, h->d_scanst,
                        (long long*)nullptr);
     cur = 1 - cur;
   }
-  hipLaunchKernelGGL(k_seg_riccati<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_el[cur], h->d_ric, N, P,
+  HSQP_LAUNCH(k_seg_riccati<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_el[cur], h->d_ric, N, P,
                      h->d_scanst, h->d_vf2, want_vf ? 0 : 2);
-  hipLaunchKernelGGL(k_ric_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_ric, N, h->d_dx, h->d_ut);
+  HSQP_LAUNCH(k_ric_forward<n>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_ric, N, h->d_dx, h->d_ut);
   return HSQP_OK;
 }
 
@@ -1227,6 +1244,12 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   if (hipMemset(h->d_rec, 0, B * N * (size_t)REC_SIZE * 8) != hipSuccess) return fail(HSQP_ERR_HIP, "memset failed");
   // the kernels use up to ~158 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   hipError_t a1 = hipFuncSetAttribute((const void*)k_lq<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWS));
+  g_poison_lds = getenv("HSQP_POISON_LDS") != nullptr;
+  if (g_poison_lds) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) g_poison_blocks = 2 * prop.multiProcessorCount;
+    if (a1 == hipSuccess) a1 = hipFuncSetAttribute((const void*)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, POISON_LDS_BYTES);
+  }
   hipError_t a2 = hipFuncSetAttribute((const void*)k_lq<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_step_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LqWST<false>));
   if (a2 == hipSuccess) a2 = hipFuncSetAttribute((const void*)k_lq_cent2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CentWST<true>));
@@ -1381,10 +1404,10 @@ int hsqp_upload_reference(hsqp_handle* h, const hsqp_problem* p, const hsqp_refe
   step(hipMemcpyAsync(h->d_u, p->u_traj, B * N * NU * 8, hipMemcpyHostToDevice, h->stream), "upload u");
   if (rc == HSQP_OK) {
     const int total = (int)(B * (N + 1));
-    hipLaunchKernelGGL(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->d_dm, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
+    HSQP_LAUNCH(k_params, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->d_dm, r->swing, r->terrain_height, r->arm_swing, (int)E, d_ne, d_ev, d_seq,
                        (int)K, d_tt, d_ts, r->t0, r->dt, (const double*)d_nt, (int)N, (int)B, h->d_par, d_bad);
     if (h->hdm.formulation == HSQP_FORM_CENTROIDAL)   // torso task-space reference of every row
-      hipLaunchKernelGGL(k_params_cent_torso, dim3(total), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_par);
+      HSQP_LAUNCH(k_params_cent_torso, dim3(total), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_par);
     step(hipGetLastError(), "k_params");
   }
   int bad = 0;
@@ -1419,7 +1442,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     const bool last = it == n_iterations - 1 || until_converged;
     if (last) HCHECK(hipEventRecord(h->ev[0], h->stream));
     if (cent) {
-      hipLaunchKernelGGL(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
+      HSQP_LAUNCH(k_lq_cent2, dim3(nodes), dim3(CLQ_THREADS), sizeof(CentWST<true>), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, h->d_rec);
     }
     else if (h->lq_limb) {   // limb lanes for the model and the node terms (16 nodes per wave), then the RK4 chain, a lane per column (hsqp_lql.h)
       // Two of the three kernels run one wave per SIMD (limb, rows), so a launch of config 4 is 1.56 rounds of the chip's 1024 SIMDs and the
@@ -1438,13 +1461,13 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         const int n0 = (int)(((long long)nodes * s / S) / QG * QG), n1 = s == S - 1 ? nodes : (int)(((long long)nodes * (s + 1) / S) / QG * QG);
         hipStream_t st = s == 0 ? h->stream : h->aux[s - 1];
         const dim3 qgrid((n1 - n0 + QG - 1) / QG);
-        hipLaunchKernelGGL(k_lq_limb, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
-        hipLaunchKernelGGL(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
-        hipLaunchKernelGGL(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0);
+        HSQP_LAUNCH(k_lq_limb, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
+        HSQP_LAUNCH(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
+        HSQP_LAUNCH(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0);
         if (s > 0) { HCHECK(hipEventRecord(h->ev_join[s - 1], st)); HCHECK(hipStreamWaitEvent(h->stream, h->ev_join[s - 1], 0)); }
       }
     } else
-      hipLaunchKernelGGL(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
+      HSQP_LAUNCH(k_lq<true>, dim3(nodes), dim3(LQ_THREADS), sizeof(LqWS), h->stream, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N,
                          h->d_rec, (double*)nullptr, h->d_prof, (const LsState*)nullptr);
     if (last) HCHECK(hipEventRecord(h->ev[1], h->stream));
     // The backward sweep: serial recursion, or — one or two instances on a long horizon, or on request — the associative scan over the
@@ -1470,8 +1493,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // The joint rows of A~ / B~ (46 of 58: scaled copies of rows of [Px | Pu]) are written only for those who read A~ / B~ as dense blocks: the
     // parallel-in-time and two-level sweeps, the KKT report, the centroidal stage.  The whole-body serial sweep works on the factors.
     const bool joint_rows = cent || !h->ric_fact || scan || want_kkt;
-    hipLaunchKernelGGL(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0, joint_rows ? 1 : 0);
-    if (h->has_events) hipLaunchKernelGGL(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
+    HSQP_LAUNCH(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0, joint_rows ? 1 : 0);
+    if (h->has_events) HSQP_LAUNCH(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     if (want_kkt && !h->d_vf) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
@@ -1487,33 +1510,33 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       if (use_scan && segP > 0) return cent ? launch_segmented<CNX>(h, B, N, segP, want_kkt != 0) : launch_segmented<NX>(h, B, N, segP, want_kkt != 0);
       if (use_scan) return cent ? launch_scan<CNX>(h, B, N, need_vf, 1) : launch_scan<NX>(h, B, N, need_vf, HSQP_SCAN_WB_REFINEMENTS);
       if (cent)   // the serial recursion on the 35 centroidal states only (the padding states are decoupled)
-        hipLaunchKernelGGL(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+        HSQP_LAUNCH(k_riccati<CNX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       else if (h->ric_fact)
-        { hipLaunchKernelGGL(k_riccati_fact, dim3(B), dim3(RIC_THREADS), sizeof(RicFWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dt,
+        { HSQP_LAUNCH(k_riccati_fact, dim3(B), dim3(RIC_THREADS), sizeof(RicFWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp, h->d_dt,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut, h->d_fj); fj_given = 1; }
       else
-        hipLaunchKernelGGL(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
+        HSQP_LAUNCH(k_riccati<NX>, dim3(B), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_xinit, h->d_x, h->d_par, h->d_qp,
                            h->d_ric, N, h->d_dx, h->d_status, h->d_prof + 256, need_vf ? h->d_vf : (double*)nullptr, h->d_ut);
       return HSQP_OK;
     };
     auto launch_step = [&]() {
       if (cent)
-        hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+        HSQP_LAUNCH(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                            h->d_xnew, h->d_unew, h->d_stepinfo, ut_given, fj_given ? (const double*)h->d_fj : (const double*)nullptr);
       else if (h->value_quad) {   // whole-body: the step (HBM-bound), then the value pass on quads of lanes (hsqp_lqv.h)
-        hipLaunchKernelGGL(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
+        HSQP_LAUNCH(k_step, dim3(nodes), dim3(64), 0, h->stream, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u, N, 1.0, h->d_ut, h->d_du,
                            h->d_xnew, h->d_unew, h->d_stepinfo, ut_given, fj_given ? (const double*)h->d_fj : (const double*)nullptr);
-        hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+        HSQP_LAUNCH(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                            N, nodes, h->d_misc, (const LsState*)nullptr);
       } else   // a tree with more than four limbs: the phase form of the value pass, fused with the step (k_step_value)
-        hipLaunchKernelGGL(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
+        HSQP_LAUNCH(k_step_value, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_qp, h->d_ric, h->d_dx, h->d_x, h->d_u,
                            h->d_par, h->d_dt, N, 1.0, h->d_ut, h->d_du, h->d_xnew, h->d_unew, h->d_stepinfo, h->d_misc, h->d_prof + 384, ut_given,
                            fj_given ? (const double*)h->d_fj : (const double*)nullptr);
     };
     auto launch_kkt = [&](bool from_scan) -> int {
       if (!from_scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // kkt, |g|_inf (and the scan flags) are one block; the scan path has zeroed it before its kernels
-      hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+      HSQP_LAUNCH(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, from_scan ? h->d_vf2 : h->d_vf, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       return HSQP_OK;
     };
     if (scan) HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));   // also the flags the scan kernels OR into
@@ -1523,7 +1546,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (scan) {   // the gate's inputs: KKT residuals, |g|_inf and the scan kernels' flags travel to pinned host memory while the kernels below run
       // (two-level sweep: the gate block holds its boundary-consistency numbers instead — no KKT kernel; the KKT report, if asked for, follows the verdict)
       if (segP == 0) { const int rc = launch_kkt(true); if (rc != HSQP_OK) return rc; }
-      else hipLaunchKernelGGL(k_kkt_boundaries, dim3(B * (segP - 1)), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_vf2, h->d_dx, h->d_ut, N, segP,
+      else HSQP_LAUNCH(k_kkt_boundaries, dim3(B * (segP - 1)), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, (const double*)h->d_vf2, h->d_dx, h->d_ut, N, segP,
                               h->d_kkt, h->d_ginf);
       HCHECK(hipMemcpyAsync(h->h_gate, h->d_kkt, gate_bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (want_kkt) {
@@ -1532,9 +1555,9 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     }
     auto launch_perf = [&]() {   // value pass of the centroidal trial, performance indices before / after, line-search state of the full-step trial
       if (cent)
-        hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
+        HSQP_LAUNCH(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
                            (const LsState*)nullptr);
-      hipLaunchKernelGGL(k_perf_trio, dim3(B, 3), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_misc, 8, h->d_xnew, h->d_par, N,
+      HSQP_LAUNCH(k_perf_trio, dim3(B, 3), dim3(64), 0, h->stream, h->d_dm, h->d_rec + REC_MISC, REC_SIZE, h->d_x, h->d_misc, 8, h->d_xnew, h->d_par, N,
                          h->d_perf_before, h->d_perf_after, h->d_stepinfo, h->d_dx, h->d_ls);
     };
     launch_perf();   // speculatively on the scan's step: the gate is read only now, so the host round trip hides behind these kernels
@@ -1556,7 +1579,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
       }
       if (accept && segP > 0 && want_kkt) {   // the KKT report of an accepted two-level sweep (the gate block is reused: zero it first)
         HCHECK(hipMemsetAsync(h->d_kkt, 0, gate_bytes, h->stream));
-        hipLaunchKernelGGL(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf2, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
+        HSQP_LAUNCH(k_kkt, dim3(nodes), dim3(256), 0, h->stream, h->d_xinit, h->d_x, h->d_qp, h->d_vf2, h->d_dx, h->d_ut, N, h->d_kkt, h->d_ginf);
       }
       if (accept) h->seg_backoff_len = 0;
       else { h->seg_backoff_len = std::min(2 * h->seg_backoff_len + 1, 63); h->seg_backoff = h->seg_backoff_len; }
@@ -1588,18 +1611,18 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         int counts[2] = {0, 0};
         for (int r = 0; r < LS_SPECULATIVE && trial < max_trials; ++r, ++trial) {
           HCHECK(hipMemsetAsync(h->d_counts, 0, 2 * sizeof(int), h->stream));
-          hipLaunchKernelGGL(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
-          hipLaunchKernelGGL(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
+          HSQP_LAUNCH(k_ls_decide, dim3((B + 63) / 64), dim3(64), 0, h->stream, lst, h->d_perf_before, h->d_perf_after, B, h->d_ls, h->d_counts);
+          HSQP_LAUNCH(k_ls_retake, dim3(nodes), dim3(64), 0, h->stream, h->d_x, h->d_u, h->d_dx, h->d_du, N, h->d_ls, h->d_xnew, h->d_unew);
           if (cent)
-            hipLaunchKernelGGL(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
+            HSQP_LAUNCH(k_lq_cent2_value, dim3(nodes), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt, N, h->d_misc,
                                (const LsState*)h->d_ls);
           else if (h->value_quad)
-            hipLaunchKernelGGL(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+            HSQP_LAUNCH(k_value_quad, dim3((nodes + QV_NODES * QV_WAVES - 1) / (QV_NODES * QV_WAVES)), dim3(QV_THREADS * QV_WAVES), 0, h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, nodes, h->d_misc, (const LsState*)h->d_ls);
           else
-            hipLaunchKernelGGL(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
+            HSQP_LAUNCH(k_lq<false>, dim3(nodes), dim3(LQV_THREADS), sizeof(LqWST<false>), h->stream, h->d_dm, h->d_xnew, h->d_unew, h->d_par, h->d_dt,
                                N, (double*)nullptr, h->d_misc, (long long*)nullptr, (const LsState*)h->d_ls);
-          hipLaunchKernelGGL(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
+          HSQP_LAUNCH(k_perf_reduce, dim3(B), dim3(64), 0, h->stream, h->d_dm, h->d_misc, 8, h->d_xnew, h->d_par, N, h->d_perf_after,
                              (const LsState*)h->d_ls);
         }
         HCHECK(hipMemcpyAsync(counts, h->d_counts, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
@@ -1831,16 +1854,16 @@ static int run_policy(hsqp_handle* h, int n, bool from_solution, const double* s
   if (rc == HSQP_OK) {
     step(hipFuncSetAttribute((const void*)k_policy_torques, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicyWS)), "hipFuncSetAttribute");
     if (from_solution)
-      hipLaunchKernelGGL(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)h->d_xnew, (const double*)h->d_unew, h->N, h->dt,
+      HSQP_LAUNCH(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)h->d_xnew, (const double*)h->d_unew, h->N, h->dt,
                          h->uniform_grid ? (const double*)nullptr : (const double*)h->d_dt, (const double*)d_in, (const double*)nullptr, (const double*)nullptr, d_x, d_u);
     else
-      hipLaunchKernelGGL(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)nullptr, (const double*)nullptr, 0, 0.0, (const double*)nullptr,
+      HSQP_LAUNCH(k_policy_inputs, dim3(n), dim3(64), 0, h->stream, (const double*)nullptr, (const double*)nullptr, 0, 0.0, (const double*)nullptr,
                          (const double*)nullptr, (const double*)d_in, (const double*)(d_in + (size_t)n * NX), d_x, d_u);
     if (cent) {
-      hipLaunchKernelGGL(k_cent_policy_map, dim3(n), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, n, (const double*)d_x, (const double*)d_u, d_xw, d_uw);
-      hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_xw, (const double*)d_uw, d_tau);
+      HSQP_LAUNCH(k_cent_policy_map, dim3(n), dim3(64), sizeof(CentWST<false>), h->stream, h->d_dm, n, (const double*)d_x, (const double*)d_u, d_xw, d_uw);
+      HSQP_LAUNCH(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_xw, (const double*)d_uw, d_tau);
     } else {
-      hipLaunchKernelGGL(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_x, (const double*)d_u, d_tau);
+      HSQP_LAUNCH(k_policy_torques, dim3(n), dim3(128), sizeof(PolicyWS), h->stream, h->d_dm, (const double*)d_x, (const double*)d_u, d_tau);
     }
     step(hipGetLastError(), "k_policy");
   }

@@ -66,6 +66,7 @@ HSQP_HD const double* fact_va_row(const double* q, int k) { return k < 12 ? q + 
 HSQP_HD const double* fact_vb_row(const double* q, int k) { return k < 12 ? q + QP_B + fact_base_row(k) * NUT : q + QP_PU + k * NUT; }
 
 constexpr int LDG = NX + 2;                     // [G (58) | g] -> [K | k]: the block the elimination reads and the gains land in
+constexpr int LDA = NX + 1;                     // SA carries one more column: sb (the W' tiles of the last column tile then form A~^T sb next to W')
 constexpr int FG_GV = NX;                       // column of g (then of k)
 struct RicFWS {
   double VA[2][NF][NX];                        // Vx of this / the next stage (stage k uses VA[k & 1]); the record's rows byte for byte
@@ -75,7 +76,7 @@ struct RicFWS {
     double LinvT[LDB][LDB];                    // host build: (L^-1)^T of the generic elimination (the device's elimination does not form it)
   };
   double S[NX][NX];                            // value function
-  double SA[NX][NX];                           // S A~; its tiles on / above the diagonal are then overwritten with W' = E_J^T SA + Vx^T (F^T SA)
+  double SA[NX][LDA];                          // [S A~ | sb]; its tiles on / above the diagonal are then overwritten with W' = E_J^T SA + Vx^T (F^T SA)
   double FS[NF][NX];                           // F^T S
   double VB[NF][LDB];                          // Vu (column 23 unused, zero)
   union {
@@ -179,6 +180,10 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     else if (i < NX * NX + NX + 1 + LDB * LDB) { const int t = i - NX * NX - NX - 1; w.LinvT[t / LDB][t % LDB] = 0.0; }
     else w.VB[i - (NX * NX + NX + 1 + LDB * LDB)][NUT] = 0.0;
   }
+  // Row NUT of Zs is the Y operand of the last contraction step's fourth lane group in Ph4 (X is zero there): it has to be FINITE.  Its first columns
+  // lie over SB's last row (rewritten with finite values every stage), the rest is beyond SB and written by nobody — whatever the previous kernel
+  // left in LDS, NaN bit patterns included (an intermittent "not positive definite" on the device until this was zeroed)
+  WG_FOR(ctx, i, LDZ) w.Zs[NUT][i] = 0.0;
   WG_SYNC(ctx);
   if (vf) {
     WG_FOR(ctx, i, VF_SIZE) vf[(size_t)N * VF_SIZE + i] = i < NX * NX ? w.S[i / NX][i % NX] : w.part[4 * (i - NX * NX)];
@@ -207,40 +212,74 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
   // phase's barrier 1 - 2 k cycles AFTER the elimination, whatever they loaded (profiles/r06_ric_experiments.txt).
   constexpr int FM_NPB = 8, FM_NVB = NF * NUT;
   static_assert(128 * FM_NPB >= FM_NVB + 2 * NX + NUT, "one pass of the two memory waves");
-  int fm_src[FM_NPB], fm_dst[FM_NPB];     // source offset (doubles, from the next stage's record), LDS destination (doubles, from &w.VA[0][0][0]; -1: none)
-  // the S-update tiles this wave forms in Ph4 (waves 0 .. 3), per tile: Q~ fetch offset (from the stage's record; rows + 4 r are 4 NX further), operand
-  // offsets into Zs (steps + 4 s are 4 LDZ further), offset of the tile's element in SA / S, of its mirror image in S, and which of its four elements
-  // are stored (bit r)
-  int fs_q[3], fs_zx[3], fs_zy[3], fs_w[3], fs_m[3], fs_mask[3];
+  // ONE table of 25 integers per lane, overlaid by role (a wave's role never changes, and the registers are allotted to the kernel, not to a role):
+  //   waves 0 .. 3 (S tiles of Ph4; three tiles t):  FS_Q(t) Q~ fetch offset (from the stage's record; rows + 4 r are 4 NX further), FS_ZX / FS_ZY(t) operand offsets into Zs
+  //     (steps + 4 s are 4 LDZ further), FS_W(t) offset of the tile's element in SA / S, FS_M(t) of its mirror image in S (z lane: the first of its rows), FS_MASK(t) which of
+  //     its four elements are stored (bit r; bits 4 + r: the lane's column is z and row r exists — the new s leaves through it)
+  //   waves 4 .. 7 (K tiles of Ph4, column tile wv - 4, both row tiles t):  FK_X(t) operand offset into Ef (L^-1), FK_Y into Zs, FK_PG(t) / FK_RK(t) offsets of the tile's element
+  //     in PG and in the gains record (rows + 4 r: 4 LDG / 4 NX further), FK_MASK(t) which elements exist (bit r; bit 4 + r: also in the record)
+  //   waves 4, 5 (the memory waves of Ph3):  FM_SRC(t) source offset (doubles, from the next stage's record), FM_DST(t) LDS destination (doubles, from &w.VA[0][0][0]; -1: none)
+  int ftab[25];
+#define FS_Q(t) ftab[(t)]
+#define FS_ZX(t) ftab[3 + (t)]
+#define FS_ZY(t) ftab[6 + (t)]
+#define FS_W(t) ftab[9 + (t)]
+#define FS_M(t) ftab[12 + (t)]
+#define FS_MASK(t) ftab[15 + (t)]
+#define FK_X(t) ftab[(t)]
+#define FK_Y ftab[2]
+#define FK_PG(t) ftab[3 + (t)]
+#define FK_RK(t) ftab[5 + (t)]
+#define FK_MASK(t) ftab[7 + (t)]
+#define FM_SRC(t) ftab[9 + (t)]
+#define FM_DST(t) ftab[17 + (t)]
   int f_sfirst, f_scount;
   {
     const int tid0 = ctx_outer.tid, wv0 = tid0 >> 6, lane0 = tid0 & 63, li0 = lane0 & 15, kk0 = lane0 >> 4, pt = tid0 - 256;
     double* const lbase = &w.VA[0][0][0];
 #pragma unroll
-    for (int t = 0; t < FM_NPB; ++t) {
-      const int idx = pt + 128 * t;
-      int so = 0, dd = -1;
-      if (idx >= 0 && idx < FM_NVB) { const int kf = idx / NUT, c = idx - kf * NUT; so = (int)(fact_vb_row(qp, kf) - qp) + c; dd = (int)(&w.VB[kf][c] - lbase); }
-      else if (idx >= FM_NVB && idx < FM_NVB + NX) { so = QP_BV + idx - FM_NVB; dd = (int)(&w.bt[idx - FM_NVB] - lbase); }
-      else if (idx >= FM_NVB + NX && idx < FM_NVB + 2 * NX) { so = QP_SIZE + QP_QV + idx - FM_NVB - NX; dd = (int)(&w.dx[idx - FM_NVB - NX] - lbase); }
-      else if (idx >= FM_NVB + 2 * NX && idx < FM_NVB + 2 * NX + NUT) { so = QP_RV + idx - FM_NVB - 2 * NX; dd = (int)(&w.kv[idx - FM_NVB - 2 * NX] - lbase); }
-      fm_src[t] = so; fm_dst[t] = dd;
-    }
+    for (int i = 0; i < 25; ++i) ftab[i] = 0;
     // Ph4 per SIMD: ONE wave forms S tiles (ids 0 .. 9 of the upper triangle, row by row: waves 0, 2 three each, waves 1, 3 two each — wave 1 carries the
-    // larger share of the elimination), the other one (waves 4 .. 7) two K tiles and a quarter of the vector items
+    // larger share of the elimination), the other one (waves 4 .. 7) two K tiles
     f_sfirst = wv0 == 0 ? 0 : (wv0 == 1 ? 3 : (wv0 == 2 ? 5 : 8)); f_scount = wv0 >= 4 ? 0 : ((wv0 & 1) ? 2 : 3);
+    if (wv0 < 4) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
-      const int c = 16 * tc + li0, cc = c < NX ? c : NX - 1, rr = 16 * tr + li0 < NX ? 16 * tr + li0 : NX - 1, row0 = 16 * tr + kk0;
-      fs_q[t] = QP_Q + row0 * NX + cc;          // (rows beyond the matrix — the last tile row — address valid memory of the record; their values are never stored)
-      fs_zx[t] = kk0 * LDZ + rr;
-      fs_zy[t] = kk0 * LDZ + cc;
-      fs_w[t] = row0 * NX + cc;
-      fs_m[t] = cc * NX + row0;
-      int mask = 0;
-      for (int r = 0; r < 4; ++r) { const int row = row0 + 4 * r; if (t < f_scount && c < NX && row < NX && (tr != tc || row <= c)) mask |= 1 << r; }
-      fs_mask[t] = mask;
+      for (int t = 0; t < 3; ++t) {
+        const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
+        const int c = 16 * tc + li0, cc = c < NX ? c : NX - 1, rr = 16 * tr + li0 < NX ? 16 * tr + li0 : NX - 1, row0 = 16 * tr + kk0;
+        const bool zl = c == NX && t < f_scount;  // the lane whose column is z (column NX of [Z | z]): its accumulators are (Z^T z)[rows] — the new s leaves through it
+        FS_Q(t) = QP_Q + row0 * NX + cc;          // (rows beyond the matrix — the last tile row — address valid memory of the record; their values are never stored)
+        FS_ZX(t) = kk0 * LDZ + rr;
+        FS_ZY(t) = kk0 * LDZ + (c <= NX ? c : NX - 1);
+        FS_W(t) = row0 * NX + cc;
+        FS_M(t) = zl ? row0 : cc * NX + row0;
+        int mask = 0;
+        for (int r = 0; r < 4; ++r) { const int row = row0 + 4 * r; if (t < f_scount && c < NX && row < NX && (tr != tc || row <= c)) mask |= 1 << r; if (zl && row < NX) mask |= 16 << r; }
+        FS_MASK(t) = mask;
+      }
+    } else {
+      const int ct = wv0 - 4, c = 16 * ct + li0, cz = c <= NX ? c : NX;
+      FK_Y = kk0 * LDZ + cz;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rr = 16 * t + li0 < NUT ? 16 * t + li0 : NUT - 1, row0 = 16 * t + kk0;
+        FK_X(t) = kk0 * LDF + EF_MI + rr;
+        FK_PG(t) = row0 * LDG + cz;
+        FK_RK(t) = RIC_K + row0 * NX + (c < NX ? c : NX - 1);
+        int mask = 0;
+        for (int r = 0; r < 4; ++r) { const int row = row0 + 4 * r; if (row < NUT && c <= NX) mask |= (1 << r) | (c < NX ? 16 << r : 0); }
+        FK_MASK(t) = mask;
+      }
+#pragma unroll
+      for (int t = 0; t < FM_NPB; ++t) {
+        const int idx = pt + 128 * t;
+        int so = 0, dd = -1;
+        if (idx >= 0 && idx < FM_NVB) { const int kf = idx / NUT, c2 = idx - kf * NUT; so = (int)(fact_vb_row(qp, kf) - qp) + c2; dd = (int)(&w.VB[kf][c2] - lbase); }
+        else if (idx >= FM_NVB && idx < FM_NVB + NX) { so = QP_BV + idx - FM_NVB; dd = (int)(&w.bt[idx - FM_NVB] - lbase); }
+        else if (idx >= FM_NVB + NX && idx < FM_NVB + 2 * NX) { so = QP_SIZE + QP_QV + idx - FM_NVB - NX; dd = (int)(&w.dx[idx - FM_NVB - NX] - lbase); }
+        else if (idx >= FM_NVB + 2 * NX && idx < FM_NVB + 2 * NX + NUT) { so = QP_RV + idx - FM_NVB - 2 * NX; dd = (int)(&w.kv[idx - FM_NVB - 2 * NX] - lbase); }
+        FM_SRC(t) = so; FM_DST(t) = dd;
+      }
     }
   }
 #endif
@@ -278,7 +317,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           for (int l = 0; l < LA; ++l) { const int ll = p * LA + l, lc = ll < NX ? ll : NX - 1; const double a = w.S[r][lc], b = w.bt[lc]; sacc += ll < NX ? a * b : 0.0; }
           sacc += quad_perm_f64<0xB1>(sacc);
           sacc += quad_perm_f64<0x4E>(sacc);
-          if (p == 0) { w.sb[r] = sacc; w.SB[r][NUT] = sacc; }
+          if (p == 0) { w.sb[r] = sacc; w.SB[r][NUT] = sacc; w.SA[r][NX] = sacc; }
         } else if (it < 4 * NX + NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + it - 4 * NX] = w.PG[it - 4 * NX][FG_GV];
       }
       const int rt = wv & 3, ct = wv >> 2, r0 = rt << 4, c0 = ct << 4;
@@ -326,8 +365,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     {
       // G: one tile per wave (2 row tiles x 4 column tiles); [Lam | g]: four tiles on waves 4 .. 7 (every SIMD then carries three tiles) — as the
       // second tile of ONE call (a tile call is ~2.5 k cycles whatever it contracts: two calls in a row were the phase's critical path).  No global
-      // load in the phase: P~, R~ arrived in LDS a stage ahead.  Wave 4 first leaves fsb.
-      if (wv == 4 && lane < NFS * 4) w.fsb[lane] = lane < NF ? fact_combo(lane >> 2, lane & 3, w.sb, 1, 0, dt, hq) : 0.0;
+      // load in the phase: P~, R~ arrived in LDS a stage ahead.
       const int grt = wv >> 2, gct = wv & 3, gr0 = grt << 4, gc0 = gct << 4;
       const int gxr = gr0 + li < NUT ? gr0 + li : NUT - 1, gyc = gc0 + li < NX ? gc0 + li : NX - 1, gycp = fact_partner(gyc);
       const int lrt = (wv - 4) >> 1, lct = (wv - 4) & 1, lr0 = lrt << 4, lc0 = lct << 4;                // (waves 4 .. 7 only)
@@ -412,7 +450,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[fs_q[t] + 4 * NX * r];
+        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[FS_Q(t) + 4 * NX * r];
     };
     {
       if (wv < 2) {
@@ -437,15 +475,15 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         double* const lbase = &w.VA[0][0][0];
         if (qn) {
 #pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) pb[t] = ((hsqp_gcptr)qn)[fm_src[t]];
+          for (int t = 0; t < FM_NPB; ++t) pb[t] = ((hsqp_gcptr)qn)[FM_SRC(t)];
 #pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) if (fm_dst[t] >= 0) lbase[fm_dst[t]] = pb[t];
+          for (int t = 0; t < FM_NPB; ++t) if (FM_DST(t) >= 0) lbase[FM_DST(t)] = pb[t];
         } else {
           // the last stage to be processed has no successor: q~ alone (its table entry is relative to the record before this one)
 #pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) { const bool isq = fm_src[t] >= QP_SIZE; pb[t] = ((hsqp_gcptr)q)[isq ? fm_src[t] - QP_SIZE : 0]; }
+          for (int t = 0; t < FM_NPB; ++t) { const bool isq = FM_SRC(t) >= QP_SIZE; pb[t] = ((hsqp_gcptr)q)[isq ? FM_SRC(t) - QP_SIZE : 0]; }
 #pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) if (fm_src[t] >= QP_SIZE) lbase[fm_dst[t]] = pb[t];
+          for (int t = 0; t < FM_NPB; ++t) if (FM_SRC(t) >= QP_SIZE) lbase[FM_DST(t)] = pb[t];
         }
         }
       } else {
@@ -480,7 +518,13 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         if (!(HSQP_EXP & 8)) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
-          auto yf = [&](auto sc, int) { return fact_combo(sc, kk, &w.SA[0][0], NX, yc, dt, hq); };
+          // Column NX of the last column tile is not a column of S A~: it carries sb (as if sb were column NX of SA).  The same tiles then leave
+          // A~^T sb = E_J^T sb + Vx^T (F^T sb) in that column — the vector part of the new s, which rounds 3 - 6 summed by 232 items in Ph4
+          const bool sbl = col == NX;                                   // (lane 10 of every row group of wave 6)
+          const double* ym = &w.SA[0][0];
+          constexpr int yld = LDA;
+          const int ycs = col < NX ? col : NX;
+          auto yf = [&](auto sc, int) { return fact_combo(sc, kk, ym, yld, ycs, dt, hq); };
           auto xf = [&](auto sc, int t) {
             constexpr int s = decltype(sc)::value;
             const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1, r = 16 * t + li;
@@ -492,19 +536,26 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           else if (ct == 2) { hsqp_d4 a3[3] = {acc[0], acc[1], acc[2]}; fact_mfma<3, RIC_PF, NFS>(a3, xf, yf); acc[0] = a3[0]; acc[1] = a3[1]; acc[2] = a3[2]; }
           else fact_mfma<4, RIC_PF, NFS>(acc, xf, yf);
           // (E_J^T SA)[row][col]: row `row` of E_J^T picks row `row` (and row - 29) of SA — unconditional reads of the own column, then the stores
-          double ea[4][4], eb[4][4];
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r, rc = row < NX ? row : NX - 1; ea[t][r] = w.SA[rc][yc]; eb[t][r] = w.SA[fact_partner(rc)][yc]; }
+            for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r, rc = row < NX ? row : NX - 1; acc[t][r] += fact_ej_mix(ym[rc * yld + ycs], ym[fact_partner(rc) * yld + ycs], rc, dt); }
           WV_SYNC();   // every read of the column is done before it is overwritten
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = 16 * t + kk + 4 * r, rc = row < NX ? row : NX - 1;
-              if (t <= ct && col < NX && row < NX) w.SA[row][col] = acc[t][r] + fact_ej_mix(ea[t][r], eb[t][r], rc, dt);
+              const int row = 16 * t + kk + 4 * r;
+              if (t <= ct && col < NX && row < NX) w.SA[row][col] = acc[t][r];
             }
+          // (A~^T sb)[rows] of the sb lanes: picked up by the S tiles of the last column in Ph4.  ONE branch of the wave around all of them (a lane
+          // condition per store was 16 branches on every tile wave: 2.2 k cycles of wave 2's epilogue)
+          if (ct == 3 && sbl) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r; if (row < NX) w.sv[row] = acc[t][r]; }
+          }
         }
         // waves 2, 3 form one S tile each in Ph4: its Q~ is fetched here, behind the wave's last LDS read of the phase (they finish 2 - 3 k cycles
         // before the elimination: the round trip runs under their wait at the barrier)
@@ -525,7 +576,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         const int r = it / NX, c = it % NX;
         if (r > c) continue;
         double sacc = 0.0;
-        for (int kf = 0; kf < NF; ++kf) sacc += VA[kf][r] * fact_combo(kf >> 2, kf & 3, &w.SA[0][0], NX, c, dt, hq);
+        for (int kf = 0; kf < NF; ++kf) sacc += VA[kf][r] * fact_combo(kf >> 2, kf & 3, &w.SA[0][0], LDA, c, dt, hq);
         w.S[r][c] = sacc + fact_ej_mix(w.SA[r][c], w.SA[fact_partner(r)][c], r, dt);
       }
       // elimination of [Lam | I] column by column, the Cholesky scaling, then Z, z as products (the generic form of riccati_backward)
@@ -612,17 +663,21 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           for (int t = 0; t < NT; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
           auto xf = [&](auto sc, int t) {
             constexpr int s = decltype(sc)::value;
-            const double v = lz[fs_zx[t] + 4 * s * LDZ];
+            const double v = lz[FS_ZX(t) + 4 * s * LDZ];
             if constexpr (4 * s + 3 >= NUT) return 4 * s + kk < NUT ? v : 0.0; else return v;
           };
-          auto yf = [&](auto sc, int t) { constexpr int s = decltype(sc)::value; return lz[fs_zy[t] + 4 * s * LDZ]; };
+          auto yf = [&](auto sc, int t) { constexpr int s = decltype(sc)::value; return lz[FS_ZY(t) + 4 * s * LDZ]; };
           double wp[NT][4];
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wp[t][r] = lsa[fs_w[t] + 4 * NX * r];
+            for (int r = 0; r < 4; ++r) wp[t][r] = lsa[FS_W(t) + (16 * fact_sym_tr(sfirst + t) + kk) * (LDA - NX) + 4 * LDA * r];   // (SA's rows are LDA apart, S's NX)
           PH_LAP(ctx, HSQP_LAP_WAVE, 21);
           fact_mfma<NT, RIC_PF, NSZ>(acc, xf, yf);
+          // (the z lane's addresses are formed HERE: left to the compiler they are formed in front of the stage loop, one register per element — a spill)
+          int fm[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { fm[t] = FS_M(t); asm volatile("" : "+v"(fm[t])); }
           PH_LAP(ctx, HSQP_LAP_WAVE, 22);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -631,17 +686,49 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
               const double v = (wp[t][r] + qpre[t][r]) - acc[t][r];
               // tiles above the diagonal: stored and mirrored; diagonal tiles: the elements on / above the diagonal, each also at its mirrored
               // place, so that S is symmetric to the bit (which elements: the mask formed in front of the stage loop)
-              if ((fs_mask[t] >> r) & 1) { ls[fs_w[t] + 4 * NX * r] = v; ls[fs_m[t] + 4 * r] = v; }
+              if ((FS_MASK(t) >> r) & 1) { ls[FS_W(t) + 4 * NX * r] = v; ls[fm[t] + 4 * r] = v; }
+            }
+          // the new s = q~ + A~^T sb - Z^T z from the lane whose column is z (tiles of the last column: every row tile has one): A~^T sb from Ph3 (sv),
+          // q~ staged by the memory waves (dx); it travels in the first of the four partial-sum slots.  One branch of the wave and one of the lane
+          // per TILE, the reads unconditional inside (a lane branch per element is a dependent LDS round trip each)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (fact_sym_tc(sfirst + t) == 3 && (FS_MASK(t) >> 4)) {
+              double sa[4], sq[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const int row = ((FS_MASK(t) >> (4 + r)) & 1) ? fm[t] + 4 * r : fm[t]; sa[r] = w.sv[row]; sq[r] = w.dx[row]; }
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if ((FS_MASK(t) >> (4 + r)) & 1) w.part[4 * (fm[t] + 4 * r)] = (sa[r] + sq[r]) - acc[t][r];
             }
         };
         if (scount == 3) run(std::integral_constant<int, 3>{});
         else run(std::integral_constant<int, 2>{});
         PH_LAP(ctx, HSQP_LAP_WAVE, 23);
       } else {
-        // waves 4 .. 7: a quarter of the vector items (all 64 lanes), then [K | k] = -L^-T [Z | z]: two of the eight tiles each, one call
-        { const int it = (wv - 4) * 64 + lane; if (it < 4 * NX) s_item(it); }
+        // waves 4 .. 7: [K | k] = -L^-T [Z | z], two of the eight tiles each, one call (the vector items of the new s are gone: it leaves through the S tiles)
         PH_LAP(ctx, HSQP_LAP_WAVE, 20);
-        ric_products_ranked(ctx, wv - 4, 4, jk);
+        {
+          const double* lz = &w.Zs[0][0];
+          const double* le = &w.Ef[0][0];
+          double* lpg = &w.PG[0][0];
+          hsqp_d4 acc[2] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}, hsqp_d4{0.0, 0.0, 0.0, 0.0}};
+          auto xf = [&](auto sc, int t) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (4 * s + 3 >= NUT) { const double v = le[FK_X(t) + (4 * s + kk < NUT ? 4 * s : 4 * s - 1) * LDF]; return 4 * s + kk < NUT ? v : 0.0; }
+            else return le[FK_X(t) + 4 * s * LDF];
+          };
+          auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; return lz[FK_Y + 4 * s * LDZ]; };
+          fact_mfma<2, RIC_PF, NSZ>(acc, xf, yf);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double v = -acc[t][r];
+              if ((FK_MASK(t) >> r) & 1) lpg[FK_PG(t) + 4 * LDG * r] = v;                       // (k in column NX: picked up by the next stage's Ph1)
+              if ((FK_MASK(t) >> (4 + r)) & 1) ((hsqp_gptr)rk)[FK_RK(t) + 4 * NX * r] = v;
+            }
+        }
         PH_LAP(ctx, HSQP_LAP_WAVE, 23);
       }
 #else
