@@ -15,12 +15,14 @@
 // upper-triangle tiles of S A~ once the column is consumed).  The stage (eight waves; per SIMD the waves w and w + 4):
 //   Ph1  S B~ = (F^T S)^T Vu  (8 tiles x 9 steps, one per wave; the combinations F^T S are KEPT: FS),  sb = s + S b~  (vector items, waves 4 .. 7)
 //   Ph2  G = P~ + SB^T E_J + (F^T SB)^T Vx  (8 tiles),  [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb])  (4 tiles, second tile of waves 4 .. 7's call);
-//        P~, R~, r~ from LDS: no global load in the phase
+//        P~, R~, r~ from LDS: no global load in the phase.  Waves 0 .. 3, one tile short of the others, form the first row tile of S A~ (HSQP_SA_EARLY)
 //   Ph3  waves 0, 1: blocked elimination of [Lam | I | G | g] (hsqp_elim.h, unchanged); wave 0's hook issues every asynchronous copy of the next
-//        stage (Vx, P~, R~) and both fetch Q~ of their S tiles into registers  ||  waves 2, 3, 6, 7: S A~, then W'  ||  waves 4, 5: the next stage's
-//        Vu, b~, r~ and this stage's q~ through address tables formed once in front of the stage loop
-//   Ph4  waves 0 .. 3: S = Q~ + W' - Z^T Z  (six 23-deep steps; 3 / 2 / 3 / 2 tiles, Q~ from registers);  waves 4 .. 7: two tiles each of
-//        [K | k] = -L^-T [Z | z] and a quarter of the vector items  s = q~ + E_J^T sb + Vx^T (F^T sb) - Z^T z
+//        stage (Vx, P~, R~) and both fetch Q~ of their S tiles into registers  ||  waves 2, 3, 6, 7: the other three row tiles of S A~, then W' — whose
+//        last column tile carries sb as column NX of S A~ and leaves A~^T sb there  ||  waves 4, 5: the next stage's Vu, b~, r~ through address
+//        tables formed once in front of the stage loop
+//   Ph4  waves 0 .. 3: S = Q~ + W' - Z^T Z  (six 23-deep steps; 3 / 2 / 3 / 2 tiles, Q~ from registers) — the lane whose column is z forms the new
+//        s = (A~^T sb + q~) - Z^T z by the same expression (A~^T sb through the W' fetch, q~ through the Q~ fetch);  waves 4 .. 7: two tiles each of
+//        [K | k] = -L^-T [Z | z]
 // i.e. 633 matrix instructions per stage against 909 (1.56 x the algorithmic count instead of 2.24 x), the two 58-deep phases gone
 // from the serial path, and per stage 35 x 81 + 58 numbers of dynamics read instead of 58 x 82.  The forward sweep applies the factors
 // as well (34 instead of 48 KB per stage) and hands rows 12 .. 34 of Px dx + Pu ut to the step kernel.  The centroidal formulation (35 states:
@@ -32,6 +34,9 @@
 #define HSQP_LAP_WAVE 4   /* -DHSQP_PHASE_PROFILE builds: the wave whose Ph4 is split into laps (slots 20 .. 25) */
 #endif
 #ifndef HSQP_EXP
+#ifndef HSQP_SA_EARLY
+#define HSQP_SA_EARLY 1   /* the first row tile of SA on waves 0 .. 3 in Ph2 (0: all of SA in Ph3; A/B builds) */
+#endif
 #define HSQP_EXP 0   /* timing experiments of tuning builds (WRONG results): bit 0 memory waves without trailing copies / Q~, 1 no Vx copy, 2 memory waves idle, 3 no W' tiles, 4 no hook; (correct results:) 5 no s_setprio */
 #endif
 
@@ -210,12 +215,13 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
   // (see below), so everything derived from it is recomputed per stage — for these waves that was ~400 vector instructions of index arithmetic per
   // stage, issued in the gaps the eliminating wave of the same SIMD leaves (it is older and nearly always ready): the memory waves reached the
   // phase's barrier 1 - 2 k cycles AFTER the elimination, whatever they loaded (profiles/r06_ric_experiments.txt).
-  constexpr int FM_NPB = 8, FM_NVB = NF * NUT;
-  static_assert(128 * FM_NPB >= FM_NVB + 2 * NX + NUT, "one pass of the two memory waves");
+  constexpr int FM_NPB = 7, FM_NVB = NF * NUT;
+  static_assert(128 * FM_NPB >= FM_NVB + NX + NUT, "one pass of the two memory waves");
   // ONE table of 25 integers per lane, overlaid by role (a wave's role never changes, and the registers are allotted to the kernel, not to a role):
   //   waves 0 .. 3 (S tiles of Ph4; three tiles t):  FS_Q(t) Q~ fetch offset (from the stage's record; rows + 4 r are 4 NX further), FS_ZX / FS_ZY(t) operand offsets into Zs
   //     (steps + 4 s are 4 LDZ further), FS_W(t) offset of the tile's element in SA / S, FS_M(t) of its mirror image in S (z lane: the first of its rows), FS_MASK(t) which of
-  //     its four elements are stored (bit r; bits 4 + r: the lane's column is z and row r exists — the new s leaves through it)
+  //     its four elements are stored (bit r; bits 4 + r: the lane's column is z and row r exists — the new s leaves through it; bit 8: z lane — its FS_Q is q~, rows 4 apart,
+  //     its FS_W column NX of SA, where Ph3 left A~^T sb)
   //   waves 4 .. 7 (K tiles of Ph4, column tile wv - 4, both row tiles t):  FK_X(t) operand offset into Ef (L^-1), FK_Y into Zs, FK_PG(t) / FK_RK(t) offsets of the tile's element
   //     in PG and in the gains record (rows + 4 r: 4 LDG / 4 NX further), FK_MASK(t) which elements exist (bit r; bit 4 + r: also in the record)
   //   waves 4, 5 (the memory waves of Ph3):  FM_SRC(t) source offset (doubles, from the next stage's record), FM_DST(t) LDS destination (doubles, from &w.VA[0][0][0]; -1: none)
@@ -248,13 +254,14 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         const int id = t < f_scount ? f_sfirst + t : f_sfirst, tr = fact_sym_tr(id), tc = fact_sym_tc(id);
         const int c = 16 * tc + li0, cc = c < NX ? c : NX - 1, rr = 16 * tr + li0 < NX ? 16 * tr + li0 : NX - 1, row0 = 16 * tr + kk0;
         const bool zl = c == NX && t < f_scount;  // the lane whose column is z (column NX of [Z | z]): its accumulators are (Z^T z)[rows] — the new s leaves through it
-        FS_Q(t) = QP_Q + row0 * NX + cc;          // (rows beyond the matrix — the last tile row — address valid memory of the record; their values are never stored)
+        FS_Q(t) = zl ? QP_QV + row0 : QP_Q + row0 * NX + cc;   // (rows beyond the matrix — the last tile row — address valid memory of the record; their values are never stored; z lane: q~, rows 4 apart)
         FS_ZX(t) = kk0 * LDZ + rr;
         FS_ZY(t) = kk0 * LDZ + (c <= NX ? c : NX - 1);
-        FS_W(t) = row0 * NX + cc;
+        FS_W(t) = row0 * NX + (zl ? NX : cc);     // (z lane: column NX of SA — A~^T sb, left there by Ph3; it stores nothing through this entry)
         FS_M(t) = zl ? row0 : cc * NX + row0;
         int mask = 0;
         for (int r = 0; r < 4; ++r) { const int row = row0 + 4 * r; if (t < f_scount && c < NX && row < NX && (tr != tc || row <= c)) mask |= 1 << r; if (zl && row < NX) mask |= 16 << r; }
+        if (zl) mask |= 256;
         FS_MASK(t) = mask;
       }
     } else {
@@ -276,8 +283,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         int so = 0, dd = -1;
         if (idx >= 0 && idx < FM_NVB) { const int kf = idx / NUT, c2 = idx - kf * NUT; so = (int)(fact_vb_row(qp, kf) - qp) + c2; dd = (int)(&w.VB[kf][c2] - lbase); }
         else if (idx >= FM_NVB && idx < FM_NVB + NX) { so = QP_BV + idx - FM_NVB; dd = (int)(&w.bt[idx - FM_NVB] - lbase); }
-        else if (idx >= FM_NVB + NX && idx < FM_NVB + 2 * NX) { so = QP_SIZE + QP_QV + idx - FM_NVB - NX; dd = (int)(&w.dx[idx - FM_NVB - NX] - lbase); }
-        else if (idx >= FM_NVB + 2 * NX && idx < FM_NVB + 2 * NX + NUT) { so = QP_RV + idx - FM_NVB - 2 * NX; dd = (int)(&w.kv[idx - FM_NVB - 2 * NX] - lbase); }
+        else if (idx >= FM_NVB + NX && idx < FM_NVB + NX + NUT) { so = QP_RV + idx - FM_NVB - NX; dd = (int)(&w.kv[idx - FM_NVB - NX] - lbase); }
         FM_SRC(t) = so; FM_DST(t) = dd;
       }
     }
@@ -360,6 +366,33 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     WG_SYNC(ctx);
     PH_TICK(ctx, 2);
     PH_MARK(ctx);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // SA tiles (rt0 .. rt0 + NT - 1, ct) = FS^T Vx + S E_J: nine 35-deep steps, the E_J term from S's own column (and its partner column) in the epilogue
+    auto sa_tiles = [&](auto ntc, int rt0, int ct) {
+      constexpr int NT = decltype(ntc)::value;
+      const int col = (ct << 4) + li, yc = col < NX ? col : NX - 1, ycp = fact_partner(yc);
+      hsqp_d4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
+      auto xf = [&](auto sc, int t) {
+        constexpr int s = decltype(sc)::value;
+        const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1, r = 16 * (rt0 + t) + li;
+        const double v = w.FS[kc][r < NX ? r : NX - 1];
+        return 4 * s + kk < NF ? v : 0.0;
+      };
+      auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return VA[kc][yc]; };
+      fact_mfma<NT, RIC_PF, NFS>(acc, xf, yf);
+      double ea[NT][4], eb[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * (rt0 + t) + kk + 4 * r, rc = row < NX ? row : NX - 1; ea[t][r] = w.S[rc][yc]; eb[t][r] = w.S[rc][ycp]; }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * (rt0 + t) + kk + 4 * r; if (col < NX && row < NX) w.SA[row][col] = acc[t][r] + fact_ej_mix(ea[t][r], eb[t][r], yc, dt); }
+    };
+#endif
     // ---- Ph2: G = P~ + SB^T E_J + (F^T SB)^T Vx;  [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb]);  fsb = F^T sb
 #if defined(__HIP_DEVICE_COMPILE__)
     {
@@ -413,6 +446,9 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           }
         }
       }
+      // waves 0 .. 3 have one tile in this phase, waves 4 .. 7 two: the first row tile of SA's column tile wv (S, FS, Vx: all there since Ph1) moves
+      // from Ph3 — whose tile waves are 2 k cycles behind the elimination — into the difference
+      else if (HSQP_SA_EARLY) sa_tiles(std::integral_constant<int, 1>{}, 0, wv);
     }
 #else
     WG_FOR(ctx, it, NFS * 4) w.fsb[it] = it < NF ? fact_combo(it >> 2, it & 3, w.sb, 1, 0, dt, hq) : 0.0;
@@ -450,7 +486,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[FS_Q(t) + 4 * NX * r];
+        for (int r = 0; r < 4; ++r) qpre[t][r] = ((hsqp_gcptr)q)[FS_Q(t) + r * ((FS_MASK(t) & 256) ? 4 : 4 * NX)];
     };
     {
       if (wv < 2) {
@@ -469,7 +505,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         __builtin_amdgcn_s_setprio(0);
       } else if ((wv & 3) < 2) {
         if (HSQP_EXP & 4) {} else {
-        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  The next stage's Vu, b~, r~ and this stage's q~ (for Ph4) through the
+        // waves 4, 5 share their SIMDs with the eliminating waves: memory only.  The next stage's Vu, b~, r~ through the
         // address tables: every load in flight before the first store, no index arithmetic in here
         double pb[FM_NPB];
         double* const lbase = &w.VA[0][0][0];
@@ -478,12 +514,6 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           for (int t = 0; t < FM_NPB; ++t) pb[t] = ((hsqp_gcptr)qn)[FM_SRC(t)];
 #pragma unroll
           for (int t = 0; t < FM_NPB; ++t) if (FM_DST(t) >= 0) lbase[FM_DST(t)] = pb[t];
-        } else {
-          // the last stage to be processed has no successor: q~ alone (its table entry is relative to the record before this one)
-#pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) { const bool isq = FM_SRC(t) >= QP_SIZE; pb[t] = ((hsqp_gcptr)q)[isq ? FM_SRC(t) - QP_SIZE : 0]; }
-#pragma unroll
-          for (int t = 0; t < FM_NPB; ++t) if (FM_SRC(t) >= QP_SIZE) lbase[FM_DST(t)] = pb[t];
         }
         }
       } else {
@@ -492,27 +522,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         const int ct = wv == 2 ? 0 : (wv == 6 ? 3 : (wv == 3 ? 1 : 2)), c0 = ct << 4;
         const int col = c0 + li, yc = col < NX ? col : NX - 1, ycp = fact_partner(yc);
         hsqp_d4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = hsqp_d4{0.0, 0.0, 0.0, 0.0};
-        {
-          auto xf = [&](auto sc, int t) {
-            constexpr int s = decltype(sc)::value;
-            const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1, r = 16 * t + li;
-            const double v = w.FS[kc][r < NX ? r : NX - 1];
-            return 4 * s + kk < NF ? v : 0.0;
-          };
-          auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return VA[kc][yc]; };
-          fact_mfma<4, RIC_PF, NFS>(acc, xf, yf);
-          double ea[4][4], eb[4][4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r, rc = row < NX ? row : NX - 1; ea[t][r] = w.S[rc][yc]; eb[t][r] = w.S[rc][ycp]; }
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r; if (col < NX && row < NX) w.SA[row][col] = acc[t][r] + fact_ej_mix(ea[t][r], eb[t][r], yc, dt); }
-        }
+        if (HSQP_SA_EARLY) sa_tiles(std::integral_constant<int, 3>{}, 1, ct);   // (row tile 0 of every column tile: formed in Ph2)
+        else sa_tiles(std::integral_constant<int, 4>{}, 0, ct);
         WV_SYNC();
         // W' tiles (rt <= ct, ct) from the wave's own column of SA; the accumulators wait in registers until the column is consumed
         if (!(HSQP_EXP & 8)) {
@@ -554,7 +565,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r; if (row < NX) w.sv[row] = acc[t][r]; }
+              for (int r = 0; r < 4; ++r) { const int row = 16 * t + kk + 4 * r; if (row < NX) w.SA[row][NX] = acc[t][r]; }
           }
         }
         // waves 2, 3 form one S tile each in Ph4: its Q~ is fetched here, behind the wave's last LDS read of the phase (they finish 2 - 3 k cycles
@@ -634,7 +645,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
     WG_SYNC(ctx);
     PH_TICK(ctx, 4);
     PH_MARK(ctx);
-    // ---- Ph4: S = Q~ + W' - Z^T Z, [K | k] = -L^-T [Z | z] (into the G block and K to the record), s <- q~ + E_J^T sb + Vx^T fsb - Z^T z (four partial sums)
+    // ---- Ph4: S = Q~ + W' - Z^T Z, [K | k] = -L^-T [Z | z] (into the G block and K to the record), s <- q~ + E_J^T sb + Vx^T fsb - Z^T z (host: four partial sums; device: the z lane of the S tiles)
     {
       auto s_item = [&](int it) {
         const int r = it >> 2, p = it & 3;
@@ -688,18 +699,14 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
               // place, so that S is symmetric to the bit (which elements: the mask formed in front of the stage loop)
               if ((FS_MASK(t) >> r) & 1) { ls[FS_W(t) + 4 * NX * r] = v; ls[fm[t] + 4 * r] = v; }
             }
-          // the new s = q~ + A~^T sb - Z^T z from the lane whose column is z (tiles of the last column: every row tile has one): A~^T sb from Ph3 (sv),
-          // q~ staged by the memory waves (dx); it travels in the first of the four partial-sum slots.  One branch of the wave and one of the lane
-          // per TILE, the reads unconditional inside (a lane branch per element is a dependent LDS round trip each)
+          // the new s = (A~^T sb + q~) - Z^T z from the lane whose column is z (tiles of the last column: every row tile has one): the SAME expression as the
+          // matrix elements' — A~^T sb came in through the W' fetch (column NX of SA), q~ through the Q~ fetch; it travels in the first partial-sum slot
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             if (fact_sym_tc(sfirst + t) == 3 && (FS_MASK(t) >> 4)) {
-              double sa[4], sq[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { const int row = ((FS_MASK(t) >> (4 + r)) & 1) ? fm[t] + 4 * r : fm[t]; sa[r] = w.sv[row]; sq[r] = w.dx[row]; }
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if ((FS_MASK(t) >> (4 + r)) & 1) w.part[4 * (fm[t] + 4 * r)] = (sa[r] + sq[r]) - acc[t][r];
+                if ((FS_MASK(t) >> (4 + r)) & 1) w.part[4 * (fm[t] + 4 * r)] = (wp[t][r] + qpre[t][r]) - acc[t][r];
             }
         };
         if (scount == 3) run(std::integral_constant<int, 3>{});
@@ -776,73 +783,102 @@ HSQP_HD void riccati_forward_fact(const Ctx& ctx, RicFWS& w, const double* x_ini
   constexpr int NR1 = 4 * (NF + NUT);            // rows of [Vx | Vu] (NF), then rows of K (NUT), four partial sums each
 #if defined(__HIP_DEVICE_COMPILE__)
   {
-    // item it < NR1 owns row it >> 2 of [Vx; K] (columns p + 4c) and, if it < 4 NF, row it >> 2 of Vu as well; items NR1 .. NR1 + NUT - 1 carry k.
-    // After the quad sum every lane of a factor row's quad holds f: lane p = 0 writes the row's first state (base row, or q_j), lane p = 1 the
-    // second one of a joint row (v_j); each carries the b~ of the state it writes.  The slices travel PF stages ahead (riccati_forward).
+    // Waves 0 .. 3 carry the sweep, the others only meet them at the barriers.  Item it < NR1 owns row it >> 2 of [Vx; K] (columns p + 4c) and, if
+    // it < 4 NF, row it >> 2 of Vu as well.  A K row's first lane adds k and writes ut; after the second quad sum every lane of a factor row's quad
+    // holds f: lane p = 0 writes the row's first state (base row, or q_j), lane p = 1 the second one of a joint row (v_j); each carries the b~ of the
+    // state it writes.  The slices travel PF stages ahead in registers.
+    // EVERY load of a slice is unconditional (lanes without a row, columns beyond a row: a valid address, and the OTHER operand of the product is
+    // zeroed; the fetch index is clamped to the last stage instead of a branch around the fetch; the groups of PF stages run without a test of k):
+    // with a branch anywhere around a load the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0)) before the first use —
+    // the youngest was issued one stage earlier, so every third stage paid a memory round trip (4.1 k cycles per stage against 3.3 k now).
+    // What is left is memory: a stage reads 33 KB; at 256 instances the sweep moves 850 MB in 139 us (6.1 TB/s: the HBM roofline), and a single CU
+    // does not stream faster than ~10.6 B per cycle whatever the request pattern (loader waves writing coalesced lines to LDS slots were tried:
+    // 3.2 k cycles per stage at 32 instances, 3.9 k at 256; without their loads the sweep takes 1.8 k — profiles/r06_ric_experiments.txt).
     constexpr int PF = 3;
     const int it = ctx.tid, row = it >> 2, p = it & 3;
-    const bool rowV = it < 4 * NF, rowK = it >= 4 * NF && it < NR1, isk = it >= NR1 && it < NR1 + NUT;
+    const bool rowV = it < 4 * NF, rowK = it >= 4 * NF && it < NR1;
     const bool joint = rowV && row >= 12;
     const int out_state = !rowV ? 0 : (row < 12 ? fact_base_row(row) : (p == 0 ? row - 6 : row + 23));
     const bool writes = rowV && (p == 0 || (p == 1 && joint));
+    const bool ksum = rowK && p == 0;
+    // where the lane's slices start in stage 0's records, and how far the next stage's are
+    const int krow = rowK ? row - NF : 0, vrow = rowV ? row : 0;
+    const double* a0 = rowK ? ric + RIC_K + krow * NX : fact_va_row(qp, vrow);
+    const double* b0 = fact_vb_row(qp, vrow);
+    const double* s0 = ksum ? ric + RIC_KV + krow : qp + QP_BV + out_state;
+    const size_t astep = rowK ? (size_t)RIC_SIZE : (size_t)QP_SIZE, sstep = ksum ? (size_t)RIC_SIZE : (size_t)QP_SIZE;
+    const bool a_last_ok = p + 4 * (NC - 1) < NX, b_last_ok = p + 4 * (NCB - 1) < NUT;
+    const int ca_last = a_last_ok ? p + 4 * (NC - 1) : p, cb_last = b_last_ok ? p + 4 * (NCB - 1) : p;   // (clamped: column p again)
+    // the two states of dx a joint row's writer combines with f (lanes that write nothing read state 0)
+    const int xa = joint ? (p == 0 ? row - 6 : row + 23) : 0, xb = joint && p == 0 ? row + 23 : 0;
     double a[PF][NC], bq[PF][NCB], sc[PF], dtk[PF];
     auto fetch = [&](int k, double* av, double* bv, double& s1, double& d1) {
-      const double* q = qp + (size_t)k * QP_SIZE;
-      const double* rk = ric + (size_t)k * RIC_SIZE;
-      const double* va = rowV ? fact_va_row(q, row) : rk + RIC_K + (rowK ? row - NF : 0) * NX;
-      const double* vb = fact_vb_row(q, rowV ? row : 0);
+      const double* ap = a0 + (size_t)k * astep;
+      const double* bp = b0 + (size_t)k * QP_SIZE;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; av[c] = (cc < NX && (rowV || rowK)) ? va[cc] : 0.0; }
+      for (int c = 0; c < NC - 1; ++c) av[c] = ap[p + 4 * c];
+      av[NC - 1] = ap[ca_last];
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) { const int cc = p + 4 * c; bv[c] = (rowV && cc < NUT) ? vb[cc] : 0.0; }
-      s1 = writes ? q[QP_BV + out_state] : (isk ? rk[RIC_KV + it - NR1] : 0.0);
+      for (int c = 0; c < NCB - 1; ++c) bv[c] = bp[p + 4 * c];
+      bv[NCB - 1] = bp[cb_last];
+      s1 = s0[(size_t)k * sstep];
       d1 = dts[k];
     };
+    auto stage = [&](int k, double* av, double* bv, double& scu, double& dtu) {
+      const double* dcur = (k & 1) ? w.sv : w.dx;
+      double xv[NC];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) { if (u < N) fetch(u, a[u], bq[u], sc[u], dtk[u]); }
-    for (int k0 = 0; k0 < N; k0 += PF) {
+      for (int c = 0; c < NC - 1; ++c) xv[c] = dcur[p + 4 * c];
+      { const double xl = dcur[ca_last]; xv[NC - 1] = a_last_ok ? xl : 0.0; }
+      const double da = dcur[xa], db = dcur[xb];
+      double s1 = 0.0;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int k = k0 + u;
-        if (k < N) {
-          const double* dcur = (k & 1) ? w.sv : w.dx;
-          double* dnxt = (k & 1) ? w.dx : w.sv;
-          const double dt = dtk[u], hq = 0.5 * dt * dt;
-          double s1 = 0.0;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) { const int cc = p + 4 * c; if (cc < NX) s1 += a[u][c] * dcur[cc]; }
-          if (rowK) {          // row of K: ut_j = k_j + K_j dx
-            double s = s1;
-            s += quad_perm_f64<0xB1>(s);
-            s += quad_perm_f64<0x4E>(s);
-            if (p == 0) w.zv[row - NF] = s;
-          } else if (isk) w.kv[it - NR1] = sc[u];
-          WG_SYNC(ctx);
-          if (ut_out && it < NUT) ut_out[(size_t)k * NUT + it] = w.kv[it] + w.zv[it];
-          {
-            double s = rowV ? s1 : 0.0;
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-              const int j = p + 4 * c, jc = j < NUT ? j : NUT - 1;
-              const double utj = w.kv[jc] + w.zv[jc];
-              s += (rowV && j < NUT) ? bq[u][c] * utj : 0.0;
-            }
-            s += quad_perm_f64<0xB1>(s);
-            s += quad_perm_f64<0x4E>(s);
-            if (writes) {
-              double v;
-              if (!joint) v = s + sc[u];
-              else if (p == 0) v = ((dcur[row - 6] + dt * dcur[row + 23]) + hq * s) + sc[u];
-              else v = (dcur[row + 23] + dt * s) + sc[u];
-              dnxt[out_state] = v;
-              dx_out[(size_t)(k + 1) * NX + out_state] = v;
-              if (fj_out && joint && p == 0) fj_out[(size_t)k * NJ + row - 12] = s;
-            }
-          }
-          if (k + PF < N) fetch(k + PF, a[u], bq[u], sc[u], dtk[u]);
-          WG_SYNC(ctx);
-        }
+      for (int c = 0; c < NC; ++c) s1 += av[c] * xv[c];
+      double sk = s1;
+      sk += quad_perm_f64<0xB1>(sk);
+      sk += quad_perm_f64<0x4E>(sk);
+      if (ksum) {          // row of K: ut_j = k_j + K_j dx
+        const double ut = scu + sk;
+        w.zv[krow] = ut;
+        if (ut_out) ut_out[(size_t)k * NUT + krow] = ut;
       }
+      WG_SYNC(ctx);
+      double* dnxt = (k & 1) ? w.dx : w.sv;
+      const double dt = dtu, hq = 0.5 * dt * dt;
+      double uv[NCB];
+#pragma unroll
+      for (int c = 0; c < NCB - 1; ++c) uv[c] = w.zv[p + 4 * c];
+      { const double ul = w.zv[cb_last]; uv[NCB - 1] = b_last_ok ? ul : 0.0; }
+      double s = s1;
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) s += bv[c] * uv[c];
+      s += quad_perm_f64<0xB1>(s);
+      s += quad_perm_f64<0x4E>(s);
+      if (writes) {
+        double v;
+        if (!joint) v = s + scu;
+        else if (p == 0) v = ((da + dt * db) + hq * s) + scu;
+        else v = (da + dt * s) + scu;
+        dnxt[out_state] = v;
+        dx_out[(size_t)(k + 1) * NX + out_state] = v;
+        if (fj_out && joint && p == 0) fj_out[(size_t)k * NJ + row - 12] = s;
+      }
+      fetch(k + PF < N ? k + PF : N - 1, av, bv, scu, dtu);
+      WG_SYNC(ctx);
+    };
+    if (it < 256) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) fetch(u < N ? u : N - 1, a[u], bq[u], sc[u], dtk[u]);
+      int k0 = 0;
+      for (; k0 + PF <= N; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) stage(k0 + u, a[u], bq[u], sc[u], dtk[u]);
+      }
+      // (N % PF stages left: their slices sit in sets 0, 1)
+      if (k0 < N) stage(k0, a[0], bq[0], sc[0], dtk[0]);
+      if (k0 + 1 < N) stage(k0 + 1, a[1], bq[1], sc[1], dtk[1]);
+    } else {
+      for (int k = 0; k < N; ++k) { WG_SYNC(ctx); WG_SYNC(ctx); }
     }
     return;
   }
