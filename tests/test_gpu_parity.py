@@ -858,7 +858,7 @@ def _poisoned_and_clean(model, make, **solver_kw):
     return outs
 
 
-@pytest.mark.parametrize("form", ["serial", "limb_lanes", "linesearch", "parallel", "segmented"])
+@pytest.mark.parametrize("form", ["serial", "dense_stage", "limb_lanes", "linesearch", "parallel", "segmented"])
 def test_no_kernel_reads_lds_it_did_not_write(model, form):
     """LDS keeps what the previous kernel left in it.  A kernel that reads a word it never wrote — the padding row of an operand that is `multiplied
     by zero`, the tail of a union — works until the leftover is a NaN: the serial sweep's Ph4 did exactly that (row NUT of Zs beyond SB's storage)
@@ -868,6 +868,9 @@ def test_no_kernel_reads_lds_it_did_not_write(model, form):
     env = None
     if form == "limb_lanes":
         env = "HSQP_LQ_LIMB_FORM"
+    elif form == "dense_stage":
+        env = "HSQP_RICCATI_DENSE"
+        kw["riccati"] = "serial"
     elif form == "linesearch":
         kw["linesearch"] = True
     elif form in ("parallel", "segmented"):

@@ -6,6 +6,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "wb_humanoid_mpc_amd", "csrc", "hsqp_capi.hip")
+LAUNCH = r"(?:hipLaunchKernelGGL|HSQP_LAUNCH)\("   # HSQP_LAUNCH: hipLaunchKernelGGL behind the LDS-poisoning test aid (same arguments)
 
 
 def _kernels():
@@ -32,9 +33,9 @@ def test_constant_workgroup_sizes_match_the_launches():
     constant = {k: v for k, v in kernels.items() if "blockDim" not in v[0]}
     assert {"k_riccati", "k_project", "k_scan_combine", "k_lq_chain", "k_lq_limb", "k_lq_rows", "k_value_quad"} <= set(constant)
     for name, (size, bounds) in constant.items():
-        launches = re.findall(r"hipLaunchKernelGGL\(" + name + r"(?:<[^>]*>)?,\s*dim3\((?:[^;]*?)\),\s*dim3\(([^)]*)\)", src)
-        # launches through dim3 variables: `const dim3 qblock(EXPR);` ... hipLaunchKernelGGL(k, qgrid, qblock, ...)
-        for var in re.findall(r"hipLaunchKernelGGL\(" + name + r"(?:<[^>]*>)?,\s*\w+,\s*(\w+),", src):
+        launches = re.findall(LAUNCH + name + r"(?:<[^>]*>)?,\s*dim3\((?:[^;]*?)\),\s*dim3\(([^)]*)\)", src)
+        # launches through dim3 variables: `const dim3 qblock(EXPR);` ... HSQP_LAUNCH(k, qgrid, qblock, ...)
+        for var in re.findall(LAUNCH + name + r"(?:<[^>]*>)?,\s*\w+,\s*(\w+),", src):
             decl = re.search(r"dim3 (?:\w+\([^;]*\),\s*)?" + var + r"\(([^;]*?)\);", src)
             assert decl, (name, var)
             launches.append(decl.group(1))
