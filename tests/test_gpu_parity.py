@@ -345,13 +345,14 @@ def test_config3_exactly_against_the_oracle(model, oracle, riccati):
     assert fallbacks in ((0,) if riccati == "serial" else (0, 1)), fallbacks
 
 
-@pytest.mark.parametrize("B,N,gait", [(3, 40, "walk"), (33, 100, "run")])
+@pytest.mark.parametrize("B,N,gait", [(3, 40, "walk"), (33, 100, "run"), (2, 1, "walk"), (2, 2, "walk"), (2, 3, "run"), (2, 5, "walk"), (2, 6, "run"), (2, 7, "walk")])
 def test_factored_serial_sweep_equals_the_dense_stage_on_the_device(model, B, N, gait):
     """k_riccati_fact (csrc/hsqp_riccati_fact.h: the whole-body serial sweep on the factors of [A~ | B~], what every whole-body handle runs) against
     the dense stage k_riccati<58> (HSQP_RICCATI_DENSE in the environment at hsqp_create) on the same device, same inputs: the same minimiser to
     1e-9 of the step's scale (the yardstick of the randomly perturbed population, tests/tolerances.py: two correct f64 sweeps of the ill-conditioned
     run-gait QPs — |step| 1e3 — differ by 1.5e-10 of scale; on the walk problems by 1e-11), and bit-identical whether or not the joint rows of A~ / B~ are written (with the KKT report k_project writes them,
-    without it does not: the factored sweep may not read them)."""
+    without it does not: the factored sweep may not read them).  The short horizons cover the roll-out's groups of three stages (N % 3 = 0, 1, 2; fewer stages than
+    register sets) and the backward sweep without a successor stage."""
     from wb_humanoid_mpc_amd.solver import HipSqpSolver
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=gait, perturb=True, seed=77)
     outs = {}
