@@ -34,6 +34,9 @@
 #define HSQP_LAP_WAVE 4   /* -DHSQP_PHASE_PROFILE builds: the wave whose Ph4 is split into laps (slots 20 .. 25) */
 #endif
 #ifndef HSQP_EXP
+#ifndef HSQP_PH1_NT2
+#define HSQP_PH1_NT2 1    /* Ph1: the two column tiles of a row tile of S B~ in one call on waves 0 .. 3 (0: one tile per wave; A/B builds) */
+#endif
 #ifndef HSQP_SA_EARLY
 #define HSQP_SA_EARLY 1   /* the first row tile of SA on waves 0 .. 3 in Ph2 (0: all of SA in Ph3; A/B builds) */
 #endif
@@ -131,6 +134,32 @@ __attribute__((always_inline)) HSQP_D void fact_mfma(hsqp_d4 (&acc)[NT], XF xf, 
       constexpr std::integral_constant<int, s + PF> nx{};
 #pragma unroll
       for (int t = 0; t < NT; ++t) { pa[u][t] = xf(nx, t); pb[u][t] = yf(nx, t); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// The same with ONE A operand for all NT tiles (tiles of one row tile: xf(step) is fetched — and, where it is a combination of rows, formed — once)
+template <int NT, int PF, int NS, class XF, class YF>
+__attribute__((always_inline)) HSQP_D void fact_mfma_sx(hsqp_d4 (&acc)[NT], XF xf, YF yf) {
+  double pa[PF], pb[PF][NT];
+  static_for<PF>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u < NS) {
+      pa[u] = xf(uc);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pb[u][t] = yf(uc, t);
+    }
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<NS>([&](auto sc) {
+    constexpr int s = decltype(sc)::value, u = s % PF;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u], pb[u][t], acc[t], 0, 0, 0);
+    if constexpr (s + PF < NS) {
+      constexpr std::integral_constant<int, s + PF> nx{};
+      pa[u] = xf(nx);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pb[u][t] = yf(nx, t);
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -326,6 +355,31 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
           if (p == 0) { w.sb[r] = sacc; w.SB[r][NUT] = sacc; w.SA[r][NX] = sacc; }
         } else if (it < 4 * NX + NUT && k < N - 1) ric[(size_t)(k + 1) * RIC_SIZE + RIC_KV + it - 4 * NX] = w.PG[it - 4 * NX][FG_GV];
       }
+      if (HSQP_PH1_NT2) {
+        // waves 0 .. 3: BOTH column tiles of row tile wv in one call — the A operand (a combination of rows of S: two or three LDS reads and two
+        // multiply-adds per element) is formed once for the two tiles instead of once per tile on two waves of the same SIMD
+        if (wv < 4) {
+          const int r0 = wv << 4, xr = r0 + li < NX ? r0 + li : NX - 1;
+          hsqp_d4 acc[2] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}, hsqp_d4{0.0, 0.0, 0.0, 0.0}};
+          auto xf = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            double v = fact_combo(sc, kk, &w.S[0][0], NX, xr, dt, hq);
+            if (4 * s + 3 >= NF) v = 4 * s + kk < NF ? v : 0.0;
+            if (r0 + li < NX && 4 * s + kk < NF) w.FS[4 * s + kk][xr] = v;
+            return v;
+          };
+          auto yf = [&](auto sc, int t) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return w.VB[kc][16 * t + li < LDB ? 16 * t + li : LDB - 1]; };
+          fact_mfma_sx<2, RIC_PF, NFS>(acc, xf, yf);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int col = 16 * t + li;
+            if (col < NUT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r; if (row < NX) w.SB[row][col] = acc[t][r]; }
+            }
+          }
+        }
+      } else {
       const int rt = wv & 3, ct = wv >> 2, r0 = rt << 4, c0 = ct << 4;
       const int xr = r0 + li < NX ? r0 + li : NX - 1, yc = c0 + li < LDB ? c0 + li : LDB - 1;
       hsqp_d4 acc[1] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}};
@@ -342,6 +396,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
       if (col < NUT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int row = r0 + kk + 4 * r; if (row < NX) w.SB[row][col] = acc[0][r]; }
+      }
       }
     }
 #else
