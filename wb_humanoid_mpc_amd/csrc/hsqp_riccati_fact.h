@@ -9,11 +9,12 @@
 // So every product of the stage with A~ or B~ is a product with F^T (a row COMBINATION: copy a base row, or hq * row q_j + dt * row v_j,
 // formed while the operand is fetched) and a 35-deep contraction with V — nine 16 x 16 x 4 steps instead of fifteen — plus an E_J term
 // that is a shifted copy added in the tile epilogue.  What that buys is not the flops as such (a phase of the stage is overhead-bound)
-// but a different SCHEDULE: S A~ and W' = A~^T S A~ together are 117 matrix instructions per SIMD instead of 195 and run UNDER the
+// but a different SCHEDULE: S A~ and W' = A~^T S A~ together are 117 matrix instructions per SIMD instead of 195 and run (all but a quarter of S A~) UNDER the
 // elimination on the two SIMDs it leaves free, with no synchronisation between the four waves that form them: a wave owns one column
 // tile of S A~ (four tiles) and forms, from it alone, the tiles of W' in that column (accumulators in registers, written over the
 // upper-triangle tiles of S A~ once the column is consumed).  The stage (eight waves; per SIMD the waves w and w + 4):
-//   Ph1  S B~ = (F^T S)^T Vu  (8 tiles x 9 steps, one per wave; the combinations F^T S are KEPT: FS),  sb = s + S b~  (vector items, waves 4 .. 7)
+//   Ph1  S B~ = (F^T S)^T Vu  (8 tiles x 9 steps: waves 0 .. 3 run both column tiles of their row tile in one call, the A operand formed once; the
+//        combinations F^T S are KEPT: FS),  sb = s + S b~  (vector items: all that waves 4 .. 7 do in the phase)
 //   Ph2  G = P~ + SB^T E_J + (F^T SB)^T Vx  (8 tiles),  [Lam | g] = [R~ | r~] + Vu^T (F^T [SB | sb])  (4 tiles, second tile of waves 4 .. 7's call);
 //        P~, R~, r~ from LDS: no global load in the phase.  Waves 0 .. 3, one tile short of the others, form the first row tile of S A~ (HSQP_SA_EARLY)
 //   Ph3  waves 0, 1: blocked elimination of [Lam | I | G | g] (hsqp_elim.h, unchanged); wave 0's hook issues every asynchronous copy of the next
