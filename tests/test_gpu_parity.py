@@ -848,10 +848,12 @@ def _poisoned_and_clean(model, make, **solver_kw):
     for poison in (True, False):
         if poison:
             os.environ["HSQP_POISON_LDS"] = "1"
+            os.environ["HSQP_POISON_HBM"] = "1"   # ... and every device buffer the library allocates starts as NaN patterns instead of the allocator's zeros
         try:
             s = HipSqpSolver(model, **solver_kw)
         finally:
             os.environ.pop("HSQP_POISON_LDS", None)
+            os.environ.pop("HSQP_POISON_HBM", None)
         try:
             outs.append([s.run(*p) for p in make()])
         finally:

@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void k_poison_lds() {
   for (int i = threadIdx.x; i < POISON_LDS_BYTES / 8; i += 256) p[i] = 0x7ff8dead7ff8deadull;   // a NaN as a double and as two floats
 }
 bool g_poison_lds = false;
+bool g_poison_hbm = false;                 // HSQP_POISON_HBM (test aid, read at hsqp_create): every device buffer the library allocates starts as NaN bit patterns
+// (0xFF bytes) instead of whatever the allocator returns — usually zeros, which hide a read of something never written.  Not the LQ record: the limb-lane
+// kernels rely on its zero fill (hsqp_lql.h).
+inline void poison_hbm(void* p, size_t bytes) { if (g_poison_hbm && p) (void)hipMemset(p, 0xFF, bytes); }
 int g_poison_blocks = 512;                 // two per CU (set from the device's CU count at hsqp_create)
 #define HSQP_LAUNCH(kernel, grid, block, lds, st, ...)                                                                  \
   do {                                                                                                                 \
@@ -977,6 +981,7 @@ static void* stage_area(hsqp_handle* h, size_t bytes) {
     if (h->d_stage) (void)hipFree(h->d_stage);
     h->d_stage = nullptr; h->stage_bytes = 0;
     if (hipMalloc(&h->d_stage, bytes) != hipSuccess) return nullptr;
+    poison_hbm(h->d_stage, bytes);
     h->stage_bytes = bytes;
   }
   return h->d_stage;
@@ -999,8 +1004,10 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
   if (need > h->el_capacity) {
     for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
     h->el_capacity = 0;
-    for (auto& p : h->d_el)
+    for (auto& p : h->d_el) {
       if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (scan elements)"; return HSQP_ERR_OOM; }
+      poison_hbm(p, need * 8);
+    }
     h->el_capacity = need;
   }
   HSQP_LAUNCH(k_scan_init<n>, dim3(B * (N + 1)), dim3(SCAN_INIT_THREADS), sizeof(ScanInitWS<n>), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, N, h->d_el[0], h->d_scanst);
@@ -1013,10 +1020,12 @@ static int launch_scan(hsqp_handle* h, int B, int N, bool want_kkt, int refineme
     if (!*pv) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(pv, bytes) != hipSuccess) { *pv = nullptr; h->err = "hipMalloc failed (value functions of the scan, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+      poison_hbm(*pv, bytes);
     }
   if (!h->d_acl) {
     const size_t bytes = (size_t)h->st.max_batch * h->st.max_nodes * ACL_SIZE<n> * 8;
     if (hipMalloc(&h->d_acl, bytes) != hipSuccess) { h->d_acl = nullptr; h->err = "hipMalloc failed (closed loop of the scan path, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+    poison_hbm(h->d_acl, bytes);
   }
   // the gains passes ping-pong between the two value-function buffers; the LAST pass writes d_vf2 (what the KKT check reads) and the closed loop
   double* vbuf[2] = {(refinements & 1) ? h->d_vf : h->d_vf2, (refinements & 1) ? h->d_vf2 : h->d_vf};
@@ -1053,8 +1062,10 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
   if (need > h->el_capacity) {
     for (auto& p : h->d_el) { if (p) (void)hipFree(p); p = nullptr; }
     h->el_capacity = 0;
-    for (auto& p : h->d_el)
+    for (auto& p : h->d_el) {
       if (hipMalloc(&p, need * 8) != hipSuccess) { p = nullptr; h->err = "hipMalloc failed (segment elements)"; return HSQP_ERR_OOM; }
+      poison_hbm(p, need * 8);
+    }
     h->el_capacity = need;
   }
   const size_t BN = (size_t)h->st.max_batch * h->st.max_nodes;
@@ -1068,11 +1079,13 @@ static int launch_segmented(hsqp_handle* h, int B, int N, int P, bool want_vf) {
     if (h->d_vf0) (void)hipFree(h->d_vf0);
     h->d_vf0 = nullptr; h->vf0_capacity = 0;
     if (hipMalloc(&h->d_vf0, (size_t)B * P * VF_SIZE * 8) != hipSuccess) { h->d_vf0 = nullptr; h->err = "hipMalloc failed (segmented sweep: boundary value functions)"; return HSQP_ERR_OOM; }
+    poison_hbm(h->d_vf0, (size_t)B * P * VF_SIZE * 8);
     h->vf0_capacity = (size_t)B * P;
   }
   if (!h->d_vf2) {   // (the gate needs the value functions of the boundary stages' nodes; want_vf: of every node, for the KKT report)
     const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
     if (hipMalloc(&h->d_vf2, bytes) != hipSuccess) { h->d_vf2 = nullptr; h->err = "hipMalloc failed (value functions of the segmented sweep, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+    poison_hbm(h->d_vf2, bytes);
   }
   const int segs = B * P;
   HSQP_LAUNCH(k_seg_elem_ric<n>, dim3(segs), dim3(RIC_THREADS), sizeof(RicWS), h->stream, h->d_dm, h->d_x, h->d_par, h->d_qp, (const double*)h->d_zero, h->d_ric2,
@@ -1233,8 +1246,11 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
       {(void**)&h->d_kkt, B * 3 * 8 + ((B * sizeof(int) + 7) / 8) * 8}, {(void**)&h->d_dt, B * N * 8}, {(void**)&h->d_perf_before, B * sizeof(hsqp_perf)}, {(void**)&h->d_perf_after, B * sizeof(hsqp_perf)},
       {(void**)&h->d_status, B * sizeof(int)}, {(void**)&h->d_prof, 4 * 128 * sizeof(long long)},
       {(void**)&h->d_stepinfo, B * N * 4 * 8}, {(void**)&h->d_ls, B * sizeof(LsState)}, {(void**)&h->d_counts, 2 * sizeof(int)}};
-  for (const Alloc& a : allocs)
+  g_poison_hbm = getenv("HSQP_POISON_HBM") != nullptr;
+  for (const Alloc& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(HSQP_ERR_OOM, "hipMalloc failed (" + std::to_string(a.bytes) + " bytes)");
+    poison_hbm(*a.p, a.bytes);
+  }
   if (hipHostMalloc((void**)&h->h_gate, B * 3 * 8 + ((B * sizeof(int) + 7) / 8) * 8) != hipSuccess) { h->h_gate = nullptr; return fail(HSQP_ERR_OOM, "hipHostMalloc failed (gate block)"); }
   h->d_ginf = h->d_kkt + 2 * B;   // one block [kkt (2 per instance of max_batch) | |g|_inf | flags of the scan kernels]: one memset, one read-back for the scan's gate
   h->d_scanst = reinterpret_cast<int*>(h->d_kkt + 3 * B);
@@ -1499,6 +1515,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     if (want_kkt && !h->d_vf) {
       const size_t bytes = (size_t)h->st.max_batch * (h->st.max_nodes + 1) * VF_SIZE * 8;
       if (hipMalloc(&h->d_vf, bytes) != hipSuccess) { h->d_vf = nullptr; h->err = "hipMalloc failed (value function for the KKT check, " + std::to_string(bytes) + " bytes)"; return HSQP_ERR_OOM; }
+      poison_hbm(h->d_vf, bytes);
     }
     const int Bm = h->st.max_batch;
     const size_t gate_bytes = (size_t)Bm * 3 * 8 + (((size_t)Bm * sizeof(int) + 7) / 8) * 8;   // [kkt | |g|_inf | scan flags]
