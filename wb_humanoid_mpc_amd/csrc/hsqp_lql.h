@@ -980,8 +980,13 @@ HSQP_HD int ql_rows_column(const QlLimb& lb, int t, int kind) {
   return kind == 0 ? 3 + i + 2 : (kind == 1 ? NV + 3 + i + 2 : NX + 12 + j);
 }
 HSQP_HD void ql_rows_fetch(const double* gs, int col, double* g) {
+#if defined(HSQP_EXP_NOFETCH)   /* timing experiment only (wrong results): no stage-Jacobian column fetch, hence no wait behind the row stores */
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = 1e-3 * (col + k);
+#else
 #pragma unroll
   for (int k = 0; k < 6; ++k) g[k] = gs[col * GT_LD + k];
+#endif
 }
 // one step of the rows pass: the rows of the three columns of joint i = path[t], then up to the parent.  gcur: the stage Jacobian column of
 // (t, kind 0) on entry, of (t - 1, kind 0) on exit — every column is fetched ONE COLUMN AHEAD of its use, i.e. in front of the previous column's

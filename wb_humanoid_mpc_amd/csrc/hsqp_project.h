@@ -61,11 +61,17 @@ struct ProjWS {
       double Jt[NRP][LDTM];      // the projected residual rows of the current pass (column 81 = rho')
       double JuT[NU + 1][NRP];   // transposed input block of the residual rows of the current (next) pass (row NU: their rho); overlaps Wm
     } ps;
+#if defined(HSQP_PEXP_ALIAS)   /* timing experiment only (WRONG results): T over the first union — 28.5 KB, four to five workgroups per CU (profiles/r06_project_experiments.txt (3)) */
+    double Tm[NU + 1][LDTM];
+    double CDe[NE_MAX][LDJ];
+  };
+#else
   };
   union {
     double Tm[NU + 1][LDTM];     // [Px (58) | Pu (23) | Pe | 0 ...]; row NU = e_NTW: with rho as row NU of JuT the product J_u [Pu | Pe] also adds rho to its last column
     double CDe[NE_MAX][LDJ];     // the equality rows, until W = R1^-T [C|e] is formed (Tm is written after that)
   };
+#endif
   int ne, nut, ok;
   int jt;                        // the record's residual / equality rows are stored transposed (REC_LAYOUT)
   int nrows;                     // residual rows of the record in use (REC_NROWS); the third pass is skipped when they fit two
