@@ -655,8 +655,9 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   }
   PH_TICK(ctx, 12);
   const double* gs = grec + REC_GS;
-  double gcur[6];
-  ql_rows_fetch(gs, ql_rows_column(lb, max_len - 1, 0), gcur);
+  double gcur[3][6];   // the three stage-Jacobian columns of the step about to run (ql_rows_back_step keeps them one step ahead)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) ql_rows_fetch(gs, ql_rows_column(lb, max_len - 1, q), gcur[q]);
 #pragma unroll 1
   for (int t = max_len - 1; t >= 0; --t) ql_rows_back_step(*dm, ws.k, lb, rw, nl, xs, us, t, st, csn, CSN_LD, bk.w, gs, gcur, grec, live);
   PH_TICK(ctx, 13);

@@ -988,12 +988,11 @@ HSQP_HD void ql_rows_fetch(const double* gs, int col, double* g) {
   for (int k = 0; k < 6; ++k) g[k] = gs[col * GT_LD + k];
 #endif
 }
-// one step of the rows pass: the rows of the three columns of joint i = path[t], then up to the parent.  gcur: the stage Jacobian column of
-// (t, kind 0) on entry, of (t - 1, kind 0) on exit — every column is fetched ONE COLUMN AHEAD of its use, i.e. in front of the previous column's
-// stores: the memory counter retires in order, so a load issued behind a column's ~24 stores waits for all of them to be acknowledged.
+// one step of the rows pass: the rows of the three columns of joint i = path[t], then up to the parent.  pend: the stage Jacobian columns of
+// (t, kinds 0 .. 2) on entry, of step t - 1 on exit.
 template <class KC>
 HSQP_HD void ql_rows_back_step(const DevModel& dm, const KC& kc, const QlLimb& lb, const QlRows& rw, const QlNodeLds& nl, const double* x, const double* u, int t,
-                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], const double* gs, double* gcur, double* rec, bool live) {
+                               QlState& st, const double* csn, int csn_ld, const double (*wE)[3], const double* gs, double (*pend)[6], double* rec, bool live) {
   const bool active = t < lb.len;
   const int i = active ? (int)((lb.path >> (8 * t)) & 0xffull) : 1, j = i - 1;
   const double qd = x[NV + 6 + j], qdd = u[12 + j];
@@ -1003,14 +1002,40 @@ HSQP_HD void ql_rows_back_step(const DevModel& dm, const KC& kc, const QlLimb& l
   mxm(st.vl, S, Sd);
   const bool mine = active && ((lb.own >> t) & 1u) != 0;
   const bool sup = t <= lb.foot_step;
+  // pend: the three stage-Jacobian columns of THIS step (kinds 0, 1, 2), fetched during the step before it, in front of that step's first stores.  The wave
+  // waits for them right here — the only stores in flight are the previous step's last ones — takes them over, and sends the next step's three columns on
+  // their way.  A wait behind a column's ~22 stores drains them all (the in-order memory counter; the store count of a column is not a compile-time constant,
+  // so the compiler waits for zero): three such waits per step — every column used to be fetched one column ahead — were 0.12 ms of the LQ kernels' 1.0
+  // (DESIGN.md §7 (4)).
+  double g[3][6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(pend[q][k]));
+  QV_SCHED_FENCE();
+#endif
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[q][k] = pend[q][k];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) ql_rows_fetch(gs, ql_rows_column(lb, t - 1, q), pend[q]);
+  QV_SCHED_FENCE();
 #pragma unroll 1
   for (int kind = 0; kind < 3; ++kind) {
-    double gn[6];
-    ql_rows_fetch(gs, kind < 2 ? ql_rows_column(lb, t, kind + 1) : ql_rows_column(lb, t - 1, 0), gn);
-    QV_SCHED_FENCE();
-    if (mine) ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, gcur, ql_rows_column(lb, t, kind), rec, live);
+    double gcur[6];
+    if (kind == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) gcur[k] = gn[k];
+      for (int k = 0; k < 6; ++k) gcur[k] = g[0][k];
+    } else if (kind == 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gcur[k] = g[1][k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gcur[k] = g[2][k];
+    }
+    if (mine) ql_rows_joint(dm, rw, nl, u, kind, sup, i, S, Sd, st, wE, gcur, ql_rows_column(lb, t, kind), rec, live);
   }
   QV_SCHED_FENCE();
   if (active) ql_unwind(kc, i, S, Sd, qd, qdd, csn[t * csn_ld], csn[t * csn_ld + 1], st);
@@ -1018,32 +1043,67 @@ HSQP_HD void ql_rows_back_step(const DevModel& dm, const KC& kc, const QlLimb& l
 // the rows of the base columns (the division of labour of ql_base_columns)
 HSQP_HD void ql_rows_base(const DevModel& dm, const QlRows& rw, const QlNodeLds& nl, const double* u, int L, const QlBaseKin& bk, const QlShared& sh,
                           const double* gs, double* rec, bool live) {
-  // (every Jacobian column is fetched one column ahead of its use, in front of the previous column's stores: see ql_rows_back_step)
-  const int fo = rw.own >= 0 ? rw.own : 0, cw0 = NX + 6 * fo;
-  double gc[6], gn[6];
+  // (the columns are fetched in two batches, each in front of the stores of the columns it serves and waited for at once: see ql_rows_back_step)
+  const int fo = rw.own >= 0 ? rw.own : 0, cw0 = NX + 6 * fo, Le = L < 3 ? L : 2;
+  double e0[6], e1[6], w0[6], w1[6], w2[6];
+  auto arrive = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    QV_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { asm volatile("" : "+v"(w0[k])); asm volatile("" : "+v"(w1[k])); asm volatile("" : "+v"(w2[k])); }
+    QV_SCHED_FENCE();
+#endif
+  };
+  ql_rows_fetch(gs, 3 + Le, e0);
+  ql_rows_fetch(gs, NV + 3 + Le, e1);
+  ql_rows_fetch(gs, cw0, w0);
+  ql_rows_fetch(gs, cw0 + 1, w1);
+  ql_rows_fetch(gs, cw0 + 2, w2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { asm volatile("" : "+v"(e0[k])); asm volatile("" : "+v"(e1[k])); }
+#endif
+  arrive();
   if (L < 3) {
-    ql_rows_fetch(gs, 3 + L, gc);
 #pragma unroll 1
     for (int kind = 0; kind < 2; ++kind) {
-      ql_rows_fetch(gs, kind == 0 ? NV + 3 + L : cw0, gn);
-      QV_SCHED_FENCE();
-      ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, gc, rec, live);
+      double gc[6];
+      if (kind == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gc[k] = gn[k];
+        for (int k = 0; k < 6; ++k) gc[k] = e0[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gc[k] = e1[k];
+      }
+      ql_rows_euler(dm, rw, nl, u, kind, L, bk, sh, gc, rec, live);
     }
   } else {
-    ql_rows_fetch(gs, cw0, gc);
-    QV_SCHED_FENCE();
     ql_rows_base_linear(dm, rw, nl, rec, live);
   }
-  if (rw.own >= 0) {
 #pragma unroll 1
-    for (int k6 = 0; k6 < 6; ++k6) {
-      ql_rows_fetch(gs, cw0 + (k6 < 5 ? k6 + 1 : 5), gn);
-      QV_SCHED_FENCE();
-      ql_rows_wrench(dm, rw, nl, u, rw.own, k6, bk, gc, rec, live);
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      ql_rows_fetch(gs, cw0 + 3, w0);
+      ql_rows_fetch(gs, cw0 + 4, w1);
+      ql_rows_fetch(gs, cw0 + 5, w2);
+      arrive();
+    }
+    if (rw.own >= 0) {
+#pragma unroll 1
+      for (int q = 0; q < 3; ++q) {
+        double gc[6];
+        if (q == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gc[k] = gn[k];
+          for (int k = 0; k < 6; ++k) gc[k] = w0[k];
+        } else if (q == 1) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) gc[k] = w1[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) gc[k] = w2[k];
+        }
+        ql_rows_wrench(dm, rw, nl, u, rw.own, 3 * half + q, bk, gc, rec, live);
+      }
     }
   }
 }
@@ -1193,8 +1253,8 @@ inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, c
   const double* G = rec + REC_GS;
   for (int t = dm.limb_max_len - 1; t >= 0; --t)
     for (int L = 0; L < QV_LIMBS; ++L) {
-      double gcur[6];
-      ql_rows_fetch(G, ql_rows_column(ql_limb(dm, L), t, 0), gcur);
+      double gcur[3][6];
+      for (int q = 0; q < 3; ++q) ql_rows_fetch(G, ql_rows_column(ql_limb(dm, L), t, q), gcur[q]);
       ql_rows_back_step(dm, *kc, ql_limb(dm, L), rw[L], *nl, x, u, t, st[L], &csn[L][0][0], 2, bk[L].w, G, gcur, rec, true);
     }
   for (int L = 0; L < QV_LIMBS; ++L) ql_rows_base(dm, rw[L], *nl, u, L, bk[L], sh[L], G, rec, true);
