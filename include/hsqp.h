@@ -134,7 +134,7 @@ typedef struct hsqp_model_desc {
 /* Backward sweep of the stage QP.  Default: the serial Riccati recursion, one workgroup per instance.  With at most
  * HSQP_SCAN_AUTO_BATCH instances and at least HSQP_SCAN_AUTO_MIN_NODES shooting intervals (both formulations) the parallel-in-time
  * sweep (associative scan over the stages, ceil(log2(N+1)) levels; csrc/hsqp_scan.h) is used instead, because one or two serial
- * chains leave the device idle (N = 100, sweep + roll-out, round 6: whole-body 0.52 vs 1.20 ms; centroidal 0.30 vs 0.8 ms).  Its result agrees with the serial
+ * chains leave the device idle (N = 100, sweep + roll-out, round 6: whole-body 0.52 vs 1.11 ms; centroidal 0.30 vs 0.8 ms).  Its result agrees with the serial
  * recursion's to ~1e-11 of the step's scale on the QPs of a cold start or of a tracking MPC; it degrades on far-from-feasible
  * line-search iterates and on badly scaled QPs (cond(I + C1 J2) up to 1e9), so every scan result is GATED by the KKT residual of the
  * QP (min(1e-9 max(1, |g|_inf), 2e-8)) and the iteration is redone with the serial recursion when it fails: hsqp_scan_fallbacks()
