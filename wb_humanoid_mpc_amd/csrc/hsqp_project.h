@@ -34,7 +34,14 @@ constexpr int QP_NUT = QP_PE + NU;             // [1]  nu - ne, or -1 if D was r
 constexpr int QP_SIZE = ((QP_NUT + 1 + 7) / 8) * 8;
 
 constexpr int NTW = NX + NUT;                  // 81: projected stage variable [dx; ut]
-constexpr int LDTM = 88;                       // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows
+#ifndef HSQP_LDTM
+#define HSQP_LDTM 82    /* (88 until the end of round 6: row groups of a tile read 48 banks apart overlap in 16 banks; 82: in 4.  k_project 1.410 -> 1.397 ms) */
+#endif
+#ifndef HSQP_LDP
+#define HSQP_LDP 98     /* leading dimension of PV in LDS (the record's is LDJ = 96: sixteen lanes LDJ apart are ONE bank) */
+#endif
+constexpr int LDP = HSQP_LDP;
+constexpr int LDTM = HSQP_LDTM;                // leading dimension of Tm = [Px | Pu | Pe | pad] and of the residual rows (>= NTW + 1; tuning builds: -DHSQP_LDTM)
 // The 64 residual row slots are projected in passes of NRP rows (24 + 24 + 16) through one small LDS block; the projected
 // Gauss-Newton Hessian J~^T J~ is accumulated ACROSS the passes in registers (the matrix-core accumulators of the 15 tiles on /
 // above the diagonal of its leading 80 x 80 block, dealt to the four waves; the last projected input and the gradient column
@@ -56,7 +63,7 @@ struct ProjWS {
       double Q1T[NE_MAX][NU];    // rows 0..ned-1 of Q^T (Q1^T); the rows of Q2^T go straight into Tm
       double Wm[NE_MAX][NX + 2]; // R1^-T [C|e]
     } qr;                        // live until Tm is formed
-    double PV[2][6][LDJ];        // the non-trivial rows of [A|B]: stored while Tm is being formed, over Rm / V / the scalars (dead by then)
+    double PV[2][6][LDP];        // the non-trivial rows of [A|B]: stored while Tm is being formed, over Rm / V / the scalars (dead by then)
     struct {
       double Jt[NRP][LDTM];      // the projected residual rows of the current pass (column 81 = rho')
       double JuT[NU + 1][NRP];   // transposed input block of the residual rows of the current (next) pass (row NU: their rho); overlaps Wm
@@ -85,7 +92,7 @@ struct ProjWS {
   double bvec[64];
   double rho[NRS], d[LDJ], gd[LDJ];   // mirror one contiguous piece of the LQ record
 };
-static_assert(sizeof(double) * 2 * 6 * LDJ <= offsetof(ProjWS, qr.Q1T), "PV may only overlap what is dead while Tm is formed");
+static_assert(LDP >= LDJ && sizeof(double) * 2 * 6 * LDP <= offsetof(ProjWS, qr.Q1T), "PV may only overlap what is dead while Tm is formed");
 static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
 
 // Event interval (hsqp_problem::dt_nodes[b][k] == 0): the stage of the QP is the identity jump map
@@ -552,9 +559,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     double* pv = &w.PV[0][0][0];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[e] = tpv[j] + pv_const(e); }
+    for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[(e / LDJ) * LDP + e % LDJ] = tpv[j] + pv_const(e); }
 #else
-    WG_FOR(ctx, e, NPV) pv[e] = rec[REC_PV + e] + pv_const(e);
+    WG_FOR(ctx, e, NPV) pv[(e / LDJ) * LDP + e % LDJ] = rec[REC_PV + e] + pv_const(e);
 #endif
   };
   auto load_ju = [&](int r0, int nr) {
@@ -605,9 +612,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     const int r1 = cent ? 6 : NV;   // first row of the second dense block
     // both dense row blocks in ONE product each (twelve rows of a 16-row tile instead of twice six): the rows of the second block land r1 - 6
     // rows further down in the record (XTY_ROW_JUMP)
-    XtyJob ja = xty_job(12, NX, NU, &w.PV[0][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A, NX, &w.PV[0][0][0], LDJ);
+    XtyJob ja = xty_job(12, NX, NU, &w.PV[0][0][NX], 1, &w.Tm[0][0], LDTM, qp + QP_A, NX, &w.PV[0][0][0], LDP);
     XtyJob jb = xty_job(12, NUT, NU, &w.PV[0][0][NX], 1, &w.Tm[0][NX], LDTM, qp + QP_B, NUT);
-    ja.sx1 = LDJ; jb.sx1 = LDJ;
+    ja.sx1 = LDP; jb.sx1 = LDP;
     ja.rsplit = 6; ja.rjump = r1 - 6; jb.rsplit = 6; jb.rjump = r1 - 6;
     const XtyJob jobs[2] = {ja, jb};
     if (!(HSQP_PEXP & 16)) wg_xty_jobs<true, XTY_C_GLOBAL | XTY_ROW_JUMP>(ctx, jobs, 2);
