@@ -54,7 +54,7 @@ constexpr int LQ_THREADS = HSQP_LQ_THREADS;
 #ifndef HSQP_PROJ_WPE
 #define HSQP_PROJ_WPE 3
 #endif
-constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 51 KB workspace: three workgroups of four waves per CU
+constexpr int PROJ_THREADS = HSQP_PROJ_THREADS;   // 49.5 KB workspace: three workgroups of four waves per CU
 static_assert(PROJ_THREADS >= 256 && PROJ_THREADS % 64 == 0, "project_node hoists its staging loads assuming >= 256 threads; the Gram tiles are dealt to waves 0..3");
 // Every kernel hands its workgroup size to the device functions as the CONSTANT it is launched with (Ctx::nthreads), not as blockDim.x: the item loops
 // (WG_FOR) then have constant strides and trip counts, and the paths written for other workgroup shapes (the host build's) are not compiled into the

@@ -46,7 +46,7 @@ constexpr int LDTM = HSQP_LDTM;                // leading dimension of Tm = [Px 
 // Gauss-Newton Hessian J~^T J~ is accumulated ACROSS the passes in registers (the matrix-core accumulators of the 15 tiles on /
 // above the diagonal of its leading 80 x 80 block, dealt to the four waves; the last projected input and the gradient column
 // as per-thread sums), and the 35 input-weight rows sqrt(d_u) [Px | Pu | Pe] are accumulated straight from Tm.  Nothing of the
-// Hessian makes a round trip through memory between the passes, and the workspace is 51 KB: three workgroups per CU.
+// Hessian makes a round trip through memory between the passes, and the workspace is 49.5 KB: three workgroups per CU.
 constexpr int NRP = 24;
 static_assert(NRP % 4 == 0 && NRS == 2 * NRP + 16, "pass sizes");
 constexpr int NGT = 5;                         // 16-column tiles of the Gram matrix on the matrix cores: columns 0..79
