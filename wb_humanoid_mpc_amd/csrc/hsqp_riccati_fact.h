@@ -35,6 +35,9 @@
 #define HSQP_LAP_WAVE 4   /* -DHSQP_PHASE_PROFILE builds: the wave whose Ph4 is split into laps (slots 20 .. 25) */
 #endif
 #ifndef HSQP_EXP
+#ifndef HSQP_FACT_PF
+#define HSQP_FACT_PF RIC_PF   /* operand prefetch depth of this stage's tile loops (tuning builds) */
+#endif
 #ifndef HSQP_PH1_NT2
 #define HSQP_PH1_NT2 1    /* Ph1: the two column tiles of a row tile of S B~ in one call on waves 0 .. 3 (0: one tile per wave; A/B builds) */
 #endif
@@ -45,6 +48,7 @@
 #endif
 
 namespace hsqp {
+constexpr int FACT_PF = HSQP_FACT_PF;
 
 constexpr int NF = 12 + NJ;                   // rank of the factored part
 constexpr int NFS = (NF + 3) / 4;             // contraction steps of four (index 35 is padding)
@@ -370,7 +374,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
             return v;
           };
           auto yf = [&](auto sc, int t) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return w.VB[kc][16 * t + li < LDB ? 16 * t + li : LDB - 1]; };
-          fact_mfma_sx<2, RIC_PF, NFS>(acc, xf, yf);
+          fact_mfma_sx<2, FACT_PF, NFS>(acc, xf, yf);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int col = 16 * t + li;
@@ -392,7 +396,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         return v;
       };
       auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return w.VB[kc][yc]; };
-      fact_mfma<1, RIC_PF, NFS>(acc, xf, yf);
+      fact_mfma<1, FACT_PF, NFS>(acc, xf, yf);
       const int col = c0 + li;
       if (col < NUT) {
 #pragma unroll
@@ -437,7 +441,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         return 4 * s + kk < NF ? v : 0.0;
       };
       auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; const int kc = 4 * s + kk < NF ? 4 * s + kk : NF - 1; return VA[kc][yc]; };
-      fact_mfma<NT, RIC_PF, NFS>(acc, xf, yf);
+      fact_mfma<NT, FACT_PF, NFS>(acc, xf, yf);
       double ea[NT][4], eb[NT][4];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -471,8 +475,8 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
         return t == 0 ? VA[kc][gyc] : fact_combo(sc, kk, &w.SB[0][0], LDB, lyc, dt, hq);
       };
       hsqp_d4 acc[2] = {hsqp_d4{0.0, 0.0, 0.0, 0.0}, hsqp_d4{0.0, 0.0, 0.0, 0.0}};
-      if (wv >= 4) fact_mfma<2, RIC_PF, NFS>(acc, xf, yf);
-      else { hsqp_d4 a1[1] = {acc[0]}; fact_mfma<1, RIC_PF, NFS>(a1, xf, yf); acc[0] = a1[0]; }
+      if (wv >= 4) fact_mfma<2, FACT_PF, NFS>(acc, xf, yf);
+      else { hsqp_d4 a1[1] = {acc[0]}; fact_mfma<1, FACT_PF, NFS>(a1, xf, yf); acc[0] = a1[0]; }
       {
         // (SB^T E_J)[row][col]: column `col` of E_J picks row col (and row col - 29) of SB
         double pv[4], ea[4], eb[4];
@@ -598,10 +602,10 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
             const double v = VA[kc][r < NX ? r : NX - 1];
             return 4 * s + kk < NF ? v : 0.0;
           };
-          if (ct == 0) { hsqp_d4 a1[1] = {acc[0]}; fact_mfma<1, RIC_PF, NFS>(a1, xf, yf); acc[0] = a1[0]; }
-          else if (ct == 1) { hsqp_d4 a2[2] = {acc[0], acc[1]}; fact_mfma<2, RIC_PF, NFS>(a2, xf, yf); acc[0] = a2[0]; acc[1] = a2[1]; }
-          else if (ct == 2) { hsqp_d4 a3[3] = {acc[0], acc[1], acc[2]}; fact_mfma<3, RIC_PF, NFS>(a3, xf, yf); acc[0] = a3[0]; acc[1] = a3[1]; acc[2] = a3[2]; }
-          else fact_mfma<4, RIC_PF, NFS>(acc, xf, yf);
+          if (ct == 0) { hsqp_d4 a1[1] = {acc[0]}; fact_mfma<1, FACT_PF, NFS>(a1, xf, yf); acc[0] = a1[0]; }
+          else if (ct == 1) { hsqp_d4 a2[2] = {acc[0], acc[1]}; fact_mfma<2, FACT_PF, NFS>(a2, xf, yf); acc[0] = a2[0]; acc[1] = a2[1]; }
+          else if (ct == 2) { hsqp_d4 a3[3] = {acc[0], acc[1], acc[2]}; fact_mfma<3, FACT_PF, NFS>(a3, xf, yf); acc[0] = a3[0]; acc[1] = a3[1]; acc[2] = a3[2]; }
+          else fact_mfma<4, FACT_PF, NFS>(acc, xf, yf);
           // (E_J^T SA)[row][col]: row `row` of E_J^T picks row `row` (and row - 29) of SA — unconditional reads of the own column, then the stores
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -740,7 +744,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) wp[t][r] = lsa[FS_W(t) + (16 * fact_sym_tr(sfirst + t) + kk) * (LDA - NX) + 4 * LDA * r];   // (SA's rows are LDA apart, S's NX)
           PH_LAP(ctx, HSQP_LAP_WAVE, 21);
-          fact_mfma<NT, RIC_PF, NSZ>(acc, xf, yf);
+          fact_mfma<NT, FACT_PF, NSZ>(acc, xf, yf);
           // (the z lane's addresses are formed HERE: left to the compiler they are formed in front of the stage loop, one register per element — a spill)
           int fm[NT];
 #pragma unroll
@@ -782,7 +786,7 @@ HSQP_HD void riccati_backward_fact(const Ctx& ctx, RicFWS& w, const double* Qf, 
             else return le[FK_X(t) + 4 * s * LDF];
           };
           auto yf = [&](auto sc, int) { constexpr int s = decltype(sc)::value; return lz[FK_Y + 4 * s * LDZ]; };
-          fact_mfma<2, RIC_PF, NSZ>(acc, xf, yf);
+          fact_mfma<2, FACT_PF, NSZ>(acc, xf, yf);
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
