@@ -382,6 +382,40 @@ def test_factored_serial_sweep_equals_the_dense_stage_on_the_device(model, B, N,
         assert_kkt(f["kkt"][i], f["grad_inf"][i], f"factored sweep, instance {i}")
 
 
+@pytest.mark.parametrize("B,N,gait", [(5, 37, "walk"), (3, 20, "run")])
+def test_chain_fused_into_the_projection_equals_the_chain_kernel(model, B, N, gait):
+    """Limb-lane handles: the RK4 chain of the columns of [A|B] inside k_project (project_node, chain: from the stage Jacobians REC_GS, on the waves that
+    wait for the factorisation) against the chain in k_lq_chain with P6 / V6 through the LQ record (HSQP_LQ_CHAIN_SEPARATE at hsqp_create): the same
+    function of the same numbers (lq_chain_column_pv, hsqp_lq.h), so the step is identical bit for bit."""
+    from wb_humanoid_mpc_amd.solver import HipSqpSolver
+    x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, gait=gait, perturb=True, seed=91)
+    outs = {}
+    for name in ("separate", "fused"):
+        os.environ["HSQP_LQ_LIMB_FORM"] = "1"
+        if name == "separate":
+            os.environ["HSQP_LQ_CHAIN_SEPARATE"] = "1"
+        try:
+            s = HipSqpSolver(model, max_nodes=N, max_batch=B, riccati="serial")
+        finally:
+            os.environ.pop("HSQP_LQ_LIMB_FORM", None)
+            os.environ.pop("HSQP_LQ_CHAIN_SEPARATE", None)
+        try:
+            forms = s.kernel_forms()
+            assert forms["lq_limb"] and forms["chain_fused"] == (name == "fused")
+            s.upload(x0, x, u, par, dt)
+            s.iterate(1, take_step=False, kkt=True)
+            outs[name] = (s.download(), s.debug_read(_abi.BLK_AB)[0], s.debug_read(_abi.BLK_BVEC)[0])
+        finally:
+            s.close()
+    (a, ab_a, b_a), (f, ab_f, b_f) = outs["separate"], outs["fused"]
+    # (on a fused handle the debug read chains the columns on the HOST from the device's stage Jacobians — REC_PV does not exist there —, so the [A|B] blocks agree to
+    #  rounding; the device-side results below are compared bit for bit)
+    assert np.abs(ab_a - ab_f).max() <= 1e-13 * max(1.0, np.abs(ab_a).max()) and np.array_equal(b_a, b_f)
+    assert np.array_equal(a["dx"], f["dx"]) and np.array_equal(a["du"], f["du"])
+    for i in range(B):
+        assert_kkt(f["kkt"][i], f["grad_inf"][i], f"fused chain, instance {i}")
+
+
 def test_parallel_in_time_sweep_is_repeatable(model):
     """The scan's elimination is a pipeline over the waves of a workgroup (one wave eliminates M and posts the multipliers, seven apply
     them a chunk behind): a missing barrier or a mailbox race would show as run-to-run differences — twenty repeated solves of two

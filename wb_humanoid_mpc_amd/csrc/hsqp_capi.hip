@@ -136,11 +136,11 @@ __global__ __launch_bounds__(64) void k_params_cent_torso(const DevModel* __rest
 }
 
 // ---- projection: one workgroup per (instance, node)
-__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent, int joint_rows) {
+__global__ __launch_bounds__(PROJ_THREADS, HSQP_PROJ_WPE) void k_project(const double* __restrict__ rec, const double* __restrict__ dts, double* __restrict__ qp, long long* prof, int cent, int joint_rows, int chain) {
   ProjWS& w = *reinterpret_cast<ProjWS*>(hsqp_smem);
   const Ctx ctx{(int)threadIdx.x, PROJ_THREADS, blockIdx.x == 0 ? prof : nullptr};
   PH_TICK(ctx, 126);  // re-arm the phase clock (bucket 126 is a sink)
-  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0, joint_rows != 0);
+  project_node(ctx, w, rec + (size_t)blockIdx.x * REC_SIZE, dts[blockIdx.x], qp + (size_t)blockIdx.x * QP_SIZE, cent != 0, joint_rows != 0, chain != 0);
 }
 
 // ---- event intervals (jump_node_qp, hsqp_project.h): one workgroup per node; only launched when the grid has such intervals
@@ -671,12 +671,12 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
 #endif
 constexpr int LQC_THREADS = 128;   // (the 64 defect items must be one wave: lq_chain_node sums their squares with a butterfly)
 __global__ __launch_bounds__(LQC_THREADS, HSQP_LQC_WPE) void k_lq_chain(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ dts, int N,
-                                                         double* __restrict__ rec, int node_base) {
+                                                         double* __restrict__ rec, int node_base, int columns) {
   __shared__ LqChainWS w;
   const int node = node_base + blockIdx.x, b = node / N, k = node % N;
   const Ctx ctx{(int)threadIdx.x, LQC_THREADS, nullptr};
   const double* xk = x + ((size_t)b * (N + 1) + k) * NX;
-  lq_chain_node(ctx, w, xk, u + (size_t)node * NU, xk + NX, dts[node], rec + (size_t)node * REC_SIZE);
+  lq_chain_node(ctx, w, xk, u + (size_t)node * NU, xk + NX, dts[node], rec + (size_t)node * REC_SIZE, columns != 0);
 }
 
 // ---- line search: per-instance reduction of the step info (+ terminal node), state initialisation
@@ -937,6 +937,7 @@ struct hsqp_handle {
   bool backoff_persistent = false;            // hsqp_set_scan_backoff_persistent: uploads of the same (B, N) keep the back-off
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
+  bool chain_fused = false;                   // limb-lane form: the RK4 chain of the columns of [A|B] runs inside k_project (project_node, chain), k_lq_chain forms the defect only; HSQP_LQ_CHAIN_SEPARATE in the environment at hsqp_create keeps the chain in k_lq_chain (A/B runs)
   bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_rows + k_lq_chain) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
   bool ric_fact = false;                      // whole-body serial sweep on the factors of [A~ | B~] (hsqp_riccati_fact.h: k_riccati_fact; HSQP_RICCATI_DENSE in the environment at hsqp_create: the dense stage k_riccati<58>, for A/B runs)
   bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)
@@ -1205,6 +1206,7 @@ int hsqp_create(const hsqp_model_desc* model, const hsqp_settings* settings, hsq
   // the LQ approximation on limb lanes (hsqp_lql.h) is a throughput form like the quad value pass; same rule, same per-handle decision
   h->lq_limb = h->hdm.formulation == HSQP_FORM_WB && h->hdm.ql_ok && getenv("HSQP_LQ_PHASE_FORM") == nullptr &&
                (getenv("HSQP_LQ_LIMB_FORM") != nullptr || (size_t)settings->max_batch * settings->max_nodes >= HSQP_LQ_LIMB_MIN_NODES);
+  h->chain_fused = h->lq_limb && getenv("HSQP_LQ_CHAIN_SEPARATE") == nullptr;
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hsqp_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return fail(HSQP_ERR_HIP, "hipSetDevice failed");
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(HSQP_ERR_HIP, "hipStreamCreate failed");
@@ -1480,7 +1482,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         const dim3 qgrid((n1 - n0 + QG - 1) / QG);
         HSQP_LAUNCH(k_lq_limb, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
         HSQP_LAUNCH(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
-        HSQP_LAUNCH(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0);
+        HSQP_LAUNCH(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0, h->chain_fused ? 0 : 1);
         if (s > 0) { HCHECK(hipEventRecord(h->ev_join[s - 1], st)); HCHECK(hipStreamWaitEvent(h->stream, h->ev_join[s - 1], 0)); }
       }
     } else
@@ -1510,7 +1512,7 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
     // The joint rows of A~ / B~ (46 of 58: scaled copies of rows of [Px | Pu]) are written only for those who read A~ / B~ as dense blocks: the
     // parallel-in-time and two-level sweeps, the KKT report, the centroidal stage.  The whole-body serial sweep works on the factors.
     const bool joint_rows = cent || !h->ric_fact || scan || want_kkt;
-    HSQP_LAUNCH(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0, joint_rows ? 1 : 0);
+    HSQP_LAUNCH(k_project, dim3(nodes), dim3(PROJ_THREADS), sizeof(ProjWS), h->stream, h->d_rec, h->d_dt, h->d_qp, h->d_prof + 128, cent ? 1 : 0, joint_rows ? 1 : 0, (!cent && h->lq_limb && h->chain_fused) ? 1 : 0);
     if (h->has_events) HSQP_LAUNCH(k_jump, dim3(nodes), dim3(256), 0, h->stream, h->d_dt, h->d_rec, h->d_qp);
     if (last) HCHECK(hipEventRecord(h->ev[2], h->stream));
     if (want_kkt && !h->d_vf) {
@@ -1914,9 +1916,9 @@ int hsqp_last_kernel_ms(hsqp_handle* h, double out_ms[5]) {
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) {
   if (!h) return HSQP_ERR_BAD_ARG;
   if (what == HSQP_BLK_FORMS) {
-    const int forms[4] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, h->lq_limb ? h->lq_split : 0, h->ric_fact ? 1 : 0};
-    if (dst && bytes > 0) memcpy(dst, forms, (size_t)(bytes < 16 ? bytes : 16));
-    return 16;
+    const int forms[5] = {h->lq_limb ? 1 : 0, h->value_quad ? 1 : 0, h->lq_limb ? h->lq_split : 0, h->ric_fact ? 1 : 0, h->chain_fused ? 1 : 0};
+    if (dst && bytes > 0) memcpy(dst, forms, (size_t)(bytes < 20 ? bytes : 20));
+    return 20;
   }
   if (what == HSQP_BLK_PARAMS) {   // available as soon as a problem is resident
     if (!h->have_problem) { h->err = "no problem uploaded"; return HSQP_ERR_BAD_ARG; }
@@ -1941,7 +1943,15 @@ long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes) 
       out.resize(nodes * NX * NZ);
       for (size_t n = 0; n < nodes; ++n) {
         if (h->hdm.formulation == HSQP_FORM_CENTROIDAL) cent_expand_AB(&rec[n * REC_SIZE], h->h_dt[n], &out[n * NX * NZ]);
-        else expand_AB(&rec[n * REC_SIZE], h->h_dt[n], &out[n * NX * NZ]);
+        else {
+          if (h->lq_limb && h->chain_fused) {   // REC_PV is not written on this handle (k_project chains the columns itself): the same chain here, from the stage Jacobians
+            double* r = &rec[n * REC_SIZE];
+            double blk[3][2][6][6];
+            for (int i = 0; i < 3 * 72; ++i) blk[i / 72][(i / 36) % 2][(i / 6) % 6][i % 6] = r[REC_GS + lq_chain_blk_offset(i / 72, (i / 36) % 2, (i / 6) % 6, i % 6)];
+            for (int col = 0; col < LDJ; ++col) lq_chain_column<true>(blk, r + REC_GS, col, h->h_dt[n], r);
+          }
+          expand_AB(&rec[n * REC_SIZE], h->h_dt[n], &out[n * NX * NZ]);
+        }
       }
       break;
     }

@@ -89,12 +89,17 @@ HSQP_HD double times_vd(const double (*Gs)[LDJ], int c0, const double (*Abt)[LDJ
   return s;
 }
 
+constexpr int GT_LD = 6;   // limb-lane form (hsqp_lql.h): the stage Jacobians travel TRANSPOSED, [stage][column][6] — a lane owns a column
+// where entry (r, k) of the 6 x 6 block G_{sg+2}[:, v_b] (which = 0) / G_{sg+2}[:, q_b] (which = 1) sits in the transposed stage Jacobians (offset from REC_GS)
+HSQP_HD constexpr int lq_chain_blk_offset(int sg, int which, int r, int k) { return ((sg + 1) * LDJ + (which == 0 ? NV : 0) + k) * GT_LD + r; }
+
 // The RK4 sensitivity chain of ONE column of [A|B] (see lq_node): Ab_1 = G_1, Ab_s = direct(G_s) + c_s G_s[:, v_b] Ab_{s-1} + c_s c_{s-1} G_s[:, q_b] Ab_{s-2};
 // P6 = dt^2/6 (Ab_1 + Ab_2 + Ab_3), V6 = dt/6 (Ab_1 + 2 Ab_2 + 2 Ab_3 + Ab_4) -> rec[REC_PV].  gs = rec + REC_GS: the stage Jacobians as the
 // column phases wrote them; the own-column entries of a stage and its selection partners are fetched one stage ahead of their use.
 // GT: the stage Jacobians are stored transposed, [stage][column][6] (written by the limb lanes of hsqp_lql.h), else [stage][6][LDJ].
+// (lq_chain_column_pv: the column's twelve entries P6[r], V6[r] as values — k_project forms them itself when the chain is fused into it, hsqp_project.h)
 template <bool GT = false>
-HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* rec) {
+HSQP_HD void lq_chain_column_pv(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* P6, double* V6) {
   constexpr int RS = GT ? 1 : LDJ, CS = GT ? 6 : 1, SS = 6 * LDJ;   // strides of a row, a column, a stage
   const bool vcol = col >= NV && col < NX, acol = col >= NX + 12 && col < NZ;
   const int j = col - NX - 12;
@@ -135,8 +140,18 @@ HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
-    rec[REC_PV + r * LDJ + col] = live * (dt * dt / 6.0 * P[r]);
-    rec[REC_PV + (6 + r) * LDJ + col] = live * (dt / 6.0 * V[r]);
+    P6[r] = live * (dt * dt / 6.0 * P[r]);
+    V6[r] = live * (dt / 6.0 * V[r]);
+  }
+}
+template <bool GT = false>
+HSQP_HD void lq_chain_column(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* rec) {
+  double P6[6], V6[6];
+  lq_chain_column_pv<GT>(blk, gs, col, dt, P6, V6);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    rec[REC_PV + r * LDJ + col] = P6[r];
+    rec[REC_PV + (6 + r) * LDJ + col] = V6[r];
   }
 }
 

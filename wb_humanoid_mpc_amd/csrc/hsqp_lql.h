@@ -29,7 +29,7 @@ constexpr int QL_NODES = 16, QL_THREADS = 64;   // a wave evaluates 16 nodes, fo
 constexpr int QL_MAXLEN = NANC;                 // steps of the longest limb
 constexpr int NCMP = 28;                        // composite of a subtree: spatial inertia (10), net force (6), Bn (9), f_v (3)
 constexpr int CMP_I = 0, CMP_F = 10, CMP_BN = 16, CMP_FV = 25;
-constexpr int GT_LD = 6;                        // the stage Jacobians travel TRANSPOSED: [stage][column][6] (a lane owns a column)
+// (GT_LD = 6, hsqp_lq.h: the stage Jacobians travel TRANSPOSED, [stage][column][6] — a lane owns a column)
 
 // what every lane of a node knows after the base solve of a stage
 struct QlShared {
@@ -1114,11 +1114,12 @@ struct LqChainWS {
   double as[4][6];
   double bvec[64];
 };
-HSQP_HD void lq_chain_node(const Ctx& ctx, LqChainWS& w, const double* x, const double* u, const double* xnext, double dt, double* rec) {
+// columns = false: the defect and its squared norm only — k_project runs the column chain itself from REC_GS (`chain`, hsqp_project.h) and REC_PV is not written
+HSQP_HD void lq_chain_node(const Ctx& ctx, LqChainWS& w, const double* x, const double* u, const double* xnext, double dt, double* rec, bool columns = true) {
   WG_FOR(ctx, i, 3 * 72 + 24) {
     if (i < 3 * 72) {
       const int sg = i / 72, which = (i / 36) % 2, r = (i / 6) % 6, k = i % 6;
-      w.blk[sg][which][r][k] = rec[REC_GS + ((sg + 1) * LDJ + (which == 0 ? NV : 0) + k) * GT_LD + r];
+      if (columns) w.blk[sg][which][r][k] = rec[REC_GS + lq_chain_blk_offset(sg, which, r, k)];
     } else w.as[(i - 216) / 6][(i - 216) % 6] = rec[REC_AS + i - 216];
   }
   WG_SYNC(ctx);
@@ -1148,7 +1149,7 @@ HSQP_HD void lq_chain_node(const Ctx& ctx, LqChainWS& w, const double* x, const 
     w.bvec[i] = b;
 #endif
   }
-  WG_FOR(ctx, col, LDJ) lq_chain_column<true>(w.blk, rec + REC_GS, col, dt, rec);
+  if (columns) WG_FOR(ctx, col, LDJ) lq_chain_column<true>(w.blk, rec + REC_GS, col, dt, rec);
 #if !defined(__HIP_DEVICE_COMPILE__)
   WG_FOR(ctx, it, 1) {
     double dyn = 0.0;

@@ -94,6 +94,11 @@ struct ProjWS {
 };
 static_assert(LDP >= LDJ && sizeof(double) * 2 * 6 * LDP <= offsetof(ProjWS, qr.Q1T), "PV may only overlap what is dead while Tm is formed");
 static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
+// fused RK4 chain (project_node, chain = true): the chain's threads — waves 2, 3 minus their last 32 lanes; wave 0 runs the factorisation meanwhile — and the home of
+// the 216 block entries: rows of Tm that lie behind the equality rows (CDe) and are first written when Q2^T goes into Tm, two phases after the chain
+constexpr int PROJ_CHAIN_T0 = 128, PROJ_CHAIN_ROW = 24;
+static_assert(PROJ_CHAIN_ROW * LDTM >= NE_MAX * LDJ && PROJ_CHAIN_ROW * LDTM + 3 * 72 <= NU * LDTM, "the chain's blocks must not touch the equality rows or row NU of Tm");
+HSQP_HD double* proj_chain_blk(ProjWS& w) { return &w.Tm[PROJ_CHAIN_ROW][0]; }
 
 // Event interval (hsqp_problem::dt_nodes[b][k] == 0): the stage of the QP is the identity jump map
 // dx+ = dx + (x_k - x_{k+1}) with no cost and the inputs pinned (R~ = I, everything else zero -> ut = 0, du = 0).  b~ is the defect
@@ -246,7 +251,11 @@ HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int n
 // (PV[0] = momentum rows, PV[1] = base pose rows), rows 12..34 are q_j+ = q_j + dt qd_j, rows 35..57 padding states (A = I).
 // joint_rows = false: the 46 joint rows of A~ / B~ (scaled copies of rows 12 .. of [Px | Pu]: q_j+ = q_j + dt v_j + dt^2/2 qdd_j, v_j+ = v_j + dt qdd_j) and the
 // strictly lower triangle of Q~ are NOT written — the factored Riccati sweep (hsqp_riccati_fact.h) forms them from Px, Pu on the fly; b~ is always complete.  30 of the record's 101 KB.
-HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false, bool joint_rows = true) {
+// chain = true (device; limb-lane LQ form): the RK4 chain of the columns of [A|B] (lq_chain_column_pv, hsqp_lq.h) runs HERE, from the stage Jacobians REC_GS, on two waves
+// that would otherwise wait for the factorisation's one wave — REC_PV is neither written by the LQ kernels nor read (P6, V6 made a round trip of 18 KB per node through
+// memory and k_lq_chain read 18 KB of stage Jacobians for them; now k_lq_chain forms the defect only).
+HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false, bool joint_rows = true, bool chain = false) {
+  (void)chain;
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
   {
     static_assert(REC_B == REC_PV + 2 * 6 * LDJ && REC_J == REC_B + 64, "record layout");
@@ -278,6 +287,13 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     // structure of the equality rows (closed forms, one item per input / row): a swing foot f contributes the unit rows
     // off[f] .. off[f]+5 on the inputs 6f .. 6f+5
     WG_FOR(ctx, i, LDTM) w.Tm[NU][i] = i == NTW ? 1.0 : 0.0;   // (beyond the equality rows that share the block until Tm is formed)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the 6 x 6 blocks G_s[:, v_b], G_s[:, q_b] of stages 2 .. 4 that every column's chain multiplies with: in rows of Tm nobody touches before the W phase is over
+    if (chain) WG_FOR(ctx, i, 3 * 72) {
+      const int sg = i / 72, which = (i / 36) % 2, r = (i / 6) % 6, k = i % 6;
+      proj_chain_blk(w)[i] = rec[REC_GS + lq_chain_blk_offset(sg, which, r, k)];
+    }
+#endif
     WG_FOR(ctx, i, NU + NE_MAX + 1) {
       const int ne_ = (int)m_ne;
       const int sw0 = m_c0 == 0.0 ? 1 : 0, sw1 = m_c1 == 0.0 ? 1 : 0;
@@ -339,6 +355,9 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // norm, the dot product and the own column's row-k entry through one butterfly over the four row groups.  The partial sums are those of the
   // round-3 form (rows i mod 4, ascending; ((0 + 1) + (2 + 3))).  Same arithmetic per element as the two-phase form below
   // (which the host build runs), summation order aside.
+  double chP[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, chV[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // chain: column tid - PROJ_CHAIN_T0 of P6, V6 (threads PROJ_CHAIN_T0 .. + LDJ - 1), held until store_pv
+  if (chain && ctx.tid >= PROJ_CHAIN_T0 && ctx.tid < PROJ_CHAIN_T0 + LDJ)
+    lq_chain_column_pv<true>(reinterpret_cast<const double (*)[2][6][6]>(proj_chain_blk(w)), rec + REC_GS, ctx.tid - PROJ_CHAIN_T0, dt, chP, chV);
   if (ctx.tid < 64 && !(HSQP_PEXP & 8)) {
     const int lane = ctx.tid, g = lane >> 4, c = lane & 15;
     constexpr int NT9 = (NU + 1) / 4;
@@ -544,6 +563,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
 #endif
   auto load_pv = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (chain) return;
 #pragma unroll
     for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; tpv[j] = rec[REC_PV + (e < NPV ? e : 0)]; }
 #endif
@@ -558,6 +578,13 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   auto store_pv = [&]() {
     double* pv = &w.PV[0][0][0];
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (chain) {   // the chain's threads hold their column's twelve entries
+      if (ctx.tid >= PROJ_CHAIN_T0 && ctx.tid < PROJ_CHAIN_T0 + LDJ) {
+        const int c = ctx.tid - PROJ_CHAIN_T0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { pv[r * LDP + c] = chP[r] + pv_const(r * LDJ + c); pv[(6 + r) * LDP + c] = chV[r] + pv_const((6 + r) * LDJ + c); }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < TPV; ++j) { const int e = ctx.tid + j * ctx.nthreads; if (e < NPV) pv[(e / LDJ) * LDP + e % LDJ] = tpv[j] + pv_const(e); }
 #else

@@ -316,12 +316,12 @@ class HipSqpSolver:
         return dict(lq=ms[0], project=ms[1], riccati=ms[2], step_perf=ms[3], total=ms[4])
 
     def kernel_forms(self):
-        """Which kernel forms the handle runs (HSQP_BLK_FORMS): {"lq_limb": bool, "value_quad": bool, "lq_ranges": int, "ric_fact": bool}."""
-        f = np.zeros(4, dtype=np.int32)
+        """Which kernel forms the handle runs (HSQP_BLK_FORMS): {"lq_limb": bool, "value_quad": bool, "lq_ranges": int, "ric_fact": bool, "chain_fused": bool}."""
+        f = np.zeros(5, dtype=np.int32)
         n = self.lib.hsqp_debug_read(self.h, _abi.BLK_FORMS, f.ctypes.data_as(C.c_void_p), f.nbytes)
         if n < 0:
             self._check(int(n))
-        return {"lq_limb": bool(f[0]), "value_quad": bool(f[1]), "lq_ranges": int(f[2]), "ric_fact": bool(f[3])}
+        return {"lq_limb": bool(f[0]), "value_quad": bool(f[1]), "lq_ranges": int(f[2]), "ric_fact": bool(f[3]), "chain_fused": bool(f[4])}
 
     def set_scan_backoff_persistent(self, on=True):
         """hsqp_set_scan_backoff_persistent: the KKT gate's back-off survives uploads of the same shape (receding-horizon use)."""
