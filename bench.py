@@ -477,7 +477,9 @@ def main():
         # not part of SURVEY's count, so its fraction is reported against the same FP64 peak but its bound is VALU issue, not the matrix pipe.
         pmc, pmc_prov = pmc_kernel_info()
         forms = solver.kernel_forms()   # which kernels this handle runs (decided at hsqp_create from its size: HSQP_BLK_FORMS)
-        lq_name = "k_lq_cent2" if cent else ("k_lq_limb + k_lq_rows + k_lq_chain" if forms["lq_limb"] else "k_lq<true>")
+        # (chain_fused: the RK4 chain of the [A|B] columns runs inside k_project and the defect on the lanes of k_lq_rows — k_lq_chain is not launched; the dense RK4 count
+        #  stays with the LQ bucket, where the stage Jacobians it is made of are formed: k_project's algorithmic flops are NOT raised by the move)
+        lq_name = "k_lq_cent2" if cent else (("k_lq_limb + k_lq_rows" if forms.get("chain_fused") else "k_lq_limb + k_lq_rows + k_lq_chain") if forms["lq_limb"] else "k_lq<true>")
         step_name = ("k_step + k_lq_cent2_value (+ reductions)" if cent else
                      ("k_step + k_value_quad (+ reductions)" if forms["value_quad"] else "k_step_value (+ reductions)"))
         kern = {lq_name: (kms[0], f_rk4, "valu-issue / scattered stores (limb lanes)" if forms["lq_limb"] and not cent else "valu-issue"),

@@ -219,14 +219,21 @@ void emu_stage_eval(void* h, const double* x, const double* u, int deriv, double
 
 // the limb-lane form of the whole-body LQ approximation (hsqp_lql.h): the four lanes of a node one after the other (k_lq_limb), then the chain /
 // defect pass (k_lq_chain); rec: REC_SIZE doubles, ZERO-FILLED by the caller (entries that are zero for every state are never written)
+static double g_defect_mismatch = 0.0;   // max |b (lanes) - b (chain kernel)| of the last limb-lane node
+double emu_defect_mismatch() { return g_defect_mismatch; }
 void emu_set_lq_limb(int on) { g_lq_limb = on; }
 int emu_ql_ok(void* h) { return static_cast<DevModel*>(h)->ql_ok; }
 static void lq_limb_node(const DevModel& dm, const double* x, const double* u, const double* xnext, const double* par, double dt, double* rec) {
   Ctx ctx{0, 1, nullptr};
   ql_node_host(dm, x, u, dt, rec);
-  ql_rows_host(dm, x, u, par, dt, rec);
+  ql_rows_host(dm, x, u, par, dt, rec, xnext);   // the defect on the lanes, as the product forms it when the chain is fused into k_project
+  // the columns' chain (the device: inside k_project, lq_chain_column_pv): P6, V6 only — the chain kernel's defect must not overwrite the lanes' (the tests compare THAT with the oracle)
+  std::vector<double> tmp(rec, rec + REC_SIZE);
   auto cw = std::make_unique<LqChainWS>();
-  lq_chain_node(ctx, *cw, x, u, xnext, dt, rec);
+  lq_chain_node(ctx, *cw, x, u, xnext, dt, tmp.data());
+  for (int i = 0; i < 2 * 6 * LDJ; ++i) rec[REC_PV + i] = tmp[REC_PV + i];
+  g_defect_mismatch = 0.0;
+  for (int i = 0; i < 64; ++i) { const double d = std::fabs(tmp[REC_B + i] - rec[REC_B + i]); if (d > g_defect_mismatch) g_defect_mismatch = d; }
 }
 
 // LQ record of one node (REC_SIZE doubles) + dense expansions for comparison with the oracle

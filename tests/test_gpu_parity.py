@@ -268,7 +268,7 @@ def test_config4_instances_against_oracle_at_full_size(model, oracle):
     x0, x, u, par, dt = make_problem(model, n_nodes=N, batch=B, perturb=True)
     s = HipSqpSolver(model, max_nodes=N, max_batch=B)
     try:
-        assert s.kernel_forms() == {"lq_limb": True, "value_quad": True, "lq_ranges": 2, "ric_fact": True}
+        assert s.kernel_forms() == {"lq_limb": True, "value_quad": True, "lq_ranges": 2, "ric_fact": True, "chain_fused": True}
         out = s.run(x0, x, u, par, dt)
     finally:
         s.close()

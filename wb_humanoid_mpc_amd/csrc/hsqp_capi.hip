@@ -604,7 +604,7 @@ struct QrWS {
 static_assert(sizeof(QrWS) * (4 / QL_WAVES) <= 163840, "four waves per CU");
 __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_per_eu(HSQP_QR_WPE, HSQP_QR_WPE))) void k_lq_rows(
     const DevModel* __restrict__ dm, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ par, const double* __restrict__ dts,
-    int N, int nodes, double* __restrict__ rec, long long* prof, int node_base) {
+    int N, int nodes, double* __restrict__ rec, long long* prof, int node_base, int defect) {
   __shared__ QrWS ws;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane >> 2, L = lane & 3;
   auto& w = ws.wv[wave];
@@ -637,6 +637,8 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
   ql_base_kin(*dm, xs, 0, dt, c, bk);
   ql_kin_to_leaf(*dm, ws.k, lb, xs, us, L, bk, csn, CSN_LD, st, nl);
   ql_shared_from_record(bk, grec, sh);
+  double dsq = 0.0;   // defect = 1 (the chain is fused into k_project, k_lq_chain is not launched): the node's defect and its squared norm on the four lanes, in front of every store of the kernel
+  if (defect) dsq = ql_defect_lane(xs, us, x + ((size_t)b * (N + 1) + k + 1) * NX, grec + REC_AS, dt, L, grec, live);
   PH_TICK(ctx, 11);
   {
     // the lane's foot and its share of the cost (pass A), then what needs every lane's pass A (pass B).  The four lanes of a node sit in one
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(QL_THREADS * QL_WAVES) __attribute__((amdgpu_waves_
     const int coll = quad_sum((double)any) > 0.0 ? 1 : 0;
     ql_rows_setup(*dm, pn, L, dt, coll, rw);
     if (live && L == 0) ql_write_misc(pn, dt, cost, eq, coll, grec + REC_MISC);
+    if (defect) { dsq = quad_sum(dsq); if (live && L == 0) grec[REC_MISC + 3] = (dt > 0.0 ? dt : 1.0) * dsq; }
   }
   PH_TICK(ctx, 12);
   const double* gs = grec + REC_GS;
@@ -1481,8 +1484,8 @@ int hsqp_iterate_device(hsqp_handle* h, int n_iterations, int flags) {
         hipStream_t st = s == 0 ? h->stream : h->aux[s - 1];
         const dim3 qgrid((n1 - n0 + QG - 1) / QG);
         HSQP_LAUNCH(k_lq_limb, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
-        HSQP_LAUNCH(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0);
-        HSQP_LAUNCH(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0, h->chain_fused ? 0 : 1);
+        HSQP_LAUNCH(k_lq_rows, qgrid, qblock, 0, st, h->d_dm, h->d_x, h->d_u, h->d_par, h->d_dt, N, n1, h->d_rec, h->d_prof + 384, n0, h->chain_fused ? 1 : 0);
+        if (!h->chain_fused) HSQP_LAUNCH(k_lq_chain, dim3(n1 - n0), dim3(LQC_THREADS), 0, st, h->d_x, h->d_u, h->d_dt, N, h->d_rec, n0, 1);   // (fused: the columns' chain runs in k_project, the defect on the lanes of k_lq_rows)
         if (s > 0) { HCHECK(hipEventRecord(h->ev_join[s - 1], st)); HCHECK(hipStreamWaitEvent(h->stream, h->ev_join[s - 1], 0)); }
       }
     } else

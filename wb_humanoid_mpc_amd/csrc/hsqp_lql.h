@@ -655,6 +655,33 @@ HSQP_HD void ql_write_misc(const double* par, double dt, double cost, double eq,
   misc[9] = 1.0;                                      // REC_LAYOUT: transposed
 }
 
+// The RK4 value and the defect b = Phi(x, u) - x_next of a node on its four lanes: lane L forms the entries i = 4 j + L (the formulas of lq_chain_node below / lq_node, hsqp_lq.h
+// "RK4 value"; as = REC_AS, the base accelerations of the four stages from k_lq_limb) and returns its share of |b|^2.  What k_lq_rows runs when the chain is fused into
+// k_project (k_lq_chain is not launched then); entries NX .. 63 of REC_B are written as zeros.
+HSQP_HD double ql_defect_lane(const double* x, const double* u, const double* xnext, const double* as, double dt, int L, double* rec, bool live) {
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = 4 * j + L;
+    double b = 0.0;
+    if (i < NV) {
+      const double v0 = x[NV + i];
+      double a0, a1, a2;   // what moves the stage velocities: the previous stage's acceleration
+      if (i < 6) { a0 = as[i]; a1 = as[6 + i]; a2 = as[12 + i]; }
+      else a0 = a1 = a2 = u[12 + i - 6];
+      const double v1 = v0 + 0.5 * dt * a0, v2 = v0 + 0.5 * dt * a1, v3 = v0 + dt * a2;
+      b = x[i] + dt / 6.0 * (v0 + 2.0 * v1 + 2.0 * v2 + v3) - xnext[i];
+    } else if (i < NX) {
+      const int k = i - NV;
+      const double a = k < 6 ? (as[k] + 2.0 * as[6 + k] + 2.0 * as[12 + k] + as[18 + k]) / 6.0 : u[12 + k - 6];
+      b = x[i] + dt * a - xnext[i];
+    }
+    if (live) rec[REC_B + i] = b;
+    sq += b * b;
+  }
+  return sq;
+}
+
 // d{pos, ori, vlin, vang, alin, aang}/dz of a contact frame from the partials of its body's spatial velocity dv, spatial acceleration da (own part +
 // base chain) and of the contact point drP (foot_column "frame level", hsqp_node.h:342-365); rot: the column rotates the frame about wax
 HSQP_HD void ql_frame_rows(const QlFoot& ft, const double* dv, const double* da, const double* drP, bool rot, const double* wax, double* out) {
@@ -1223,7 +1250,7 @@ inline void ql_node_host(const DevModel& dm, const double* x, const double* u, d
 }
 // ... what k_lq_rows writes: the node terms of stage 1 (rec: REC_GS / REC_AS of the node from ql_node_host; zero-filled otherwise, as hsqp_create
 // leaves the record)
-inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, const double* par, double dt, double* rec) {
+inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, const double* par, double dt, double* rec, const double* xnext = nullptr) {
   QvConst* kc = new QvConst;
   QlNodeLds* nl = new QlNodeLds;
   memset(nl, 0, sizeof(QlNodeLds));
@@ -1251,6 +1278,11 @@ inline void ql_rows_host(const DevModel& dm, const double* x, const double* u, c
   const int coll = (any[0] + any[1] + any[2] + any[3]) > 0;
   for (int L = 0; L < QV_LIMBS; ++L) ql_rows_setup(dm, par, L, dt, coll, rw[L]);
   ql_write_misc(par, dt, ctot, etot, coll, rec + REC_MISC);
+  if (xnext) {   // the defect on the lanes (the device: when the chain is fused into k_project)
+    double sq[QV_LIMBS];
+    for (int L = 0; L < QV_LIMBS; ++L) sq[L] = ql_defect_lane(x, u, xnext, rec + REC_AS, dt, L, rec, true);
+    rec[REC_MISC + 3] = (dt > 0.0 ? dt : 1.0) * ((sq[0] + sq[1]) + (sq[2] + sq[3]));
+  }
   const double* G = rec + REC_GS;
   for (int t = dm.limb_max_len - 1; t >= 0; --t)
     for (int L = 0; L < QV_LIMBS; ++L) {
