@@ -340,13 +340,14 @@ int hsqp_download_device(hsqp_handle* h, hsqp_solution* solution);
 #define HSQP_BLK_FLOW 10        /* [B][N][58]       xdot at (x_k,u_k)                                      */
 #define HSQP_BLK_PARAMS 11      /* [B][N+1][72]     the per-node parameter table resident on the device    */
 #define HSQP_BLK_FORMS 12       /* int32[5]         which kernel forms the handle runs (decided at hsqp_create from its size): [0] whole-body LQ approximation
-                                                    on limb lanes (k_lq_limb + k_lq_rows + k_lq_chain) instead of k_lq<true>, [1] value pass on quads of lanes
+                                                    on limb lanes (k_lq_limb + k_lq_rows; see [4]) instead of k_lq<true>, [1] value pass on quads of lanes
                                                     (k_value_quad) instead of k_step_value; [2] node ranges the limb-lane LQ kernels are launched in, each on a
                                                     stream of its own, once a launch exceeds one round of the chip (0: phase form; HSQP_LQ_SPLIT in the
                                                     environment at hsqp_create overrides the default 2); [3] the whole-body serial sweep runs on the factors of [A~ | B~]
                                                     (k_riccati_fact; HSQP_RICCATI_DENSE in the environment at hsqp_create: the dense stage k_riccati<58>); [4] limb-lane form: the RK4
-                                                    chain of the columns of [A|B] runs inside k_project and k_lq_chain forms the defect only (HSQP_LQ_CHAIN_SEPARATE in the
-                                                    environment at hsqp_create: the chain in k_lq_chain, P6 / V6 through the LQ record).  Available at any time */
+                                                    chain of the columns of [A|B] runs inside k_project, the defect on the lanes of k_lq_rows, and k_lq_chain is not launched
+                                                    (HSQP_LQ_CHAIN_SEPARATE in the environment at hsqp_create: chain and defect in k_lq_chain, P6 / V6 through the LQ record).
+                                                    Available at any time */
 long long hsqp_debug_read(hsqp_handle* h, int what, void* dst, long long bytes);
 
 /* Elapsed device time (ms) of the kernels of the last hsqp_iterate_device call,

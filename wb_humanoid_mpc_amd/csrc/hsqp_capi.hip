@@ -940,7 +940,7 @@ struct hsqp_handle {
   bool backoff_persistent = false;            // hsqp_set_scan_backoff_persistent: uploads of the same (B, N) keep the back-off
   long long backoff_iterations = 0;           // iterations that ran the serial recursion because of the back-off (hsqp_scan_backoffs)
   bool seg_debug = false;                     // HSQP_SEG_DEBUG in the environment at hsqp_create
-  bool chain_fused = false;                   // limb-lane form: the RK4 chain of the columns of [A|B] runs inside k_project (project_node, chain), k_lq_chain forms the defect only; HSQP_LQ_CHAIN_SEPARATE in the environment at hsqp_create keeps the chain in k_lq_chain (A/B runs)
+  bool chain_fused = false;                   // limb-lane form: the RK4 chain of the columns of [A|B] runs inside k_project (project_node, chain), the defect on the lanes of k_lq_rows (ql_defect_lane), k_lq_chain is not launched; HSQP_LQ_CHAIN_SEPARATE in the environment at hsqp_create keeps the chain in k_lq_chain (A/B runs)
   bool lq_limb = false;                       // whole-body LQ approximation on limb lanes (hsqp_lql.h: k_lq_limb + k_lq_rows + k_lq_chain) instead of the phase form k_lq<true> (HSQP_LQ_PHASE_FORM / HSQP_LQ_LIMB_FORM in the environment at hsqp_create force either)
   bool ric_fact = false;                      // whole-body serial sweep on the factors of [A~ | B~] (hsqp_riccati_fact.h: k_riccati_fact; HSQP_RICCATI_DENSE in the environment at hsqp_create: the dense stage k_riccati<58>, for A/B runs)
   bool value_quad = false;                    // whole-body value pass on quads of lanes (hsqp_lqv.h): the tree has at most four limbs (HSQP_VALUE_PHASE_FORM in the environment at hsqp_create: the phase form, for A/B runs)

@@ -253,7 +253,7 @@ HSQP_HD void gram_store(const Ctx& ctx, const GramAcc& g, const ProjWS& w, int n
 // strictly lower triangle of Q~ are NOT written — the factored Riccati sweep (hsqp_riccati_fact.h) forms them from Px, Pu on the fly; b~ is always complete.  30 of the record's 101 KB.
 // chain = true (device; limb-lane LQ form): the RK4 chain of the columns of [A|B] (lq_chain_column_pv, hsqp_lq.h) runs HERE, from the stage Jacobians REC_GS, on two waves
 // that would otherwise wait for the factorisation's one wave — REC_PV is neither written by the LQ kernels nor read (P6, V6 made a round trip of 18 KB per node through
-// memory and k_lq_chain read 18 KB of stage Jacobians for them; now k_lq_chain forms the defect only).
+// memory and k_lq_chain read 18 KB of stage Jacobians for them; the defect moves to the lanes of k_lq_rows and k_lq_chain is not launched).
 HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double dt, double* qp, bool cent = false, bool joint_rows = true, bool chain = false) {
   (void)chain;
   // ---- load: record pieces [REC_B, REC_J) -> bvec and [REC_RHO, REC_MISC) -> rho, d, gd, CDe; 8 loads in flight per item
