@@ -426,6 +426,9 @@ static_assert(ROWQ_COLL + 16 == NRS && ROWQ_FM + 16 == ROWQ_COLL, "row slots");
 // Entries that are zero for every state (a column that can never move a row: an arm joint and the friction rows, ...) are never written: the
 // record is zero-filled when it is allocated (hsqp_create) and only this kernel writes these regions.
 
+#ifndef HSQP_QL_MERGED_STORES
+#define HSQP_QL_MERGED_STORES 1   /* ql_put_foot: full and half blocks stored by the same wave instructions (0: one branch each; A/B builds) */
+#endif
 HSQP_HD void ql_st2(double* p, double a, double b) {
 #if defined(HSQP_EXP_FEWSTORES)   /* timing experiment only (wrong results): one store in eight reaches memory */
   if ((reinterpret_cast<unsigned long long>(p) >> 4) & 7ull) return;
@@ -716,14 +719,24 @@ HSQP_HD void ql_frame_rows_base(const QlFoot& ft, const double* dab, double* out
 }
 
 // the task-space rows of foot f in column `col` (full: all fifteen, else the six acceleration rows) and the foot's equality rows ef[7]
-HSQP_HD void ql_put_foot(const DevModel& dm, const QlRows& rw, int f, bool full, const double* out, int col, double* rec, bool live, double* ef, int unit_row) {
+// zpairs: bit j set = the row pair (2 j, 2 j + 1) of a FULL block is zero for every state in this column (a d/dqd column moves no orientation row: bit 0; a d/dqdd column
+// only the acceleration rows: bits 0 .. 3; a base linear velocity neither orientation nor angular velocity: bits 0, 3) — not stored, like every other structural zero of
+// the record (profiles/r06_lq_store_diet.txt).  Wave-uniform at every call site.
+HSQP_HD void ql_put_foot(const DevModel& dm, const QlRows& rw, int f, bool full, const double* out, int col, double* rec, bool live, double* ef, int unit_row, unsigned zpairs = 0u) {
   if (live) {
     double* jt = rec + REC_J + col * NRS + ROWQ_FOOT + 16 * f;
     const double sc = rw.imp[f];
     const double* w = dm.foot_sqrt_w + 3;
+#if HSQP_QL_MERGED_STORES
+    // ONE store instruction per row pair for the lanes that write the whole block and those that write its acceleration half (rows 8 .. 15; their out[11] is zero):
+    // the two groups used to run their stores one after the other, twelve wave instructions per foot and column instead of eight
+#pragma unroll
+    for (int k = 0; k < 16; k += 2)
+      if (!((zpairs >> (k / 2)) & 1u) || k >= 8) { if (full || k >= 8) ql_st2(jt + k, sc * w[k] * out[3 + k], k < 14 ? sc * w[k + 1] * out[4 + k] : 0.0); }
+#else
     if (full) {
 #pragma unroll
-      for (int k = 0; k < 14; k += 2) ql_st2(jt + k, sc * w[k] * out[3 + k], sc * w[k + 1] * out[4 + k]);
+      for (int k = 0; k < 14; k += 2) if (!((zpairs >> (k / 2)) & 1u)) ql_st2(jt + k, sc * w[k] * out[3 + k], sc * w[k + 1] * out[4 + k]);
       ql_st2(jt + 14, sc * w[14] * out[17], 0.0);
     } else {
       ql_st2(jt + 8, 0.0, sc * w[9] * out[12]);
@@ -731,6 +744,7 @@ HSQP_HD void ql_put_foot(const DevModel& dm, const QlRows& rw, int f, bool full,
       ql_st2(jt + 12, sc * w[12] * out[15], sc * w[13] * out[16]);
       ql_st2(jt + 14, sc * w[14] * out[17], 0.0);
     }
+#endif
   }
   const int cf = f == 0 ? rw.c0 : rw.c1;
   if (cf) {
@@ -761,7 +775,7 @@ HSQP_HD void ql_put_cde(const QlRows& rw, const double* e0, const double* e1, in
   ql_st2(ct + 8, c0 ? e1[2] : e1[1], c0 ? e1[3] : e1[2]);
   ql_st2(ct + 10, c0 ? e1[4] : e1[3], c0 ? e1[5] : e1[4]);
   ql_st2(ct + 12, c0 ? e1[6] : e1[5], c0 ? 0.0 : e1[6]);
-  ql_st2(ct + 14, 0.0, 0.0);
+  // (rows 14, 15 of a column's slot are padding beyond NE_MAX: never read, zero since hsqp_create — no store: LQ kernels 0.759 -> 0.733 ms, profiles/r06_lq_store_diet.txt)
 }
 // friction / moment rows of foot f in a column that rotates the foot frame about w (v[0..3] = 0) or that is a wrench component (cu = 0..5)
 HSQP_HD void ql_put_fm(const DevModel& dm, const QlFoot& ft, int f, const double* u, const double* w, int cu, int col, double* rec, bool live) {
@@ -850,7 +864,7 @@ HSQP_HD void ql_rows_joint(const DevModel& dm, const QlRows& rw, const QlNodeLds
     for (int k = 0; k < 18; ++k) { if (rw.own == 0) out[0][k] = o[k]; else out[1][k] = o[k]; }
   }
 #pragma unroll
-  for (int f = 0; f < 2; ++f) ql_put_foot(dm, rw, f, full && f == rw.own, out[f], col, rec, live, ef[f], -1);
+  for (int f = 0; f < 2; ++f) ql_put_foot(dm, rw, f, full && f == rw.own, out[f], col, rec, live, ef[f], -1, kind == 0 ? 0u : (kind == 1 ? 1u : 0xFu));
   ql_put_cde(rw, ef[0], ef[1], col, rec, live);
   if (kind == 0 && full) ql_put_fm(dm, nl.ft[rw.own], rw.own, u, S, 0, col, rec, live);
   if (kind == 0 && rw.coll) ql_put_coll(dm, nl, S, st.r, i, i + dm.subtree_size[i], col, rec, live);
@@ -891,7 +905,7 @@ HSQP_HD void ql_rows_euler(const DevModel& dm, const QlRows& rw, const QlNodeLds
     }
     for (int k = 0; k < 6; ++k) da[k] += dab[k];
     ql_frame_rows(ft, dv, da, drP, kind == 0, S, out);
-    ql_put_foot(dm, rw, f, true, out, col, rec, live, ef[f], -1);
+    ql_put_foot(dm, rw, f, true, out, col, rec, live, ef[f], -1, kind == 0 ? 0u : 1u);
     if (kind == 0) ql_put_fm(dm, ft, f, u, S, 0, col, rec, live);
   }
   ql_put_cde(rw, ef[0], ef[1], col, rec, live);
@@ -912,7 +926,7 @@ HSQP_HD void ql_rows_base_linear(const DevModel& dm, const QlRows& rw, const QlN
       mxm(ft.vl, Sx, t);
       for (int k = 0; k < 6; ++k) { dv[k] = Sx[k]; da[k] = -t[k]; }
       ql_frame_rows(ft, dv, da, drP, false, Sx, out);
-      ql_put_foot(dm, rw, f, true, out, NV + c, rec, live, ef[f], -1);
+      ql_put_foot(dm, rw, f, true, out, NV + c, rec, live, ef[f], -1, 0x9u);
     }
     ql_put_cde(rw, ef[0], ef[1], NV + c, rec, live);
   }
