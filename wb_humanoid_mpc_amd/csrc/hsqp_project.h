@@ -96,7 +96,11 @@ static_assert(LDP >= LDJ && sizeof(double) * 2 * 6 * LDP <= offsetof(ProjWS, qr.
 static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
 // fused RK4 chain (project_node, chain = true): the chain's threads — waves 2, 3 minus their last 32 lanes; wave 0 runs the factorisation meanwhile — and the home of
 // the 216 block entries: rows of Tm that lie behind the equality rows (CDe) and are first written when Q2^T goes into Tm, two phases after the chain
-constexpr int PROJ_CHAIN_T0 = 128, PROJ_CHAIN_ROW = 24;
+#ifndef HSQP_PROJ_CHAIN_T0
+#define HSQP_PROJ_CHAIN_T0 128   /* first thread of the fused chain (tuning builds: 64 = waves 1, 2) */
+#endif
+constexpr int PROJ_CHAIN_T0 = HSQP_PROJ_CHAIN_T0, PROJ_CHAIN_ROW = 24;
+static_assert(PROJ_CHAIN_T0 >= 64 && PROJ_CHAIN_T0 + LDJ <= 256, "the chain's threads: not wave 0 (the factorisation), inside the workgroup");
 static_assert(PROJ_CHAIN_ROW * LDTM >= NE_MAX * LDJ && PROJ_CHAIN_ROW * LDTM + 3 * 72 <= NU * LDTM, "the chain's blocks must not touch the equality rows or row NU of Tm");
 HSQP_HD double* proj_chain_blk(ProjWS& w) { return &w.Tm[PROJ_CHAIN_ROW][0]; }
 
