@@ -98,9 +98,26 @@ HSQP_HD constexpr int lq_chain_blk_offset(int sg, int which, int r, int k) { ret
 // column phases wrote them; the own-column entries of a stage and its selection partners are fetched one stage ahead of their use.
 // GT: the stage Jacobians are stored transposed, [stage][column][6] (written by the limb lanes of hsqp_lql.h), else [stage][6][LDJ].
 // (lq_chain_column_pv: the column's twelve entries P6[r], V6[r] as values — k_project forms them itself when the chain is fused into it, hsqp_project.h)
-template <bool GT = false>
+// BG (with GT): the 6 x 6 blocks are read from the transposed stage Jacobians themselves (blk unused) — their addresses are the same in every lane, so a device build fetches them
+// through the scalar cache and they never occupy a vector register or LDS (k_project); the six entries of a column are fetched as three 16-byte pieces.
+template <bool GT = false, bool BG = false>
 HSQP_HD void lq_chain_column_pv(const double (*blk)[2][6][6], const double* gs, int col, double dt, double* P6, double* V6) {
+  static_assert(GT || !BG, "blocks from the record: transposed stage Jacobians only");
   constexpr int RS = GT ? 1 : LDJ, CS = GT ? 6 : 1, SS = 6 * LDJ;   // strides of a row, a column, a stage
+  auto B = [&](int sg, int which, int r, int k) -> double { if constexpr (BG) return gs[lq_chain_blk_offset(sg, which, r, k)]; else return blk[sg][which][r][k]; };
+  // the six entries of column i of stage st (element r at gs[st * SS + r * RS + i * CS])
+  auto col6 = [&](int st, int i, double* o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (GT) {   // contiguous, 16-byte aligned (REC_GS and 6 * i are even)
+      const double2* p2 = reinterpret_cast<const double2*>(gs + st * SS + i * CS);
+      const double2 q0 = p2[0], q1 = p2[1], q2 = p2[2];
+      o[0] = q0.x; o[1] = q0.y; o[2] = q1.x; o[3] = q1.y; o[4] = q2.x; o[5] = q2.y;
+      return;
+    }
+#endif
+#pragma unroll
+    for (int r = 0; r < 6; ++r) o[r] = gs[st * SS + r * RS + i * CS];
+  };
   const bool vcol = col >= NV && col < NX, acol = col >= NX + 12 && col < NZ;
   const int j = col - NX - 12;
   const int iA = col < NZ ? col : 0, iB = vcol ? col - NV : (acol ? NV + 6 + j : iA), iC = acol ? 6 + j : iA;
@@ -108,10 +125,10 @@ HSQP_HD void lq_chain_column_pv(const double (*blk)[2][6][6], const double* gs, 
   const double cs[3] = {0.5 * dt, 0.5 * dt, dt};
   double a2[6], a1[6], P[6], V[6];   // Ab_{s-2}, Ab_{s-1}
   double gA[6], gB[6], gC[6];
+  col6(0, iA, a1);
 #pragma unroll
-  for (int r = 0; r < 6; ++r) { a1[r] = live * gs[r * RS + iA * CS]; a2[r] = 0.0; P[r] = a1[r]; V[r] = a1[r]; }
-#pragma unroll
-  for (int r = 0; r < 6; ++r) { gA[r] = gs[SS + r * RS + iA * CS]; gB[r] = gs[SS + r * RS + iB * CS]; gC[r] = gs[SS + r * RS + iC * CS]; }
+  for (int r = 0; r < 6; ++r) { a1[r] = live * a1[r]; a2[r] = 0.0; P[r] = a1[r]; V[r] = a1[r]; }
+  col6(1, iA, gA); col6(1, iB, gB); col6(1, iC, gC);
 #pragma unroll
   for (int sg = 0; sg < 3; ++sg) {
     const double c = cs[sg], cprev = sg == 0 ? 0.0 : cs[sg - 1];
@@ -120,16 +137,13 @@ HSQP_HD void lq_chain_column_pv(const double (*blk)[2][6][6], const double* gs, 
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);   // keep the ILP scheduler from hoisting the block loads of all three stages to the top (1.3 KB of spills per lane)
 #endif
-    if (sg < 2) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) { nA[r] = gs[(sg + 2) * SS + r * RS + iA * CS]; nB[r] = gs[(sg + 2) * SS + r * RS + iB * CS]; nC[r] = gs[(sg + 2) * SS + r * RS + iC * CS]; }
-    }
+    if (sg < 2) { col6(sg + 2, iA, nA); col6(sg + 2, iB, nB); col6(sg + 2, iC, nC); }
 #pragma unroll 2
     for (int r = 0; r < 6; ++r) {   // (two rows at a time: fully unrolled, the scheduler fetches all 72 block entries first and spills)
       const double v = live * gA[r] + wB * gB[r] + wC * gC[r];
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { s1 += blk[sg][0][r][k] * a1[k]; s2 += blk[sg][1][r][k] * a2[k]; }
+      for (int k = 0; k < 6; ++k) { s1 += B(sg, 0, r, k) * a1[k]; s2 += B(sg, 1, r, k) * a2[k]; }
       an[r] = v + c * (s1 + cprev * s2);
     }
 #pragma unroll

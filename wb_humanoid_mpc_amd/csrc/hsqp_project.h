@@ -96,6 +96,9 @@ static_assert(LDP >= LDJ && sizeof(double) * 2 * 6 * LDP <= offsetof(ProjWS, qr.
 static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
 // fused RK4 chain (project_node, chain = true): the chain's threads — waves 2, 3 minus their last 32 lanes; wave 0 runs the factorisation meanwhile — and the home of
 // the 216 block entries: rows of Tm that lie behind the equality rows (CDe) and are first written when Q2^T goes into Tm, two phases after the chain
+#ifndef HSQP_PROJ_CHAIN_BLK_LDS
+#define HSQP_PROJ_CHAIN_BLK_LDS 0   /* 1: the chain's 6 x 6 blocks staged in LDS (rows of Tm) instead of read through the scalar cache (A/B builds) */
+#endif
 #ifndef HSQP_PROJ_CHAIN_T0
 #define HSQP_PROJ_CHAIN_T0 128   /* first thread of the fused chain (tuning builds: 64 = waves 1, 2) */
 #endif
@@ -293,7 +296,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     WG_FOR(ctx, i, LDTM) w.Tm[NU][i] = i == NTW ? 1.0 : 0.0;   // (beyond the equality rows that share the block until Tm is formed)
 #if defined(__HIP_DEVICE_COMPILE__)
     // the 6 x 6 blocks G_s[:, v_b], G_s[:, q_b] of stages 2 .. 4 that every column's chain multiplies with: in rows of Tm nobody touches before the W phase is over
-    if (chain) WG_FOR(ctx, i, 3 * 72) {
+    if (chain && HSQP_PROJ_CHAIN_BLK_LDS) WG_FOR(ctx, i, 3 * 72) {
       const int sg = i / 72, which = (i / 36) % 2, r = (i / 6) % 6, k = i % 6;
       proj_chain_blk(w)[i] = rec[REC_GS + lq_chain_blk_offset(sg, which, r, k)];
     }
@@ -361,7 +364,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
   // (which the host build runs), summation order aside.
   double chP[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, chV[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // chain: column tid - PROJ_CHAIN_T0 of P6, V6 (threads PROJ_CHAIN_T0 .. + LDJ - 1), held until store_pv
   if (chain && ctx.tid >= PROJ_CHAIN_T0 && ctx.tid < PROJ_CHAIN_T0 + LDJ)
-    lq_chain_column_pv<true>(reinterpret_cast<const double (*)[2][6][6]>(proj_chain_blk(w)), rec + REC_GS, ctx.tid - PROJ_CHAIN_T0, dt, chP, chV);
+    lq_chain_column_pv<true, !HSQP_PROJ_CHAIN_BLK_LDS>(reinterpret_cast<const double (*)[2][6][6]>(proj_chain_blk(w)), rec + REC_GS, ctx.tid - PROJ_CHAIN_T0, dt, chP, chV);
   if (ctx.tid < 64 && !(HSQP_PEXP & 8)) {
     const int lane = ctx.tid, g = lane >> 4, c = lane & 15;
     constexpr int NT9 = (NU + 1) / 4;
