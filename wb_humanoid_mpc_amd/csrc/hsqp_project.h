@@ -94,8 +94,9 @@ struct ProjWS {
 };
 static_assert(LDP >= LDJ && sizeof(double) * 2 * 6 * LDP <= offsetof(ProjWS, qr.Q1T), "PV may only overlap what is dead while Tm is formed");
 static_assert(sizeof(ProjWS) <= 163840 / 3 - 256, "three workgroups per CU");
-// fused RK4 chain (project_node, chain = true): the chain's threads — waves 2, 3 minus their last 32 lanes; wave 0 runs the factorisation meanwhile — and the home of
-// the 216 block entries: rows of Tm that lie behind the equality rows (CDe) and are first written when Q2^T goes into Tm, two phases after the chain
+// fused RK4 chain (project_node, chain = true): the chain's threads — waves 2, 3 minus their last 32 lanes; wave 0 runs the factorisation meanwhile.  The 216 entries of the
+// 6 x 6 blocks have wave-uniform addresses and come through the scalar cache; the A/B form (HSQP_PROJ_CHAIN_BLK_LDS) stages them in rows of Tm that lie behind the equality
+// rows (CDe) and are first written when Q2^T goes into Tm, two phases after the chain
 #ifndef HSQP_PROJ_CHAIN_BLK_LDS
 #define HSQP_PROJ_CHAIN_BLK_LDS 0   /* 1: the chain's 6 x 6 blocks staged in LDS (rows of Tm) instead of read through the scalar cache (A/B builds) */
 #endif
@@ -295,7 +296,7 @@ HSQP_HD void project_node(const Ctx& ctx, ProjWS& w, const double* rec, double d
     // off[f] .. off[f]+5 on the inputs 6f .. 6f+5
     WG_FOR(ctx, i, LDTM) w.Tm[NU][i] = i == NTW ? 1.0 : 0.0;   // (beyond the equality rows that share the block until Tm is formed)
 #if defined(__HIP_DEVICE_COMPILE__)
-    // the 6 x 6 blocks G_s[:, v_b], G_s[:, q_b] of stages 2 .. 4 that every column's chain multiplies with: in rows of Tm nobody touches before the W phase is over
+    // (A/B form only) the 6 x 6 blocks G_s[:, v_b], G_s[:, q_b] of stages 2 .. 4 that every column's chain multiplies with: in rows of Tm nobody touches before the W phase is over
     if (chain && HSQP_PROJ_CHAIN_BLK_LDS) WG_FOR(ctx, i, 3 * 72) {
       const int sg = i / 72, which = (i / 36) % 2, r = (i / 6) % 6, k = i % 6;
       proj_chain_blk(w)[i] = rec[REC_GS + lq_chain_blk_offset(sg, which, r, k)];
